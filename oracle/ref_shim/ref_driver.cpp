@@ -1,0 +1,158 @@
+// ref_driver.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// A flat C interface over the UNMODIFIED reference classes (CimgDecode,
+// CwindowBuf, CDocLog compiled in place from /root/reference/source), with the
+// same call sequence CjfifDecode drives them with (reference
+// source/JfifDecode.cpp:3581,3600,4648,5008-5025,5161,5291,5299).  The entry
+// points mirror include/jsnoop_gpu.h one-for-one so that the parity tests can run
+// the same script against (a) this library, (b) oracle/oracle_imgdecode.c and
+// (c) the HIP path.  `#define private public` exposes the decoder's internal maps
+// and per-function probes (IDCT, colour) for known-answer tests only.
+#include "stdafx.h"
+#define private public
+#include "ImgDecode.h"
+#undef private
+#include "JPEGsnoop.h"
+
+std::vector<std::string>& ShimLog();
+CSnoopConfig* ShimConfig();
+
+struct JsRef {
+    CDocLog     log;
+    CwindowBuf  wbuf;
+    CimgDecode* dec;
+    CFile*      file;
+    std::vector<BYTE> bytes;
+    JsRef() : dec(nullptr), file(nullptr) { (void)AfxGetApp(); dec = new CimgDecode(&log, &wbuf); }
+    ~JsRef() { delete dec; wbuf.BufFileUnset(); delete file; }
+};
+
+extern "C" {
+
+void* jsref_create(void) { return new JsRef(); }
+void  jsref_destroy(void* h) { delete (JsRef*)h; }
+void  jsref_reset_state(void* h) { ((JsRef*)h)->dec->ResetState(); }
+void  jsref_reset(void* h) { ((JsRef*)h)->dec->Reset(); }
+
+void jsref_set_options(int decode_ac, int histo_en, int stat_clip_en, unsigned err_max)
+{
+    CSnoopConfig* c = ShimConfig();
+    c->bDecodeScanImgAc = decode_ac != 0;
+    c->bHistoEn = histo_en != 0;
+    c->bStatClipEn = stat_clip_en != 0;
+    c->nErrMaxDecodeScan = err_max;
+}
+
+int jsref_set_dqt_entry(void* h, unsigned tbl, unsigned nat, unsigned zz, unsigned val)
+{ return ((JsRef*)h)->dec->SetDqtEntry(tbl, nat, zz, (unsigned short)val); }
+int jsref_set_dqt_tables(void* h, unsigned comp, unsigned tbl)
+{ return ((JsRef*)h)->dec->SetDqtTables(comp, tbl); }
+unsigned jsref_get_dqt_entry(void* h, unsigned tbl, unsigned nat)
+{ return ((JsRef*)h)->dec->GetDqtEntry(tbl, nat); }
+int jsref_set_dht_entry(void* h, unsigned dest, unsigned cls, unsigned ind, unsigned len,
+                        unsigned bits, unsigned mask, unsigned code)
+{ return ((JsRef*)h)->dec->SetDhtEntry(dest, cls, ind, len, bits, mask, code); }
+int jsref_set_dht_size(void* h, unsigned dest, unsigned cls, unsigned n)
+{ return ((JsRef*)h)->dec->SetDhtSize(dest, cls, n); }
+int jsref_set_dht_tables(void* h, unsigned comp, unsigned dc, unsigned ac)
+{ return ((JsRef*)h)->dec->SetDhtTables(comp, dc, ac); }
+void jsref_set_sof_samp_factors(void* h, unsigned comp, unsigned sh, unsigned sv)
+{ ((JsRef*)h)->dec->SetSofSampFactors(comp, sh, sv); }
+void jsref_set_precision(void* h, unsigned p) { ((JsRef*)h)->dec->SetPrecision(p); }
+void jsref_set_image_details(void* h, unsigned x, unsigned y, unsigned nf, unsigned ns,
+                             int rst_en, unsigned rst_interval)
+{ ((JsRef*)h)->dec->SetImageDetails(x, y, nf, ns, rst_en != 0, rst_interval); }
+
+// Hands the whole file to the reference's own sliding-window reader through a
+// memory-backed CFile, then runs the scan decode from byte offset `start`.
+void jsref_decode_scan_img(void* hv, const unsigned char* file, size_t len, unsigned start,
+                           int display, int quiet)
+{
+    JsRef* h = (JsRef*)hv;
+    ShimLog().clear();
+    h->wbuf.BufFileUnset();
+    delete h->file;
+    h->bytes.assign(file, file + len);
+    h->file = new CFile(h->bytes.data(), h->bytes.size());
+    h->wbuf.BufFileSet(h->file);
+    h->wbuf.BufLoadWindow(0);
+    h->dec->DecodeScanImg(start, display != 0, quiet != 0);
+}
+
+int  jsref_is_preview_ready(void* h) { return ((JsRef*)h)->dec->IsPreviewReady(); }
+void jsref_get_image_size(void* h, unsigned* x, unsigned* y)
+{ unsigned a = 0, b = 0; ((JsRef*)h)->dec->GetImageSize(a, b); *x = a; *y = b; }
+const unsigned char* jsref_get_bitmap_ptr(void* h)
+{ unsigned char* p = nullptr; ((JsRef*)h)->dec->GetBitmapPtr(p); return p; }
+void jsref_get_pixmap_ptrs(void* h, const short** y, const short** cb, const short** cr)
+{ CimgDecode* d = ((JsRef*)h)->dec; *y = d->m_pPixValY; *cb = d->m_pPixValCb; *cr = d->m_pPixValCr; }
+void jsref_lookup_file_pos_mcu(void* h, unsigned mx, unsigned my, unsigned* byte, unsigned* bit)
+{ unsigned a = 0, b = 0; ((JsRef*)h)->dec->LookupFilePosMcu(mx, my, a, b); *byte = a; *bit = b; }
+void jsref_lookup_blk_ycc(void* h, unsigned bx, unsigned by, int* y, int* cb, int* cr)
+{ int a = 0, b = 0, c = 0; ((JsRef*)h)->dec->LookupBlkYCC(bx, by, a, b, c); *y = a; *cb = b; *cr = c; }
+
+// ---- internals, for side-output parity and KATs -----------------------------
+void jsref_get_geometry(void* h, unsigned* out8)
+{
+    CimgDecode* d = ((JsRef*)h)->dec;
+    out8[0] = d->m_nMcuWidth; out8[1] = d->m_nMcuHeight; out8[2] = d->m_nMcuXMax; out8[3] = d->m_nMcuYMax;
+    out8[4] = d->m_nBlkXMax;  out8[5] = d->m_nBlkYMax;   out8[6] = d->m_nImgSizeX; out8[7] = d->m_nImgSizeY;
+}
+const unsigned* jsref_mcu_file_map(void* h) { return ((JsRef*)h)->dec->m_pMcuFileMap; }
+void jsref_blk_dc_ptrs(void* h, const short** y, const short** cb, const short** cr)
+{ CimgDecode* d = ((JsRef*)h)->dec; *y = d->m_pBlkDcValY; *cb = d->m_pBlkDcValCb; *cr = d->m_pBlkDcValCr; }
+const unsigned* jsref_dht_histo(void* h) { return &((JsRef*)h)->dec->m_anDhtHisto[0][0][0]; }  // [2][4][17]
+void jsref_scan_status(void* h, unsigned* out8)
+{
+    CimgDecode* d = ((JsRef*)h)->dec;
+    out8[0] = d->m_bScanBad; out8[1] = d->m_bScanEnd; out8[2] = d->m_nRestartRead; out8[3] = d->m_nNumPixels;
+    out8[4] = d->m_anScanBuffPtr_pos[0]; out8[5] = d->m_nScanBuffPtr_align; out8[6] = d->m_nWarnBadScanNum;
+    out8[7] = d->m_nScanBuffPtr_first;
+}
+void jsref_bright_avg(void* h, int* out10)
+{
+    CimgDecode* d = ((JsRef*)h)->dec;
+    out10[0] = d->m_bBrightValid; out10[1] = d->m_nBrightY; out10[2] = d->m_nBrightCb; out10[3] = d->m_nBrightCr;
+    out10[4] = (int)d->m_nBrightR; out10[5] = (int)d->m_nBrightG; out10[6] = (int)d->m_nBrightB;
+    out10[7] = d->m_ptBrightMcu.x; out10[8] = d->m_ptBrightMcu.y; out10[9] = (int)d->m_nAvgY;
+}
+const float* jsref_idct_lut(void* h) { return &((JsRef*)h)->dec->m_afIdctLookup[0][0]; }       // [64][64]
+const unsigned* jsref_dht_lookupfast(void* h) { return &((JsRef*)h)->dec->m_anDhtLookupfast[0][0][0]; } // [2][4][1024]
+
+// Runs the reference's own IDCT on one natural-order coefficient block.
+void jsref_idct_block(void* h, const short* coef64, float* out64)
+{
+    CimgDecode* d = ((JsRef*)h)->dec;
+    for (int i = 0; i < 64; i++) d->m_anDctBlock[i] = coef64[i];
+    d->DecodeIdctCalcFloat(64);
+    for (int i = 0; i < 64; i++) out64[i] = d->m_afIdctBlock[i];
+}
+// Runs the reference's own fast-float colour conversion on n pre-range triples.
+void jsref_color_fast(void* h, const int* ycc, unsigned char* rgb, size_t n)
+{
+    CimgDecode* d = ((JsRef*)h)->dec;
+    for (size_t i = 0; i < n; i++) {
+        PixelCc px; memset(&px, 0, sizeof px);
+        px.nPrerangeY = ycc[3 * i]; px.nPrerangeCb = ycc[3 * i + 1]; px.nPrerangeCr = ycc[3 * i + 2];
+        d->ConvertYCCtoRGBFastFloat(px);
+        rgb[3 * i] = px.nFinalR; rgb[3 * i + 1] = px.nFinalG; rgb[3 * i + 2] = px.nFinalB;
+    }
+}
+// FNV-1a-64 over all 2^24 (Y,Cb,Cr) triples, R,G,B byte order.
+unsigned long long jsref_color_exhaustive_fnv(void* h)
+{
+    CimgDecode* d = ((JsRef*)h)->dec;
+    unsigned long long f = 0xcbf29ce484222325ULL;
+    for (int y = -128; y < 128; y++) for (int cb = -128; cb < 128; cb++) for (int cr = -128; cr < 128; cr++) {
+        PixelCc px; memset(&px, 0, sizeof px);
+        px.nPrerangeY = 8 * y; px.nPrerangeCb = 8 * cb; px.nPrerangeCr = 8 * cr;
+        d->ConvertYCCtoRGBFastFloat(px);
+        f ^= px.nFinalR; f *= 0x100000001b3ULL; f ^= px.nFinalG; f *= 0x100000001b3ULL; f ^= px.nFinalB; f *= 0x100000001b3ULL;
+    }
+    return f;
+}
+
+size_t jsref_log_count(void) { return ShimLog().size(); }
+const char* jsref_log_line(size_t i) { return i < ShimLog().size() ? ShimLog()[i].c_str() : ""; }
+
+} // extern "C"
