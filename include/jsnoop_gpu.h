@@ -1,0 +1,175 @@
+/* jsnoop_gpu.h -- C ABI of libjsnoop_gpu.so, the MI355X-native scan-decode stage.
+ *
+ * This is the drop-in boundary for the reference's scan decoder.  The reference
+ * has no FFI; its boundary is the public C++ method set of `CimgDecode`
+ * (reference source/ImgDecode.h:286-356,384-385,407-425) as driven by
+ * `CjfifDecode` and re-exported by `CJPEGsnoopCore::I_*` (source/JPEGsnoopCore.h:79-117).
+ * One `JsnoopDecoder` handle == one `CimgDecode` object; each entry point cites the
+ * method it replaces.  All pointers are plain host or device addresses, no C++ or
+ * torch types cross this line.  INTEGRATION.md shows the `CimgDecode`-shaped C++
+ * wrapper (jpegsnoop_amd/csrc/ImgDecodeGpu.h) a reference maintainer would bind.
+ *
+ * Threading: like the reference (single-threaded, non-re-entrant objects,
+ * source/JPEGsnoopCore.cpp:46) a handle may be used from one host thread at a
+ * time; different handles are independent.  Work is issued on the handle's own HIP
+ * stream (or the caller's, see jsnoop_batch_create).
+ *
+ * Errors: setters return 0 / 1 like the reference's bool setters; decode entry
+ * points return void like DecodeScanImg and report through jsnoop_is_preview_ready,
+ * the status words and the log callback (the reference's CDocLog sink).  If the HIP
+ * runtime or device is unavailable, jsnoop_create returns NULL and
+ * jsnoop_last_error() says why -- there is no CPU fallback in this library.
+ */
+#ifndef JSNOOP_GPU_H
+#define JSNOOP_GPU_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JSNOOP_ABI_VERSION 1
+
+typedef struct JsnoopDecoder JsnoopDecoder;
+typedef struct JsnoopBatch   JsnoopBatch;
+
+/* ---- library / device ------------------------------------------------------ */
+int         jsnoop_abi_version(void);
+const char* jsnoop_last_error(void);                /* thread-local text of the last failure      */
+int         jsnoop_device_count(void);              /* number of visible HIP devices (0 = none)   */
+int         jsnoop_set_device(int device);          /* device used by objects created afterwards  */
+
+/* log sink: replaces CDocLog::AddLine / AddLineWarn / AddLineErr (source/DocLog.cpp:102-194).
+ * level: 0 = info, 1 = warning, 2 = error.  NULL disables logging (default). */
+typedef void (*jsnoop_log_fn)(void* user, int level, const char* text);
+
+/* ---- lifecycle: CimgDecode ctor :142, dtor :239, Reset :49, ResetState :286 ---- */
+JsnoopDecoder* jsnoop_create(void);
+void           jsnoop_destroy(JsnoopDecoder*);
+void           jsnoop_reset(JsnoopDecoder*);
+void           jsnoop_reset_state(JsnoopDecoder*);
+void           jsnoop_set_log_callback(JsnoopDecoder*, jsnoop_log_fn fn, void* user);
+
+/* ---- options: the CSnoopConfig fields read at ImgDecode.cpp:2730-2741 ---------
+ * decode_ac = bDecodeScanImgAc ("Full IDCT"), histo_en = bHistoEn,
+ * stat_clip_en = bStatClipEn, err_max = nErrMaxDecodeScan.                      */
+void jsnoop_set_options(JsnoopDecoder*, int decode_ac, int histo_en, int stat_clip_en, unsigned err_max);
+
+/* ---- tables (SetDqtEntry :424, SetDqtTables :505, GetDqtEntry :466, SetDhtEntry :748,
+ *      SetDhtSize :834, SetDhtTables :536) -- same argument meaning and range checks */
+int      jsnoop_set_dqt_entry(JsnoopDecoder*, unsigned tbl_dest_id, unsigned coeff_ind, unsigned coeff_ind_zz, unsigned value);
+int      jsnoop_set_dqt_tables(JsnoopDecoder*, unsigned comp_ind, unsigned tbl);
+unsigned jsnoop_get_dqt_entry(JsnoopDecoder*, unsigned tbl_dest_id, unsigned coeff_ind);
+int      jsnoop_set_dht_entry(JsnoopDecoder*, unsigned dest_id, unsigned cls, unsigned ind, unsigned len,
+                              unsigned bits_left_just, unsigned mask_left_just, unsigned code);
+int      jsnoop_set_dht_size(JsnoopDecoder*, unsigned dest_id, unsigned cls, unsigned size);
+int      jsnoop_set_dht_tables(JsnoopDecoder*, unsigned comp_ind, unsigned tbl_dc, unsigned tbl_ac);
+
+/* ---- geometry (SetSofSampFactors :619, SetPrecision :564, SetImageDetails :590) */
+void jsnoop_set_sof_samp_factors(JsnoopDecoder*, unsigned comp_ind, unsigned samp_h, unsigned samp_v);
+void jsnoop_set_precision(JsnoopDecoder*, unsigned precision);
+void jsnoop_set_image_details(JsnoopDecoder*, unsigned dim_x, unsigned dim_y, unsigned comps_sof, unsigned comps_sos,
+                              int rst_en, unsigned rst_interval);
+
+/* ---- decode: DecodeScanImg(nStart,bDisplay,bQuiet) :2723 ------------------------
+ * `file`/`len` is the whole file image that the reference reads through
+ * CwindowBuf::Buf (source/WindowBuf.cpp:639; bytes past `len` read as 0).  The bytes are
+ * staged through pinned host memory with hipMemcpyAsync; overlays must be applied by
+ * the caller beforehand.  Blocks until the DIB is resident in HBM.                  */
+void jsnoop_decode_scan_img(JsnoopDecoder*, const uint8_t* file, size_t len, unsigned start, int display, int quiet);
+
+/* ---- results: IsPreviewReady :3753, GetImageSize :4929, GetBitmapPtr :4940,
+ *      GetPixMapPtrs :4913, LookupFilePosMcu :5020, LookupFilePosPix :5001, LookupBlkYCC :5037.
+ * Host pointers are owned by the decoder and stay valid until the next
+ * Reset / DecodeScanImg / destroy (same ownership rule as the reference); they are
+ * filled by a D2H copy on first request.  The *_dev variants return the HBM copies. */
+int            jsnoop_is_preview_ready(JsnoopDecoder*);
+void           jsnoop_get_image_size(JsnoopDecoder*, unsigned* x, unsigned* y);
+const uint8_t* jsnoop_get_bitmap_ptr(JsnoopDecoder*);
+const void*    jsnoop_get_bitmap_dev(JsnoopDecoder*);
+void           jsnoop_get_pixmap_ptrs(JsnoopDecoder*, const int16_t** y, const int16_t** cb, const int16_t** cr);
+void           jsnoop_lookup_file_pos_mcu(JsnoopDecoder*, unsigned mcu_x, unsigned mcu_y, unsigned* byte, unsigned* bit);
+void           jsnoop_lookup_file_pos_pix(JsnoopDecoder*, unsigned pix_x, unsigned pix_y, unsigned* byte, unsigned* bit);
+void           jsnoop_lookup_blk_ycc(JsnoopDecoder*, unsigned blk_x, unsigned blk_y, int* y, int* cb, int* cr);
+
+/* ---- preview re-render on the retained planes: SetPreviewMode :633,
+ *      SetPreviewYccOffset :650 (each re-runs the colour kernel only)            */
+void     jsnoop_set_preview_mode(JsnoopDecoder*, unsigned mode);
+unsigned jsnoop_get_preview_mode(JsnoopDecoder*);
+void     jsnoop_set_preview_ycc_offset(JsnoopDecoder*, unsigned mcu_x, unsigned mcu_y, int y, int cb, int cr);
+
+/* ---- decoder internals that the reference keeps in public/inspectable members and
+ *      that the log / hover UI consume (side outputs).
+ *      Layouts match oracle/ref_shim/ref_driver.cpp so the same parity script runs
+ *      against reference, oracle and this library.                                  */
+void            jsnoop_get_geometry(JsnoopDecoder*, unsigned* out8);   /* McuW,McuH,McuXMax,McuYMax,BlkXMax,BlkYMax,ImgSizeX,ImgSizeY */
+const uint32_t* jsnoop_mcu_file_map(JsnoopDecoder*);                   /* m_pMcuFileMap [McuYMax][McuXMax], PackFileOffset :5104 */
+void            jsnoop_blk_dc_ptrs(JsnoopDecoder*, const int16_t** y, const int16_t** cb, const int16_t** cr);
+const uint32_t* jsnoop_dht_histo(JsnoopDecoder*);                      /* m_anDhtHisto [2][4][17] */
+void            jsnoop_scan_status(JsnoopDecoder*, unsigned* out8);    /* scan_bad, scan_end, #RST, num_pixels, pos0, align, warn_bad, first */
+void            jsnoop_bright_avg(JsnoopDecoder*, int* out10);         /* brightest pixel + average Y (:4722-4730, :4802-4819) */
+const float*    jsnoop_idct_lut(JsnoopDecoder*);                       /* m_afIdctLookup [64][64] as uploaded to the device */
+const uint32_t* jsnoop_dht_lookupfast(JsnoopDecoder*);                 /* m_anDhtLookupfast [2][4][1024] */
+void            jsnoop_idct_block(JsnoopDecoder*, const int16_t* coef64, float* out64);   /* one block through the device IDCT */
+/* which device path decoded the last image: 1 = parallel (self-synchronising) entropy
+ * decode, 2 = sequential exact-mirror entropy kernel (taken for streams the parallel
+ * path flags as malformed), 0 = nothing decoded */
+int             jsnoop_last_path(JsnoopDecoder*);
+uint32_t        jsnoop_last_flags(JsnoopDecoder*);                     /* JSNOOP_FLAG_* raised by the parallel path */
+
+#define JSNOOP_FLAG_BAD_CODE      0x0001u  /* no Huffman code matches                                   */
+#define JSNOOP_FLAG_OVERRUN       0x0002u  /* code or extra bits run past the interval / scan end       */
+#define JSNOOP_FLAG_COEF_OVERFLOW 0x0004u  /* coefficient index > 63                                    */
+#define JSNOOP_FLAG_RST_MISALIGN  0x0008u  /* RSTn not on an MCU boundary                               */
+#define JSNOOP_FLAG_SHORT         0x0010u  /* entropy data ends before all MCUs are decoded             */
+#define JSNOOP_FLAG_TABLES        0x0020u  /* tables not expressible in the parallel path's LUT form    */
+#define JSNOOP_FLAG_MARKER        0x0040u  /* non-RST marker or FFFF inside the scan                    */
+#define JSNOOP_FLAG_NOSYNC        0x0080u  /* sub-sequence chain failed to converge                     */
+#define JSNOOP_FLAG_FORCED        0x8000u  /* caller forced the exact path                              */
+
+/* ---- batch submit: N files -> N DIBs, all resident in HBM --------------------------
+ * The batched analogue of CJPEGsnoopCore::DoBatchFileProcess (source/JPEGsnoopCore.cpp:765),
+ * whose per-file semantics are preserved: every image is decoded exactly as a fresh
+ * CimgDecode would.  `stream` is a hipStream_t (NULL = the batch creates its own).  */
+JsnoopBatch* jsnoop_batch_create(void* stream);
+void         jsnoop_batch_destroy(JsnoopBatch*);
+void         jsnoop_batch_clear(JsnoopBatch*);
+void         jsnoop_batch_set_options(JsnoopBatch*, int decode_ac, int want_planes, int force_exact_path);
+/* Adds one image using the table/geometry state currently held by `tables`
+ * (i.e. after the SetDqt/SetDht/SetSof/SetImageDetails calls of its header).
+ * The file bytes are copied into the batch's pinned staging arena.
+ * Returns the image index, or -1 with jsnoop_last_error() set.                      */
+int          jsnoop_batch_add(JsnoopBatch*, const JsnoopDecoder* tables, const uint8_t* file, size_t len, unsigned scan_start);
+/* Adds one JPEG file image, walking its header with the built-in minimal JFIF front
+ * end (the subset of CjfifDecode::DecodeMarker that feeds CimgDecode).               */
+int          jsnoop_batch_add_jpeg(JsnoopBatch*, const uint8_t* file, size_t len);
+/* Tiles already-added images so the batch holds `total` images (image i reuses the
+ * bytes of image i % n): the bench's "N distinct seeds tiled to 1024".               */
+int          jsnoop_batch_tile(JsnoopBatch*, int total);
+int          jsnoop_batch_count(const JsnoopBatch*);
+int          jsnoop_batch_upload(JsnoopBatch*);      /* pinned host -> HBM (async), builds device descriptors */
+int          jsnoop_batch_decode(JsnoopBatch*);      /* HBM -> HBM, asynchronous on the batch stream          */
+int          jsnoop_batch_sync(JsnoopBatch*);        /* waits; then re-decodes flagged images on the exact path */
+/* Timed decode: `reps` decodes bracketed by hipEvents on the batch stream; per-stage
+ * average milliseconds into stage_ms[JSNOOP_NUM_STAGES] (may be NULL).  Returns the
+ * average milliseconds per whole decode, < 0 on error.                              */
+#define JSNOOP_NUM_STAGES 8
+double       jsnoop_batch_decode_timed(JsnoopBatch*, int reps, double* stage_ms);
+const char*  jsnoop_stage_name(int stage);
+/* per-image results */
+int          jsnoop_batch_image_info(const JsnoopBatch*, int i, unsigned* out16);  /* dim_x,dim_y,img_x,img_y,mcu_w,mcu_h,mcu_xmax,mcu_ymax,
+                                                                                     blk_xmax,blk_ymax,scan_bytes,flags,path,ns,file_len,0 */
+const void*  jsnoop_batch_dib_dev(const JsnoopBatch*, int i);                      /* bottom-up BGRA, img_x*img_y*4 bytes in HBM */
+int          jsnoop_batch_read_dib(JsnoopBatch*, int i, uint8_t* host_dst);        /* D2H copy of one DIB */
+int          jsnoop_batch_read_planes(JsnoopBatch*, int i, int16_t* y, int16_t* cb, int16_t* cr);
+int          jsnoop_batch_read_coefs(JsnoopBatch*, int i, int16_t* dst, size_t max_blocks); /* dequantised blocks, decode order */
+/* 64-bit FNV-1a of every DIB computed on the device (one word per image), for
+ * whole-batch parity checks without moving 8 GB over PCIe.                          */
+int          jsnoop_batch_dib_hashes(JsnoopBatch*, uint64_t* host_dst);
+uint64_t     jsnoop_batch_algorithmic_bytes(const JsnoopBatch*);                   /* sum(scan bytes + DIB bytes), SURVEY.md 8(d) */
+uint64_t     jsnoop_batch_pixels(const JsnoopBatch*);                              /* sum(SOF X*Y) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,8 @@
+"""jpegsnoop_amd -- MI355X-native JPEGsnoop scan-decode stage.
+
+The product is `libjsnoop_gpu.so` (hand-written HIP kernels behind the C ABI of
+include/jsnoop_gpu.h).  This package is its binding layer: `CimgDecode` mirrors the
+reference's decoder object, `JpegBatch` is the batched submit.
+"""
+from .capi import load, last_error, LIB_PATH  # noqa: F401
+from .imgdecode import CimgDecode, JpegBatch, dib_checksum_numpy  # noqa: F401

@@ -1,0 +1,603 @@
+// jsnoop_host.cpp -- host side of libjsnoop_gpu.so: the CimgDecode-shaped decoder state,
+// batch arenas in HBM, pinned staging (the CwindowBuf replacement) and the C ABI of
+// include/jsnoop_gpu.h.  Reference line numbers refer to source/ImgDecode.cpp unless
+// another file is named.  There is no CPU decode path in this library: every pixel
+// comes out of the HIP kernels in jsnoop_kernels.hip.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include "../../include/jsnoop_gpu.h"
+#include "jsnoop_types.h"
+#include "jsnoop_launch.h"
+#include "jsnoop_host.h"
+
+// ------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+void js_set_error(const char* fmt, ...)
+{
+    char buf[1024]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap); g_err = buf;
+}
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    js_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return -1; } } while (0)
+
+static int g_device = 0;
+
+static const uint8_t kZigZag[64] = {
+     0, 1, 8,16, 9, 2, 3,10, 17,24,32,25,18,11, 4, 5, 12,19,26,33,40,48,41,34, 27,20,13, 6, 7,14,21,28,
+    35,42,49,56,57,50,43,36, 29,22,15,23,30,37,44,51, 58,59,52,45,38,31,39,46, 53,60,61,54,47,55,62,63 };
+
+// ------------------------------------------------------------------------------ decoder state
+JsnoopDecoder::JsnoopDecoder()
+{
+    memset(&t, 0, sizeof t);
+    opt_decode_ac = 1; opt_histo_en = 0; opt_stat_clip_en = 0; opt_err_max = 20;
+    log_fn = nullptr; log_user = nullptr; batch = nullptr;
+    preview_mode = 1; shift_y = shift_cb = shift_cr = 0; shift_mcu_x = shift_mcu_y = 0;
+    preview_is_jpeg = false; have_image = false; host_valid = 0; last_path = 0; last_flags = 0;
+    memset(geom, 0, sizeof geom);
+    reset_state();
+}
+void JsnoopDecoder::log(int level, const char* fmt, ...)
+{
+    if (!log_fn) return;
+    char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    log_fn(log_user, level, buf);
+}
+void JsnoopDecoder::reset_state()                                              // ResetState :286-306
+{
+    memset(t.dht_histo_unused, 0, sizeof t.dht_histo_unused);
+    memset(t.dht_setmax, 0, sizeof t.dht_setmax); memset(t.dht_size, 0, sizeof t.dht_size);
+    memset(t.dht_bitlen, 0, sizeof t.dht_bitlen); memset(t.dht_bits, 0, sizeof t.dht_bits);
+    memset(t.dht_mask, 0, sizeof t.dht_mask); memset(t.dht_code, 0, sizeof t.dht_code);
+    memset(t.dht_fast, 0xFF, sizeof t.dht_fast);                               // DHT_CODE_UNUSED :391
+    for (int c = 0; c < 2; c++) for (int i = 0; i < 5; i++) t.dht_sel[c][i] = -1;
+    for (int i = 0; i < 256; i++) t.dqt_sel[i] = -1;
+    memset(t.dqt_nat, 0, sizeof t.dqt_nat); memset(t.dqt_zz, 0, sizeof t.dqt_zz);
+    memset(t.samp_h, 0, sizeof t.samp_h); memset(t.samp_v, 0, sizeof t.samp_v);
+    t.details_set = 0; t.num_sof = 0; t.num_sos = 0; t.precision = 0;
+}
+
+// The geometry and readiness checks DecodeScanImg performs before its MCU loop (:2755-3123),
+// restated on the table state.  Returns false (with a log line) exactly where the reference returns early.
+bool js_describe_image(JsnoopDecoder* d, JsImage* im, JsTableSet* ts, uint32_t file_len, uint32_t scan_start, int display)
+{
+    JsTables& t = d->t;
+    memset(im, 0, sizeof *im);
+    if (!t.details_set) { d->log(2, "*** ERROR: Decoding image before Image components defined ***"); return false; }
+    if (t.num_sos != 1 && t.num_sos != 3) { d->log(1, "  NOTE: Number of SOS components not supported [%u]", t.num_sos); return false; }
+    uint32_t hmax = 0, vmax = 0;
+    for (uint32_t c = 1; c <= t.num_sos; c++) { hmax = std::max(hmax, t.samp_h[c]); vmax = std::max(vmax, t.samp_v[c]); }
+    if (t.num_sos == 1) {                                                       // :2805-2817
+        if (t.samp_h[1] != 1 || t.samp_v[1] != 1) d->log(1, "    Altering sampling factor for single component scan to 0x11");
+        t.samp_h[1] = t.samp_v[1] = 1; hmax = vmax = 1;
+    }
+    if (hmax == 0 || vmax == 0 || hmax > 4 || vmax > 4) {
+        d->log(1, "  NOTE: Degree of subsampling factor not supported [HMax=%u, VMax=%u]", hmax, vmax); return false; }
+    im->mcu_w = hmax * 8; im->mcu_h = vmax * 8; im->ncomp = t.num_sos;
+    uint32_t nb = 0;
+    for (uint32_t c = 1; c <= t.num_sos; c++) {
+        if (t.samp_h[c] == 0 || t.samp_v[c] == 0) { d->log(2, "*** ERROR: zero sampling factor for component %u ***", c); return false; }
+        im->samp_h[c] = t.samp_h[c]; im->samp_v[c] = t.samp_v[c];
+        im->expand_h[c] = hmax / t.samp_h[c]; im->expand_v[c] = vmax / t.samp_v[c];
+        for (uint32_t v = 0; v < t.samp_v[c]; v++) for (uint32_t h = 0; h < t.samp_h[c]; h++) {
+            im->blk_comp[nb] = (uint8_t)c; im->blk_ch[nb] = (uint8_t)h; im->blk_cv[nb] = (uint8_t)v; nb++; }
+    }
+    im->blk_per_mcu = nb;
+    im->dim_x = t.dim_x; im->dim_y = t.dim_y;
+    im->mcu_xmax = t.dim_x / im->mcu_w + (t.dim_x % im->mcu_w ? 1 : 0);
+    im->mcu_ymax = t.dim_y / im->mcu_h + (t.dim_y % im->mcu_h ? 1 : 0);
+    im->blk_xmax = im->mcu_xmax * hmax; im->blk_ymax = im->mcu_ymax * vmax;
+    if (im->blk_xmax == 0 || im->blk_ymax == 0) return false;
+    im->img_x = im->mcu_xmax * im->mcu_w; im->img_y = im->mcu_ymax * im->mcu_h;
+    im->total_blocks = im->mcu_xmax * im->mcu_ymax * nb;
+    d->geom[0] = im->mcu_w; d->geom[1] = im->mcu_h; d->geom[2] = im->mcu_xmax; d->geom[3] = im->mcu_ymax;
+    d->geom[4] = im->blk_xmax; d->geom[5] = im->blk_ymax; d->geom[6] = im->img_x; d->geom[7] = im->img_y;
+    if (t.num_sof != 1 && t.num_sof != 3) { d->log(1, "  NOTE: Number of Image Components not supported [%u]", t.num_sof); return false; }
+    for (uint32_t i = 1; i <= t.num_sos; i++) if (t.dqt_sel[i] < 0) {
+        d->log(2, "*** ERROR: Decoding image before DQT Table Selection via JFIF_SOF ***"); return false; }
+    bool ready = true;
+    for (int cls = 0; cls < 2; cls++) for (uint32_t i = 1; i <= t.num_sos; i++) {
+        int sel = t.dht_sel[cls][i];
+        if (sel < 0 || sel >= 4 || t.dht_size[cls][sel] == 0) ready = false;
+    }
+    if (!ready) { d->log(2, "*** ERROR: Decoding image before DHT Table Selection via JFIF_SOS ***"); return false; }
+
+    im->precision = t.precision; im->rst_en = t.rst_en; im->rst_interval = t.rst_interval;
+    im->decode_ac = display ? (uint32_t)d->opt_decode_ac : 0; im->err_max = d->opt_err_max;
+    im->file_len = file_len; im->scan_start = scan_start;
+    im->preview_mode = d->preview_mode; im->shift_y = d->shift_y; im->shift_cb = d->shift_cb; im->shift_cr = d->shift_cr;
+    im->shift_mcu_x = d->shift_mcu_x; im->shift_mcu_y = d->shift_mcu_y;
+
+    // resolve the selected tables per scan component
+    memset(ts, 0, sizeof *ts);
+    for (uint32_t c = 1; c <= t.num_sos; c++) {
+        for (int cls = 0; cls < 2; cls++) {
+            const int sel = t.dht_sel[cls][c], slot = (int)(c - 1) * 2 + cls;
+            memcpy(ts->fast[slot], t.dht_fast[cls][sel], sizeof ts->fast[slot]);
+            ts->size[slot] = t.dht_size[cls][sel]; ts->dest_id[slot] = (uint32_t)sel;
+            memcpy(ts->bitlen[slot], t.dht_bitlen[cls][sel], sizeof ts->bitlen[slot]);
+            memcpy(ts->bits[slot], t.dht_bits[cls][sel], sizeof ts->bits[slot]);
+            memcpy(ts->mask[slot], t.dht_mask[cls][sel], sizeof ts->mask[slot]);
+            memcpy(ts->code[slot], t.dht_code[cls][sel], sizeof ts->code[slot]);
+        }
+        memcpy(ts->qzz[c - 1], t.dqt_zz[t.dqt_sel[c] & 3], sizeof ts->qzz[c - 1]);
+    }
+    js_build_parallel_luts(ts, t.num_sos);
+    return true;
+}
+
+// ------------------------------------------------------------------------------ batch
+static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+JsnoopBatch::JsnoopBatch(void* user_stream)
+{
+    stream = (hipStream_t)user_stream; own_stream = false;
+    opt_decode_ac = 1; opt_want_planes = 0; opt_force_exact = 0;
+    memset(&dev, 0, sizeof dev); memset(&cap, 0, sizeof cap);
+    pinned = nullptr; pinned_cap = 0; raw_bytes = 0; uploaded = false;
+    for (auto& e : ev) e = nullptr;
+    d_lut = nullptr;
+}
+int JsnoopBatch::init()
+{
+    HIP_TRY(hipSetDevice(g_device));
+    device = g_device;
+    if (!stream) { HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    // PrecalcIdct :2313-2351: built once on the host in fp32, then transposed to [vu][yx] for lane-contiguous reads
+    const float pi = (float)3.141592654, rh = (float)0.707106781;
+    for (unsigned y = 0; y < 8; y++) for (unsigned x = 0; x < 8; x++) for (unsigned v = 0; v < 8; v++) for (unsigned u = 0; u < 8; u++) {
+        float cu = (u == 0) ? rh : 1, cv = (v == 0) ? rh : 1;
+        float cp = cosf((2 * x + 1) * u * pi / 16) * cosf((2 * y + 1) * v * pi / 16);
+        lut[y * 8 + x][v * 8 + u] = cu * cv * cp;
+    }
+    std::vector<float> lt(64 * 64);
+    for (int yx = 0; yx < 64; yx++) for (int vu = 0; vu < 64; vu++) lt[vu * 64 + yx] = lut[yx][vu];
+    HIP_TRY(hipMalloc(&d_lut, 64 * 64 * sizeof(float)));
+    HIP_TRY(hipMemcpy(d_lut, lt.data(), 64 * 64 * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+JsnoopBatch::~JsnoopBatch()
+{
+    hipSetDevice(device);
+    if (stream) hipStreamSynchronize(stream);
+    for (void** p : { (void**)&dev.raw, (void**)&dev.ustr, (void**)&dev.coef, (void**)&dev.dccum, (void**)&dev.dib, (void**)&dev.planes,
+                      (void**)&dev.side, (void**)&dev.imgs, (void**)&dev.tables, (void**)&dev.wg_base, (void**)&dev.sel, (void**)&dev.sums,
+                      (void**)&dev.sub, (void**)&dev.probe }) if (*p) hipFree(*p);
+    if (d_lut) hipFree(d_lut);
+    if (pinned) hipHostFree(pinned);
+    for (auto& e : ev) if (e) hipEventDestroy(e);
+    if (own_stream && stream) hipStreamDestroy(stream);
+}
+void JsnoopBatch::clear()
+{
+    imgs.clear(); tables.clear(); raw_bytes = 0; uploaded = false; host_flags.clear();
+}
+int JsnoopBatch::reserve_pinned(size_t need)
+{
+    if (need <= pinned_cap) return 0;
+    size_t ncap = std::max(need, pinned_cap * 2 + (1u << 20));
+    uint8_t* np = nullptr;
+    HIP_TRY(hipHostMalloc((void**)&np, ncap, hipHostMallocDefault));
+    if (pinned) { memcpy(np, pinned, raw_bytes); hipHostFree(pinned); }
+    pinned = np; pinned_cap = ncap;
+    return 0;
+}
+int JsnoopBatch::add(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned scan_start, int display)
+{
+    if (len >= (1ull << 32) - 64) { js_set_error("file too large for the 32-bit offsets of the reference format"); return -1; }
+    JsImage im; JsTableSet* ts = new JsTableSet;
+    if (!js_describe_image(d, &im, ts, (uint32_t)len, scan_start, display)) { delete ts; js_set_error("image not decodable (see log callback)"); return -1; }
+    im.decode_ac = display ? (uint32_t)(d->batch == this ? d->opt_decode_ac : opt_decode_ac) : 0;
+    // scan length: up to the first marker that is neither stuffing nor RSTn (what pass 1 of the SOS
+    // handler skips over, source/JfifDecode.cpp:5207-5265); bytes past `len` read as zero.
+    uint32_t q = scan_start;
+    while (q + 1 < len) { if (file[q] == 0xFF && file[q + 1] != 0 && !(file[q + 1] >= 0xD0 && file[q + 1] <= 0xD7)) break; q++; }
+    if (q + 1 >= len) q = (uint32_t)len;
+    im.scan_len = q > scan_start ? q - scan_start : 0;
+    // stage the file bytes (the CwindowBuf replacement: whole file in pinned host memory)
+    const uint64_t off = align_up(raw_bytes, 16);
+    if (reserve_pinned(off + len + 16)) { delete ts; return -1; }
+    memset(pinned + raw_bytes, 0, off - raw_bytes);
+    memcpy(pinned + off, file, len); memset(pinned + off + len, 0, 16);
+    raw_bytes = off + len + 16; im.file_off = off;
+    // de-duplicate the table set
+    uint32_t tsi = (uint32_t)tables.size();
+    for (uint32_t i = 0; i < tables.size(); i++) if (!memcmp(&tables[i], ts, sizeof *ts)) { tsi = i; break; }
+    if (tsi == tables.size()) tables.push_back(*ts);
+    delete ts;
+    im.tableset = tsi;
+    imgs.push_back(im); uploaded = false;
+    return (int)imgs.size() - 1;
+}
+int JsnoopBatch::tile(int total)
+{
+    const size_t n = imgs.size();
+    if (!n) { js_set_error("tile: empty batch"); return -1; }
+    for (size_t i = n; i < (size_t)total; i++) imgs.push_back(imgs[i % n]);
+    uploaded = false;
+    return (int)imgs.size();
+}
+template <class T> static int grow(T** p, size_t* cap, size_t need_bytes)
+{
+    if (need_bytes <= *cap && *p) return 0;
+    if (*p) { hipFree(*p); *p = nullptr; }
+    size_t nb = need_bytes + need_bytes / 16 + 256;
+    hipError_t e = hipMalloc((void**)p, nb);
+    if (e != hipSuccess) { js_set_error("hipMalloc(%zu) failed: %s", nb, hipGetErrorString(e)); *cap = 0; return -1; }
+    *cap = nb; return 0;
+}
+int JsnoopBatch::upload()
+{
+    HIP_TRY(hipSetDevice(device));
+    const size_t n = imgs.size();
+    if (!n) { js_set_error("upload: empty batch"); return -1; }
+    uint64_t blocks = 0, dibb = 0, plane = 0, side = 0, ustr = 0, subs = 0;
+    std::vector<uint32_t> wg(n + 1);
+    uint64_t total_strips = 0;
+    for (size_t i = 0; i < n; i++) { const JsImage& im = imgs[i]; uint32_t G = 128 / im.mcu_w; total_strips += (uint64_t)((im.mcu_xmax + G - 1) / G) * im.mcu_ymax; }
+    strips_per_wg = (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(1, total_strips / 8192));
+    uint32_t wgs = 0;
+    for (size_t i = 0; i < n; i++) {
+        JsImage& im = imgs[i];
+        im.want_planes = (uint32_t)opt_want_planes;
+        im.coef_off = blocks; blocks += im.total_blocks;
+        im.dib_off = dibb; dibb += align_up((uint64_t)im.img_x * im.img_y * 4, 256);
+        im.plane_off = plane; if (opt_want_planes) plane += align_up((uint64_t)im.blk_xmax * 8 * im.blk_ymax * 8 * 3, 64);
+        im.side_off = side; side += align_up(js_side_words(im.mcu_xmax * im.mcu_ymax, im.blk_xmax * im.blk_ymax), 4);
+        im.ustr_off = ustr; im.ustr_cap = (uint32_t)align_up(im.scan_len + 64, 64); ustr += im.ustr_cap;
+        im.n_subseq = (im.ustr_cap + JS_SUBSEQ_BYTES - 1) / JS_SUBSEQ_BYTES; im.subseq_off = subs; subs += align_up(im.n_subseq, 256);
+        const uint32_t G = 128 / im.mcu_w, strips = ((im.mcu_xmax + G - 1) / G) * im.mcu_ymax;
+        wg[i] = wgs; wgs += std::max(1u, (strips + strips_per_wg - 1) / strips_per_wg);
+    }
+    wg[n] = wgs; total_wgs = wgs; total_blocks = blocks; dib_bytes = dibb; side_words = side; total_subseq = subs; ustr_bytes = ustr;
+    if (grow(&dev.raw, &cap.raw, raw_bytes + 64) || grow(&dev.coef, &cap.coef, blocks * 128) || grow(&dev.dccum, &cap.dccum, blocks * 2 + 64) ||
+        grow(&dev.dib, &cap.dib, dibb) || grow(&dev.side, &cap.side, side * 4) || grow(&dev.imgs, &cap.imgs, n * sizeof(JsImage)) ||
+        grow(&dev.tables, &cap.tables, tables.size() * sizeof(JsTableSet)) || grow(&dev.wg_base, &cap.wg_base, (n + 1) * 4) ||
+        grow(&dev.sel, &cap.sel, n * 4) || grow(&dev.sums, &cap.sums, n * 8) || grow(&dev.ustr, &cap.ustr, ustr + 64) ||
+        grow(&dev.sub, &cap.sub, subs * 16 + 64) || grow(&dev.probe, &cap.probe, 1024)) return -1;
+    if (opt_want_planes && grow(&dev.planes, &cap.planes, plane * 2)) return -1;
+    HIP_TRY(hipMemcpyAsync(dev.raw, pinned, raw_bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(dev.imgs, imgs.data(), n * sizeof(JsImage), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(dev.tables, tables.data(), tables.size() * sizeof(JsTableSet), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(dev.wg_base, wg.data(), (n + 1) * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));          // host vectors above may go out of scope
+    uploaded = true;
+    return 0;
+}
+static const char* kStageName[JSNOOP_NUM_STAGES] = { "clear", "unstuff", "sync", "blockscan", "write", "dcscan", "idct_color", "exact" };
+
+int JsnoopBatch::decode(bool timed)
+{
+    HIP_TRY(hipSetDevice(device));
+    if (!uploaded && upload()) return -1;
+    const uint32_t n = (uint32_t)imgs.size();
+    if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
+    HIP_TRY(hipMemsetAsync(dev.coef, 0, total_blocks * 128, stream));
+    HIP_TRY(hipMemsetAsync(dev.dccum, 0, total_blocks * 2, stream));
+    HIP_TRY(hipMemsetAsync(dev.side, 0, side_words * 4, stream));
+    if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
+    // parallel path stages 1..5 (k_unstuff .. k_dc_scan) are launched by js_parallel_entropy
+    int used_parallel = opt_force_exact ? 0 : js_parallel_entropy(this, timed);
+    if (used_parallel < 0) return -1;
+    if (timed && !used_parallel) for (int s = 2; s <= 6; s++) HIP_TRY(hipEventRecord(ev[s], stream));
+    if (!used_parallel) js_launch_entropy_exact(stream, dev.imgs, nullptr, n, dev.tables, dev.raw, dev.coef, dev.dccum, dev.side);
+    if (timed) HIP_TRY(hipEventRecord(ev[7], stream));
+    js_launch_idct_color(stream, dev.imgs, dev.wg_base, n, total_wgs, strips_per_wg, d_lut, dev.coef, dev.dccum, dev.dib, dev.planes, dev.side);
+    if (timed) HIP_TRY(hipEventRecord(ev[8], stream));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int JsnoopBatch::sync()
+{
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return js_parallel_fixup(this);     // re-decodes flagged images on the exact path (no-op when none)
+}
+
+// ------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int jsnoop_abi_version(void) { return JSNOOP_ABI_VERSION; }
+const char* jsnoop_last_error(void) { return g_err.c_str(); }
+int jsnoop_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+int jsnoop_set_device(int device)
+{
+    int n = jsnoop_device_count();
+    if (device < 0 || device >= n) { js_set_error("device %d not available (%d visible)", device, n); return -1; }
+    HIP_TRY(hipSetDevice(device)); g_device = device; return 0;
+}
+
+JsnoopDecoder* jsnoop_create(void)
+{
+    if (jsnoop_device_count() <= 0) { js_set_error("no HIP device visible: libjsnoop_gpu has no CPU fallback"); return nullptr; }
+    JsnoopDecoder* d = new JsnoopDecoder();
+    d->batch = new JsnoopBatch(nullptr);
+    if (d->batch->init()) { delete d->batch; delete d; return nullptr; }
+    d->batch->opt_want_planes = 1;        // the reference always keeps m_pPixValY/Cb/Cr
+    return d;
+}
+void jsnoop_destroy(JsnoopDecoder* d) { if (!d) return; delete d->batch; delete d; }
+void jsnoop_reset(JsnoopDecoder* d)                                             // Reset :49-138
+{ d->have_image = false; d->host_valid = 0; memset(d->geom, 0, sizeof d->geom); d->geom[0] = d->geom[1] = 1; }
+void jsnoop_reset_state(JsnoopDecoder* d) { d->reset_state(); }
+void jsnoop_set_log_callback(JsnoopDecoder* d, jsnoop_log_fn fn, void* user) { d->log_fn = fn; d->log_user = user; }
+void jsnoop_set_options(JsnoopDecoder* d, int ac, int histo, int clip, unsigned err_max)
+{ d->opt_decode_ac = ac; d->opt_histo_en = histo; d->opt_stat_clip_en = clip; d->opt_err_max = err_max; }
+
+int jsnoop_set_dqt_entry(JsnoopDecoder* d, unsigned tbl, unsigned nat, unsigned zz, unsigned val)      // :424-453
+{
+    if (tbl < 4 && nat < 64) { d->t.dqt_nat[tbl][nat] = (uint16_t)val; d->t.dqt_zz[tbl][zz & 63] = (uint16_t)val; return 1; }
+    d->log(2, "ERROR: Attempt to set DQT entry out of range (nTblDestId=%u, nCoeffInd=%u, nCoeffVal=%u)", tbl, nat, val); return 0;
+}
+unsigned jsnoop_get_dqt_entry(JsnoopDecoder* d, unsigned tbl, unsigned nat)                            // :466-490
+{
+    if (tbl < 4 && nat < 64) return d->t.dqt_nat[tbl][nat];
+    d->log(2, "ERROR: GetDqtEntry(nTblDestId=%u, nCoeffInd=%u) out of indexed range", tbl, nat); return 0;
+}
+int jsnoop_set_dqt_tables(JsnoopDecoder* d, unsigned comp, unsigned tbl)                               // :505-520
+{
+    if (comp < 256 && tbl < 4) { d->t.dqt_sel[comp] = (int)tbl; return 1; }
+    d->log(2, "ERROR: SetDqtTables(Comp ID=%u, Table=%u) out of indexed range", comp, tbl); return 0;
+}
+int jsnoop_set_dht_tables(JsnoopDecoder* d, unsigned comp, unsigned dc, unsigned ac)                   // :536-553
+{
+    if (comp >= 1 && comp < 5 && dc < 4 && ac < 4) { d->t.dht_sel[0][comp] = (int)dc; d->t.dht_sel[1][comp] = (int)ac; return 1; }
+    d->log(2, "ERROR: SetDhtTables(comp=%u, TblDC=%u TblAC=%u) out of indexed range", comp, dc, ac); return 0;
+}
+int jsnoop_set_dht_entry(JsnoopDecoder* d, unsigned dest, unsigned cls, unsigned ind, unsigned len,
+                         unsigned bits, unsigned mask, unsigned code)                                  // :748-820
+{
+    if (dest >= 4 || cls >= 2 || ind >= JS_DHT_CODES) { d->log(2, "ERROR: Attempt to set DHT entry out of range"); return 0; }
+    JsTables& t = d->t;
+    t.dht_bitlen[cls][dest][ind] = len; t.dht_bits[cls][dest][ind] = bits; t.dht_mask[cls][dest][ind] = mask; t.dht_code[cls][dest][ind] = code;
+    if (dest > t.dht_setmax[cls]) t.dht_setmax[cls] = dest;
+    if (len <= JS_FAST_BITS) {
+        unsigned lo = (bits & mask) >> (32 - JS_FAST_BITS), hi = lo + ((1u << (JS_FAST_BITS - len)) - 1);
+        for (unsigned i = lo; i <= hi && i < 1024; i++) t.dht_fast[cls][dest][i] = code + (len << 8);
+    }
+    return 1;
+}
+int jsnoop_set_dht_size(JsnoopDecoder* d, unsigned dest, unsigned cls, unsigned n)                     // :834-847
+{
+    if (dest >= 4 || cls >= 2 || n >= JS_DHT_CODES) { d->log(2, "ERROR: Attempt to set DHT table size out of range"); return 0; }
+    d->t.dht_size[cls][dest] = n; return 1;
+}
+void jsnoop_set_sof_samp_factors(JsnoopDecoder* d, unsigned comp, unsigned h, unsigned v) { if (comp < 256) { d->t.samp_h[comp] = h; d->t.samp_v[comp] = v; } }
+void jsnoop_set_precision(JsnoopDecoder* d, unsigned p) { d->t.precision = p; }
+void jsnoop_set_image_details(JsnoopDecoder* d, unsigned x, unsigned y, unsigned nf, unsigned ns, int rst_en, unsigned rst_int)
+{ JsTables& t = d->t; t.details_set = 1; t.dim_x = x; t.dim_y = y; t.num_sof = nf; t.num_sos = ns; t.rst_en = rst_en != 0; t.rst_interval = rst_int; }
+
+void jsnoop_decode_scan_img(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned start, int display, int quiet)
+{
+    (void)quiet;
+    jsnoop_reset(d);
+    JsnoopBatch* b = d->batch;
+    b->clear();
+    b->opt_decode_ac = d->opt_decode_ac;
+    d->last_path = 0; d->last_flags = 0;
+    if (b->add(d, file, len, start, display) < 0) return;          // early returns of DecodeScanImg: no preview
+    d->preview_is_jpeg = false;                                     // :2978
+    if (b->upload() || b->decode(false) || b->sync()) { d->log(2, "*** ERROR: device decode failed: %s", g_err.c_str()); return; }
+    d->have_image = true; d->host_valid = 0;
+    if (display) d->preview_is_jpeg = true;
+    d->fetch_side();
+    d->last_path = (int)d->h_side[9]; d->last_flags = d->h_side[8];
+}
+
+int  jsnoop_is_preview_ready(JsnoopDecoder* d) { return d->preview_is_jpeg; }
+void jsnoop_get_image_size(JsnoopDecoder* d, unsigned* x, unsigned* y) { *x = d->geom[6]; *y = d->geom[7]; }
+void jsnoop_get_geometry(JsnoopDecoder* d, unsigned* o) { memcpy(o, d->geom, sizeof d->geom); }
+const uint8_t* jsnoop_get_bitmap_ptr(JsnoopDecoder* d)
+{
+    if (!d->have_image) return nullptr;
+    if (!(d->host_valid & 1)) {
+        const JsImage& im = d->batch->imgs[0];
+        d->h_dib.resize((size_t)im.img_x * im.img_y * 4);
+        if (d->batch->read_dib(0, d->h_dib.data())) return nullptr;
+        d->host_valid |= 1;
+    }
+    return d->h_dib.data();
+}
+const void* jsnoop_get_bitmap_dev(JsnoopDecoder* d) { return d->have_image ? d->batch->dev.dib + d->batch->imgs[0].dib_off : nullptr; }
+void jsnoop_get_pixmap_ptrs(JsnoopDecoder* d, const int16_t** y, const int16_t** cb, const int16_t** cr)
+{
+    *y = *cb = *cr = nullptr;
+    if (!d->have_image) return;
+    const JsImage& im = d->batch->imgs[0];
+    const size_t psz = (size_t)im.blk_xmax * 8 * im.blk_ymax * 8;
+    if (!(d->host_valid & 2)) {
+        d->h_planes.assign(psz * 3, 0);
+        if (d->batch->read_planes(0, d->h_planes.data(), d->h_planes.data() + psz, d->h_planes.data() + 2 * psz)) return;
+        d->host_valid |= 2;
+    }
+    *y = d->h_planes.data();
+    if (im.ncomp == 3) { *cb = d->h_planes.data() + psz; *cr = d->h_planes.data() + 2 * psz; }
+}
+void jsnoop_lookup_file_pos_mcu(JsnoopDecoder* d, unsigned mx, unsigned my, unsigned* byte, unsigned* bit)
+{
+    *byte = *bit = 0; if (!d->have_image || mx >= d->geom[2] || my >= d->geom[3]) return;
+    uint32_t p = d->h_side[JS_SIDE_MCUMAP + mx + my * d->geom[2]]; *bit = p & 7; *byte = p >> 4;     // UnpackFileOffset :5123
+}
+void jsnoop_lookup_file_pos_pix(JsnoopDecoder* d, unsigned px, unsigned py, unsigned* byte, unsigned* bit)
+{ jsnoop_lookup_file_pos_mcu(d, px / d->geom[0], py / d->geom[1], byte, bit); }                      // :5001-5009
+const uint32_t* jsnoop_mcu_file_map(JsnoopDecoder* d) { return d->have_image ? d->h_side.data() + JS_SIDE_MCUMAP : nullptr; }
+void jsnoop_blk_dc_ptrs(JsnoopDecoder* d, const int16_t** y, const int16_t** cb, const int16_t** cr)
+{
+    *y = *cb = *cr = nullptr; if (!d->have_image) return;
+    const uint32_t nmcu = d->geom[2] * d->geom[3], nblk = d->geom[4] * d->geom[5], w = 2 * ((nblk + 1) / 2);
+    const int16_t* base = (const int16_t*)(d->h_side.data() + JS_SIDE_MCUMAP + nmcu);
+    *y = base; if (d->batch->imgs[0].ncomp == 3) { *cb = base + w; *cr = base + 2 * w; }
+}
+void jsnoop_lookup_blk_ycc(JsnoopDecoder* d, unsigned bx, unsigned by, int* y, int* cb, int* cr)      // :5037-5047
+{
+    const int16_t *py, *pcb, *pcr; jsnoop_blk_dc_ptrs(d, &py, &pcb, &pcr);
+    *y = *cb = *cr = 0; if (!py || bx >= d->geom[4] || by >= d->geom[5]) return;
+    size_t i = bx + (size_t)by * d->geom[4]; *y = py[i]; if (pcb) { *cb = pcb[i]; *cr = pcr[i]; }
+}
+const uint32_t* jsnoop_dht_histo(JsnoopDecoder* d) { return d->have_image ? d->h_side.data() + JS_SIDE_HISTO : d->zero_histo; }
+void jsnoop_scan_status(JsnoopDecoder* d, unsigned* o) { for (int i = 0; i < 8; i++) o[i] = d->have_image ? d->h_side[i] : 0; }
+void jsnoop_bright_avg(JsnoopDecoder* d, int* o)
+{
+    memset(o, 0, 10 * sizeof(int)); o[1] = o[2] = o[3] = -32768;
+    if (!d->have_image || !d->preview_is_jpeg) return;
+    const JsImage& im = d->batch->imgs[0];
+    const uint64_t key = ((uint64_t)d->h_side[13] << 32) | d->h_side[12];
+    const uint32_t yk = (uint32_t)(key >> 32), idx = 0xFFFFFFFFu - (uint32_t)key;
+    o[0] = 1;
+    if (yk != 0) {            // some pixel beat the -32768 start value (:4723-4730)
+        const int16_t *py, *pcb, *pcr; jsnoop_get_pixmap_ptrs(d, &py, &pcb, &pcr);
+        const uint32_t px = idx % im.img_x, pyy = idx / im.img_x; const size_t pi = (size_t)pyy * im.blk_xmax * 8 + px;
+        o[1] = (int)yk - 32768; o[2] = pcb ? pcb[pi] : 0; o[3] = pcr ? pcr[pi] : 0; o[7] = (int)(px / im.mcu_w); o[8] = (int)(pyy / im.mcu_h);
+    }
+    {   // RGB of the brightest pixel through the device colour routine (:4805-4811)
+        JsnoopBatch* b = d->batch; uint32_t bgra = 0; hipSetDevice(b->device);
+        js_launch_color_probe(b->stream, o[1], o[2], o[3], (uint32_t*)b->dev.probe);
+        hipMemcpyAsync(&bgra, b->dev.probe, 4, hipMemcpyDeviceToHost, b->stream); hipStreamSynchronize(b->stream);
+        o[4] = (bgra >> 16) & 255; o[5] = (bgra >> 8) & 255; o[6] = bgra & 255;
+    }
+    unsigned long npix = (unsigned)((im.img_y + 1) * (im.img_x + 1)); if (!npix) npix = 1;
+    o[9] = (int)(d->h_side[15] / npix);
+}
+const float* jsnoop_idct_lut(JsnoopDecoder* d) { return &d->batch->lut[0][0]; }
+const uint32_t* jsnoop_dht_lookupfast(JsnoopDecoder* d) { return &d->t.dht_fast[0][0][0]; }
+void jsnoop_idct_block(JsnoopDecoder* d, const int16_t* coef64, float* out64)
+{
+    JsnoopBatch* b = d->batch; hipSetDevice(b->device);
+    size_t c = b->cap.probe; if (grow(&b->dev.probe, &c, 1024)) return; b->cap.probe = c;
+    hipMemcpyAsync(b->dev.probe, coef64, 128, hipMemcpyHostToDevice, b->stream);
+    js_launch_idct_probe(b->stream, b->d_lut, (const int16_t*)b->dev.probe, (float*)(b->dev.probe + 256));
+    hipMemcpyAsync(out64, b->dev.probe + 256, 256, hipMemcpyDeviceToHost, b->stream);
+    hipStreamSynchronize(b->stream);
+}
+int jsnoop_last_path(JsnoopDecoder* d) { return d->last_path; }
+uint32_t jsnoop_last_flags(JsnoopDecoder* d) { return d->last_flags; }
+
+void jsnoop_set_preview_mode(JsnoopDecoder* d, unsigned mode) { d->preview_mode = mode; d->rerender(); }      // :633-639
+unsigned jsnoop_get_preview_mode(JsnoopDecoder* d) { return d->preview_mode; }
+void jsnoop_set_preview_ycc_offset(JsnoopDecoder* d, unsigned mx, unsigned my, int y, int cb, int cr)       // :650-659
+{ d->shift_mcu_x = mx; d->shift_mcu_y = my; d->shift_y = y; d->shift_cb = cb; d->shift_cr = cr; d->rerender(); }
+
+// ---- batch ---------------------------------------------------------------------------
+JsnoopBatch* jsnoop_batch_create(void* stream)
+{
+    if (jsnoop_device_count() <= 0) { js_set_error("no HIP device visible: libjsnoop_gpu has no CPU fallback"); return nullptr; }
+    JsnoopBatch* b = new JsnoopBatch(stream);
+    if (b->init()) { delete b; return nullptr; }
+    return b;
+}
+void jsnoop_batch_destroy(JsnoopBatch* b) { delete b; }
+void jsnoop_batch_clear(JsnoopBatch* b) { b->clear(); }
+void jsnoop_batch_set_options(JsnoopBatch* b, int decode_ac, int want_planes, int force_exact)
+{ b->opt_decode_ac = decode_ac; b->opt_want_planes = want_planes; b->opt_force_exact = force_exact; b->uploaded = false; }
+int jsnoop_batch_add(JsnoopBatch* b, const JsnoopDecoder* tables, const uint8_t* file, size_t len, unsigned scan_start)
+{ return b->add(const_cast<JsnoopDecoder*>(tables), file, len, scan_start, 1); }
+int jsnoop_batch_add_jpeg(JsnoopBatch* b, const uint8_t* file, size_t len)
+{
+    JsnoopDecoder tmp; unsigned scan_start = 0;
+    if (js_jfif_walk(&tmp, file, len, &scan_start)) return -1;
+    return b->add(&tmp, file, len, scan_start, 1);
+}
+int jsnoop_batch_tile(JsnoopBatch* b, int total) { return b->tile(total); }
+int jsnoop_batch_count(const JsnoopBatch* b) { return (int)b->imgs.size(); }
+int jsnoop_batch_upload(JsnoopBatch* b) { return b->upload(); }
+int jsnoop_batch_decode(JsnoopBatch* b) { return b->decode(false); }
+int jsnoop_batch_sync(JsnoopBatch* b) { return b->sync(); }
+const char* jsnoop_stage_name(int s) { return s >= 0 && s < JSNOOP_NUM_STAGES ? kStageName[s] : ""; }
+double jsnoop_batch_decode_timed(JsnoopBatch* b, int reps, double* stage_ms)
+{
+    if (reps < 1) reps = 1;
+    double tot[JSNOOP_NUM_STAGES] = {0}, whole = 0;
+    for (int r = 0; r < reps; r++) {
+        if (b->decode(true)) return -1;
+        if (hipStreamSynchronize(b->stream) != hipSuccess) { js_set_error("stream sync failed"); return -1; }
+        for (int s = 0; s < JSNOOP_NUM_STAGES; s++) { float ms = 0; hipEventElapsedTime(&ms, b->ev[s], b->ev[s + 1]); tot[s] += ms; }
+        float ms = 0; hipEventElapsedTime(&ms, b->ev[0], b->ev[JSNOOP_NUM_STAGES]); whole += ms;
+    }
+    if (stage_ms) for (int s = 0; s < JSNOOP_NUM_STAGES; s++) stage_ms[s] = tot[s] / reps;
+    return whole / reps;
+}
+int jsnoop_batch_image_info(const JsnoopBatch* b, int i, unsigned* o)
+{
+    if (i < 0 || (size_t)i >= b->imgs.size()) return -1;
+    const JsImage& im = b->imgs[i];
+    unsigned v[16] = { im.dim_x, im.dim_y, im.img_x, im.img_y, im.mcu_w, im.mcu_h, im.mcu_xmax, im.mcu_ymax, im.blk_xmax, im.blk_ymax,
+                       im.scan_len, (size_t)i < b->host_flags.size() ? b->host_flags[i] : 0u, (size_t)i < b->host_path.size() ? b->host_path[i] : 0u,
+                       im.ncomp, im.file_len, im.total_blocks };
+    memcpy(o, v, sizeof v); return 0;
+}
+const void* jsnoop_batch_dib_dev(const JsnoopBatch* b, int i) { return (i < 0 || (size_t)i >= b->imgs.size() || !b->dev.dib) ? nullptr : b->dev.dib + b->imgs[i].dib_off; }
+int jsnoop_batch_read_dib(JsnoopBatch* b, int i, uint8_t* dst) { return b->read_dib(i, dst); }
+int jsnoop_batch_read_planes(JsnoopBatch* b, int i, int16_t* y, int16_t* cb, int16_t* cr) { return b->read_planes(i, y, cb, cr); }
+int jsnoop_batch_read_coefs(JsnoopBatch* b, int i, int16_t* dst, size_t max_blocks)
+{
+    if (i < 0 || (size_t)i >= b->imgs.size()) return -1;
+    const JsImage& im = b->imgs[i]; size_t nb = std::min<size_t>(max_blocks, im.total_blocks);
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipMemcpyAsync(dst, b->dev.coef + im.coef_off * 64, nb * 128, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return (int)nb;
+}
+int jsnoop_batch_dib_hashes(JsnoopBatch* b, uint64_t* dst)
+{
+    HIP_TRY(hipSetDevice(b->device));
+    const uint32_t n = (uint32_t)b->imgs.size();
+    HIP_TRY(hipMemsetAsync(b->dev.sums, 0, n * 8, b->stream));
+    js_launch_dib_checksum(b->stream, b->dev.imgs, n, b->dev.dib, (unsigned long long*)b->dev.sums);
+    HIP_TRY(hipMemcpyAsync(dst, b->dev.sums, n * 8, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+}
+uint64_t jsnoop_batch_algorithmic_bytes(const JsnoopBatch* b)
+{ uint64_t s = 0; for (const JsImage& im : b->imgs) s += (uint64_t)im.scan_len + (uint64_t)im.img_x * im.img_y * 4; return s; }
+uint64_t jsnoop_batch_pixels(const JsnoopBatch* b)
+{ uint64_t s = 0; for (const JsImage& im : b->imgs) s += (uint64_t)im.dim_x * im.dim_y; return s; }
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------ helpers
+int JsnoopBatch::read_dib(int i, uint8_t* dst)
+{
+    if (i < 0 || (size_t)i >= imgs.size()) { js_set_error("image index out of range"); return -1; }
+    const JsImage& im = imgs[i];
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpyAsync(dst, dev.dib + im.dib_off, (size_t)im.img_x * im.img_y * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+}
+int JsnoopBatch::read_planes(int i, int16_t* y, int16_t* cb, int16_t* cr)
+{
+    if (i < 0 || (size_t)i >= imgs.size() || !opt_want_planes) { js_set_error("planes not available"); return -1; }
+    const JsImage& im = imgs[i]; const size_t psz = (size_t)im.blk_xmax * 8 * im.blk_ymax * 8;
+    int16_t* dst[3] = { y, cb, cr };
+    HIP_TRY(hipSetDevice(device));
+    for (uint32_t c = 0; c < im.ncomp; c++) if (dst[c]) HIP_TRY(hipMemcpyAsync(dst[c], dev.planes + im.plane_off + c * psz, psz * 2, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+}
+void JsnoopDecoder::fetch_side()
+{
+    const JsImage& im = batch->imgs[0];
+    h_side.assign(js_side_words(im.mcu_xmax * im.mcu_ymax, im.blk_xmax * im.blk_ymax), 0);
+    hipSetDevice(batch->device);
+    hipMemcpyAsync(h_side.data(), batch->dev.side + im.side_off, h_side.size() * 4, hipMemcpyDeviceToHost, batch->stream);
+    hipStreamSynchronize(batch->stream);
+}
+void JsnoopDecoder::rerender()                                  // CalcChannelPreview :4965 on the retained data: colour kernel only
+{
+    if (!have_image) return;
+    JsnoopBatch* b = batch; JsImage& im = b->imgs[0];
+    im.preview_mode = preview_mode; im.shift_y = shift_y; im.shift_cb = shift_cb; im.shift_cr = shift_cr; im.shift_mcu_x = shift_mcu_x; im.shift_mcu_y = shift_mcu_y;
+    hipSetDevice(b->device);
+    hipMemcpyAsync(b->dev.imgs, &im, sizeof im, hipMemcpyHostToDevice, b->stream);
+    hipMemsetAsync(b->dev.side + im.side_off + 12, 0, 16, b->stream);      // brightest-pixel key and sum of Y are recomputed
+    js_launch_idct_color(b->stream, b->dev.imgs, b->dev.wg_base, 1, b->total_wgs, b->strips_per_wg, b->d_lut, b->dev.coef, b->dev.dccum, b->dev.dib, b->dev.planes, b->dev.side);
+    hipStreamSynchronize(b->stream);
+    host_valid = 0; fetch_side();
+}

@@ -1,0 +1,78 @@
+// jsnoop_host.h -- host-side objects behind the opaque handles of include/jsnoop_gpu.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+#include "../../include/jsnoop_gpu.h"
+#include "jsnoop_types.h"
+
+// The table / frame state that CjfifDecode pushes into CimgDecode through its setters
+// (member arrays of reference source/ImgDecode.h:531-615, same shapes).
+struct JsTables {
+    uint16_t dqt_nat[4][64], dqt_zz[4][64]; int dqt_sel[256];
+    int      dht_sel[2][5];
+    uint32_t dht_setmax[2], dht_size[2][4];
+    uint32_t dht_bitlen[2][4][JS_DHT_CODES], dht_bits[2][4][JS_DHT_CODES], dht_mask[2][4][JS_DHT_CODES], dht_code[2][4][JS_DHT_CODES];
+    uint32_t dht_fast[2][4][2 << JS_FAST_BITS];
+    uint32_t dht_histo_unused[1];
+    int      details_set; uint32_t dim_x, dim_y, num_sof, num_sos, precision;
+    uint32_t samp_h[256], samp_v[256];
+    int      rst_en; uint32_t rst_interval;
+};
+
+struct JsnoopBatch;
+
+struct JsnoopDecoder {
+    JsTables t;
+    int opt_decode_ac, opt_histo_en, opt_stat_clip_en; unsigned opt_err_max;
+    jsnoop_log_fn log_fn; void* log_user;
+    JsnoopBatch* batch;                         // private batch of one image (single-image API)
+    unsigned preview_mode; int shift_y, shift_cb, shift_cr; unsigned shift_mcu_x, shift_mcu_y;
+    bool preview_is_jpeg, have_image; int host_valid; int last_path; uint32_t last_flags;
+    unsigned geom[8];
+    std::vector<uint8_t> h_dib; std::vector<int16_t> h_planes; std::vector<uint32_t> h_side;
+    uint32_t zero_histo[2 * 4 * 17] = {0};
+    JsnoopDecoder();
+    void reset_state();
+    void log(int level, const char* fmt, ...);
+    void fetch_side();
+    void rerender();
+};
+
+struct JsDeviceArenas {
+    uint8_t* raw; uint8_t* ustr; int16_t* coef; int16_t* dccum; uint8_t* dib; int16_t* planes; uint32_t* side;
+    JsImage* imgs; JsTableSet* tables; uint32_t* wg_base; uint32_t* sel; uint64_t* sums; uint8_t* sub; uint8_t* probe;
+};
+struct JsArenaCaps { size_t raw, ustr, coef, dccum, dib, planes, side, imgs, tables, wg_base, sel, sums, sub, probe; };
+
+struct JsnoopBatch {
+    int device; hipStream_t stream; bool own_stream;
+    int opt_decode_ac, opt_want_planes, opt_force_exact;
+    std::vector<JsImage> imgs; std::vector<JsTableSet> tables;
+    std::vector<uint32_t> host_flags, host_path;
+    uint8_t* pinned; size_t pinned_cap; uint64_t raw_bytes;
+    JsDeviceArenas dev; JsArenaCaps cap;
+    bool uploaded;
+    uint64_t total_blocks, dib_bytes, side_words, total_subseq, ustr_bytes; uint32_t total_wgs, strips_per_wg;
+    hipEvent_t ev[JSNOOP_NUM_STAGES + 1];
+    float lut[64][64]; float* d_lut;
+    explicit JsnoopBatch(void* user_stream);
+    ~JsnoopBatch();
+    int  init();
+    void clear();
+    int  reserve_pinned(size_t need);
+    int  add(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned scan_start, int display);
+    int  tile(int total);
+    int  upload();
+    int  decode(bool timed);
+    int  sync();
+    int  read_dib(int i, uint8_t* dst);
+    int  read_planes(int i, int16_t* y, int16_t* cb, int16_t* cr);
+};
+
+void js_set_error(const char* fmt, ...);
+bool js_describe_image(JsnoopDecoder* d, JsImage* im, JsTableSet* ts, uint32_t file_len, uint32_t scan_start, int display);
+void js_build_parallel_luts(JsTableSet* ts, uint32_t ncomp);          // jsnoop_parallel.cpp
+int  js_parallel_entropy(JsnoopBatch* b, bool timed);                 // 1 = launched, 0 = not applicable, <0 error
+int  js_parallel_fixup(JsnoopBatch* b);
+int  js_jfif_walk(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned* scan_start);   // jfif_front.cpp

@@ -1,0 +1,77 @@
+// jsnoop_types.h -- device-visible descriptors shared by the host code and the HIP kernels.
+//
+// HBM layout of one batch (all arenas are single hipMalloc blocks; offsets are per image):
+//
+//   raw    u8   file bytes of every image, 16-byte aligned starts     (read once by the entropy front end)
+//   ustr   u8   un-stuffed entropy segment of every image (FF00->FF, RSTn removed) + interval table
+//   coef   i16  [total_blocks][64] dequantised coefficients, NATURAL order, blocks in decode order
+//               (mcu * blocks_per_mcu + block_in_mcu); slot 0 = dequantised DC difference
+//   dccum  i16  [total_blocks] cumulative (predicted) DC per block = CimgDecode's m_nDcLum/Cb/Cr at that block
+//   dib    u8   [img_y][img_x][4] bottom-up BGRA per image                (written once)
+//   planes i16  3 x [blk_ymax*8][blk_xmax*8] per image (optional; m_pPixValY/Cb/Cr)
+//   side   u32  per image: MCU file map, block-DC maps, Huffman histogram, status words
+//
+// Names follow the reference (MCU, block, restart interval, DIB), see SURVEY.md section 8.
+#pragma once
+#include <stdint.h>
+
+#define JS_MAX_BLK_PER_MCU 48      // 3 components x (4 x 4) sampling factors (MAX_SAMP_FACT_H/V, ImgDecode.h:79-80)
+#define JS_DHT_CODES       260     // MAX_DHT_CODES, ImgDecode.h:68
+#define JS_FAST_BITS       9       // DHT_FAST_SIZE, ImgDecode.h:96
+#define JS_CODE_UNUSED     0xFFFFFFFFu
+#define JS_LUT2_MAX        1536    // second-level entries per table in the parallel path's LUT form
+#define JS_SUBSEQ_BYTES    128     // bytes of un-stuffed stream per sub-sequence (parallel entropy path)
+
+// One distinct set of Huffman + quantisation tables, resolved per scan component
+// (index t = (comp-1)*2 + class, class 0 = DC, 1 = AC).  De-duplicated across a batch.
+struct JsTableSet {
+    // --- exact-mirror form: the arrays CimgDecode::SetDhtEntry fills (ImgDecode.cpp:748-820)
+    uint32_t fast[6][1 << JS_FAST_BITS];    // m_anDhtLookupfast: (len<<8)+code, 0xFFFFFFFF = miss
+    uint32_t size[6];                       // m_anDhtLookupSize
+    uint32_t bitlen[6][JS_DHT_CODES], bits[6][JS_DHT_CODES], mask[6][JS_DHT_CODES], code[6][JS_DHT_CODES];
+    uint32_t dest_id[6];                    // DHT destination id behind each slot (histogram index)
+    uint16_t qzz[3][64];                    // m_anDqtCoeffZz of the table selected for each component
+    // --- parallel-path form: 9-bit first level + canonical second level
+    //     entry: bit15 = 0 : [12:8] = code length (0 = invalid), [7:0] = symbol (run<<4 | size)
+    //            bit15 = 1 : [14:12] = extra index bits nb, [11:0] = base into lut2
+    uint16_t lut1[6][1 << JS_FAST_BITS];
+    uint16_t lut2[6][JS_LUT2_MAX];
+    uint32_t lut_ok;                        // 1 when every table fits the LUT form and is a canonical prefix code
+};
+
+struct JsImage {
+    // frame / scan description (SetImageDetails :590, SetSofSampFactors :619, SetPrecision :564)
+    uint32_t dim_x, dim_y, ncomp, precision, rst_en, rst_interval, decode_ac, want_planes;
+    // geometry (DecodeScanImg :2831-2872)
+    uint32_t mcu_w, mcu_h, mcu_xmax, mcu_ymax, blk_xmax, blk_ymax, img_x, img_y;
+    uint32_t samp_h[4], samp_v[4], expand_h[4], expand_v[4];       // index 1..3 = Y, Cb, Cr
+    uint32_t blk_per_mcu, total_blocks;
+    uint8_t  blk_comp[JS_MAX_BLK_PER_MCU], blk_ch[JS_MAX_BLK_PER_MCU], blk_cv[JS_MAX_BLK_PER_MCU];
+    // inputs
+    uint64_t file_off;  uint32_t file_len, scan_start, scan_len;    // scan_len = bytes up to the terminating marker
+    uint64_t ustr_off;  uint32_t ustr_cap;                          // un-stuffed stream capacity (= scan_len + slack)
+    uint32_t tableset;
+    // outputs
+    uint64_t coef_off;      // in blocks
+    uint64_t dib_off;       // in bytes
+    uint64_t plane_off;     // in samples (3 planes of blk_xmax*8 x blk_ymax*8 follow each other)
+    uint64_t side_off;      // in u32 words, see JS_SIDE_*
+    uint64_t subseq_off;    // first sub-sequence slot of this image
+    uint32_t n_subseq;      // capacity in sub-sequences
+    // preview controls (SetPreviewMode :633, SetPreviewYccOffset :650)
+    uint32_t preview_mode; int32_t shift_y, shift_cb, shift_cr; uint32_t shift_mcu_x, shift_mcu_y;
+    uint32_t err_max;
+};
+
+// Per-image side block (u32 words, in this order):
+//   [0..15]   status: 0 scan_bad, 1 scan_end, 2 #RST read, 3 num_pixels, 4 pos0, 5 align, 6 warn_bad, 7 first,
+//             8 flags (JSNOOP_FLAG_*), 9 path, 10 un-stuffed length, 11 #intervals, 12 blocks decoded,
+//             13 bright key hi, 14 bright key lo, 15 sum of final Y
+//   [16..151] Huffman code-length histogram [2][4][17]
+//   [152..]   MCU file map [mcu_ymax*mcu_xmax], then three block-DC maps (i16 packed as u16 pairs, each
+//             padded to a whole word count), sized by the image
+#define JS_SIDE_STATUS 0
+#define JS_SIDE_HISTO  16
+#define JS_SIDE_MCUMAP 152
+
+static inline uint32_t js_side_words(uint32_t nmcu, uint32_t nblk) { return JS_SIDE_MCUMAP + nmcu + 3 * ((nblk + 1) / 2); }

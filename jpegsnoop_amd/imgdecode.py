@@ -1,0 +1,197 @@
+"""Host-side mirror of the reference's operator interface for the scan-decode path.
+
+`CimgDecode` keeps the reference's method names, argument meaning and error behaviour
+(reference source/ImgDecode.h:286-356) on top of the C ABI; `JpegBatch` is the batched
+submit that replaces the strictly sequential per-file loop of
+CJPEGsnoopCore::DoBatchFileProcess (source/JPEGsnoopCore.cpp:765).  Python is only the
+binding layer here: decode happens in libjsnoop_gpu.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class CimgDecode:
+    """One decoder object == one `CimgDecode` of the reference."""
+
+    PREVIEW_RGB, PREVIEW_YCC, PREVIEW_R, PREVIEW_G, PREVIEW_B, PREVIEW_Y, PREVIEW_CB, PREVIEW_CR = range(1, 9)
+
+    def __init__(self, log=None):
+        self._lib = capi.load()
+        self._h = self._lib.jsnoop_create()
+        if not self._h:
+            raise RuntimeError("jsnoop_create failed: " + capi.last_error())
+        self._log_cb = None
+        if log is not None:
+            self._log_cb = capi.LOG_FN(lambda _u, lvl, txt: log(lvl, txt.decode(errors="replace")))
+            self._lib.jsnoop_set_log_callback(self._h, self._log_cb, None)
+        self._buf = None
+
+    def close(self):
+        if self._h:
+            self._lib.jsnoop_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- lifecycle / options -------------------------------------------------------
+    def Reset(self): self._lib.jsnoop_reset(self._h)
+    def ResetState(self): self._lib.jsnoop_reset_state(self._h)
+    def SetOptions(self, bDecodeScanImgAc=True, bHistoEn=False, bStatClipEn=False, nErrMaxDecodeScan=20):
+        self._lib.jsnoop_set_options(self._h, int(bDecodeScanImgAc), int(bHistoEn), int(bStatClipEn), nErrMaxDecodeScan)
+
+    # --- tables / geometry ------------------------------------------------------------
+    def SetDqtEntry(self, nTblDestId, nCoeffInd, nCoeffIndZz, nCoeffVal):
+        return bool(self._lib.jsnoop_set_dqt_entry(self._h, nTblDestId, nCoeffInd, nCoeffIndZz, nCoeffVal))
+    def SetDqtTables(self, nCompInd, nTbl): return bool(self._lib.jsnoop_set_dqt_tables(self._h, nCompInd, nTbl))
+    def GetDqtEntry(self, nTblDestId, nCoeffInd): return self._lib.jsnoop_get_dqt_entry(self._h, nTblDestId, nCoeffInd)
+    def SetDhtEntry(self, nDestId, nClass, nInd, nLen, nBits, nMask, nCode):
+        return bool(self._lib.jsnoop_set_dht_entry(self._h, nDestId, nClass, nInd, nLen, nBits, nMask, nCode))
+    def SetDhtSize(self, nDestId, nClass, nSize): return bool(self._lib.jsnoop_set_dht_size(self._h, nDestId, nClass, nSize))
+    def SetDhtTables(self, nCompInd, nTblDc, nTblAc): return bool(self._lib.jsnoop_set_dht_tables(self._h, nCompInd, nTblDc, nTblAc))
+    def SetSofSampFactors(self, nCompInd, nSampFactH, nSampFactV): self._lib.jsnoop_set_sof_samp_factors(self._h, nCompInd, nSampFactH, nSampFactV)
+    def SetPrecision(self, nPrecision): self._lib.jsnoop_set_precision(self._h, nPrecision)
+    def SetImageDetails(self, nDimX, nDimY, nCompsSOF, nCompsSOS, bRstEn, nRstInterval):
+        self._lib.jsnoop_set_image_details(self._h, nDimX, nDimY, nCompsSOF, nCompsSOS, int(bRstEn), nRstInterval)
+
+    # --- decode -------------------------------------------------------------------------
+    def DecodeScanImg(self, file_bytes: bytes, nStart: int, bDisplay=True, bQuiet=False):
+        """`file_bytes` stands for what the reference reads through CwindowBuf::Buf."""
+        self._buf = (C.c_uint8 * len(file_bytes)).from_buffer_copy(file_bytes)
+        self._lib.jsnoop_decode_scan_img(self._h, C.cast(self._buf, C.c_void_p), len(file_bytes), nStart, int(bDisplay), int(bQuiet))
+
+    # --- results ---------------------------------------------------------------------------
+    def IsPreviewReady(self): return bool(self._lib.jsnoop_is_preview_ready(self._h))
+    def GetImageSize(self):
+        x, y = C.c_uint(), C.c_uint()
+        self._lib.jsnoop_get_image_size(self._h, C.byref(x), C.byref(y))
+        return x.value, y.value
+    def GetBitmapPtr(self):
+        x, y = self.GetImageSize()
+        p = self._lib.jsnoop_get_bitmap_ptr(self._h)
+        if not p:
+            return None
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(y, x, 4))
+    def GetPixMapPtrs(self):
+        g = (C.c_uint * 8)()
+        self._lib.jsnoop_get_geometry(self._h, g)
+        ptrs = [C.c_void_p() for _ in range(3)]
+        self._lib.jsnoop_get_pixmap_ptrs(self._h, *[C.byref(q) for q in ptrs])
+        return [np.ctypeslib.as_array(C.cast(q, C.POINTER(C.c_int16)), shape=(g[5] * 8, g[4] * 8)) if q.value else None for q in ptrs]
+    def LookupFilePosMcu(self, nMcuX, nMcuY):
+        a, b = C.c_uint(), C.c_uint()
+        self._lib.jsnoop_lookup_file_pos_mcu(self._h, nMcuX, nMcuY, C.byref(a), C.byref(b))
+        return a.value, b.value
+    def LookupFilePosPix(self, nPixX, nPixY):
+        a, b = C.c_uint(), C.c_uint()
+        self._lib.jsnoop_lookup_file_pos_pix(self._h, nPixX, nPixY, C.byref(a), C.byref(b))
+        return a.value, b.value
+    def LookupBlkYCC(self, nBlkX, nBlkY):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self._lib.jsnoop_lookup_blk_ycc(self._h, nBlkX, nBlkY, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+    def SetPreviewMode(self, nMode): self._lib.jsnoop_set_preview_mode(self._h, nMode)
+    def GetPreviewMode(self): return self._lib.jsnoop_get_preview_mode(self._h)
+    def SetPreviewYccOffset(self, nMcuX, nMcuY, nY, nCb, nCr): self._lib.jsnoop_set_preview_ycc_offset(self._h, nMcuX, nMcuY, nY, nCb, nCr)
+    def LastPath(self): return self._lib.jsnoop_last_path(self._h)
+    def LastFlags(self): return self._lib.jsnoop_last_flags(self._h)
+
+
+class JpegBatch:
+    """N JPEG files -> N DIBs resident in HBM (device-side batch)."""
+
+    def __init__(self, stream=None, decode_ac=True, want_planes=False, force_exact=False):
+        self._lib = capi.load()
+        self._h = self._lib.jsnoop_batch_create(C.c_void_p(stream) if stream else None)
+        if not self._h:
+            raise RuntimeError("jsnoop_batch_create failed: " + capi.last_error())
+        self._lib.jsnoop_batch_set_options(self._h, int(decode_ac), int(want_planes), int(force_exact))
+        self.want_planes = want_planes
+
+    def close(self):
+        if self._h:
+            self._lib.jsnoop_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc < 0:
+            raise RuntimeError(f"{what} failed: {capi.last_error()}")
+        return rc
+
+    def add_jpeg(self, data: bytes) -> int:
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        return self._chk(self._lib.jsnoop_batch_add_jpeg(self._h, C.cast(buf, C.c_void_p), len(data)), "batch_add_jpeg")
+
+    def tile(self, total: int) -> int: return self._chk(self._lib.jsnoop_batch_tile(self._h, total), "batch_tile")
+    def clear(self): self._lib.jsnoop_batch_clear(self._h)
+    def __len__(self): return self._lib.jsnoop_batch_count(self._h)
+    def upload(self): self._chk(self._lib.jsnoop_batch_upload(self._h), "batch_upload")
+    def decode(self): self._chk(self._lib.jsnoop_batch_decode(self._h), "batch_decode")
+    def sync(self): self._chk(self._lib.jsnoop_batch_sync(self._h), "batch_sync")
+
+    def decode_timed(self, reps=1):
+        st = (C.c_double * capi.NUM_STAGES)()
+        ms = self._lib.jsnoop_batch_decode_timed(self._h, reps, st)
+        if ms < 0:
+            raise RuntimeError("batch_decode_timed failed: " + capi.last_error())
+        return ms, {self._lib.jsnoop_stage_name(i).decode(): st[i] for i in range(capi.NUM_STAGES)}
+
+    def info(self, i):
+        o = (C.c_uint * 16)()
+        self._chk(self._lib.jsnoop_batch_image_info(self._h, i, o), "batch_image_info")
+        keys = "dim_x dim_y img_x img_y mcu_w mcu_h mcu_xmax mcu_ymax blk_xmax blk_ymax scan_bytes flags path ncomp file_len total_blocks".split()
+        return dict(zip(keys, o))
+
+    def dib(self, i):
+        inf = self.info(i)
+        out = np.empty((inf["img_y"], inf["img_x"], 4), np.uint8)
+        self._chk(self._lib.jsnoop_batch_read_dib(self._h, i, out.ctypes.data), "batch_read_dib")
+        return out
+
+    def planes(self, i):
+        inf = self.info(i)
+        shp = (inf["blk_ymax"] * 8, inf["blk_xmax"] * 8)
+        ps = [np.zeros(shp, np.int16) for _ in range(3)]
+        self._chk(self._lib.jsnoop_batch_read_planes(self._h, i, *[p.ctypes.data for p in ps]), "batch_read_planes")
+        return ps[: inf["ncomp"]]
+
+    def coefs(self, i):
+        inf = self.info(i)
+        out = np.empty((inf["total_blocks"], 64), np.int16)
+        self._chk(self._lib.jsnoop_batch_read_coefs(self._h, i, out.ctypes.data, inf["total_blocks"]), "batch_read_coefs")
+        return out
+
+    def dib_checksums(self):
+        out = np.zeros(len(self), np.uint64)
+        self._chk(self._lib.jsnoop_batch_dib_hashes(self._h, out.ctypes.data), "batch_dib_hashes")
+        return out
+
+    def algorithmic_bytes(self): return int(self._lib.jsnoop_batch_algorithmic_bytes(self._h))
+    def pixels(self): return int(self._lib.jsnoop_batch_pixels(self._h))
+
+
+def dib_checksum_numpy(dib: np.ndarray) -> int:
+    """The position-keyed checksum of k_dib_checksum, recomputed on the host from a DIB array
+    (used by tests to compare a device DIB against the oracle's without a D2H copy)."""
+    px = np.ascontiguousarray(dib).view(np.uint32).reshape(-1).astype(np.uint64)
+    z = (np.arange(px.size, dtype=np.uint64) << np.uint64(32)) | px
+    with np.errstate(over="ignore"):
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+        return int(z.sum(dtype=np.uint64))

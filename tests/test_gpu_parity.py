@@ -1,0 +1,123 @@
+"""-m gpu: the HIP path against the oracle (and the compiled reference when its .so travelled),
+through the C ABI, on seeded synthetic JPEGs.  Bit-exact for every output (integer / byte work;
+the fp32 IDCT and colour stages are bit-exact by construction of the summation order)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    dict(width=640, height=480, hs=1, vs=1),                      # BASELINE config 1 geometry
+    dict(width=333, height=217),                                   # odd size 4:2:0 -> 336x224
+    dict(width=333, height=217, gray=1),
+    dict(width=640, height=360, hs=2, vs=1, restart_interval=40),  # 4:2:2 with RSTn every MCU row
+    dict(width=256, height=256, optimize_huffman=1, quality=95),
+    dict(width=200, height=100, quality=20, restart_interval=1),
+    dict(width=1920, height=1080),                                 # config 3 geometry (DIB 1920x1088)
+]
+
+
+def compare(H, a, b, side=True):
+    da, db = a.dib(), b.dib()
+    assert (da is None) == (db is None)
+    if da is None:
+        return
+    assert a.image_size() == b.image_size()
+    assert np.array_equal(da, db), "DIB differs"
+    for pa, pb in zip(a.planes(), b.planes()):
+        if pa is not None:
+            assert np.array_equal(pa, pb), "int16 plane differs"
+    if side:
+        assert np.array_equal(a.mcu_map(), b.mcu_map()), "MCU file map differs"
+        for pa, pb in zip(a.blk_dc(), b.blk_dc()):
+            if pa is not None:
+                assert np.array_equal(pa, pb), "block DC map differs"
+        assert np.array_equal(a.dht_histo(), b.dht_histo()), "Huffman histogram differs"
+        assert a.status() == b.status()
+        assert a.bright_avg() == b.bright_avg()
+
+
+@pytest.mark.parametrize("kw", CASES, ids=lambda k: "-".join(f"{a}{b}" for a, b in k.items()))
+def test_single_image_parity(harness, oracle, gpu, kw):
+    data = harness.synth_jpeg(seed=11, **kw)
+    harness.drive(oracle, data)
+    harness.drive(gpu, data)
+    compare(harness, oracle, gpu)
+    if harness.have_ref():
+        r = harness.ref_backend()
+        harness.drive(r, data)
+        compare(harness, r, gpu)
+        r.close()
+
+
+def test_idct_lut_and_probe(harness, oracle, gpu):
+    assert np.array_equal(oracle.idct_lut().view(np.uint32), gpu.idct_lut().view(np.uint32))
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        c = np.zeros(64, np.int16)
+        nz = rng.integers(1, 64)
+        idx = rng.choice(64, nz, replace=False)
+        c[idx] = rng.integers(-2000, 2000, nz)
+        assert np.array_equal(oracle.idct_block(c).view(np.uint32), gpu.idct_block(c).view(np.uint32))
+
+
+def test_dc_only_mode(harness, oracle, gpu):
+    data = harness.synth_jpeg(width=320, height=240, seed=3)
+    for b in (oracle, gpu):
+        b.set_options(decode_ac=0)
+        harness.drive(b, data)
+    try:
+        compare(harness, oracle, gpu)
+    finally:
+        for b in (oracle, gpu):
+            b.set_options(decode_ac=1)
+
+
+def test_corrupt_streams_exact_path(harness, oracle, gpu):
+    """Malformed scans take the sequential exact-mirror device kernel and must still match the reference semantics."""
+    rng = np.random.default_rng(7)
+    base = [harness.synth_jpeg(width=96, height=64, seed=s, **kw) for s, kw in enumerate(
+        [dict(), dict(hs=1, vs=1), dict(hs=2, vs=1, restart_interval=3), dict(gray=1), dict(restart_interval=1, quality=30)])]
+    for it in range(60):
+        d = bytearray(base[it % len(base)])
+        p = harness.parse_jpeg(bytes(d))
+        s, e = p.scan_start, p.scan_end
+        mode = it % 6
+        if mode == 0:
+            d[rng.integers(s, e)] = rng.integers(0, 256)
+        elif mode == 1:
+            d = d[: rng.integers(s + 1, len(d))]
+        elif mode == 2:
+            i = rng.integers(s, e); d[i:i] = bytes([0xFF, int(rng.integers(1, 256))])
+        elif mode == 3:
+            i = rng.integers(s, e); d[i:i] = bytes([0xFF] * int(rng.integers(2, 5)))
+        elif mode == 4:
+            i = rng.integers(s, e - 4); del d[i:i + int(rng.integers(1, 4))]
+        else:
+            i = rng.integers(s, e); d[i:i] = bytes([0xFF, 0xD0 + int(rng.integers(0, 8))])
+        d = bytes(d)
+        harness.drive(oracle, d, p)
+        harness.drive(gpu, d, p)
+        compare(harness, oracle, gpu)
+
+
+def test_batch_api(harness, oracle):
+    import jpegsnoop_amd as J
+    kws = [dict(width=320, height=240), dict(width=333, height=217, hs=1, vs=1), dict(width=160, height=120, gray=1),
+           dict(width=640, height=360, hs=2, vs=1, restart_interval=40)]
+    files = [harness.synth_jpeg(seed=20 + i, **kw) for i, kw in enumerate(kws)]
+    b = J.JpegBatch(want_planes=True)
+    for f in files:
+        b.add_jpeg(f)
+    b.tile(8)
+    b.upload(); b.decode(); b.sync()
+    sums = b.dib_checksums()
+    for i in range(8):
+        harness.drive(oracle, files[i % 4])
+        assert np.array_equal(b.dib(i), oracle.dib())
+        for pa, pb in zip(oracle.planes(), b.planes(i)):
+            if pa is not None:
+                assert np.array_equal(pa, pb)
+        assert int(sums[i]) == J.dib_checksum_numpy(oracle.dib())
+        assert np.array_equal(b.coefs(i), harness.oracle_coefs(oracle))
+    b.close()
