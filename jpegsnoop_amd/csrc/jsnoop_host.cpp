@@ -39,7 +39,7 @@ JsnoopDecoder::JsnoopDecoder()
     opt_decode_ac = 1; opt_histo_en = 0; opt_stat_clip_en = 0; opt_err_max = 20;
     log_fn = nullptr; log_user = nullptr; batch = nullptr;
     preview_mode = 1; shift_y = shift_cb = shift_cr = 0; shift_mcu_x = shift_mcu_y = 0;
-    preview_is_jpeg = false; have_image = false; host_valid = 0; last_path = 0; last_flags = 0;
+    preview_is_jpeg = false; have_image = false; host_valid = 0; last_path = 0; last_flags = 0; side_ready = false;
     memset(geom, 0, sizeof geom);
     reset_state();
 }
@@ -140,7 +140,7 @@ JsnoopBatch::JsnoopBatch(void* user_stream)
     stream = (hipStream_t)user_stream; own_stream = false;
     opt_decode_ac = 1; opt_want_planes = 0; opt_force_exact = 0;
     memset(&dev, 0, sizeof dev); memset(&cap, 0, sizeof cap);
-    pinned = nullptr; pinned_cap = 0; raw_bytes = 0; uploaded = false;
+    pinned = nullptr; pinned_cap = 0; raw_bytes = 0; uploaded = false; sync_launches = 2;
     for (auto& e : ev) e = nullptr;
     d_lut = nullptr;
 }
@@ -169,7 +169,8 @@ JsnoopBatch::~JsnoopBatch()
     if (stream) hipStreamSynchronize(stream);
     for (void** p : { (void**)&dev.raw, (void**)&dev.ustr, (void**)&dev.coef, (void**)&dev.dccum, (void**)&dev.dib, (void**)&dev.planes,
                       (void**)&dev.side, (void**)&dev.imgs, (void**)&dev.tables, (void**)&dev.wg_base, (void**)&dev.sel, (void**)&dev.sums,
-                      (void**)&dev.sub, (void**)&dev.probe }) if (*p) hipFree(*p);
+                      (void**)&dev.sub, (void**)&dev.probe, (void**)&dev.seg, (void**)&dev.chunk_keep, (void**)&dev.chunk_rst, (void**)&dev.us_base,
+                      (void**)&dev.sy_base, (void**)&dev.mcu_rst, (void**)&dev.flags }) if (*p) hipFree(*p);
     if (d_lut) hipFree(d_lut);
     if (pinned) hipHostFree(pinned);
     for (auto& e : ev) if (e) hipEventDestroy(e);
@@ -239,8 +240,8 @@ int JsnoopBatch::upload()
     const size_t n = imgs.size();
     if (!n) { js_set_error("upload: empty batch"); return -1; }
     uint64_t blocks = 0, dibb = 0, plane = 0, side = 0, ustr = 0, subs = 0;
-    std::vector<uint32_t> wg(n + 1);
-    uint64_t total_strips = 0;
+    std::vector<uint32_t> wg(n + 1), usb(n + 1), syb(n + 1);
+    uint64_t total_strips = 0, segw = 0, mcub = 0; uint32_t usc = 0, syw = 0;
     for (size_t i = 0; i < n; i++) { const JsImage& im = imgs[i]; uint32_t G = 128 / im.mcu_w; total_strips += (uint64_t)((im.mcu_xmax + G - 1) / G) * im.mcu_ymax; }
     strips_per_wg = (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(1, total_strips / 8192));
     uint32_t wgs = 0;
@@ -253,25 +254,37 @@ int JsnoopBatch::upload()
         im.side_off = side; side += align_up(js_side_words(im.mcu_xmax * im.mcu_ymax, im.blk_xmax * im.blk_ymax), 4);
         im.ustr_off = ustr; im.ustr_cap = (uint32_t)align_up(im.scan_len + 64, 64); ustr += im.ustr_cap;
         im.n_subseq = (im.ustr_cap + JS_SUBSEQ_BYTES - 1) / JS_SUBSEQ_BYTES; im.subseq_off = subs; subs += align_up(im.n_subseq, 256);
+        const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax;
+        const uint64_t want_seg = im.rst_interval ? (uint64_t)nmcu / im.rst_interval + 2 : 1;
+        im.seg_cap = (uint32_t)std::min<uint64_t>(65535, want_seg * 2 + 16); im.seg_off = segw; segw += align_up(im.seg_cap, 4);
+        im.mcu_off = mcub; mcub += align_up(nmcu, 16);
+        usb[i] = usc; usc += (uint32_t)(((im.scan_start & 15) + (uint64_t)im.scan_len + JS_US_CHUNK - 1) / JS_US_CHUNK);
+        syb[i] = syw; syw += (im.n_subseq + JS_SY_THREADS - 1) / JS_SY_THREADS;
         const uint32_t G = 128 / im.mcu_w, strips = ((im.mcu_xmax + G - 1) / G) * im.mcu_ymax;
         wg[i] = wgs; wgs += std::max(1u, (strips + strips_per_wg - 1) / strips_per_wg);
     }
+    usb[n] = usc; syb[n] = syw; us_chunks = usc; sy_wgs = syw; seg_words = segw; mcu_bytes = mcub;
     wg[n] = wgs; total_wgs = wgs; total_blocks = blocks; dib_bytes = dibb; side_words = side; total_subseq = subs; ustr_bytes = ustr;
     if (grow(&dev.raw, &cap.raw, raw_bytes + 64) || grow(&dev.coef, &cap.coef, blocks * 128) || grow(&dev.dccum, &cap.dccum, blocks * 2 + 64) ||
         grow(&dev.dib, &cap.dib, dibb) || grow(&dev.side, &cap.side, side * 4) || grow(&dev.imgs, &cap.imgs, n * sizeof(JsImage)) ||
         grow(&dev.tables, &cap.tables, tables.size() * sizeof(JsTableSet)) || grow(&dev.wg_base, &cap.wg_base, (n + 1) * 4) ||
         grow(&dev.sel, &cap.sel, n * 4) || grow(&dev.sums, &cap.sums, n * 8) || grow(&dev.ustr, &cap.ustr, ustr + 64) ||
-        grow(&dev.sub, &cap.sub, subs * 16 + 64) || grow(&dev.probe, &cap.probe, 1024)) return -1;
+        grow(&dev.sub, &cap.sub, subs * 24 + 64) || grow(&dev.probe, &cap.probe, 1024) || grow(&dev.seg, &cap.seg, segw * 4 + 64) ||
+        grow(&dev.chunk_keep, &cap.chunk_keep, (size_t)usc * 4 + 64) || grow(&dev.chunk_rst, &cap.chunk_rst, (size_t)usc * 4 + 64) ||
+        grow(&dev.us_base, &cap.us_base, (n + 1) * 4) || grow(&dev.sy_base, &cap.sy_base, (n + 1) * 4) ||
+        grow(&dev.mcu_rst, &cap.mcu_rst, mcub + 64) || grow(&dev.flags, &cap.flags, n * 4 + 64)) return -1;
     if (opt_want_planes && grow(&dev.planes, &cap.planes, plane * 2)) return -1;
     HIP_TRY(hipMemcpyAsync(dev.raw, pinned, raw_bytes, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(dev.imgs, imgs.data(), n * sizeof(JsImage), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(dev.tables, tables.data(), tables.size() * sizeof(JsTableSet), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(dev.wg_base, wg.data(), (n + 1) * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(dev.us_base, usb.data(), (n + 1) * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(dev.sy_base, syb.data(), (n + 1) * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));          // host vectors above may go out of scope
     uploaded = true;
     return 0;
 }
-static const char* kStageName[JSNOOP_NUM_STAGES] = { "clear", "unstuff", "sync", "blockscan", "write", "dcscan", "idct_color", "exact" };
+static const char* kStageName[JSNOOP_NUM_STAGES] = { "clear", "unstuff", "sync", "blockscan", "write", "dcscan", "exact", "idct_color" };
 
 int JsnoopBatch::decode(bool timed)
 {
@@ -282,12 +295,14 @@ int JsnoopBatch::decode(bool timed)
     HIP_TRY(hipMemsetAsync(dev.coef, 0, total_blocks * 128, stream));
     HIP_TRY(hipMemsetAsync(dev.dccum, 0, total_blocks * 2, stream));
     HIP_TRY(hipMemsetAsync(dev.side, 0, side_words * 4, stream));
+    HIP_TRY(hipMemsetAsync(dev.mcu_rst, 0, mcu_bytes, stream));
+    HIP_TRY(hipMemsetAsync(dev.flags, 0, (size_t)n * 4, stream));
     if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
     // parallel path stages 1..5 (k_unstuff .. k_dc_scan) are launched by js_parallel_entropy
     int used_parallel = opt_force_exact ? 0 : js_parallel_entropy(this, timed);
     if (used_parallel < 0) return -1;
     if (timed && !used_parallel) for (int s = 2; s <= 6; s++) HIP_TRY(hipEventRecord(ev[s], stream));
-    if (!used_parallel) js_launch_entropy_exact(stream, dev.imgs, nullptr, n, dev.tables, dev.raw, dev.coef, dev.dccum, dev.side);
+    if (!used_parallel) js_launch_entropy_exact(stream, dev.imgs, nullptr, n, dev.tables, dev.raw, dev.coef, dev.dccum, dev.side, 0);
     if (timed) HIP_TRY(hipEventRecord(ev[7], stream));
     js_launch_idct_color(stream, dev.imgs, dev.wg_base, n, total_wgs, strips_per_wg, d_lut, dev.coef, dev.dccum, dev.dib, dev.planes, dev.side);
     if (timed) HIP_TRY(hipEventRecord(ev[8], stream));
@@ -387,8 +402,9 @@ void jsnoop_decode_scan_img(JsnoopDecoder* d, const uint8_t* file, size_t len, u
     if (b->upload() || b->decode(false) || b->sync()) { d->log(2, "*** ERROR: device decode failed: %s", g_err.c_str()); return; }
     d->have_image = true; d->host_valid = 0;
     if (display) d->preview_is_jpeg = true;
+    d->last_path = (int)b->host_path[0]; d->last_flags = b->host_flags[0];
+    d->side_ready = d->last_path == 2;          // the exact-mirror kernel fills the side block as it goes
     d->fetch_side();
-    d->last_path = (int)d->h_side[9]; d->last_flags = d->h_side[8];
 }
 
 int  jsnoop_is_preview_ready(JsnoopDecoder* d) { return d->preview_is_jpeg; }
@@ -422,14 +438,16 @@ void jsnoop_get_pixmap_ptrs(JsnoopDecoder* d, const int16_t** y, const int16_t**
 }
 void jsnoop_lookup_file_pos_mcu(JsnoopDecoder* d, unsigned mx, unsigned my, unsigned* byte, unsigned* bit)
 {
+    d->ensure_side();
     *byte = *bit = 0; if (!d->have_image || mx >= d->geom[2] || my >= d->geom[3]) return;
     uint32_t p = d->h_side[JS_SIDE_MCUMAP + mx + my * d->geom[2]]; *bit = p & 7; *byte = p >> 4;     // UnpackFileOffset :5123
 }
 void jsnoop_lookup_file_pos_pix(JsnoopDecoder* d, unsigned px, unsigned py, unsigned* byte, unsigned* bit)
 { jsnoop_lookup_file_pos_mcu(d, px / d->geom[0], py / d->geom[1], byte, bit); }                      // :5001-5009
-const uint32_t* jsnoop_mcu_file_map(JsnoopDecoder* d) { return d->have_image ? d->h_side.data() + JS_SIDE_MCUMAP : nullptr; }
+const uint32_t* jsnoop_mcu_file_map(JsnoopDecoder* d) { d->ensure_side(); return d->have_image ? d->h_side.data() + JS_SIDE_MCUMAP : nullptr; }
 void jsnoop_blk_dc_ptrs(JsnoopDecoder* d, const int16_t** y, const int16_t** cb, const int16_t** cr)
 {
+    d->ensure_side();
     *y = *cb = *cr = nullptr; if (!d->have_image) return;
     const uint32_t nmcu = d->geom[2] * d->geom[3], nblk = d->geom[4] * d->geom[5], w = 2 * ((nblk + 1) / 2);
     const int16_t* base = (const int16_t*)(d->h_side.data() + JS_SIDE_MCUMAP + nmcu);
@@ -441,8 +459,8 @@ void jsnoop_lookup_blk_ycc(JsnoopDecoder* d, unsigned bx, unsigned by, int* y, i
     *y = *cb = *cr = 0; if (!py || bx >= d->geom[4] || by >= d->geom[5]) return;
     size_t i = bx + (size_t)by * d->geom[4]; *y = py[i]; if (pcb) { *cb = pcb[i]; *cr = pcr[i]; }
 }
-const uint32_t* jsnoop_dht_histo(JsnoopDecoder* d) { return d->have_image ? d->h_side.data() + JS_SIDE_HISTO : d->zero_histo; }
-void jsnoop_scan_status(JsnoopDecoder* d, unsigned* o) { for (int i = 0; i < 8; i++) o[i] = d->have_image ? d->h_side[i] : 0; }
+const uint32_t* jsnoop_dht_histo(JsnoopDecoder* d) { d->ensure_side(); return d->have_image ? d->h_side.data() + JS_SIDE_HISTO : d->zero_histo; }
+void jsnoop_scan_status(JsnoopDecoder* d, unsigned* o) { d->ensure_side(); for (int i = 0; i < 8; i++) o[i] = d->have_image ? d->h_side[i] : 0; }
 void jsnoop_bright_avg(JsnoopDecoder* d, int* o)
 {
     memset(o, 0, 10 * sizeof(int)); o[1] = o[2] = o[3] = -32768;
@@ -580,6 +598,11 @@ int JsnoopBatch::read_planes(int i, int16_t* y, int16_t* cb, int16_t* cr)
     for (uint32_t c = 0; c < im.ncomp; c++) if (dst[c]) HIP_TRY(hipMemcpyAsync(dst[c], dev.planes + im.plane_off + c * psz, psz * 2, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return 0;
+}
+void JsnoopDecoder::ensure_side()
+{
+    if (!have_image || side_ready) return;
+    if (js_side_only(batch, 0) == 0) { side_ready = true; fetch_side(); }
 }
 void JsnoopDecoder::fetch_side()
 {

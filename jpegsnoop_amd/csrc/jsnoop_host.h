@@ -36,14 +36,18 @@ struct JsnoopDecoder {
     void reset_state();
     void log(int level, const char* fmt, ...);
     void fetch_side();
+    void ensure_side();      // side outputs are produced on first request when the parallel path decoded the image
+    bool side_ready;
     void rerender();
 };
 
 struct JsDeviceArenas {
     uint8_t* raw; uint8_t* ustr; int16_t* coef; int16_t* dccum; uint8_t* dib; int16_t* planes; uint32_t* side;
     JsImage* imgs; JsTableSet* tables; uint32_t* wg_base; uint32_t* sel; uint64_t* sums; uint8_t* sub; uint8_t* probe;
+    uint32_t* seg; uint32_t* chunk_keep; uint32_t* chunk_rst; uint32_t* us_base; uint32_t* sy_base; uint8_t* mcu_rst; uint32_t* flags;
 };
-struct JsArenaCaps { size_t raw, ustr, coef, dccum, dib, planes, side, imgs, tables, wg_base, sel, sums, sub, probe; };
+struct JsArenaCaps { size_t raw, ustr, coef, dccum, dib, planes, side, imgs, tables, wg_base, sel, sums, sub, probe,
+                            seg, chunk_keep, chunk_rst, us_base, sy_base, mcu_rst, flags; };
 
 struct JsnoopBatch {
     int device; hipStream_t stream; bool own_stream;
@@ -53,7 +57,8 @@ struct JsnoopBatch {
     uint8_t* pinned; size_t pinned_cap; uint64_t raw_bytes;
     JsDeviceArenas dev; JsArenaCaps cap;
     bool uploaded;
-    uint64_t total_blocks, dib_bytes, side_words, total_subseq, ustr_bytes; uint32_t total_wgs, strips_per_wg;
+    uint64_t total_blocks, dib_bytes, side_words, total_subseq, ustr_bytes, seg_words, mcu_bytes; uint32_t total_wgs, strips_per_wg, us_chunks, sy_wgs;
+    int sync_launches;
     hipEvent_t ev[JSNOOP_NUM_STAGES + 1];
     float lut[64][64]; float* d_lut;
     explicit JsnoopBatch(void* user_stream);
@@ -68,6 +73,7 @@ struct JsnoopBatch {
     int  sync();
     int  read_dib(int i, uint8_t* dst);
     int  read_planes(int i, int16_t* y, int16_t* cb, int16_t* cr);
+    int  run_exact(const std::vector<uint32_t>& which);
 };
 
 void js_set_error(const char* fmt, ...);
@@ -75,4 +81,5 @@ bool js_describe_image(JsnoopDecoder* d, JsImage* im, JsTableSet* ts, uint32_t f
 void js_build_parallel_luts(JsTableSet* ts, uint32_t ncomp);          // jsnoop_parallel.cpp
 int  js_parallel_entropy(JsnoopBatch* b, bool timed);                 // 1 = launched, 0 = not applicable, <0 error
 int  js_parallel_fixup(JsnoopBatch* b);
+int  js_side_only(JsnoopBatch* b, uint32_t i);
 int  js_jfif_walk(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned* scan_start);   // jfif_front.cpp

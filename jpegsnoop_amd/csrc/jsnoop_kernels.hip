@@ -185,8 +185,11 @@ __device__ int16_t ex_decode_block(ExactReader& r, uint32_t comp, uint32_t decod
 
 __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sel, uint32_t nsel,
                                                       const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ raw,
-                                                      int16_t* __restrict__ coef, int16_t* __restrict__ dccum, uint32_t* __restrict__ side)
+                                                      int16_t* __restrict__ coef, int16_t* __restrict__ dccum, uint32_t* __restrict__ side, int side_only)
 {
+    // side_only: recompute only the decoder's side outputs (MCU file map, block-DC maps, code-length
+    // histogram, status words) for an image whose pixels came from the parallel path.
+    int16_t scratch[64];
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nsel) return;
     const JsImage& im = imgs[sel ? sel[j] : j];
@@ -217,13 +220,13 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
                 const uint32_t comp = im.blk_comp[c];
                 const size_t b = (size_t)mi * im.blk_per_mcu + c;
                 const uint32_t rst_before = r.rst_handled;
-                int16_t d0 = ex_decode_block(r, comp, im.decode_ac, cbase + b * 64, dc_y, dc_cb, dc_cr);
+                int16_t d0 = ex_decode_block(r, comp, im.decode_ac, side_only ? scratch : cbase + b * 64, dc_y, dc_cb, dc_cr);
                 if (r.rst_handled != rst_before) for (int cc = 0; cc < 3; cc++) for (int i = 0; i < 16; i++) css[cc][i] = 0;
                 if (r.cur_err) { if (r.warn_bad < r.err_max) r.warn_bad++; r.cur_err = 0; }   // CheckScanErrors :2605
                 int16_t* acc = comp == 1 ? &dc_y : comp == 2 ? &dc_cb : &dc_cr;
                 *acc = (int16_t)(*acc + d0);
                 css[comp - 1][im.blk_cv[c] * 4 + im.blk_ch[c]] = *acc;
-                dbase[b] = *acc;
+                if (!side_only) dbase[b] = *acc;
                 if (comp == 1) num_pixels += 64;
             }
             {   // per-block cumulative DC maps :3524-3608 (sequential overwrite order preserved)
@@ -240,7 +243,7 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
         }
     }
     sd[0] = r.scan_bad; sd[1] = r.scan_end; sd[2] = r.rst_count; sd[3] = num_pixels;
-    sd[4] = r.pos0; sd[5] = r.align; sd[6] = r.warn_bad; sd[7] = r.ptr_first; sd[9] = 2;
+    sd[4] = r.pos0; sd[5] = r.align; sd[6] = r.warn_bad; sd[7] = r.ptr_first; if (!side_only) sd[9] = 2;
 }
 
 // =====================================================================================
@@ -250,7 +253,9 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
 //  (lane-contiguous rows => conflict-free ds_read_b32); samples are staged in LDS as
 //  full-resolution int16 planes so the DIB rows leave as 16-byte coalesced stores.
 // =====================================================================================
-#define BK_THREADS 256
+#define BK_THREADS 512
+#define BK_WAVES (BK_THREADS / 64)
+#define BK_CHUNK 6
 #define BK_MAX_STRIP_W 128
 #define BK_MAX_MCU_H 32
 
@@ -286,13 +291,10 @@ __device__ __forceinline__ void ycc_to_rgb(int py, int pcb, int pcr, uint32_t mo
 
 // DecodeIdctCalcFloat(64) :2372-2392 on one block held one coefficient per lane, then
 // SetFullRes :2468-2561 into the strip's LDS planes (replicated eH x eV times).
-__device__ __forceinline__ void idct_block_to_lds(const JsImage& im, const int16_t* __restrict__ cbase, const int16_t* __restrict__ dbase,
-                                                  const float* s_lut, int16_t (*s_pl)[BK_MAX_MCU_H][BK_MAX_STRIP_W],
-                                                  uint32_t my, uint32_t mx0, uint32_t bb, uint32_t nb, uint32_t lane)
+__device__ __forceinline__ void idct_block_to_lds(const JsImage& im, int cv16, int16_t dc, const float* s_lut,
+                                                  int16_t (*s_pl)[BK_MAX_MCU_H][BK_MAX_STRIP_W], uint32_t bb, uint32_t nb, uint32_t lane)
 {
     const uint32_t m = bb / nb, c = bb % nb;
-    const size_t b = (size_t)(my * im.mcu_xmax + mx0 + m) * nb + c;
-    const int cv16 = cbase[b * 64 + lane];
     const float cf = (float)cv16;
     uint64_t mask = __ballot(cv16 != 0) & ~1ull;                 // DC is excluded from the sum (:2381)
     float acc = 0.0f;
@@ -303,7 +305,6 @@ __device__ __forceinline__ void idct_block_to_lds(const JsImage& im, const int16
         acc = __fadd_rn(acc, __fmul_rn(s_lut[vu * 64 + lane], cvu));   // separate mul and add, ascending natural order
     }
     acc = __fmul_rn(acc, 0.25f);
-    const int16_t dc = dbase[b];
     const int16_t smp = (int16_t)((int16_t)(int)__fmul_rn(acc, 8.0f) + dc);   // SetFullRes :2517-2519
     const uint32_t comp = im.blk_comp[c], eh = im.expand_h[comp], ev = im.expand_v[comp];
     const uint32_t x0 = m * im.mcu_w + im.blk_ch[c] * 8 + (lane & 7) * eh, y0 = im.blk_cv[c] * 8 + (lane >> 3) * ev;
@@ -344,15 +345,29 @@ __global__ void __launch_bounds__(BK_THREADS) k_idct_color(const JsImage* __rest
         const uint32_t my = s / strips_x, mx0 = (s % strips_x) * G;
         const uint32_t gm = min(G, im.mcu_xmax - mx0), sw = gm * im.mcu_w;
         const uint32_t nblocks = gm * nb;
-        // ---- IDCT: one wave per 8x8 block -------------------------------------------------------
+        // ---- IDCT: one wave per 8x8 block; each wave first issues the loads of BK_CHUNK blocks
+        //      (one coalesced 128-byte row each) so their HBM latencies overlap ------------------
+        const size_t b0 = (size_t)(my * im.mcu_xmax + mx0) * nb;       // blocks of a strip are contiguous in decode order
         if (!overlap) {
-            for (uint32_t bb = wave; bb < nblocks; bb += 4)
-                idct_block_to_lds(im, cbase, dbase, s_lut, s_pl, my, mx0, bb, nb, lane);
+            for (uint32_t base = 0; base < nblocks; base += BK_WAVES * BK_CHUNK) {
+                int cv[BK_CHUNK]; int16_t dcv[BK_CHUNK];
+                #pragma unroll
+                for (int j = 0; j < BK_CHUNK; j++) {
+                    const uint32_t bb = base + j * BK_WAVES + wave;
+                    cv[j] = bb < nblocks ? (int)cbase[(b0 + bb) * 64 + lane] : 0;
+                    dcv[j] = bb < nblocks ? dbase[b0 + bb] : (int16_t)0;
+                }
+                #pragma unroll
+                for (int j = 0; j < BK_CHUNK; j++) {
+                    const uint32_t bb = base + j * BK_WAVES + wave;
+                    if (bb < nblocks) idct_block_to_lds(im, cv[j], dcv[j], s_lut, s_pl, bb, nb, lane);
+                }
+            }
         } else {
             // A component that is both multi-block and expanded overlaps its own blocks
             // (SetFullRes :2498-2557): later blocks must overwrite earlier ones, so serialise.
             for (uint32_t bb = 0; bb < nblocks; bb++) {
-                if (wave == 0) idct_block_to_lds(im, cbase, dbase, s_lut, s_pl, my, mx0, bb, nb, lane);
+                if (wave == 0) idct_block_to_lds(im, (int)cbase[(b0 + bb) * 64 + lane], dbase[b0 + bb], s_lut, s_pl, bb, nb, lane);
                 __syncthreads();
             }
         }
@@ -438,10 +453,10 @@ __global__ void __launch_bounds__(256) k_dib_checksum(const JsImage* __restrict_
 
 // ------------------------------------------------------------------------------ launch wrappers
 void js_launch_entropy_exact(hipStream_t st, const JsImage* imgs, const uint32_t* sel, uint32_t nsel, const JsTableSet* tables,
-                             const uint8_t* raw, int16_t* coef, int16_t* dccum, uint32_t* side)
+                             const uint8_t* raw, int16_t* coef, int16_t* dccum, uint32_t* side, int side_only)
 {
     if (!nsel) return;
-    hipLaunchKernelGGL(k_entropy_exact, dim3((nsel + 63) / 64), dim3(64), 0, st, imgs, sel, nsel, tables, raw, coef, dccum, side);
+    hipLaunchKernelGGL(k_entropy_exact, dim3((nsel + 63) / 64), dim3(64), 0, st, imgs, sel, nsel, tables, raw, coef, dccum, side, side_only);
 }
 void js_launch_idct_color(hipStream_t st, const JsImage* imgs, const uint32_t* wg_base, uint32_t nimg, uint32_t total_wgs, uint32_t strips_per_wg,
                           const float* lut_t, const int16_t* coef, const int16_t* dccum, uint8_t* dib, int16_t* planes, uint32_t* side)
@@ -459,3 +474,422 @@ void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, 
     const uint32_t chunks = 64;
     hipLaunchKernelGGL(k_dib_checksum, dim3(chunks, nimg), dim3(256), 0, st, imgs, chunks, dib, sums);
 }
+
+// =====================================================================================
+//  Parallel entropy path.
+//
+//  (1) k_unstuff_count / k_unstuff_scan / k_unstuff_write : apply the reference's byte rules
+//      (BuffAddByte :1386-1573) once, in parallel: drop the 00 after FF, cut the stream at every
+//      RSTn into restart intervals (interval table = start byte of each interval in the
+//      compacted stream).  After this the bit cursor can be advanced with plain word loads.
+//  (2) k_sync : every thread owns one 1024-bit sub-sequence.  It first decodes speculatively
+//      from its own first bit, then repeatedly re-decodes from its left neighbour's exit state
+//      until the exit states stop changing (Huffman codes self-synchronise after a few
+//      symbols).  A fixed point of the chain is exactly the sequential decode.
+//  (3) k_block_scan : exclusive prefix sum of "blocks completed per sub-sequence" = the
+//      absolute block index at which every sub-sequence starts writing.
+//  (4) k_write : final decode from the synchronised entry states; dequantise + de-zigzag
+//      (DecodeIdctSet :2270-2303) straight into the coefficient arena; verifies the chain.
+//  (5) k_dc_scan : int16 wrapping prefix sum of the DC differences per component, reset at
+//      every interval boundary actually present in the stream (:3280, :2693-2703, :1660).
+//  Anything that deviates from a well-formed scan raises a JSNOOP_FLAG_* bit for the image;
+//  flagged images are re-decoded by k_entropy_exact so malformed streams stay reference-exact.
+// =====================================================================================
+#define US_THREADS 256
+#define US_CHUNK   (US_THREADS * 16)
+#define SY_THREADS 256
+#define SUB_BITS   (JS_SUBSEQ_BYTES * 8)
+
+#define F_BAD_CODE      0x0001u
+#define F_OVERRUN       0x0002u
+#define F_COEF_OVERFLOW 0x0004u
+#define F_RST_MISALIGN  0x0008u
+#define F_SHORT         0x0010u
+#define F_NOSYNC        0x0080u
+
+struct UsBytes { uint32_t keep_mask, rst_mask; };
+
+// Classifies the 16 bytes at absolute raw offset `o16` of image `im` (scan range [s,e)).
+__device__ __forceinline__ UsBytes us_classify(const uint8_t* __restrict__ raw, uint64_t o16, uint64_t s, uint64_t e)
+{
+    UsBytes r; r.keep_mask = 0; r.rst_mask = 0;
+    if (o16 + 16 <= s || o16 >= e) return r;
+    const uint4 v = *reinterpret_cast<const uint4*>(raw + o16);
+    const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+    uint32_t prev = o16 > s ? raw[o16 - 1] : 0u;             // bytes before the scan start never count as FF
+    const uint32_t next16 = (o16 + 16 < e) ? raw[o16 + 16] : 0u;
+    #pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint64_t o = o16 + j;
+        const uint32_t b = (w[j >> 2] >> ((j & 3) * 8)) & 255u;
+        const uint32_t nb = j < 15 ? ((w[(j + 1) >> 2] >> (((j + 1) & 3) * 8)) & 255u) : next16;
+        const bool in = o >= s && o < e;
+        const bool is_rst = in && b == 0xFF && (o + 1 < e) && nb >= 0xD0 && nb <= 0xD7;
+        const bool drop = (prev == 0xFF && o > s) || is_rst;    // the byte after an FF is a stuffed 00 or the RSTn code
+        if (in && !drop) r.keep_mask |= 1u << j;
+        if (is_rst) r.rst_mask |= 1u << j;
+        prev = b;
+    }
+    return r;
+}
+
+// Finds (image, chunk) of a workgroup from an exclusive prefix table.
+__device__ __forceinline__ uint32_t find_image(const uint32_t* __restrict__ base, uint32_t nimg, uint32_t wg)
+{
+    uint32_t lo = 0, hi = nimg;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (base[mid] <= wg) lo = mid; else hi = mid; }
+    return lo;
+}
+
+__global__ void __launch_bounds__(US_THREADS) k_unstuff_count(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ us_base, uint32_t nimg,
+                                                              const uint8_t* __restrict__ raw, uint32_t* __restrict__ chunk_keep, uint32_t* __restrict__ chunk_rst)
+{
+    const uint32_t img = find_image(us_base, nimg, blockIdx.x);
+    const JsImage& im = imgs[img];
+    const uint64_t s = im.file_off + im.scan_start, e = s + im.scan_len;
+    const uint64_t o16 = (s & ~15ull) + (uint64_t)(blockIdx.x - us_base[img]) * US_CHUNK + threadIdx.x * 16;
+    const UsBytes c = us_classify(raw, o16, s, e);
+    uint32_t nk = __popc(c.keep_mask), nr = __popc(c.rst_mask);
+    for (int off = 32; off > 0; off >>= 1) { nk += __shfl_down(nk, off); nr += __shfl_down(nr, off); }
+    __shared__ uint32_t sk[US_THREADS / 64], sr[US_THREADS / 64];
+    if ((threadIdx.x & 63) == 0) { sk[threadIdx.x >> 6] = nk; sr[threadIdx.x >> 6] = nr; }
+    __syncthreads();
+    if (threadIdx.x == 0) { chunk_keep[blockIdx.x] = sk[0] + sk[1] + sk[2] + sk[3]; chunk_rst[blockIdx.x] = sr[0] + sr[1] + sr[2] + sr[3]; }
+}
+
+// One workgroup per image: exclusive scan over its chunks (in place), totals into the side block,
+// interval table entry 0 and the end sentinel.
+__global__ void __launch_bounds__(256) k_unstuff_scan(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ us_base,
+                                                      uint32_t* __restrict__ chunk_keep, uint32_t* __restrict__ chunk_rst,
+                                                      uint32_t* __restrict__ seg_tab, uint32_t* __restrict__ side, uint32_t* __restrict__ flags)
+{
+    const uint32_t img = blockIdx.x; const JsImage& im = imgs[img];
+    const uint32_t c0 = us_base[img], nc = us_base[img + 1] - c0;
+    __shared__ uint32_t s_k[256], s_r[256]; __shared__ uint32_t run_k, run_r;
+    if (threadIdx.x == 0) { run_k = 0; run_r = 0; }
+    __syncthreads();
+    for (uint32_t b = 0; b < nc; b += 256) {
+        const uint32_t i = b + threadIdx.x;
+        uint32_t k = i < nc ? chunk_keep[c0 + i] : 0, r = i < nc ? chunk_rst[c0 + i] : 0;
+        s_k[threadIdx.x] = k; s_r[threadIdx.x] = r; __syncthreads();
+        for (uint32_t d = 1; d < 256; d <<= 1) {                           // Hillis-Steele inclusive scan
+            uint32_t ak = threadIdx.x >= d ? s_k[threadIdx.x - d] : 0, ar = threadIdx.x >= d ? s_r[threadIdx.x - d] : 0;
+            __syncthreads(); s_k[threadIdx.x] += ak; s_r[threadIdx.x] += ar; __syncthreads();
+        }
+        if (i < nc) { chunk_keep[c0 + i] = run_k + s_k[threadIdx.x] - k; chunk_rst[c0 + i] = run_r + s_r[threadIdx.x] - r; }
+        __syncthreads();
+        if (threadIdx.x == 255) { run_k += s_k[255]; run_r += s_r[255]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        uint32_t* sd = side + im.side_off; uint32_t* st = seg_tab + im.seg_off;
+        sd[10] = run_k; sd[11] = run_r + 1;
+        st[0] = 0;
+        if (run_r + 2 <= im.seg_cap) st[run_r + 1] = run_k; else atomicOr(&flags[img], F_OVERRUN);
+    }
+}
+
+__global__ void __launch_bounds__(US_THREADS) k_unstuff_write(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ us_base, uint32_t nimg,
+                                                              const uint8_t* __restrict__ raw, const uint32_t* __restrict__ chunk_keep,
+                                                              const uint32_t* __restrict__ chunk_rst, uint8_t* __restrict__ ustr, uint32_t* __restrict__ seg_tab)
+{
+    const uint32_t img = find_image(us_base, nimg, blockIdx.x);
+    const JsImage& im = imgs[img];
+    const uint64_t s = im.file_off + im.scan_start, e = s + im.scan_len;
+    const uint64_t o16 = (s & ~15ull) + (uint64_t)(blockIdx.x - us_base[img]) * US_CHUNK + threadIdx.x * 16;
+    const UsBytes c = us_classify(raw, o16, s, e);
+    const uint32_t nk = __popc(c.keep_mask), nr = __popc(c.rst_mask), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t pk = nk, pr = nr;                                             // inclusive wave scans
+    for (int off = 1; off < 64; off <<= 1) { uint32_t a = __shfl_up(pk, off), b = __shfl_up(pr, off); if (lane >= (uint32_t)off) { pk += a; pr += b; } }
+    __shared__ uint32_t wk[US_THREADS / 64], wr[US_THREADS / 64];
+    if (lane == 63) { wk[wave] = pk; wr[wave] = pr; }
+    __syncthreads();
+    uint32_t bk = chunk_keep[blockIdx.x], br = chunk_rst[blockIdx.x];
+    for (uint32_t w = 0; w < wave; w++) { bk += wk[w]; br += wr[w]; }
+    uint32_t out = bk + pk - nk, seg = br + pr - nr;                       // exclusive prefixes of this thread
+    if (!(c.keep_mask | c.rst_mask)) return;
+    uint8_t* dst = ustr + im.ustr_off; uint32_t* st = seg_tab + im.seg_off;
+    const uint4 v = *reinterpret_cast<const uint4*>(raw + o16);
+    const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
+    #pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if (c.rst_mask & (1u << j)) { seg++; if (seg + 1 < im.seg_cap) st[seg] = out; }     // interval `seg` starts at the next kept byte
+        if (c.keep_mask & (1u << j)) dst[out++] = (uint8_t)(w4[j >> 2] >> ((j & 3) * 8));
+    }
+}
+
+// ---- Huffman symbol walk shared by the sync and write passes ------------------------------
+struct SubTabs {                       // per-workgroup LDS copy of one image's decode tables
+    uint16_t lut1[6][1 << JS_FAST_BITS];
+    uint16_t lut2[JS_LUT2_MAX];
+    uint16_t qzz[3][64];
+    uint8_t  slot_dc[JS_MAX_BLK_PER_MCU];  // table slot (comp-1)*2 of each block of the MCU
+    uint8_t  zz[64];
+};
+
+struct Cursor {                        // MSB-first 64-bit window over the compacted stream
+    const uint32_t* words; uint32_t widx; uint64_t buf; int cnt; uint32_t p;
+};
+__device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
+__device__ __forceinline__ void cur_init(Cursor& c, const uint32_t* words, uint32_t p)
+{
+    c.words = words; c.p = p; c.widx = p >> 5;
+    const uint64_t w0 = bswap32(words[c.widx]), w1 = bswap32(words[c.widx + 1]);
+    const uint32_t sh = p & 31;
+    c.buf = ((w0 << 32) | w1) << sh; c.cnt = 64 - (int)sh; c.widx += 2;
+}
+__device__ __forceinline__ void cur_refill(Cursor& c)
+{ if (c.cnt <= 32) { c.buf |= (uint64_t)bswap32(c.words[c.widx++]) << (32 - c.cnt); c.cnt += 32; } }
+__device__ __forceinline__ void cur_skip(Cursor& c, uint32_t n) { c.buf <<= n; c.cnt -= (int)n; c.p += n; }
+
+// state word: [31:16] interval index, [15:8] block-in-MCU, [7:0] next coefficient index (0 = DC)
+#define ST_SEG(s) ((s) >> 16)
+#define ST_C(s)   (((s) >> 8) & 255u)
+#define ST_K(s)   ((s) & 255u)
+#define ST_MAKE(seg, c, k) (((seg) << 16) | ((c) << 8) | (k))
+#define P_END 0xFFFFFFFFu
+
+template <bool WRITE>
+__device__ __forceinline__ void walk_subseq(const JsImage& im, const SubTabs& T, const uint32_t* __restrict__ words, const uint32_t* __restrict__ st,
+                                            uint32_t nseg, uint32_t total_bits, uint32_t own_end, uint32_t& p_io, uint32_t& s_io, uint32_t& nblk_out,
+                                            int16_t* __restrict__ cbase, int16_t* __restrict__ dbase, uint8_t* __restrict__ mcu_rst, uint32_t blk0, uint32_t& flags)
+{
+    uint32_t p = p_io, seg = ST_SEG(s_io), c = ST_C(s_io), k = ST_K(s_io), nblk = 0;
+    if (p == P_END || (p >= total_bits && seg + 1 >= nseg)) { p_io = P_END; s_io = 0; nblk_out = 0; return; }
+    uint32_t seg_end = st[seg + 1] * 8;
+    const uint32_t nb = im.blk_per_mcu, prec_shift = im.precision >= 8 ? ((im.precision - 8) & 31) : 0;
+    Cursor cur; cur_init(cur, words, p);
+    uint32_t blk = blk0;                                   // WRITE: absolute block index being filled
+    int16_t* out = WRITE ? cbase + (size_t)blk * 64 : nullptr;
+    while (cur.p < own_end) {
+        cur_refill(cur);
+        const uint32_t slot = T.slot_dc[c] + (k ? 1u : 0u);
+        uint32_t e = T.lut1[slot][cur.buf >> 55];
+        if (e & 0x8000u) { const uint32_t nbx = (e >> 12) & 7u; e = T.lut2[(e & 0xFFFu) + ((uint32_t)(cur.buf >> (55 - nbx)) & ((1u << nbx) - 1u))]; }
+        const uint32_t len = (e >> 8) & 31u, sym = e & 255u, size = sym & 15u, run = sym >> 4;
+        const uint32_t remain = seg_end > cur.p ? seg_end - cur.p : 0u;   // bits left in this restart interval
+        if (len == 0 || len > remain) {
+            // No code fits in what is left of the interval: what the reference sees as RSV_RST_TERM
+            // (:1167-1176) when an RSTn follows, or the end of the entropy data otherwise.
+            if (seg + 1 < nseg) {
+                if (WRITE) {
+                    if (k != 0 || c != 0 || remain >= 8) flags |= F_RST_MISALIGN;   // well-formed: < 8 pad bits, on an MCU boundary
+                    if (blk < im.total_blocks) mcu_rst[blk / nb] = 1;
+                }
+                seg++; const uint32_t np = seg_end; seg_end = st[seg + 1] * 8; c = 0; k = 0;
+                if (WRITE && seg_end == np && seg + 1 < nseg) flags |= F_RST_MISALIGN;       // back-to-back RSTn
+                cur_init(cur, words, np);
+                continue;
+            }
+            if (WRITE && blk < im.total_blocks) flags |= (len == 0 && remain >= 16) ? F_BAD_CODE : F_SHORT;
+            cur.p = P_END; c = 0; k = 0; seg = 0;
+            break;
+        }
+        if (len + size > remain) { if (WRITE && blk < im.total_blocks) flags |= F_OVERRUN; }
+        if (WRITE && blk < im.total_blocks && (k == 0 || im.decode_ac)) {
+            // value bits: EXTEND (HuffmanDc2Signed :859), precision divide (:1234-1238), dequantise (:2278)
+            int32_t val = 0;
+            if (size) {
+                const uint32_t v = (uint32_t)((cur.buf << len) >> (64 - size));
+                val = v >= (1u << (size - 1)) ? (int32_t)v : (int32_t)(v - ((1u << size) - 1u));
+                if (prec_shift) val /= (int32_t)(1u << prec_shift);
+            }
+            const uint32_t ind = k == 0 ? 0u : k + run;
+            if (ind < 64 && (k == 0 || size)) {
+                const int16_t dq = (int16_t)((int32_t)(int16_t)val * (int32_t)T.qzz[T.slot_dc[c] >> 1][ind]);
+                out[T.zz[ind]] = dq;
+                if (k == 0) dbase[blk] = dq;
+            }
+        }
+        cur_skip(cur, len + size);
+        bool done;
+        if (k == 0) { k = 1; done = false; }
+        else if (sym == 0) done = true;                         // EOB
+        else { k += run + 1; done = k >= 64; if (WRITE && k > 64 && blk < im.total_blocks) flags |= F_COEF_OVERFLOW; }
+        if (done) { k = 0; c = c + 1 == nb ? 0 : c + 1; nblk++; if (WRITE) { blk++; out += 64; } }
+    }
+    p_io = cur.p; s_io = cur.p == P_END ? 0u : ST_MAKE(seg, c, k); nblk_out = nblk;
+}
+
+__device__ __forceinline__ void load_subtabs(SubTabs& T, const JsImage& im, const JsTableSet& ts, uint32_t tid, uint32_t nthreads)
+{
+    for (uint32_t i = tid; i < 6 * (1u << JS_FAST_BITS); i += nthreads) (&T.lut1[0][0])[i] = (&ts.lut1[0][0])[i];
+    for (uint32_t i = tid; i < JS_LUT2_MAX; i += nthreads) T.lut2[i] = ts.lut2[i];
+    for (uint32_t i = tid; i < 3 * 64; i += nthreads) (&T.qzz[0][0])[i] = (&ts.qzz[0][0])[i];
+    if (tid < JS_MAX_BLK_PER_MCU) T.slot_dc[tid] = tid < im.blk_per_mcu ? (uint8_t)((im.blk_comp[tid] - 1) * 2) : 0;
+    if (tid < 64) T.zz[tid] = c_zigzag[tid];
+}
+// upper_bound(seg table, byte) - 1 : the interval a speculative start position lies in
+__device__ __forceinline__ uint32_t find_interval(const uint32_t* __restrict__ st, uint32_t nseg, uint32_t byte)
+{
+    uint32_t lo = 0, hi = nseg;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (st[mid] <= byte) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// sub-sequence state arrays (SoA, one u32 each per sub-sequence slot)
+struct SubArrays { uint32_t *out_p, *out_s, *in_p, *in_s, *nblk, *base; };
+
+__global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sy_base, uint32_t nimg,
+                                                     const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr,
+                                                     const uint32_t* __restrict__ seg_tab, const uint32_t* __restrict__ side, SubArrays A, int first_pass)
+{
+    __shared__ SubTabs T;
+    __shared__ uint32_t s_p[SY_THREADS], s_s[SY_THREADS];
+    __shared__ int s_changed;
+    const uint32_t img = find_image(sy_base, nimg, blockIdx.x);
+    const JsImage& im = imgs[img];
+    if (!tables[im.tableset].lut_ok) return;
+    const uint32_t* sd = side + im.side_off;
+    const uint32_t total_bits = sd[10] * 8, nseg = min(sd[11], im.seg_cap - 1);
+    const uint32_t sub0 = (blockIdx.x - sy_base[img]) * SY_THREADS, i = sub0 + threadIdx.x;
+    if (sub0 * SUB_BITS >= total_bits && sub0) return;          // whole workgroup lies past the end of the data
+    load_subtabs(T, im, tables[im.tableset], threadIdx.x, SY_THREADS);
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);
+    const uint32_t* st = seg_tab + im.seg_off;
+    const size_t g = im.subseq_off + i;
+    const uint32_t own_end = min((i + 1) * SUB_BITS, total_bits);
+    uint32_t my_in_p, my_in_s, out_p, out_s, nblk = 0, dummy = 0;
+    if (first_pass) { my_in_p = 0xFFFFFFFEu; my_in_s = 0; out_p = 0; out_s = 0; }
+    else { my_in_p = A.in_p[g]; my_in_s = A.in_s[g]; out_p = A.out_p[g]; out_s = A.out_s[g]; nblk = A.nblk[g]; }
+    s_p[threadIdx.x] = out_p; s_s[threadIdx.x] = out_s;
+    __syncthreads();
+    for (int it = 0; it < SY_THREADS + 2; it++) {
+        uint32_t ip, is;
+        if (first_pass && it == 0) {                             // speculative start at the first bit of the sub-sequence
+            ip = i * SUB_BITS; is = i * SUB_BITS < total_bits ? ST_MAKE(find_interval(st, nseg, i * (SUB_BITS / 8)), 0u, 0u) : 0u;
+            if (i * SUB_BITS >= total_bits) ip = P_END;
+        } else if (i == 0) { ip = 0; is = 0; }                   // true start of the scan: interval 0, block 0, DC
+        else if (threadIdx.x == 0) { ip = A.out_p[g - 1]; is = A.out_s[g - 1]; }
+        else { ip = s_p[threadIdx.x - 1]; is = s_s[threadIdx.x - 1]; }
+        if (threadIdx.x == 0) s_changed = 0;
+        __syncthreads();
+        if (ip != my_in_p || is != my_in_s) {
+            my_in_p = ip; my_in_s = is;
+            uint32_t p = ip, s = is;
+            if (p != P_END && p >= own_end) { nblk = 0; }        // owns no symbol: state passes through
+            else walk_subseq<false>(im, T, words, st, nseg, total_bits, own_end, p, s, nblk, nullptr, nullptr, nullptr, 0, dummy);
+            if (p != out_p || s != out_s) { out_p = p; out_s = s; s_changed = 1; }
+        }
+        __syncthreads();
+        s_p[threadIdx.x] = out_p; s_s[threadIdx.x] = out_s;
+        const int ch = s_changed;
+        __syncthreads();
+        if (!ch && !(first_pass && it == 0)) break;
+    }
+    A.out_p[g] = out_p; A.out_s[g] = out_s; A.in_p[g] = my_in_p; A.in_s[g] = my_in_s; A.nblk[g] = nblk;
+}
+
+// One workgroup per image: exclusive scan of blocks-per-sub-sequence.
+__global__ void __launch_bounds__(256) k_block_scan(const JsImage* __restrict__ imgs, const JsTableSet* __restrict__ tables,
+                                                    SubArrays A, uint32_t* side, uint32_t* __restrict__ flags)
+{
+    const uint32_t img = blockIdx.x; const JsImage& im = imgs[img];
+    if (!tables[im.tableset].lut_ok) { if (threadIdx.x == 0) atomicOr(&flags[img], 0x0020u); return; }
+    const uint32_t total_bits = side[im.side_off + 10] * 8;
+    const uint32_t n = min(im.n_subseq, (total_bits + SUB_BITS - 1) / SUB_BITS);
+    __shared__ uint32_t s_v[256]; __shared__ uint32_t run;
+    if (threadIdx.x == 0) run = 0;
+    __syncthreads();
+    for (uint32_t b = 0; b < n; b += 256) {
+        const uint32_t i = b + threadIdx.x; const uint32_t v = i < n ? A.nblk[im.subseq_off + i] : 0;
+        s_v[threadIdx.x] = v; __syncthreads();
+        for (uint32_t d = 1; d < 256; d <<= 1) { uint32_t a = threadIdx.x >= d ? s_v[threadIdx.x - d] : 0; __syncthreads(); s_v[threadIdx.x] += a; __syncthreads(); }
+        if (i < n) A.base[im.subseq_off + i] = run + s_v[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255) run += s_v[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { side[im.side_off + 14] = run; if (run < im.total_blocks) atomicOr(&flags[img], F_SHORT); }
+}
+
+__global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sy_base, uint32_t nimg,
+                                                      const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr,
+                                                      const uint32_t* __restrict__ seg_tab, const uint32_t* __restrict__ side, SubArrays A,
+                                                      int16_t* __restrict__ coef, int16_t* __restrict__ dccum, uint8_t* __restrict__ mcu_rst, uint32_t* __restrict__ flags)
+{
+    __shared__ SubTabs T;
+    const uint32_t img = find_image(sy_base, nimg, blockIdx.x);
+    const JsImage& im = imgs[img];
+    if (!tables[im.tableset].lut_ok) return;
+    const uint32_t* sd = side + im.side_off;
+    const uint32_t total_bits = sd[10] * 8, nseg = min(sd[11], im.seg_cap - 1);
+    const uint32_t sub0 = (blockIdx.x - sy_base[img]) * SY_THREADS, i = sub0 + threadIdx.x;
+    if (sub0 * SUB_BITS >= total_bits) return;
+    load_subtabs(T, im, tables[im.tableset], threadIdx.x, SY_THREADS);
+    __syncthreads();
+    if (i * SUB_BITS >= total_bits) return;
+    const size_t g = im.subseq_off + i;
+    uint32_t p = i ? A.out_p[g - 1] : 0u, s = i ? A.out_s[g - 1] : 0u, nblk = 0, fl = 0;
+    const uint32_t own_end = min((i + 1) * SUB_BITS, total_bits), blk0 = A.base[g];
+    if (!(p != P_END && p >= own_end)) {
+        if (blk0 < im.total_blocks || p == P_END)
+            walk_subseq<true>(im, T, reinterpret_cast<const uint32_t*>(ustr + im.ustr_off), seg_tab + im.seg_off, nseg, total_bits, own_end, p, s, nblk,
+                              coef + im.coef_off * 64, dccum + im.coef_off, mcu_rst + im.mcu_off, blk0, fl);
+        else { p = A.out_p[g]; s = A.out_s[g]; }                 // everything this thread owns lies past the last MCU
+    }
+    if (p != A.out_p[g] || s != A.out_s[g]) fl |= F_NOSYNC;      // the chain was not at its fixed point
+    if (fl) atomicOr(&flags[img], fl);
+}
+
+// One workgroup per image: DC differences (in dccum, decode order) -> cumulative DC per block.
+__global__ void __launch_bounds__(256) k_dc_scan(const JsImage* __restrict__ imgs, const JsTableSet* __restrict__ tables,
+                                                 int16_t* __restrict__ dccum, const uint8_t* __restrict__ mcu_rst)
+{
+    const uint32_t img = blockIdx.x; const JsImage& im = imgs[img];
+    if (!tables[im.tableset].lut_ok) return;
+    const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax, nb = im.blk_per_mcu, per = (nmcu + 255) / 256;
+    const uint32_t m0 = min(threadIdx.x * per, nmcu), m1 = min(m0 + per, nmcu);
+    int16_t* d = dccum + im.coef_off; const uint8_t* rf = mcu_rst + im.mcu_off;
+    // pass 1: per-thread (sum since last reset, saw reset) per component
+    int16_t sum[3] = {0, 0, 0}; bool rst = false;
+    for (uint32_t m = m0; m < m1; m++) {
+        if (rf[m]) { sum[0] = sum[1] = sum[2] = 0; rst = true; }
+        for (uint32_t c = 0; c < nb; c++) { const uint32_t comp = im.blk_comp[c] - 1; sum[comp] = (int16_t)(sum[comp] + d[(size_t)m * nb + c]); }
+    }
+    __shared__ int16_t s_sum[256][3]; __shared__ uint8_t s_rst[256];
+    s_sum[threadIdx.x][0] = sum[0]; s_sum[threadIdx.x][1] = sum[1]; s_sum[threadIdx.x][2] = sum[2]; s_rst[threadIdx.x] = rst;
+    __syncthreads();
+    // carry-in = combination of all earlier threads, stopping at the nearest reset (serial over <=255 entries per thread is
+    // cheap next to the decode; done by walking backwards)
+    int16_t carry[3] = {0, 0, 0};
+    for (int t = (int)threadIdx.x - 1; t >= 0; t--) {
+        carry[0] = (int16_t)(carry[0] + s_sum[t][0]); carry[1] = (int16_t)(carry[1] + s_sum[t][1]); carry[2] = (int16_t)(carry[2] + s_sum[t][2]);
+        if (s_rst[t]) break;
+    }
+    // pass 2: rewrite in place
+    for (uint32_t m = m0; m < m1; m++) {
+        if (rf[m]) carry[0] = carry[1] = carry[2] = 0;
+        for (uint32_t c = 0; c < nb; c++) {
+            const uint32_t comp = im.blk_comp[c] - 1; const size_t b = (size_t)m * nb + c;
+            carry[comp] = (int16_t)(carry[comp] + d[b]); d[b] = carry[comp];
+        }
+    }
+}
+
+void js_launch_unstuff(hipStream_t st, const JsImage* imgs, const uint32_t* us_base, uint32_t nimg, uint32_t total_chunks, const uint8_t* raw,
+                       uint32_t* chunk_keep, uint32_t* chunk_rst, uint8_t* ustr, uint32_t* seg_tab, uint32_t* side, uint32_t* flags)
+{
+    if (!total_chunks) return;
+    hipLaunchKernelGGL(k_unstuff_count, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst);
+    hipLaunchKernelGGL(k_unstuff_scan, dim3(nimg), dim3(256), 0, st, imgs, us_base, chunk_keep, chunk_rst, seg_tab, side, flags);
+    hipLaunchKernelGGL(k_unstuff_write, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, ustr, seg_tab);
+}
+static SubArrays sub_arrays(uint32_t* sub, uint64_t n) { SubArrays a; a.out_p = sub; a.out_s = sub + n; a.in_p = sub + 2 * n; a.in_s = sub + 3 * n; a.nblk = sub + 4 * n; a.base = sub + 5 * n; return a; }
+void js_launch_sync(hipStream_t st, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
+                    const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub, int first_pass)
+{
+    if (!total_wgs) return;
+    hipLaunchKernelGGL(k_sync, dim3(total_wgs), dim3(SY_THREADS), 0, st, imgs, sy_base, nimg, tables, ustr, seg_tab, side, sub_arrays(sub, nsub), first_pass);
+}
+void js_launch_block_scan(hipStream_t st, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, uint32_t* sub, uint64_t nsub, uint32_t* side, uint32_t* flags)
+{ if (nimg) hipLaunchKernelGGL(k_block_scan, dim3(nimg), dim3(256), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags); }
+void js_launch_write(hipStream_t st, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
+                     const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub,
+                     int16_t* coef, int16_t* dccum, uint8_t* mcu_rst, uint32_t* flags)
+{
+    if (!total_wgs) return;
+    hipLaunchKernelGGL(k_write, dim3(total_wgs), dim3(SY_THREADS), 0, st, imgs, sy_base, nimg, tables, ustr, seg_tab, side, sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags);
+}
+void js_launch_dc_scan(hipStream_t st, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, int16_t* dccum, const uint8_t* mcu_rst)
+{ if (nimg) hipLaunchKernelGGL(k_dc_scan, dim3(nimg), dim3(256), 0, st, imgs, tables, dccum, mcu_rst); }

@@ -1,8 +1,137 @@
-// jsnoop_parallel.cpp -- host side of the parallel (self-synchronising) entropy path.
+// jsnoop_parallel.cpp -- host side of the parallel (self-synchronising) entropy path:
+// LUT construction from the DHT code lists, stage launches, and the re-decode of flagged
+// images on the sequential exact-mirror kernel (all on the device; no CPU decode).
 #include <string.h>
+#include <vector>
 #include "jsnoop_host.h"
 #include "jsnoop_launch.h"
 
-void js_build_parallel_luts(JsTableSet* ts, uint32_t ncomp) { (void)ncomp; ts->lut_ok = 0; }
-int  js_parallel_entropy(JsnoopBatch* b, bool timed) { (void)b; (void)timed; return 0; }
-int  js_parallel_fixup(JsnoopBatch* b) { (void)b; return 0; }
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    js_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return -1; } } while (0)
+
+// Builds the two-level decode tables of the parallel path from the code list the caller pushed
+// through SetDhtEntry (canonical order, left-justified bits; reference source/JfifDecode.cpp:3535-3600).
+// lut_ok stays 0 -- and the image goes to the exact-mirror kernel -- unless every table is a
+// well-formed canonical prefix code whose symbols the fast path can interpret.
+void js_build_parallel_luts(JsTableSet* ts, uint32_t ncomp)
+{
+    ts->lut_ok = 0;
+    memset(ts->lut1, 0, sizeof ts->lut1); memset(ts->lut2, 0, sizeof ts->lut2);
+    uint32_t l2_used = 0;
+    for (uint32_t slot = 0; slot < ncomp * 2; slot++) {
+        const uint32_t n = ts->size[slot]; const bool is_dc = (slot & 1) == 0;
+        if (n == 0 || n > 256) return;
+        uint32_t prev_len = 0; uint64_t next_code = 0;           // canonical: codes count up, shifted left when the length grows
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t len = ts->bitlen[slot][i], bits = ts->bits[slot][i], sym = ts->code[slot][i];
+            if (len < 1 || len > 16 || len < prev_len || sym > 255) return;
+            if (ts->mask[slot][i] != (0xFFFFFFFFu << (32 - len))) return;
+            next_code <<= (len - prev_len);
+            if ((uint64_t)(bits >> (32 - len)) != next_code || (bits & ~ts->mask[slot][i])) return;
+            if (next_code >= (1ull << len)) return;               // over-subscribed
+            if (is_dc && (sym >> 4)) return;                       // a DC category with a run nibble: exact path mirrors the quirk
+            next_code++; prev_len = len;
+        }
+        // first level: codes of <= 9 bits
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t len = ts->bitlen[slot][i], top = ts->bits[slot][i] >> (32 - JS_FAST_BITS), sym = ts->code[slot][i];
+            if (len <= JS_FAST_BITS) for (uint32_t k = 0; k < (1u << (JS_FAST_BITS - len)); k++) ts->lut1[slot][top + k] = (uint16_t)((len << 8) | sym);
+        }
+        // second level: group the longer codes by their 9-bit prefix
+        for (uint32_t i = 0; i < n; ) {
+            const uint32_t len = ts->bitlen[slot][i];
+            if (len <= JS_FAST_BITS) { i++; continue; }
+            const uint32_t prefix = ts->bits[slot][i] >> (32 - JS_FAST_BITS);
+            uint32_t j = i, maxlen = len;
+            while (j < n && (ts->bits[slot][j] >> (32 - JS_FAST_BITS)) == prefix) { maxlen = ts->bitlen[slot][j]; j++; }
+            const uint32_t nb = maxlen - JS_FAST_BITS;             // 1..7 extra index bits
+            if (l2_used + (1u << nb) > JS_LUT2_MAX) return;
+            ts->lut1[slot][prefix] = (uint16_t)(0x8000u | (nb << 12) | l2_used);
+            for (uint32_t k = i; k < j; k++) {
+                const uint32_t l = ts->bitlen[slot][k], sym = ts->code[slot][k];
+                const uint32_t sub = (ts->bits[slot][k] >> (32 - JS_FAST_BITS - nb)) & ((1u << nb) - 1);
+                for (uint32_t q = 0; q < (1u << (JS_FAST_BITS + nb - l)); q++) ts->lut2[l2_used + sub + q] = (uint16_t)((l << 8) | sym);
+            }
+            l2_used += 1u << nb;
+            i = j;
+        }
+    }
+    ts->lut_ok = 1;
+}
+
+// Launches stages 1..5 (unstuff, sync, block scan, write, DC scan) for the whole batch.
+int js_parallel_entropy(JsnoopBatch* b, bool timed)
+{
+    const uint32_t n = (uint32_t)b->imgs.size();
+    bool any = false;
+    for (const JsTableSet& t : b->tables) any = any || t.lut_ok;
+    if (!any) return 0;
+    uint32_t* sub = (uint32_t*)b->dev.sub;
+    js_launch_unstuff(b->stream, b->dev.imgs, b->dev.us_base, n, b->us_chunks, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst,
+                      b->dev.ustr, b->dev.seg, b->dev.side, b->dev.flags);
+    if (timed) HIP_TRY(hipEventRecord(b->ev[2], b->stream));
+    for (int l = 0; l < b->sync_launches; l++)
+        js_launch_sync(b->stream, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, l == 0);
+    if (timed) HIP_TRY(hipEventRecord(b->ev[3], b->stream));
+    js_launch_block_scan(b->stream, b->dev.imgs, n, b->dev.tables, sub, b->total_subseq, b->dev.side, b->dev.flags);
+    if (timed) HIP_TRY(hipEventRecord(b->ev[4], b->stream));
+    js_launch_write(b->stream, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
+                    b->dev.coef, b->dev.dccum, b->dev.mcu_rst, b->dev.flags);
+    if (timed) HIP_TRY(hipEventRecord(b->ev[5], b->stream));
+    js_launch_dc_scan(b->stream, b->dev.imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst);
+    if (timed) { HIP_TRY(hipEventRecord(b->ev[6], b->stream)); }
+    return 1;
+}
+
+// Sequential exact-mirror decode of the listed images (their intermediate ranges are cleared first),
+// followed by the back end.  Used for images the parallel path flagged and for side-output requests.
+int JsnoopBatch::run_exact(const std::vector<uint32_t>& which)
+{
+    if (which.empty()) return 0;
+    HIP_TRY(hipSetDevice(device));
+    for (uint32_t i : which) {
+        const JsImage& im = imgs[i];
+        HIP_TRY(hipMemsetAsync(dev.coef + im.coef_off * 64, 0, (size_t)im.total_blocks * 128, stream));
+        HIP_TRY(hipMemsetAsync(dev.dccum + im.coef_off, 0, (size_t)im.total_blocks * 2, stream));
+        HIP_TRY(hipMemsetAsync(dev.side + im.side_off, 0, (size_t)js_side_words(im.mcu_xmax * im.mcu_ymax, im.blk_xmax * im.blk_ymax) * 4, stream));
+    }
+    HIP_TRY(hipMemcpyAsync(dev.sel, which.data(), which.size() * 4, hipMemcpyHostToDevice, stream));
+    js_launch_entropy_exact(stream, dev.imgs, dev.sel, (uint32_t)which.size(), dev.tables, dev.raw, dev.coef, dev.dccum, dev.side, 0);
+    js_launch_idct_color(stream, dev.imgs, dev.wg_base, (uint32_t)imgs.size(), total_wgs, strips_per_wg, d_lut, dev.coef, dev.dccum, dev.dib, dev.planes, dev.side);
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int js_parallel_fixup(JsnoopBatch* b)
+{
+    const uint32_t n = (uint32_t)b->imgs.size();
+    b->host_flags.assign(n, 0); b->host_path.assign(n, b->opt_force_exact ? 2u : 1u);
+    if (b->opt_force_exact) { for (uint32_t i = 0; i < n; i++) b->host_flags[i] = JSNOOP_FLAG_FORCED; return 0; }
+    HIP_TRY(hipMemcpyAsync(b->host_flags.data(), b->dev.flags, (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    std::vector<uint32_t> bad;
+    for (uint32_t i = 0; i < n; i++) if (b->host_flags[i]) { bad.push_back(i); b->host_path[i] = 2; }
+    if (bad.empty()) return 0;
+    // The back end already ran on the flagged images' (partial) coefficients; their sums in the side block
+    // (brightest pixel, sum of Y) are cleared together with the side block in run_exact and recomputed.
+    // Unflagged images must not accumulate twice: clear every image's two reduction words, the back end
+    // below recomputes them for the whole batch.
+    for (uint32_t i = 0; i < n; i++) { HIP_TRY(hipMemsetAsync(b->dev.side + b->imgs[i].side_off + 12, 0, 16, b->stream)); }
+    return b->run_exact(bad);
+}
+
+// Side outputs (MCU file map, block-DC maps, Huffman code-length histogram, status words) of image i,
+// recomputed by the exact-mirror kernel without touching the coefficient / pixel data.
+int js_side_only(JsnoopBatch* b, uint32_t i)
+{
+    HIP_TRY(hipSetDevice(b->device));
+    const JsImage& im = b->imgs[i];
+    const size_t words = js_side_words(im.mcu_xmax * im.mcu_ymax, im.blk_xmax * im.blk_ymax);
+    HIP_TRY(hipMemsetAsync(b->dev.side + im.side_off, 0, 8 * 4, b->stream));
+    HIP_TRY(hipMemsetAsync(b->dev.side + im.side_off + JS_SIDE_HISTO, 0, (words - JS_SIDE_HISTO) * 4, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->dev.sel, &i, 4, hipMemcpyHostToDevice, b->stream));
+    js_launch_entropy_exact(b->stream, b->dev.imgs, b->dev.sel, 1, b->dev.tables, b->dev.raw, b->dev.coef, b->dev.dccum, b->dev.side, 1);
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+}

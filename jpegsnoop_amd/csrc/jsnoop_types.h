@@ -19,7 +19,7 @@
 #define JS_DHT_CODES       260     // MAX_DHT_CODES, ImgDecode.h:68
 #define JS_FAST_BITS       9       // DHT_FAST_SIZE, ImgDecode.h:96
 #define JS_CODE_UNUSED     0xFFFFFFFFu
-#define JS_LUT2_MAX        1536    // second-level entries per table in the parallel path's LUT form
+#define JS_LUT2_MAX        2048    // second-level entries (all six tables together) in the parallel path's LUT form
 #define JS_SUBSEQ_BYTES    128     // bytes of un-stuffed stream per sub-sequence (parallel entropy path)
 
 // One distinct set of Huffman + quantisation tables, resolved per scan component
@@ -35,7 +35,7 @@ struct JsTableSet {
     //     entry: bit15 = 0 : [12:8] = code length (0 = invalid), [7:0] = symbol (run<<4 | size)
     //            bit15 = 1 : [14:12] = extra index bits nb, [11:0] = base into lut2
     uint16_t lut1[6][1 << JS_FAST_BITS];
-    uint16_t lut2[6][JS_LUT2_MAX];
+    uint16_t lut2[JS_LUT2_MAX];
     uint32_t lut_ok;                        // 1 when every table fits the LUT form and is a canonical prefix code
 };
 
@@ -58,6 +58,9 @@ struct JsImage {
     uint64_t side_off;      // in u32 words, see JS_SIDE_*
     uint64_t subseq_off;    // first sub-sequence slot of this image
     uint32_t n_subseq;      // capacity in sub-sequences
+    uint64_t seg_off;       // first entry of this image's restart-interval table (u32 start bytes + end sentinel)
+    uint32_t seg_cap;       // entries available
+    uint64_t mcu_off;       // first byte of this image's per-MCU restart flags
     // preview controls (SetPreviewMode :633, SetPreviewYccOffset :650)
     uint32_t preview_mode; int32_t shift_y, shift_cb, shift_cr; uint32_t shift_mcu_x, shift_mcu_y;
     uint32_t err_max;
@@ -65,8 +68,8 @@ struct JsImage {
 
 // Per-image side block (u32 words, in this order):
 //   [0..15]   status: 0 scan_bad, 1 scan_end, 2 #RST read, 3 num_pixels, 4 pos0, 5 align, 6 warn_bad, 7 first,
-//             8 flags (JSNOOP_FLAG_*), 9 path, 10 un-stuffed length, 11 #intervals, 12 blocks decoded,
-//             13 bright key hi, 14 bright key lo, 15 sum of final Y
+//             8 flags (JSNOOP_FLAG_*), 9 path, 10 un-stuffed length, 11 #intervals,
+//             12-13 brightest-pixel key (64-bit: Y+32768 high, ~raster index low), 14 blocks decoded, 15 sum of final Y
 //   [16..151] Huffman code-length histogram [2][4][17]
 //   [152..]   MCU file map [mcu_ymax*mcu_xmax], then three block-DC maps (i16 packed as u16 pairs, each
 //             padded to a whole word count), sized by the image

@@ -42,6 +42,7 @@ def test_single_image_parity(harness, oracle, gpu, kw):
     data = harness.synth_jpeg(seed=11, **kw)
     harness.drive(oracle, data)
     harness.drive(gpu, data)
+    assert gpu.lib.jsnoop_last_path(gpu.h) == 1 and gpu.lib.jsnoop_last_flags(gpu.h) == 0, "well-formed scan must take the parallel path"
     compare(harness, oracle, gpu)
     if harness.have_ref():
         r = harness.ref_backend()
@@ -78,7 +79,8 @@ def test_corrupt_streams_exact_path(harness, oracle, gpu):
     rng = np.random.default_rng(7)
     base = [harness.synth_jpeg(width=96, height=64, seed=s, **kw) for s, kw in enumerate(
         [dict(), dict(hs=1, vs=1), dict(hs=2, vs=1, restart_interval=3), dict(gray=1), dict(restart_interval=1, quality=30)])]
-    for it in range(60):
+    paths = {}
+    for it in range(120):
         d = bytearray(base[it % len(base)])
         p = harness.parse_jpeg(bytes(d))
         s, e = p.scan_start, p.scan_end
@@ -98,20 +100,24 @@ def test_corrupt_streams_exact_path(harness, oracle, gpu):
         d = bytes(d)
         harness.drive(oracle, d, p)
         harness.drive(gpu, d, p)
+        paths[gpu.lib.jsnoop_last_path(gpu.h)] = paths.get(gpu.lib.jsnoop_last_path(gpu.h), 0) + 1
         compare(harness, oracle, gpu)
+    assert paths.get(2, 0) > 0, "some malformed scans must have been routed to the exact-mirror kernel"
 
 
-def test_batch_api(harness, oracle):
+@pytest.mark.parametrize("force_exact", [False, True])
+def test_batch_api(harness, oracle, force_exact):
     import jpegsnoop_amd as J
     kws = [dict(width=320, height=240), dict(width=333, height=217, hs=1, vs=1), dict(width=160, height=120, gray=1),
            dict(width=640, height=360, hs=2, vs=1, restart_interval=40)]
     files = [harness.synth_jpeg(seed=20 + i, **kw) for i, kw in enumerate(kws)]
-    b = J.JpegBatch(want_planes=True)
+    b = J.JpegBatch(want_planes=True, force_exact=force_exact)
     for f in files:
         b.add_jpeg(f)
     b.tile(8)
     b.upload(); b.decode(); b.sync()
     sums = b.dib_checksums()
+    assert all(b.info(i)['path'] == (2 if force_exact else 1) for i in range(8))
     for i in range(8):
         harness.drive(oracle, files[i % 4])
         assert np.array_equal(b.dib(i), oracle.dib())
