@@ -668,6 +668,13 @@ __device__ __forceinline__ void walk_subseq(const JsImage& im, const SubTabs& T,
         if (e & 0x8000u) { const uint32_t nbx = (e >> 12) & 7u; e = T.lut2[(e & 0xFFFu) + ((uint32_t)(cur.buf >> (55 - nbx)) & ((1u << nbx) - 1u))]; }
         const uint32_t len = (e >> 8) & 31u, sym = e & 255u, size = sym & 15u, run = sym >> 4;
         const uint32_t remain = seg_end > cur.p ? seg_end - cur.p : 0u;   // bits left in this restart interval
+        if (len == 0 && remain >= 16) {
+            // No code matches although a whole code could still fit: a corrupt stream (the reference skips one bit
+            // and reports it, :1178-1186) -- or simply a speculative walk that is not synchronised yet.
+            if (WRITE && blk < im.total_blocks) flags |= F_BAD_CODE;
+            cur_skip(cur, 1);
+            continue;
+        }
         if (len == 0 || len > remain) {
             // No code fits in what is left of the interval: what the reference sees as RSV_RST_TERM
             // (:1167-1176) when an RSTn follows, or the end of the entropy data otherwise.
@@ -681,7 +688,7 @@ __device__ __forceinline__ void walk_subseq(const JsImage& im, const SubTabs& T,
                 cur_init(cur, words, np);
                 continue;
             }
-            if (WRITE && blk < im.total_blocks) flags |= (len == 0 && remain >= 16) ? F_BAD_CODE : F_SHORT;
+            if (WRITE && blk < im.total_blocks) flags |= F_SHORT;
             cur.p = P_END; c = 0; k = 0; seg = 0;
             break;
         }
@@ -760,7 +767,10 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
             ip = i * SUB_BITS; is = i * SUB_BITS < total_bits ? ST_MAKE(find_interval(st, nseg, i * (SUB_BITS / 8)), 0u, 0u) : 0u;
             if (i * SUB_BITS >= total_bits) ip = P_END;
         } else if (i == 0) { ip = 0; is = 0; }                   // true start of the scan: interval 0, block 0, DC
-        else if (threadIdx.x == 0) { ip = A.out_p[g - 1]; is = A.out_s[g - 1]; }
+        else if (threadIdx.x == 0) {
+            if (first_pass) { ip = my_in_p; is = my_in_s; }      // left neighbour lives in another workgroup: keep the speculative start
+            else { ip = A.out_p[g - 1]; is = A.out_s[g - 1]; }   // ... its exit state as of the previous launch
+        }
         else { ip = s_p[threadIdx.x - 1]; is = s_s[threadIdx.x - 1]; }
         if (threadIdx.x == 0) s_changed = 0;
         __syncthreads();
@@ -822,13 +832,16 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
     const size_t g = im.subseq_off + i;
     uint32_t p = i ? A.out_p[g - 1] : 0u, s = i ? A.out_s[g - 1] : 0u, nblk = 0, fl = 0;
     const uint32_t own_end = min((i + 1) * SUB_BITS, total_bits), blk0 = A.base[g];
+    bool walked = false;
     if (!(p != P_END && p >= own_end)) {
+        walked = true;
         if (blk0 < im.total_blocks || p == P_END)
             walk_subseq<true>(im, T, reinterpret_cast<const uint32_t*>(ustr + im.ustr_off), seg_tab + im.seg_off, nseg, total_bits, own_end, p, s, nblk,
                               coef + im.coef_off * 64, dccum + im.coef_off, mcu_rst + im.mcu_off, blk0, fl);
-        else { p = A.out_p[g]; s = A.out_s[g]; }                 // everything this thread owns lies past the last MCU
+        else { p = A.out_p[g]; s = A.out_s[g]; walked = false; } // everything this thread owns lies past the last MCU
     }
-    if (p != A.out_p[g] || s != A.out_s[g]) fl |= F_NOSYNC;      // the chain was not at its fixed point
+    // the chain must be at its fixed point, and the block count that fed the prefix sum must be the real one
+    if (p != A.out_p[g] || s != A.out_s[g] || (walked && nblk != A.nblk[g])) fl |= F_NOSYNC;
     if (fl) atomicOr(&flags[img], fl);
 }
 

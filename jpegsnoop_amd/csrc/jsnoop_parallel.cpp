@@ -103,6 +103,29 @@ int JsnoopBatch::run_exact(const std::vector<uint32_t>& which)
     return 0;
 }
 
+// Continues the sub-sequence synchronisation from its current state (extra k_sync launches) and redoes
+// everything downstream.  Used when k_write found the chain short of its fixed point (JSNOOP_FLAG_NOSYNC).
+static int js_parallel_resume(JsnoopBatch* b, int extra_launches)
+{
+    const uint32_t n = (uint32_t)b->imgs.size();
+    uint32_t* sub = (uint32_t*)b->dev.sub;
+    HIP_TRY(hipMemsetAsync(b->dev.coef, 0, b->total_blocks * 128, b->stream));
+    HIP_TRY(hipMemsetAsync(b->dev.dccum, 0, b->total_blocks * 2, b->stream));
+    HIP_TRY(hipMemsetAsync(b->dev.mcu_rst, 0, b->mcu_bytes, b->stream));
+    HIP_TRY(hipMemsetAsync(b->dev.flags, 0, (size_t)n * 4, b->stream));
+    for (uint32_t i = 0; i < n; i++) HIP_TRY(hipMemsetAsync(b->dev.side + b->imgs[i].side_off + 12, 0, 16, b->stream));
+    for (int l = 0; l < extra_launches; l++)
+        js_launch_sync(b->stream, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, 0);
+    js_launch_block_scan(b->stream, b->dev.imgs, n, b->dev.tables, sub, b->total_subseq, b->dev.side, b->dev.flags);
+    js_launch_write(b->stream, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
+                    b->dev.coef, b->dev.dccum, b->dev.mcu_rst, b->dev.flags);
+    js_launch_dc_scan(b->stream, b->dev.imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst);
+    js_launch_idct_color(b->stream, b->dev.imgs, b->dev.wg_base, n, b->total_wgs, b->strips_per_wg, b->d_lut, b->dev.coef, b->dev.dccum, b->dev.dib, b->dev.planes, b->dev.side);
+    HIP_TRY(hipMemcpyAsync(b->host_flags.data(), b->dev.flags, (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
 int js_parallel_fixup(JsnoopBatch* b)
 {
     const uint32_t n = (uint32_t)b->imgs.size();
@@ -110,12 +133,19 @@ int js_parallel_fixup(JsnoopBatch* b)
     if (b->opt_force_exact) { for (uint32_t i = 0; i < n; i++) b->host_flags[i] = JSNOOP_FLAG_FORCED; return 0; }
     HIP_TRY(hipMemcpyAsync(b->host_flags.data(), b->dev.flags, (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
+    // An unconverged chain is not a malformed stream: give it more synchronisation rounds first.
+    for (int attempt = 0, extra = 4; attempt < 4; attempt++, extra *= 4) {
+        bool nosync = false;
+        for (uint32_t i = 0; i < n; i++) nosync = nosync || (b->host_flags[i] & JSNOOP_FLAG_NOSYNC);
+        if (!nosync) break;
+        if (js_parallel_resume(b, extra)) return -1;
+    }
     std::vector<uint32_t> bad;
     for (uint32_t i = 0; i < n; i++) if (b->host_flags[i]) { bad.push_back(i); b->host_path[i] = 2; }
     if (bad.empty()) return 0;
     // The back end already ran on the flagged images' (partial) coefficients; their sums in the side block
     // (brightest pixel, sum of Y) are cleared together with the side block in run_exact and recomputed.
-    // Unflagged images must not accumulate twice: clear every image's two reduction words, the back end
+    // Unflagged images must not accumulate twice: clear every image's reduction words, the back end
     // below recomputes them for the whole batch.
     for (uint32_t i = 0; i < n; i++) { HIP_TRY(hipMemsetAsync(b->dev.side + b->imgs[i].side_off + 12, 0, 16, b->stream)); }
     return b->run_exact(bad);
