@@ -211,6 +211,9 @@ class Backend:
             f(fn).restype = C.c_void_p
             f(fn).argtypes = [C.c_void_p]
         f("idct_block").argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        if prefix == "jsnoop_":
+            f("set_preview_mode").argtypes = [C.c_void_p, C.c_uint]
+            f("set_preview_ycc_offset").argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int]
         self.h = f("create")()
 
     def _f(self, name):

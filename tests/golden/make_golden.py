@@ -1,0 +1,115 @@
+"""Generates tests/golden/: small JPEG inputs + the outputs of the UNMODIFIED reference on them.
+
+Run in the build container (needs /root/reference):  python tests/golden/make_golden.py
+The reference is compiled in place by `make -C oracle ref` (oracle/_ref/libjsnoop_ref.so); the
+fixtures committed here are what travels to machines without /root/reference (the GPU box).
+
+For every case the manifest stores sha256 of: DIB bytes, the three int16 planes, the MCU file map,
+the block-DC maps, the Huffman code-length histogram, plus the status words, brightest-pixel /
+average-Y record and image size, all as produced by reference CimgDecode::DecodeScanImg in
+Full-IDCT mode (bDecodeScanImgAc=true, bHistoEn=false) -- and a second record for DC-only mode.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import harness as H  # noqa: E402
+
+
+def record(b):
+    dib = b.dib()
+    if dib is None:
+        return {"preview": False, "size": list(b.image_size())}
+    r = {"preview": bool(b.is_preview_ready()), "size": list(b.image_size()), "dib": H.hash_bytes(dib)}
+    r["planes"] = [H.hash_bytes(p) if p is not None else None for p in b.planes()]
+    r["mcu_map"] = H.hash_bytes(b.mcu_map())
+    r["blk_dc"] = [H.hash_bytes(p) if p is not None else None for p in b.blk_dc()]
+    r["histo"] = H.hash_bytes(b.dht_histo())
+    r["status"] = {k: int(v) for k, v in b.status().items()}
+    r["bright_avg"] = [int(v) for v in b.bright_avg()]
+    return r
+
+
+def corrupt(data, mode, rng):
+    d = bytearray(data)
+    p = H.parse_jpeg(data)
+    s, e = p.scan_start, p.scan_end
+    if mode == "flip":
+        for _ in range(3):
+            d[int(rng.integers(s, e))] = int(rng.integers(0, 256))
+    elif mode == "trunc":
+        d = d[: int(rng.integers(s + 1, e))]
+    elif mode == "marker":
+        i = int(rng.integers(s, e)); d[i:i] = bytes([0xFF, 0xC4])
+    elif mode == "ffff":
+        i = int(rng.integers(s, e)); d[i:i] = bytes([0xFF, 0xFF, 0xFF])
+    elif mode == "delete":
+        i = int(rng.integers(s, e - 4)); del d[i:i + 2]
+    elif mode == "stray_rst":
+        i = int(rng.integers(s, e)); d[i:i] = bytes([0xFF, 0xD3])
+    return bytes(d)
+
+
+def main():
+    H.build(["oracle", "synth", "ref"])
+    assert H.have_ref(), "needs the compiled reference (oracle/_ref)"
+    rng = np.random.default_rng(2024)
+    cases = {
+        "c1_444_160x120": dict(width=160, height=120, hs=1, vs=1, seed=1),
+        "420_odd_141x93": dict(width=141, height=93, seed=2),
+        "420_q50_128x128": dict(width=128, height=128, quality=50, seed=3),
+        "420_q95_opt_96x96": dict(width=96, height=96, quality=95, optimize_huffman=1, seed=4),
+        "422_rst_row_160x64": dict(width=160, height=64, hs=2, vs=1, restart_interval=10, seed=5),
+        "420_rst1_64x48": dict(width=64, height=48, restart_interval=1, quality=30, seed=6),
+        "gray_101x77": dict(width=101, height=77, gray=1, seed=7),
+        "440_96x80": dict(width=96, height=80, hs=1, vs=2, seed=8),
+        "420_flat_64x64": dict(width=64, height=64, noise_sigma=0, quality=10, seed=9),
+        "420_ff_dense_128x96": dict(width=128, height=96, quality=100, noise_sigma=40, seed=10),
+    }
+    manifest = {"generator": "tests/golden/make_golden.py", "reference": "JPEGsnoop 1.8.0 source compiled in place (oracle/Makefile ref)", "cases": {}}
+    ref = H.ref_backend()
+    files = {}
+    for name, kw in cases.items():
+        files[name] = H.synth_jpeg(**kw)
+    base_for_corrupt = ["420_odd_141x93", "422_rst_row_160x64", "c1_444_160x120", "gray_101x77"]
+    for bi, bname in enumerate(base_for_corrupt):
+        for mode in ("flip", "trunc", "marker", "ffff", "delete", "stray_rst"):
+            files[f"bad_{mode}_{bname}"] = corrupt(files[bname], mode, rng)
+    for name, data in files.items():
+        with open(os.path.join(HERE, name + ".jpg"), "wb") as f:
+            f.write(data)
+        entry = {"bytes": len(data), "sha256": H.hash_bytes(data)}
+        for mode, ac in (("full_idct", 1), ("dc_only", 0)):
+            ref.set_options(decode_ac=ac)
+            H.drive(ref, data)
+            entry[mode] = record(ref)
+        ref.set_options(decode_ac=1)
+        manifest["cases"][name] = entry
+    # known-answer values of the two fp32 stages, straight from the compiled reference
+    lut = ref.idct_lut()
+    manifest["kat"] = {
+        "idct_lut_sha256": H.hash_bytes(lut),
+        "idct_lut_fnv1a64": "%016x" % H.fnv1a64(lut.tobytes()),
+        "idct_lut_spot": {"[0][0]": float(lut[0, 0]).hex(), "[1][8]": float(lut[1, 8]).hex(), "[9][9]": float(lut[9, 9]).hex(), "[63][63]": float(lut[63, 63]).hex()},
+    }
+    ref.lib.jsref_color_exhaustive_fnv.restype = __import__("ctypes").c_uint64
+    manifest["kat"]["color_exhaustive_fnv1a64"] = "%016x" % ref.lib.jsref_color_exhaustive_fnv(__import__("ctypes").c_void_p(ref.h))
+    blocks = []
+    for i in range(64):
+        c = np.zeros(64, np.int16)
+        nz = int(rng.integers(1, 40))
+        idx = rng.choice(63, nz, replace=False) + 1
+        c[idx] = rng.integers(-1500, 1500, nz)
+        blocks.append({"coef": [int(v) for v in c], "out_sha256": H.hash_bytes(ref.idct_block(c))})
+    manifest["kat"]["idct_blocks"] = blocks
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    print("wrote", len(files), "fixtures,", sum(len(v) for v in files.values()), "bytes of JPEG")
+
+
+if __name__ == "__main__":
+    main()

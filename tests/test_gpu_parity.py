@@ -127,3 +127,57 @@ def test_batch_api(harness, oracle, force_exact):
         assert int(sums[i]) == J.dib_checksum_numpy(oracle.dib())
         assert np.array_equal(b.coefs(i), harness.oracle_coefs(oracle))
     b.close()
+
+
+def test_golden_fixtures(harness, gpu):
+    """The HIP path against the committed outputs of the compiled reference (tests/golden/manifest.json)."""
+    from golden_util import load_case, manifest, record
+    M = manifest()
+    for name in sorted(M["cases"]):
+        data = load_case(name)
+        for mode, ac in (("full_idct", 1), ("dc_only", 0)):
+            gpu.set_options(decode_ac=ac)
+            try:
+                harness.drive(gpu, data)
+                assert record(harness, gpu) == M["cases"][name][mode], f"{name} [{mode}]"
+            finally:
+                gpu.set_options(decode_ac=1)
+    for blk in M["kat"]["idct_blocks"]:
+        assert harness.hash_bytes(gpu.idct_block(np.array(blk["coef"], np.int16))) == blk["out_sha256"]
+    assert harness.hash_bytes(gpu.idct_lut()) == M["kat"]["idct_lut_sha256"]
+
+
+def test_preview_modes_and_shift(harness, oracle, gpu):
+    """SetPreviewMode / SetPreviewYccOffset re-render (reference :633-659): colour kernel only, on the retained data."""
+    data = harness.synth_jpeg(width=160, height=96, seed=8)
+    harness.drive(gpu, data)
+    base = gpu.dib().copy()
+    planes = oracle and None
+    harness.drive(oracle, data)
+    py, pcb, pcr = [p.astype(np.int64) for p in oracle.planes()]
+    H8, W8 = py.shape
+
+    def expect(mode, sy=0, scb=0, scr=0, smx=0, smy=0):
+        import ctypes as C
+        mi = (np.arange(H8)[:, None] // 16) * (W8 // 16) + (np.arange(W8)[None, :] // 16)
+        sel = mi >= smy * (W8 // 16) + smx
+        ycc = np.stack([py + sel * sy, pcb + sel * scb, pcr + sel * scr], -1).astype(np.int32).reshape(-1, 3)
+        rgb = np.zeros((ycc.shape[0], 3), np.uint8)
+        oracle.lib.orc_color_fast(ycc.ctypes.data_as(C.c_void_p), rgb.ctypes.data_as(C.c_void_p), C.c_size_t(ycc.shape[0]))
+        fin = np.clip(ycc >> 3, -128, 127) + 128
+        r, g, b = rgb[:, 0], rgb[:, 1], rgb[:, 2]
+        fy, fcb, fcr = fin[:, 0], fin[:, 1], fin[:, 2]
+        R, G, B = {1: (r, g, b), 2: (fcr, fy, fcb), 3: (r, r, r), 4: (g, g, g), 5: (b, b, b), 6: (fy, fy, fy), 7: (fcb, fcb, fcb), 8: (fcr, fcr, fcr)}[mode]
+        out = np.zeros((H8, W8, 4), np.uint8)
+        out[..., 0], out[..., 1], out[..., 2] = B.reshape(H8, W8), G.reshape(H8, W8), R.reshape(H8, W8)
+        return out[::-1]
+
+    assert np.array_equal(base, expect(1))
+    for mode in range(2, 9):
+        gpu.set_preview_mode(mode)
+        assert np.array_equal(gpu.dib(), expect(mode)), mode
+    gpu.set_preview_mode(1)
+    gpu.set_preview_ycc_offset(3, 2, 160, -80, 40)
+    assert np.array_equal(gpu.dib(), expect(1, 160, -80, 40, 3, 2))
+    gpu.set_preview_ycc_offset(0, 0, 0, 0, 0)
+    assert np.array_equal(gpu.dib(), base)

@@ -1,0 +1,98 @@
+"""CPU: the oracle against the compiled reference itself (oracle/_ref/libjsnoop_ref.so), when available:
+in this container it is built from /root/reference by `make -C oracle ref`.  Covers well-formed streams,
+header variations (odd sampling factors) and a fuzz sweep over corrupted scans; every output byte-equal."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def ref(harness):
+    if not harness.have_ref():
+        pytest.skip("compiled reference not available (no /root/reference and no prebuilt oracle/_ref)")
+    b = harness.ref_backend()
+    yield b
+    b.close()
+
+
+def same(H, a, b):
+    da, db = a.dib(), b.dib()
+    if (da is None) != (db is None):
+        return False
+    if da is None:
+        return a.image_size() == b.image_size()
+    ok = np.array_equal(da, db) and a.image_size() == b.image_size()
+    ok = ok and all(np.array_equal(x, y) for x, y in zip(a.planes(), b.planes()) if x is not None)
+    ok = ok and np.array_equal(a.mcu_map(), b.mcu_map()) and np.array_equal(a.dht_histo(), b.dht_histo())
+    ok = ok and all(np.array_equal(x, y) for x, y in zip(a.blk_dc(), b.blk_dc()) if x is not None)
+    return ok and a.status() == b.status() and a.bright_avg() == b.bright_avg() and a.is_preview_ready() == b.is_preview_ready()
+
+
+CASES = [dict(width=640, height=480, hs=1, vs=1), dict(width=333, height=217), dict(width=333, height=217, gray=1),
+         dict(width=640, height=360, hs=2, vs=1, restart_interval=40), dict(width=256, height=256, optimize_huffman=1, quality=95),
+         dict(width=200, height=100, quality=20, restart_interval=1), dict(width=96, height=80, hs=1, vs=2)]
+
+
+@pytest.mark.parametrize("kw", CASES, ids=lambda k: "-".join(f"{a}{b}" for a, b in k.items()))
+def test_wellformed(harness, oracle, ref, kw):
+    data = harness.synth_jpeg(seed=5, **kw)
+    for ac in (1, 0):
+        for b in (oracle, ref):
+            b.set_options(decode_ac=ac)
+            harness.drive(b, data)
+        assert same(harness, ref, oracle)
+    for b in (oracle, ref):
+        b.set_options(decode_ac=1)
+
+
+def test_table_kats(harness, oracle, ref):
+    assert np.array_equal(ref.idct_lut().view(np.uint32), oracle.idct_lut().view(np.uint32))
+    data = harness.synth_jpeg(width=64, height=64, optimize_huffman=1, seed=9)
+    harness.drive(ref, data)
+    harness.drive(oracle, data)
+    assert np.array_equal(ref.lookupfast(), oracle.lookupfast())
+
+
+def test_header_variations(harness, oracle, ref):
+    """Sampling factors the synthetic encoder cannot produce: rewrite the SOF of a valid file.  The scan then
+    decodes to garbage, but deterministically, and exercises the replication/geometry arithmetic."""
+    data = harness.synth_jpeg(width=160, height=96, seed=4)
+    p = harness.parse_jpeg(data)
+    for samp in ([(4, 1), (1, 1), (1, 1)], [(1, 4), (1, 1), (1, 1)], [(4, 2), (2, 1), (1, 2)], [(2, 2), (2, 1), (1, 1)],
+                 [(1, 1), (2, 2), (2, 2)], [(3, 1), (1, 1), (1, 1)], [(2, 2), (2, 2), (2, 2)], [(4, 4), (1, 1), (2, 2)]):
+        q = harness.parse_jpeg(data)
+        q.comps = [(c[0], h, v, c[3]) for c, (h, v) in zip(p.comps, samp)]
+        harness.drive(ref, data, q)
+        harness.drive(oracle, data, q)
+        assert same(harness, ref, oracle), samp
+
+
+def test_fuzz_corrupt_scans(harness, oracle, ref):
+    rng = np.random.default_rng(7)
+    base = [harness.synth_jpeg(width=96, height=64, seed=s, **kw) for s, kw in enumerate(
+        [dict(), dict(hs=1, vs=1), dict(hs=2, vs=1, restart_interval=3), dict(gray=1), dict(restart_interval=1, quality=30), dict(optimize_huffman=1)])]
+    for it in range(400):
+        d = bytearray(base[it % len(base)])
+        p = harness.parse_jpeg(bytes(d))
+        s, e = p.scan_start, p.scan_end
+        mode = it % 8
+        if mode == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                d[int(rng.integers(s, e))] = int(rng.integers(0, 256))
+        elif mode == 1:
+            d = d[: int(rng.integers(s + 1, len(d)))]
+        elif mode == 2:
+            i = int(rng.integers(s, e)); d[i:i] = bytes([0xFF, int(rng.integers(1, 256))])
+        elif mode == 3:
+            i = int(rng.integers(s, e)); d[i:i] = bytes([0xFF] * int(rng.integers(2, 5)))
+        elif mode == 4:
+            i = int(rng.integers(s, e - 4)); del d[i:i + int(rng.integers(1, 4))]
+        elif mode == 5:
+            i = int(rng.integers(s, e)); d[i:i] = bytes([0xFF, 0xD0 + int(rng.integers(0, 8))])
+        elif mode == 6:
+            i = int(rng.integers(s, e)); d[i] ^= 1 << int(rng.integers(0, 8))
+        else:
+            i = int(rng.integers(s, e)); d[i:e] = bytes(e - i)
+        d = bytes(d)
+        harness.drive(ref, d, p)
+        harness.drive(oracle, d, p)
+        assert same(harness, ref, oracle), (it, mode)
