@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpixels/s of the MI355X scan-decode path on BASELINE.json's headline workload.
+
+Workload (N = 1): BASELINE config 3, a batch of 1024 baseline 4:2:0 1920x1080 JPEGs per GPU
+(`--distinct` different synthetic pictures, tiled to `--images`), compressed bytes already
+resident in HBM when the timed region starts, DIBs left in HBM (timing scope T1 of SURVEY.md 8d).
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns its own 1024-image
+shard (weak scaling, BASELINE config 4 at N = 8); no data-path collective, RCCL only for the
+barrier and the all-reduce of the job scalars.
+
+A "step" is one decode of the whole resident batch: unstuff -> sub-sequence synchronisation ->
+block scan -> coefficient write -> DC scan -> IDCT + colour -> DIB.  Prints ONE JSON line
+(rank 0).  `value` counts SOF pixels (X*Y) of every image of every rank per second, and is only
+reported when every DIB checksum equals the oracle's (bit-exact gate).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--images", type=int, default=1024, help="images per GPU")
+    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic pictures per GPU (tiled to --images)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
+    ap.add_argument("--single-image", action="store_true", help="also time BASELINE config 2 (one 3840x2160 image)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as G
+    import jpegsnoop_amd as J
+    from oracle import harness as H            # checker + input generator only (cpu_baseline leg, parity gate)
+
+    if not (os.path.exists(J.LIB_PATH) and os.path.exists(H.ORC_SO) and os.path.exists(H.SYNTH_SO)):
+        if local_rank == 0:
+            G.build()
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+    lib = J.load()
+    assert lib.jsnoop_set_device(local_rank) == 0, J.last_error()
+    dev = torch.device("cuda", local_rank)
+
+    # ---- synthetic inputs: seeded per (rank, index) so every shard holds different pictures -----
+    t0 = time.time()
+    files = [H.synth_jpeg(width=args.width, height=args.height, hs=2, vs=2, quality=85, seed=1000 * rank + i + 1)
+             for i in range(args.distinct)]
+    t_gen = time.time() - t0
+    batch = J.JpegBatch(want_planes=False)
+    for f in files:
+        batch.add_jpeg(f)
+    batch.tile(args.images)
+    batch.upload()                                   # pinned host -> HBM, outside the timed region
+    pixels = batch.pixels()
+    alg_bytes = batch.algorithmic_bytes()
+
+    # ---- parity gate + cpu_baseline sample (the oracle is only the checker / the baseline here) ----
+    batch.decode(); batch.sync()
+    sums = batch.dib_checksums()
+    flags = [batch.info(i)["flags"] for i in range(len(batch))]
+    paths = [batch.info(i)["path"] for i in range(len(batch))]
+    orc = H.oracle_backend()
+    n_cpu, cpu_time, errors = 0, 0.0, 0
+    budget = args.cpu_seconds if (rank == 0 and world == 1) else 0.0
+    check_idx = list(range(args.distinct)) if budget > 0 else list(range(min(2, args.distinct)))
+    for j in check_idx:
+        t1 = time.perf_counter()
+        H.drive(orc, files[j])
+        dt = time.perf_counter() - t1
+        want = J.dib_checksum_numpy(orc.dib())
+        for i in range(j, args.images, args.distinct):
+            errors += int(int(sums[i]) != want)
+        if budget > 0:
+            n_cpu += 1
+            cpu_time += dt
+            if cpu_time > budget:
+                break
+    errors += sum(1 for f in flags if f)
+    ref_rate = None
+    if budget > 0 and H.have_ref():                  # the compiled reference, when its .so travelled (never reads /root/reference)
+        ref = H.ref_backend()
+        t1 = time.perf_counter(); H.drive(ref, files[0]); H.drive(ref, files[min(1, args.distinct - 1)]); dt = time.perf_counter() - t1
+        ref_rate = 2 * args.width * args.height / dt / 1e6
+        ref.close()
+
+    # ---- timed region -----------------------------------------------------------------------
+    for _ in range(args.warmup):
+        batch.decode()
+    batch.sync()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.decode()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t1
+    batch.sync()
+    flags2 = [batch.info(i)["flags"] for i in range(len(batch))]
+    errors += sum(1 for f in flags2 if f)
+    sums2 = batch.dib_checksums()
+    errors += int((sums2 != sums).sum())
+
+    # per-stage device time (hipEvents on the batch stream, same resident batch)
+    ms_whole, stages = batch.decode_timed(max(3, min(10, args.steps)))
+    dom = max(stages, key=stages.get)
+
+    tot_px, max_el, _ck, tot_err = J.reduce_job_stats(pixels * args.steps, elapsed, int(np.bitwise_xor.reduce(sums)), errors, dev if world > 1 else None)
+
+    extra = {}
+    if args.single_image and rank == 0:
+        one = J.JpegBatch()
+        f4k = H.synth_jpeg(width=3840, height=2160, hs=2, vs=2, quality=85, seed=77)
+        one.add_jpeg(f4k); one.upload(); one.decode(); one.sync()
+        ms1, st1 = one.decode_timed(10)
+        H.drive(orc, f4k)
+        extra["config2_single_3840x2160"] = {"ms": round(ms1, 4), "mpix_per_s": round(3840 * 2160 / ms1 / 1e3, 1),
+                                              "bit_exact": bool(int(one.dib_checksums()[0]) == J.dib_checksum_numpy(orc.dib())),
+                                              "stages_ms": {k: round(v, 4) for k, v in st1.items()}}
+        one.close()
+
+    if rank == 0:
+        value = tot_px / max_el / 1e6 if tot_err == 0 else 0.0
+        out = {
+            "metric": "Mpixels/sec decoded (baseline 4:2:0 JPEG), bit-exact vs CPU CimgDecode",
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(max_el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/i16 entropy+DIB, f32 IDCT+colour", "data": "synthetic",
+            "config": {"workload": f"{args.images} x {args.width}x{args.height} baseline 4:2:0 q85 JPEG per GPU "
+                                   f"({args.distinct} distinct seeds tiled; BASELINE config 3, config 4 at 8 GPUs), HBM->HBM (T1)",
+                       "images_per_gpu": args.images, "distinct": args.distinct, "subsampling": "4:2:0", "quality": 85,
+                       "parallelism": f"shard{world}" if world > 1 else "single", "entropy_path": "parallel" if all(p == 1 for p in paths) else "mixed"},
+            "bit_exact": tot_err == 0, "parity_errors": tot_err,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(alg_bytes / (stages[dom] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(alg_bytes / (stages[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stages[dom], 4),
+                         "pipeline": {"ms": round(ms_whole, 4), "achieved": round(alg_bytes / (ms_whole * 1e-3) / 1e9, 1),
+                                      "frac": round(alg_bytes / (ms_whole * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+                         "stages_ms": {k: round(v, 4) for k, v in stages.items()}},
+        }
+        if budget > 0 and n_cpu:
+            out["cpu_baseline"] = {"value": round(n_cpu * args.width * args.height / cpu_time / 1e6, 2), "unit": "Mpixels/s", "cores": 1,
+                                   "kind": "port", "sample": f"{n_cpu} x {args.width}x{args.height} 4:2:0 images of this workload, oracle/oracle_imgdecode.c, "
+                                                             f"1 thread, {cpu_time:.1f} s" + (f"; compiled reference on 2 images: {ref_rate:.2f} Mpixels/s" if ref_rate else "")}
+        out["setup_s"] = {"synth": round(t_gen, 1)}
+        out.update(extra)
+        print(json.dumps(out))
+    batch.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
