@@ -242,10 +242,10 @@ int JsnoopBatch::upload()
     if (!n) { js_set_error("upload: empty batch"); return -1; }
     uint64_t blocks = 0, dibb = 0, plane = 0, side = 0, ustr = 0, subs = 0;
     std::vector<uint32_t> wg(n + 1), usb(n + 1), syb(n + 1);
-    uint64_t total_strips = 0, segw = 0, mcub = 0; uint32_t usc = 0, syw = 0;
-    for (size_t i = 0; i < n; i++) { const JsImage& im = imgs[i]; uint32_t G = 128 / im.mcu_w; total_strips += (uint64_t)((im.mcu_xmax + G - 1) / G) * im.mcu_ymax; }
-    strips_per_wg = (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(1, total_strips / 8192));
-    uint32_t wgs = 0;
+    uint64_t segw = 0, mcub = 0; uint32_t usc = 0, syw = 0;
+    strips_per_wg = 0; uint64_t total_mcus = 0; for (const JsImage& im : imgs) total_mcus += (uint64_t)im.mcu_xmax * im.mcu_ymax;
+    const uint32_t mcus_per_wave = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, total_mcus / (8 * 4096)));
+    uint32_t wgs = 0; max_mcu_h = 8; max_mcu_w = 8;
     for (size_t i = 0; i < n; i++) {
         JsImage& im = imgs[i];
         im.want_planes = (uint32_t)opt_want_planes;
@@ -253,7 +253,7 @@ int JsnoopBatch::upload()
         im.dib_off = dibb; dibb += align_up((uint64_t)im.img_x * im.img_y * 4, 256);
         im.plane_off = plane; if (opt_want_planes) plane += align_up((uint64_t)im.blk_xmax * 8 * im.blk_ymax * 8 * 3, 64);
         im.side_off = side; side += align_up(js_side_words(im.mcu_xmax * im.mcu_ymax, im.blk_xmax * im.blk_ymax), 4);
-        im.ustr_off = ustr; im.ustr_cap = (uint32_t)align_up(im.scan_len + 64, 64); ustr += im.ustr_cap;
+        im.ustr_off = ustr; im.ustr_cap = (uint32_t)align_up((uint64_t)im.scan_len + 64, 8192); ustr += im.ustr_cap;   // whole 64-sub-sequence groups
         im.n_subseq = (im.ustr_cap + JS_SUBSEQ_BYTES - 1) / JS_SUBSEQ_BYTES; im.subseq_off = subs; subs += align_up(im.n_subseq, 256);
         const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax;
         const uint64_t want_seg = im.rst_interval ? (uint64_t)nmcu / im.rst_interval + 2 : 1;
@@ -261,8 +261,8 @@ int JsnoopBatch::upload()
         im.mcu_off = mcub; mcub += align_up(nmcu, 16);
         usb[i] = usc; usc += (uint32_t)(((im.scan_start & 15) + (uint64_t)im.scan_len + JS_US_CHUNK - 1) / JS_US_CHUNK);
         syb[i] = syw; syw += (im.n_subseq + JS_SY_THREADS - 1) / JS_SY_THREADS;
-        const uint32_t G = 128 / im.mcu_w, strips = ((im.mcu_xmax + G - 1) / G) * im.mcu_ymax;
-        wg[i] = wgs; wgs += std::max(1u, (strips + strips_per_wg - 1) / strips_per_wg);
+        max_mcu_h = std::max(max_mcu_h, im.mcu_h); max_mcu_w = std::max(max_mcu_w, im.mcu_w);
+        wg[i] = wgs; wgs += std::max(1u, (nmcu + 8 * mcus_per_wave - 1) / (8 * mcus_per_wave));     // 8 waves per workgroup, one MCU per wave at a time
     }
     usb[n] = usc; syb[n] = syw; us_chunks = usc; sy_wgs = syw; seg_words = segw; mcu_bytes = mcub;
     wg[n] = wgs; total_wgs = wgs; total_blocks = blocks; dib_bytes = dibb; side_words = side; total_subseq = subs; ustr_bytes = ustr;
@@ -293,8 +293,11 @@ int JsnoopBatch::decode(bool timed)
     if (!uploaded && upload()) return -1;
     const uint32_t n = (uint32_t)imgs.size();
     if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
-    HIP_TRY(hipMemsetAsync(dev.coef, 0, total_blocks * 128, stream));
-    HIP_TRY(hipMemsetAsync(dev.dccum, 0, total_blocks * 2, stream));
+    bool parallel_ok = !opt_force_exact; if (parallel_ok) { parallel_ok = false; for (const JsTableSet& t : tables) parallel_ok = parallel_ok || t.lut_ok; }
+    if (!parallel_ok) {           // the exact-mirror kernel stores only what it decodes; the parallel path writes every block whole
+        HIP_TRY(hipMemsetAsync(dev.coef, 0, total_blocks * 128, stream));
+        HIP_TRY(hipMemsetAsync(dev.dccum, 0, total_blocks * 2, stream));
+    }
     HIP_TRY(hipMemsetAsync(dev.side, 0, side_words * 4, stream));
     HIP_TRY(hipMemsetAsync(dev.mcu_rst, 0, mcu_bytes, stream));
     HIP_TRY(hipMemsetAsync(dev.flags, 0, (size_t)n * 4, stream));
@@ -305,7 +308,7 @@ int JsnoopBatch::decode(bool timed)
     if (timed && !used_parallel) for (int s = 2; s <= 6; s++) HIP_TRY(hipEventRecord(ev[s], stream));
     if (!used_parallel) js_launch_entropy_exact(stream, dev.imgs, nullptr, n, dev.tables, dev.raw, dev.coef, dev.dccum, dev.side, 0);
     if (timed) HIP_TRY(hipEventRecord(ev[7], stream));
-    js_launch_idct_color(stream, dev.imgs, dev.wg_base, n, total_wgs, strips_per_wg, d_lut, dev.coef, dev.dccum, dev.dib, dev.planes, dev.side);
+    js_launch_idct_color(stream, dev.imgs, dev.wg_base, n, total_wgs, max_mcu_w, max_mcu_h, d_lut, dev.coef, dev.dccum, dev.dib, dev.planes, dev.side);
     if (timed) HIP_TRY(hipEventRecord(ev[8], stream));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -634,7 +637,7 @@ void JsnoopDecoder::rerender()                                  // CalcChannelPr
     hipSetDevice(b->device);
     hipMemcpyAsync(b->dev.imgs, &im, sizeof im, hipMemcpyHostToDevice, b->stream);
     hipMemsetAsync(b->dev.side + im.side_off + 12, 0, 16, b->stream);      // brightest-pixel key and sum of Y are recomputed
-    js_launch_idct_color(b->stream, b->dev.imgs, b->dev.wg_base, 1, b->total_wgs, b->strips_per_wg, b->d_lut, b->dev.coef, b->dev.dccum, b->dev.dib, b->dev.planes, b->dev.side);
+    js_launch_idct_color(b->stream, b->dev.imgs, b->dev.wg_base, 1, b->total_wgs, b->max_mcu_w, b->max_mcu_h, b->d_lut, b->dev.coef, b->dev.dccum, b->dev.dib, b->dev.planes, b->dev.side);
     hipStreamSynchronize(b->stream);
     host_valid = 0; fetch_side();
 }

@@ -57,7 +57,7 @@ struct JsnoopBatch {
     uint8_t* pinned; size_t pinned_cap; uint64_t raw_bytes;
     JsDeviceArenas dev; JsArenaCaps cap;
     bool uploaded;
-    uint64_t total_blocks, dib_bytes, side_words, total_subseq, ustr_bytes, seg_words, mcu_bytes; uint32_t total_wgs, strips_per_wg, us_chunks, sy_wgs;
+    uint64_t total_blocks, dib_bytes, side_words, total_subseq, ustr_bytes, seg_words, mcu_bytes; uint32_t total_wgs, strips_per_wg, us_chunks, sy_wgs, max_mcu_h, max_mcu_w;
     int sync_launches;
     hipEvent_t ev[JSNOOP_NUM_STAGES + 1];
     float lut[64][64]; float* d_lut;

@@ -255,8 +255,9 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
 // =====================================================================================
 #define BK_THREADS 512
 #define BK_WAVES (BK_THREADS / 64)
-#define BK_CHUNK 6
+#define BK_CHUNK 6                      // blocks per wave held in registers at a time (8 waves x 6 = one 4:2:0 strip of 8 MCUs)
 #define BK_MAX_STRIP_W 128
+#define BK_ROW 144                      // int16 per LDS plane row: 128 + padding so the 8 rows of a block fall in distinct banks
 #define BK_MAX_MCU_H 32
 
 __device__ __forceinline__ void ycc_to_rgb(int py, int pcb, int pcr, uint32_t mode, uint32_t& out_bgra, uint32_t& final_y)
@@ -288,128 +289,149 @@ __device__ __forceinline__ void ycc_to_rgb(int py, int pcb, int pcr, uint32_t mo
     out_bgra = B | (G << 8) | (R << 16);          // bytes B,G,R,0 (:4786-4789)
 }
 
-
-// DecodeIdctCalcFloat(64) :2372-2392 on one block held one coefficient per lane, then
-// SetFullRes :2468-2561 into the strip's LDS planes (replicated eH x eV times).
-__device__ __forceinline__ void idct_block_to_lds(const JsImage& im, int cv16, int16_t dc, const float* s_lut,
-                                                  int16_t (*s_pl)[BK_MAX_MCU_H][BK_MAX_STRIP_W], uint32_t bb, uint32_t nb, uint32_t lane)
+// DecodeIdctCalcFloat(64) :2372-2392 on one block held one coefficient per lane.  Only non-zero
+// coefficients are visited, in ascending natural order.  The wave first compacts them into a small LDS
+// list (row offset of the cosine table, coefficient as fp32) with one ballot + mbcnt, padded to a
+// multiple of four with (DC row, 0.0f) entries whose products are exact +-0 and leave the fp32 sum
+// unchanged; the accumulation loop then needs no scalar bit-twiddling: four broadcast list reads and
+// four table reads in flight per trip, then four dependent mul/add pairs in the reference's order.
+__device__ __forceinline__ float idct_sparse(int cv16, const float* s_lut, uint2* s_list /*this wave's 68 slots*/, uint32_t lane)
 {
-    const uint32_t m = bb / nb, c = bb % nb;
-    const float cf = (float)cv16;
-    uint64_t mask = __ballot(cv16 != 0) & ~1ull;                 // DC is excluded from the sum (:2381)
+    const bool nz = cv16 != 0 && lane != 0;                      // DC is excluded from the sum (:2381)
+    const uint64_t mask = __ballot(nz);
+    const uint32_t n = (uint32_t)__builtin_popcountll(mask);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    if (nz) s_list[rank] = make_uint2(lane * 256u, __float_as_uint((float)cv16));
+    if (lane < 4) s_list[n + lane] = make_uint2(0u, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     float acc = 0.0f;
-    while (mask) {
-        const uint32_t vu = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
-        mask &= mask - 1;
-        const float cvu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cf), vu));
-        acc = __fadd_rn(acc, __fmul_rn(s_lut[vu * 64 + lane], cvu));   // separate mul and add, ascending natural order
+    const uint32_t lane4 = lane * 4u;
+    const char* lut_b = reinterpret_cast<const char*>(s_lut);
+    for (uint32_t j = 0; j < n; j += 4) {
+        uint2 e[4]; float l[4];
+        #pragma unroll
+        for (int q = 0; q < 4; q++) e[q] = s_list[j + q];
+        #pragma unroll
+        for (int q = 0; q < 4; q++) l[q] = *reinterpret_cast<const float*>(lut_b + e[q].x + lane4);
+        #pragma unroll
+        for (int q = 0; q < 4; q++) acc = __fadd_rn(acc, __fmul_rn(l[q], __uint_as_float(e[q].y)));   // separate mul and add
     }
-    acc = __fmul_rn(acc, 0.25f);
-    const int16_t smp = (int16_t)((int16_t)(int)__fmul_rn(acc, 8.0f) + dc);   // SetFullRes :2517-2519
-    const uint32_t comp = im.blk_comp[c], eh = im.expand_h[comp], ev = im.expand_v[comp];
-    const uint32_t x0 = m * im.mcu_w + im.blk_ch[c] * 8 + (lane & 7) * eh, y0 = im.blk_cv[c] * 8 + (lane >> 3) * ev;
-    for (uint32_t jy = 0; jy < ev; jy++) for (uint32_t ix = 0; ix < eh; ix++) s_pl[comp - 1][y0 + jy][x0 + ix] = smp;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return __fmul_rn(acc, 0.25f);
+}
+// SetFullRes :2468-2561 into the wave's LDS MCU tile (replicated eH x eV times).
+// meta = comp-1 | eh<<4 | ev<<8 | (blk_ch*8)<<12 | (blk_cv*8)<<20 of the block's slot in the MCU.
+__device__ __forceinline__ void sample_to_lds(uint32_t meta, float idct, int16_t dc, int16_t* tile, uint32_t plane_elems, uint32_t rs, uint32_t lane)
+{
+    const int16_t smp = (int16_t)((int16_t)(int)__fmul_rn(idct, 8.0f) + dc);   // :2517-2519
+    const uint32_t comp0 = meta & 15u, eh = (meta >> 4) & 15u, ev = (meta >> 8) & 15u;
+    const uint32_t x0 = ((meta >> 12) & 255u) + (lane & 7) * eh, y0 = ((meta >> 20) & 255u) + (lane >> 3) * ev;
+    int16_t* pl = tile + comp0 * plane_elems + y0 * rs + x0;
+    for (uint32_t jy = 0; jy < ev; jy++) for (uint32_t ix = 0; ix < eh; ix++) pl[jy * rs + ix] = smp;
 }
 
+// One WAVE owns one MCU at a time: IDCT of its blocks in decode order (so self-overlapping replication,
+// SetFullRes :2498-2557, resolves exactly as in the reference: later blocks overwrite earlier ones),
+// samples staged in a wave-private LDS tile, then colour conversion and the MCU's DIB rows.  No
+// workgroup barrier in the loop; the next MCU's coefficient rows are prefetched into registers while
+// the current MCU is converted.
 __global__ void __launch_bounds__(BK_THREADS) k_idct_color(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ wg_base, uint32_t nimg,
-                                                           uint32_t strips_per_wg, const float* __restrict__ lut_t /*[vu][yx]*/,
+                                                           uint32_t tile_bytes, const float* __restrict__ lut_t /*[vu][yx]*/,
                                                            const int16_t* __restrict__ coef, const int16_t* __restrict__ dccum,
                                                            uint8_t* __restrict__ dib, int16_t* __restrict__ planes, uint32_t* __restrict__ side)
 {
-    __shared__ float s_lut[64 * 64];
-    __shared__ __attribute__((aligned(16))) int16_t s_pl[3][BK_MAX_MCU_H][BK_MAX_STRIP_W];
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    float* s_lut = reinterpret_cast<float*>(s_dyn);                               // 16 KiB transposed cosine table
+    uint32_t* s_meta = reinterpret_cast<uint32_t*>(s_dyn + 64 * 64 * sizeof(float)); // per block-in-MCU placement word
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint8_t* wave_mem = s_dyn + 64 * 64 * sizeof(float) + JS_MAX_BLK_PER_MCU * 4 + wave * (68 * 8 + tile_bytes);
+    uint2* s_list = reinterpret_cast<uint2*>(wave_mem);                           // this wave's non-zero list
+    int16_t* tile = reinterpret_cast<int16_t*>(wave_mem + 68 * 8);                // this wave's MCU tile: 3 planes x mcu_h x rs
 
-    // which image does this workgroup belong to?  (wg_base is an exclusive prefix, nimg+1 entries)
-    uint32_t lo = 0, hi = nimg;
+    uint32_t lo = 0, hi = nimg;                                  // wg_base is an exclusive prefix, nimg+1 entries
     while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (wg_base[mid] <= blockIdx.x) lo = mid; else hi = mid; }
     const JsImage& im = imgs[lo];
     const uint32_t wg_in_img = blockIdx.x - wg_base[lo], wgs_in_img = wg_base[lo + 1] - wg_base[lo];
 
     for (uint32_t i = tid; i < 64 * 64; i += BK_THREADS) s_lut[i] = lut_t[i];
+    if (tid < im.blk_per_mcu) { const uint32_t comp = im.blk_comp[tid];
+        s_meta[tid] = (comp - 1) | (im.expand_h[comp] << 4) | (im.expand_v[comp] << 8) | ((uint32_t)im.blk_ch[tid] * 8u << 12) | ((uint32_t)im.blk_cv[tid] * 8u << 20); }
+    __syncthreads();
 
-    const uint32_t G = BK_MAX_STRIP_W / im.mcu_w;                      // MCUs per strip
-    const uint32_t strips_x = (im.mcu_xmax + G - 1) / G, nstrips = strips_x * im.mcu_ymax;
-    const uint32_t nb = im.blk_per_mcu, pw = im.blk_xmax * 8;
+    const uint32_t nb = im.blk_per_mcu, nmcu = im.mcu_xmax * im.mcu_ymax, pw = im.blk_xmax * 8;
+    const uint32_t mw = im.mcu_w, mh = im.mcu_h, rs = mw + 8, plane_elems = mh * rs, ncomp = im.ncomp;
     const int16_t* cbase = coef + im.coef_off * 64;
     const int16_t* dbase = dccum + im.coef_off;
     uint8_t* dibp = dib + im.dib_off;
-    const uint32_t mcus_across = im.img_x / im.mcu_w, shift_ind = im.shift_mcu_y * mcus_across + im.shift_mcu_x;
-    const bool overlap = (im.samp_h[1] > 1 && im.expand_h[1] > 1) || (im.samp_v[1] > 1 && im.expand_v[1] > 1) ||
-                         (im.ncomp == 3 && ((im.samp_h[2] > 1 && im.expand_h[2] > 1) || (im.samp_v[2] > 1 && im.expand_v[2] > 1) ||
-                                            (im.samp_h[3] > 1 && im.expand_h[3] > 1) || (im.samp_v[3] > 1 && im.expand_v[3] > 1)));
-    (void)strips_per_wg;
-    __syncthreads();
+    const uint32_t mcus_across = im.img_x / mw, shift_ind = im.shift_mcu_y * mcus_across + im.shift_mcu_x;
+    const uint32_t img_x = im.img_x, img_y = im.img_y, mode = im.preview_mode; const int sh_y = im.shift_y, sh_cb = im.shift_cb, sh_cr = im.shift_cr;
+    const bool want_planes = im.want_planes != 0;
+    uint64_t bright = 0; uint32_t sum_y = 0;
+    if (ncomp == 1) for (uint32_t i = lane; i < 2 * plane_elems; i += 64) tile[plane_elems + i] = 0;   // Cb = Cr = 0 for grayscale (:4709-4715)
 
-    for (uint32_t s = wg_in_img; s < nstrips; s += wgs_in_img) {
-        const uint32_t my = s / strips_x, mx0 = (s % strips_x) * G;
-        const uint32_t gm = min(G, im.mcu_xmax - mx0), sw = gm * im.mcu_w;
-        const uint32_t nblocks = gm * nb;
-        // ---- IDCT: one wave per 8x8 block; each wave first issues the loads of BK_CHUNK blocks
-        //      (one coalesced 128-byte row each) so their HBM latencies overlap ------------------
-        const size_t b0 = (size_t)(my * im.mcu_xmax + mx0) * nb;       // blocks of a strip are contiguous in decode order
-        if (!overlap) {
-            for (uint32_t base = 0; base < nblocks; base += BK_WAVES * BK_CHUNK) {
-                int cv[BK_CHUNK]; int16_t dcv[BK_CHUNK];
-                #pragma unroll
-                for (int j = 0; j < BK_CHUNK; j++) {
-                    const uint32_t bb = base + j * BK_WAVES + wave;
-                    cv[j] = bb < nblocks ? (int)cbase[(b0 + bb) * 64 + lane] : 0;
-                    dcv[j] = bb < nblocks ? dbase[b0 + bb] : (int16_t)0;
-                }
-                #pragma unroll
-                for (int j = 0; j < BK_CHUNK; j++) {
-                    const uint32_t bb = base + j * BK_WAVES + wave;
-                    if (bb < nblocks) idct_block_to_lds(im, cv[j], dcv[j], s_lut, s_pl, bb, nb, lane);
-                }
-            }
-        } else {
-            // A component that is both multi-block and expanded overlaps its own blocks
-            // (SetFullRes :2498-2557): later blocks must overwrite earlier ones, so serialise.
-            for (uint32_t bb = 0; bb < nblocks; bb++) {
-                if (wave == 0) idct_block_to_lds(im, (int)cbase[(b0 + bb) * 64 + lane], dbase[b0 + bb], s_lut, s_pl, bb, nb, lane);
-                __syncthreads();
-            }
+    int cv[BK_CHUNK]; int16_t dcv[BK_CHUNK];
+    auto load_chunk = [&](uint32_t m, uint32_t base) {
+        #pragma unroll
+        for (int j = 0; j < BK_CHUNK; j++) {
+            const uint32_t c = base + j;
+            cv[j] = c < nb ? (int)cbase[((size_t)m * nb + c) * 64 + lane] : 0;
+            dcv[j] = c < nb ? dbase[(size_t)m * nb + c] : (int16_t)0;
         }
-        __syncthreads();
-        // ---- colour conversion + DIB rows: 4 pixels (16 bytes) per thread -------------------------
-        const uint32_t quads = sw / 4, total = quads * im.mcu_h;
-        uint64_t bright = 0; uint32_t sum_y = 0;
-        for (uint32_t p = tid; p < total; p += BK_THREADS) {
+    };
+    const uint32_t wstride = wgs_in_img * BK_WAVES;
+    uint32_t m = wg_in_img * BK_WAVES + wave;
+    if (m < nmcu) load_chunk(m, 0);
+    for (; m < nmcu; m += wstride) {
+        // ---- IDCT of the MCU's blocks, decode order ---------------------------------------------------
+        for (uint32_t base = 0; base < nb; base += BK_CHUNK) {
+            if (base) load_chunk(m, base);
+            #pragma unroll
+            for (int j = 0; j < BK_CHUNK; j++)
+                if (base + j < nb) sample_to_lds(s_meta[base + j], idct_sparse(cv[j], s_lut, s_list, lane), dcv[j], tile, plane_elems, rs, lane);
+        }
+        if (m + wstride < nmcu) load_chunk(m + wstride, 0);           // next MCU's rows fly during the colour phase
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        // ---- colour conversion + DIB rows: 4 pixels (16 bytes) per lane ---------------------------------
+        const uint32_t mx = m % im.mcu_xmax, my = m / im.mcu_xmax, quads = mw / 4, total = quads * mh;
+        const bool shifted = my * mcus_across + mx >= shift_ind;
+        for (uint32_t p = lane; p < total; p += 64) {
             const uint32_t y = p / quads, x = (p % quads) * 4;
-            const uint32_t py = my * im.mcu_h + y, px = mx0 * im.mcu_w + x;
+            const uint32_t py = my * mh + y, px = mx * mw + x;
+            const uint2 qy = *reinterpret_cast<const uint2*>(tile + y * rs + x);
+            const uint2 qcb = *reinterpret_cast<const uint2*>(tile + plane_elems + y * rs + x);
+            const uint2 qcr = *reinterpret_cast<const uint2*>(tile + 2 * plane_elems + y * rs + x);
             uint32_t o[4];
             #pragma unroll
             for (int k = 0; k < 4; k++) {
-                int vy = s_pl[0][y][x + k], vcb = 0, vcr = 0;
-                if (im.ncomp == 3) { vcb = s_pl[1][y][x + k]; vcr = s_pl[2][y][x + k]; }
+                int vy  = (int)(int16_t)((k < 2 ? qy.x  : qy.y)  >> ((k & 1) * 16));
+                int vcb = (int)(int16_t)((k < 2 ? qcb.x : qcb.y) >> ((k & 1) * 16));
+                int vcr = (int)(int16_t)((k < 2 ? qcr.x : qcr.y) >> ((k & 1) * 16));
                 // brightest-pixel search (:4722-4730): larger Y wins, earlier raster position breaks ties
-                const uint64_t key = ((uint64_t)(uint32_t)(vy + 32768) << 32) | (0xFFFFFFFFu - (py * im.img_x + px + k));
+                const uint64_t key = ((uint64_t)(uint32_t)(vy + 32768) << 32) | (0xFFFFFFFFu - (py * img_x + px + k));
                 bright = key > bright ? key : bright;
-                const uint32_t mi = (py / im.mcu_h) * mcus_across + (px + k) / im.mcu_w;
-                if (mi >= shift_ind) { vy += im.shift_y; vcb += im.shift_cb; vcr += im.shift_cr; }
-                uint32_t fy; ycc_to_rgb(vy, vcb, vcr, im.preview_mode, o[k], fy);
+                if (shifted) { vy += sh_y; vcb += sh_cb; vcr += sh_cr; }       // nMcuInd >= nMcuShiftInd (:4735-4739)
+                uint32_t fy; ycc_to_rgb(vy, vcb, vcr, mode, o[k], fy);
                 sum_y += fy;                                   // nSumY += nFinalY (:4751), wraps mod 2^32 like the reference
             }
             uint4 v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
-            *reinterpret_cast<uint4*>(dibp + ((size_t)(im.img_y - 1 - py) * im.img_x + px) * 4) = v;
-            if (im.want_planes) {
+            *reinterpret_cast<uint4*>(dibp + ((size_t)(img_y - 1 - py) * img_x + px) * 4) = v;
+            if (want_planes) {
                 int16_t* pb = planes + im.plane_off;
                 const size_t pi = (size_t)py * pw + px, psz = (size_t)pw * im.blk_ymax * 8;
-                for (uint32_t cc = 0; cc < im.ncomp; cc++)
-                    *reinterpret_cast<uint2*>(pb + cc * psz + pi) = *reinterpret_cast<const uint2*>(&s_pl[cc][y][x]);
+                *reinterpret_cast<uint2*>(pb + pi) = qy;
+                if (ncomp == 3) { *reinterpret_cast<uint2*>(pb + psz + pi) = qcb; *reinterpret_cast<uint2*>(pb + 2 * psz + pi) = qcr; }
             }
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            const uint64_t ob = __shfl_down(bright, off); bright = ob > bright ? ob : bright;
-            sum_y += __shfl_down(sum_y, off);
-        }
-        if (lane == 0) {
-            uint32_t* sd = side + im.side_off;
-            atomicMax(reinterpret_cast<unsigned long long*>(sd + 12), (unsigned long long)bright);
-            atomicAdd(sd + 15, sum_y);
-        }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t ob = __shfl_down(bright, off); bright = ob > bright ? ob : bright;
+        sum_y += __shfl_down(sum_y, off);
+    }
+    if (lane == 0) {
+        uint32_t* sd = side + im.side_off;
+        atomicMax(reinterpret_cast<unsigned long long*>(sd + 12), (unsigned long long)bright);
+        atomicAdd(sd + 15, sum_y);
     }
 }
 
@@ -458,11 +480,13 @@ void js_launch_entropy_exact(hipStream_t st, const JsImage* imgs, const uint32_t
     if (!nsel) return;
     hipLaunchKernelGGL(k_entropy_exact, dim3((nsel + 63) / 64), dim3(64), 0, st, imgs, sel, nsel, tables, raw, coef, dccum, side, side_only);
 }
-void js_launch_idct_color(hipStream_t st, const JsImage* imgs, const uint32_t* wg_base, uint32_t nimg, uint32_t total_wgs, uint32_t strips_per_wg,
+void js_launch_idct_color(hipStream_t st, const JsImage* imgs, const uint32_t* wg_base, uint32_t nimg, uint32_t total_wgs, uint32_t max_mcu_w, uint32_t max_mcu_h,
                           const float* lut_t, const int16_t* coef, const int16_t* dccum, uint8_t* dib, int16_t* planes, uint32_t* side)
 {
     if (!total_wgs) return;
-    hipLaunchKernelGGL(k_idct_color, dim3(total_wgs), dim3(BK_THREADS), 0, st, imgs, wg_base, nimg, strips_per_wg, lut_t, coef, dccum, dib, planes, side);
+    const uint32_t tile_bytes = ((3u * max_mcu_h * (max_mcu_w + 8u) * 2u) + 15u) & ~15u;
+    const size_t lds = 64 * 64 * sizeof(float) + JS_MAX_BLK_PER_MCU * 4 + (size_t)BK_WAVES * (68 * 8 + tile_bytes);
+    hipLaunchKernelGGL(k_idct_color, dim3(total_wgs), dim3(BK_THREADS), lds, st, imgs, wg_base, nimg, tile_bytes, lut_t, coef, dccum, dib, planes, side);
 }
 void js_launch_idct_probe(hipStream_t st, const float* lut_t, const int16_t* coef64, float* out64)
 { hipLaunchKernelGGL(k_idct_probe, dim3(1), dim3(64), 0, st, lut_t, coef64, out64); }
@@ -506,6 +530,13 @@ void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, 
 #define F_RST_MISALIGN  0x0008u
 #define F_SHORT         0x0010u
 #define F_NOSYNC        0x0080u
+
+// Physical layout of the compacted stream: 64 consecutive sub-sequences (64 x 128 B = 8 KiB) form a group
+// stored word-interleaved -- word w of sub-sequence l sits at 32-bit index (group*32 + w)*64 + l -- so that
+// the 64 lanes of a wave, each walking its own sub-sequence at roughly the same pace, read one coalesced
+// 256-byte row per refill instead of 64 different cache lines.
+__device__ __forceinline__ uint32_t phys_word(uint32_t W) { return (W & ~2047u) | ((W & 31u) << 6) | ((W >> 5) & 63u); }
+__device__ __forceinline__ uint32_t phys_byte(uint32_t B) { return (phys_word(B >> 2) << 2) | (B & 3u); }
 
 struct UsBytes { uint32_t keep_mask, rst_mask; };
 
@@ -614,7 +645,7 @@ __global__ void __launch_bounds__(US_THREADS) k_unstuff_write(const JsImage* __r
     #pragma unroll
     for (int j = 0; j < 16; j++) {
         if (c.rst_mask & (1u << j)) { seg++; if (seg + 1 < im.seg_cap) st[seg] = out; }     // interval `seg` starts at the next kept byte
-        if (c.keep_mask & (1u << j)) dst[out++] = (uint8_t)(w4[j >> 2] >> ((j & 3) * 8));
+        if (c.keep_mask & (1u << j)) dst[phys_byte(out++)] = (uint8_t)(w4[j >> 2] >> ((j & 3) * 8));
     }
 }
 
@@ -627,19 +658,20 @@ struct SubTabs {                       // per-workgroup LDS copy of one image's 
     uint8_t  zz[64];
 };
 
-struct Cursor {                        // MSB-first 64-bit window over the compacted stream
-    const uint32_t* words; uint32_t widx; uint64_t buf; int cnt; uint32_t p;
+struct Cursor {                        // MSB-first 64-bit window over the compacted stream, one word prefetched
+    const uint32_t* words; uint32_t widx; uint64_t buf; int cnt; uint32_t p; uint32_t nxt;
 };
 __device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
 __device__ __forceinline__ void cur_init(Cursor& c, const uint32_t* words, uint32_t p)
 {
     c.words = words; c.p = p; c.widx = p >> 5;
-    const uint64_t w0 = bswap32(words[c.widx]), w1 = bswap32(words[c.widx + 1]);
+    const uint64_t w0 = bswap32(words[phys_word(c.widx)]), w1 = bswap32(words[phys_word(c.widx + 1)]);
+    c.nxt = words[phys_word(c.widx + 2)];
     const uint32_t sh = p & 31;
-    c.buf = ((w0 << 32) | w1) << sh; c.cnt = 64 - (int)sh; c.widx += 2;
+    c.buf = ((w0 << 32) | w1) << sh; c.cnt = 64 - (int)sh; c.widx += 3;
 }
 __device__ __forceinline__ void cur_refill(Cursor& c)
-{ if (c.cnt <= 32) { c.buf |= (uint64_t)bswap32(c.words[c.widx++]) << (32 - c.cnt); c.cnt += 32; } }
+{ if (c.cnt <= 32) { c.buf |= (uint64_t)bswap32(c.nxt) << (32 - c.cnt); c.cnt += 32; c.nxt = c.words[phys_word(c.widx++)]; } }
 __device__ __forceinline__ void cur_skip(Cursor& c, uint32_t n) { c.buf <<= n; c.cnt -= (int)n; c.p += n; }
 
 // state word: [31:16] interval index, [15:8] block-in-MCU, [7:0] next coefficient index (0 = DC)
@@ -649,19 +681,32 @@ __device__ __forceinline__ void cur_skip(Cursor& c, uint32_t n) { c.buf <<= n; c
 #define ST_MAKE(seg, c, k) (((seg) << 16) | ((c) << 8) | (k))
 #define P_END 0xFFFFFFFFu
 
+#define WR_STRIDE 68                   // int16 per thread-private LDS block buffer (64 + pad: 8-byte aligned, banks staggered)
+
+// Walks the symbols that START inside [entry position, own_end).  SYNC flavour (WRITE = false): state only.
+// WRITE flavour: every 8x8 block is written by exactly one thread -- the one that decodes its DC symbol.
+// A thread entering mid-block (k > 0) parses the rest of that block without output; a thread whose last
+// block is unfinished at own_end keeps decoding past it until the block completes.  Coefficients are
+// gathered in a thread-private LDS block buffer and leave as one full 128-byte block (16 x 8-byte stores
+// back to back), so HBM sees whole lines instead of scattered 2-byte read-modify-writes -- and no memset
+// of the coefficient arena is needed.  The exit state / block count reported back are those at own_end.
 template <bool WRITE>
 __device__ __forceinline__ void walk_subseq(const JsImage& im, const SubTabs& T, const uint32_t* __restrict__ words, const uint32_t* __restrict__ st,
                                             uint32_t nseg, uint32_t total_bits, uint32_t own_end, uint32_t& p_io, uint32_t& s_io, uint32_t& nblk_out,
-                                            int16_t* __restrict__ cbase, int16_t* __restrict__ dbase, uint8_t* __restrict__ mcu_rst, uint32_t blk0, uint32_t& flags)
+                                            int16_t* __restrict__ cbase, int16_t* __restrict__ dbase, uint8_t* __restrict__ mcu_rst, uint32_t blk0, uint32_t& flags,
+                                            int16_t* lbuf)
 {
     uint32_t p = p_io, seg = ST_SEG(s_io), c = ST_C(s_io), k = ST_K(s_io), nblk = 0;
     if (p == P_END || (p >= total_bits && seg + 1 >= nseg)) { p_io = P_END; s_io = 0; nblk_out = 0; return; }
     uint32_t seg_end = st[seg + 1] * 8;
     const uint32_t nb = im.blk_per_mcu, prec_shift = im.precision >= 8 ? ((im.precision - 8) & 31) : 0;
     Cursor cur; cur_init(cur, words, p);
-    uint32_t blk = blk0;                                   // WRITE: absolute block index being filled
-    int16_t* out = WRITE ? cbase + (size_t)blk * 64 : nullptr;
-    while (cur.p < own_end) {
+    uint32_t blk = blk0;                                   // WRITE: index of the block in progress / next to start
+    bool skip = WRITE && k != 0;                           // the block in progress belongs to an earlier thread
+    bool captured = false; int16_t dq0 = 0;
+    for (;;) {
+        if (cur.p >= own_end && !captured) { captured = true; p_io = cur.p; s_io = ST_MAKE(seg, c, k); nblk_out = nblk; }
+        if (cur.p >= own_end && (!WRITE || k == 0 || skip)) break;
         cur_refill(cur);
         const uint32_t slot = T.slot_dc[c] + (k ? 1u : 0u);
         uint32_t e = T.lut1[slot][cur.buf >> 55];
@@ -681,7 +726,7 @@ __device__ __forceinline__ void walk_subseq(const JsImage& im, const SubTabs& T,
             if (seg + 1 < nseg) {
                 if (WRITE) {
                     if (k != 0 || c != 0 || remain >= 8) flags |= F_RST_MISALIGN;   // well-formed: < 8 pad bits, on an MCU boundary
-                    if (blk < im.total_blocks) mcu_rst[blk / nb] = 1;
+                    if (blk < im.total_blocks && !captured) mcu_rst[blk / nb] = 1;
                 }
                 seg++; const uint32_t np = seg_end; seg_end = st[seg + 1] * 8; c = 0; k = 0;
                 if (WRITE && seg_end == np && seg + 1 < nseg) flags |= F_RST_MISALIGN;       // back-to-back RSTn
@@ -690,10 +735,11 @@ __device__ __forceinline__ void walk_subseq(const JsImage& im, const SubTabs& T,
             }
             if (WRITE && blk < im.total_blocks) flags |= F_SHORT;
             cur.p = P_END; c = 0; k = 0; seg = 0;
+            if (!captured) { captured = true; p_io = P_END; s_io = 0; nblk_out = nblk; }
             break;
         }
         if (len + size > remain) { if (WRITE && blk < im.total_blocks) flags |= F_OVERRUN; }
-        if (WRITE && blk < im.total_blocks && (k == 0 || im.decode_ac)) {
+        if (WRITE && !skip && (k == 0 || im.decode_ac)) {
             // value bits: EXTEND (HuffmanDc2Signed :859), precision divide (:1234-1238), dequantise (:2278)
             int32_t val = 0;
             if (size) {
@@ -704,8 +750,8 @@ __device__ __forceinline__ void walk_subseq(const JsImage& im, const SubTabs& T,
             const uint32_t ind = k == 0 ? 0u : k + run;
             if (ind < 64 && (k == 0 || size)) {
                 const int16_t dq = (int16_t)((int32_t)(int16_t)val * (int32_t)T.qzz[T.slot_dc[c] >> 1][ind]);
-                out[T.zz[ind]] = dq;
-                if (k == 0) dbase[blk] = dq;
+                lbuf[T.zz[ind]] = dq;
+                if (k == 0) dq0 = dq;
             }
         }
         cur_skip(cur, len + size);
@@ -713,9 +759,22 @@ __device__ __forceinline__ void walk_subseq(const JsImage& im, const SubTabs& T,
         if (k == 0) { k = 1; done = false; }
         else if (sym == 0) done = true;                         // EOB
         else { k += run + 1; done = k >= 64; if (WRITE && k > 64 && blk < im.total_blocks) flags |= F_COEF_OVERFLOW; }
-        if (done) { k = 0; c = c + 1 == nb ? 0 : c + 1; nblk++; if (WRITE) { blk++; out += 64; } }
+        if (done) {
+            k = 0; c = c + 1 == nb ? 0 : c + 1;
+            if (!captured) nblk++;
+            if (WRITE) {
+                if (!skip && blk < im.total_blocks) {               // one whole block leaves as 16 back-to-back 8-byte stores
+                    uint2* dst = reinterpret_cast<uint2*>(cbase + (size_t)blk * 64);
+                    uint2* src = reinterpret_cast<uint2*>(lbuf);
+                    #pragma unroll
+                    for (int j = 0; j < 16; j++) { dst[j] = src[j]; src[j] = make_uint2(0u, 0u); }
+                    dbase[blk] = dq0;
+                }
+                skip = false; blk++;
+            }
+        }
     }
-    p_io = cur.p; s_io = cur.p == P_END ? 0u : ST_MAKE(seg, c, k); nblk_out = nblk;
+    if (!captured) { p_io = cur.p; s_io = cur.p == P_END ? 0u : ST_MAKE(seg, c, k); nblk_out = nblk; }
 }
 
 __device__ __forceinline__ void load_subtabs(SubTabs& T, const JsImage& im, const JsTableSet& ts, uint32_t tid, uint32_t nthreads)
@@ -778,7 +837,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
             my_in_p = ip; my_in_s = is;
             uint32_t p = ip, s = is;
             if (p != P_END && p >= own_end) { nblk = 0; }        // owns no symbol: state passes through
-            else walk_subseq<false>(im, T, words, st, nseg, total_bits, own_end, p, s, nblk, nullptr, nullptr, nullptr, 0, dummy);
+            else walk_subseq<false>(im, T, words, st, nseg, total_bits, own_end, p, s, nblk, nullptr, nullptr, nullptr, 0, dummy, nullptr);
             if (p != out_p || s != out_s) { out_p = p; out_s = s; s_changed = 1; }
         }
         __syncthreads();
@@ -819,6 +878,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
                                                       int16_t* __restrict__ coef, int16_t* __restrict__ dccum, uint8_t* __restrict__ mcu_rst, uint32_t* __restrict__ flags)
 {
     __shared__ SubTabs T;
+    __shared__ __attribute__((aligned(16))) int16_t s_blk[SY_THREADS][WR_STRIDE];
     const uint32_t img = find_image(sy_base, nimg, blockIdx.x);
     const JsImage& im = imgs[img];
     if (!tables[im.tableset].lut_ok) return;
@@ -827,6 +887,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
     const uint32_t sub0 = (blockIdx.x - sy_base[img]) * SY_THREADS, i = sub0 + threadIdx.x;
     if (sub0 * SUB_BITS >= total_bits) return;
     load_subtabs(T, im, tables[im.tableset], threadIdx.x, SY_THREADS);
+    { uint2* z = reinterpret_cast<uint2*>(s_blk[threadIdx.x]); for (int j = 0; j < WR_STRIDE / 4; j++) z[j] = make_uint2(0u, 0u); }
     __syncthreads();
     if (i * SUB_BITS >= total_bits) return;
     const size_t g = im.subseq_off + i;
@@ -837,7 +898,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         walked = true;
         if (blk0 < im.total_blocks || p == P_END)
             walk_subseq<true>(im, T, reinterpret_cast<const uint32_t*>(ustr + im.ustr_off), seg_tab + im.seg_off, nseg, total_bits, own_end, p, s, nblk,
-                              coef + im.coef_off * 64, dccum + im.coef_off, mcu_rst + im.mcu_off, blk0, fl);
+                              coef + im.coef_off * 64, dccum + im.coef_off, mcu_rst + im.mcu_off, blk0, fl, s_blk[threadIdx.x]);
         else { p = A.out_p[g]; s = A.out_s[g]; walked = false; } // everything this thread owns lies past the last MCU
     }
     // the chain must be at its fixed point, and the block count that fed the prefix sum must be the real one

@@ -97,7 +97,7 @@ int JsnoopBatch::run_exact(const std::vector<uint32_t>& which)
     }
     HIP_TRY(hipMemcpyAsync(dev.sel, which.data(), which.size() * 4, hipMemcpyHostToDevice, stream));
     js_launch_entropy_exact(stream, dev.imgs, dev.sel, (uint32_t)which.size(), dev.tables, dev.raw, dev.coef, dev.dccum, dev.side, 0);
-    js_launch_idct_color(stream, dev.imgs, dev.wg_base, (uint32_t)imgs.size(), total_wgs, strips_per_wg, d_lut, dev.coef, dev.dccum, dev.dib, dev.planes, dev.side);
+    js_launch_idct_color(stream, dev.imgs, dev.wg_base, (uint32_t)imgs.size(), total_wgs, max_mcu_w, max_mcu_h, d_lut, dev.coef, dev.dccum, dev.dib, dev.planes, dev.side);
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -120,7 +120,7 @@ static int js_parallel_resume(JsnoopBatch* b, int extra_launches)
     js_launch_write(b->stream, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
                     b->dev.coef, b->dev.dccum, b->dev.mcu_rst, b->dev.flags);
     js_launch_dc_scan(b->stream, b->dev.imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst);
-    js_launch_idct_color(b->stream, b->dev.imgs, b->dev.wg_base, n, b->total_wgs, b->strips_per_wg, b->d_lut, b->dev.coef, b->dev.dccum, b->dev.dib, b->dev.planes, b->dev.side);
+    js_launch_idct_color(b->stream, b->dev.imgs, b->dev.wg_base, n, b->total_wgs, b->max_mcu_w, b->max_mcu_h, b->d_lut, b->dev.coef, b->dev.dccum, b->dev.dib, b->dev.planes, b->dev.side);
     HIP_TRY(hipMemcpyAsync(b->host_flags.data(), b->dev.flags, (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return 0;
