@@ -275,6 +275,7 @@ int JsnoopBatch::upload()
         grow(&dev.us_base, &cap.us_base, (n + 1) * 4) || grow(&dev.sy_base, &cap.sy_base, (n + 1) * 4) ||
         grow(&dev.mcu_rst, &cap.mcu_rst, mcub + 64) || grow(&dev.flags, &cap.flags, n * 4 + 64)) return -1;
     if (opt_want_planes && grow(&dev.planes, &cap.planes, plane * 2)) return -1;
+    tab_rows = 1; tab_lut2 = 0; for (const JsTableSet& t : tables) { tab_rows = std::max(tab_rows, t.n_rows); tab_lut2 = std::max(tab_lut2, t.lut2_used); }
     HIP_TRY(hipMemcpyAsync(dev.raw, pinned, raw_bytes, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(dev.imgs, imgs.data(), n * sizeof(JsImage), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(dev.tables, tables.data(), tables.size() * sizeof(JsTableSet), hipMemcpyHostToDevice, stream));

@@ -58,7 +58,7 @@ struct JsnoopBatch {
     JsDeviceArenas dev; JsArenaCaps cap;
     bool uploaded;
     uint64_t total_blocks, dib_bytes, side_words, total_subseq, ustr_bytes, seg_words, mcu_bytes; uint32_t total_wgs, strips_per_wg, us_chunks, sy_wgs, max_mcu_h, max_mcu_w;
-    int sync_launches;
+    int sync_launches; uint32_t tab_rows, tab_lut2;     // largest decode-table footprint in the batch (sizes the kernels' LDS)
     hipEvent_t ev[JSNOOP_NUM_STAGES + 1];
     float lut[64][64]; float* d_lut;
     explicit JsnoopBatch(void* user_stream);

@@ -650,29 +650,53 @@ __global__ void __launch_bounds__(US_THREADS) k_unstuff_write(const JsImage* __r
 }
 
 // ---- Huffman symbol walk shared by the sync and write passes ------------------------------
-struct SubTabs {                       // per-workgroup LDS copy of one image's decode tables
-    uint16_t lut1[6][1 << JS_FAST_BITS];
-    uint16_t lut2[JS_LUT2_MAX];
-    uint16_t qzz[3][64];
-    uint8_t  slot_dc[JS_MAX_BLK_PER_MCU];  // table slot (comp-1)*2 of each block of the MCU
-    uint8_t  zz[64];
+// Per-workgroup LDS view of one image's decode tables (dynamic shared memory, sized by the batch).
+struct SubTabs {
+    const uint16_t* lut1;              // n_rows x 2048 entries
+    const uint16_t* lut2;              // second level (codes longer than 11 bits)
+    const uint16_t* qzz;               // 3 x 64 quantiser entries, zig-zag order
+    const uint8_t*  zz;                // 64: zig-zag index -> natural index
+    uint32_t rows01, rows2;            // per component 16 bits: first-level row of its DC table | AC table << 8
+    uint32_t n1, n2, nb;               // block-in-MCU index where Cb / Cr blocks start; blocks per MCU
 };
+__device__ __forceinline__ size_t subtabs_bytes(uint32_t tab_rows, uint32_t tab_lut2)
+{ return (size_t)tab_rows * (2u << JS_L1_BITS) + (((size_t)tab_lut2 * 2 + 15) & ~15ull) + 3 * 64 * 2 + 64; }
 
-struct Cursor {                        // MSB-first 64-bit window over the compacted stream, one word prefetched
-    const uint32_t* words; uint32_t widx; uint64_t buf; int cnt; uint32_t p; uint32_t nxt;
+__device__ __forceinline__ void load_subtabs(SubTabs& T, uint8_t* lds, const JsImage& im, const JsTableSet& ts, uint32_t tab_rows, uint32_t tab_lut2,
+                                             uint32_t tid, uint32_t nthreads)
+{
+    uint16_t* l1 = reinterpret_cast<uint16_t*>(lds);
+    uint16_t* l2 = l1 + (size_t)tab_rows * (1u << JS_L1_BITS);
+    uint16_t* q = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(l2) + (((size_t)tab_lut2 * 2 + 15) & ~15ull));
+    uint8_t* z = reinterpret_cast<uint8_t*>(q + 3 * 64);
+    const uint32_t* src1 = reinterpret_cast<const uint32_t*>(&ts.lut1[0][0]);
+    uint32_t* dst1 = reinterpret_cast<uint32_t*>(l1);
+    for (uint32_t i = tid; i < ts.n_rows * (1u << JS_L1_BITS) / 2; i += nthreads) dst1[i] = src1[i];
+    for (uint32_t i = tid; i < ts.lut2_used; i += nthreads) l2[i] = ts.lut2[i];
+    for (uint32_t i = tid; i < 3 * 64; i += nthreads) q[i] = (&ts.qzz[0][0])[i];
+    if (tid < 64) z[tid] = c_zigzag[tid];
+    T.lut1 = l1; T.lut2 = l2; T.qzz = q; T.zz = z;
+    T.rows01 = ts.slot_row[0] | (ts.slot_row[1] << 8) | (ts.slot_row[2] << 16) | (ts.slot_row[3] << 24); T.rows2 = ts.slot_row[4] | (ts.slot_row[5] << 8);
+    T.nb = im.blk_per_mcu; T.n1 = im.samp_h[1] * im.samp_v[1]; T.n2 = im.ncomp == 3 ? T.n1 + im.samp_h[2] * im.samp_v[2] : T.nb;
+}
+
+struct Cursor {                        // MSB-first bit cursor: two byte-swapped words + bit offset, one raw word prefetched
+    const uint32_t* words; uint32_t widx, w0, w1, nxt, off, p;
 };
 __device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
 __device__ __forceinline__ void cur_init(Cursor& c, const uint32_t* words, uint32_t p)
 {
-    c.words = words; c.p = p; c.widx = p >> 5;
-    const uint64_t w0 = bswap32(words[phys_word(c.widx)]), w1 = bswap32(words[phys_word(c.widx + 1)]);
-    c.nxt = words[phys_word(c.widx + 2)];
-    const uint32_t sh = p & 31;
-    c.buf = ((w0 << 32) | w1) << sh; c.cnt = 64 - (int)sh; c.widx += 3;
+    c.words = words; c.p = p; c.widx = p >> 5; c.off = p & 31u;
+    c.w0 = bswap32(words[phys_word(c.widx)]); c.w1 = bswap32(words[phys_word(c.widx + 1)]);
+    c.nxt = words[phys_word(c.widx + 2)]; c.widx += 3;
 }
-__device__ __forceinline__ void cur_refill(Cursor& c)
-{ if (c.cnt <= 32) { c.buf |= (uint64_t)bswap32(c.nxt) << (32 - c.cnt); c.cnt += 32; c.nxt = c.words[phys_word(c.widx++)]; } }
-__device__ __forceinline__ void cur_skip(Cursor& c, uint32_t n) { c.buf <<= n; c.cnt -= (int)n; c.p += n; }
+// the next 32 bits of the stream (one v_alignbit_b32)
+__device__ __forceinline__ uint32_t cur_peek(const Cursor& c) { return __funnelshift_l(c.w1, c.w0, c.off); }
+__device__ __forceinline__ void cur_skip(Cursor& c, uint32_t n)      // n <= 32
+{
+    c.off += n; c.p += n;
+    if (c.off >= 32u) { c.off -= 32u; c.w0 = c.w1; c.w1 = bswap32(c.nxt); c.nxt = c.words[phys_word(c.widx++)]; }
+}
 
 // state word: [31:16] interval index, [15:8] block-in-MCU, [7:0] next coefficient index (0 = DC)
 #define ST_SEG(s) ((s) >> 16)
@@ -680,111 +704,154 @@ __device__ __forceinline__ void cur_skip(Cursor& c, uint32_t n) { c.buf <<= n; c
 #define ST_K(s)   ((s) & 255u)
 #define ST_MAKE(seg, c, k) (((seg) << 16) | ((c) << 8) | (k))
 #define P_END 0xFFFFFFFFu
-
 #define WR_STRIDE 68                   // int16 per thread-private LDS block buffer (64 + pad: 8-byte aligned, banks staggered)
 
-// Walks the symbols that START inside [entry position, own_end).  SYNC flavour (WRITE = false): state only.
+// component (0..2) of block-in-MCU index c, without a table lookup
+__device__ __forceinline__ uint32_t comp_of(const SubTabs& T, uint32_t c) { return (c >= T.n1 ? 1u : 0u) + (c >= T.n2 ? 1u : 0u); }
+__device__ __forceinline__ uint32_t rows_of(const SubTabs& T, uint32_t comp) { return comp == 2 ? T.rows2 : (T.rows01 >> (comp * 16u)) & 0xFFFFu; }
+
+// One symbol: table entry for the 32-bit window `win` under the DC (k == 0) or AC table of `rp`.
+__device__ __forceinline__ uint32_t sym_lookup(const SubTabs& T, uint32_t win, uint32_t rp, uint32_t k)
+{
+    const uint32_t row = (k ? rp >> 8 : rp) & 255u;
+    uint32_t e = T.lut1[(row << JS_L1_BITS) + (win >> (32 - JS_L1_BITS))];
+    if (__builtin_expect(e & 0x8000u, 0)) {                      // < 0.5 % of symbols: code longer than 11 bits
+        const uint32_t nbx = (e >> 12) & 7u;
+        e = T.lut2[(e & 0xFFFu) + ((win >> (32 - JS_L1_BITS - nbx)) & ((1u << nbx) - 1u))];
+    }
+    return e;
+}
+
+// What the reference sees as RSV_RST_TERM (:1167-1176) -- no code fits in what is left of the interval --
+// or a code that matches nothing.  Returns false when the walk is over (end of the entropy data).
+template <bool WRITE>
+__device__ __forceinline__ bool walk_slow(const JsImage& im, const uint32_t* __restrict__ words, const uint32_t* __restrict__ st, uint32_t nseg,
+                                       Cursor& cur, uint32_t len, uint32_t& seg, uint32_t& seg_end, uint32_t& c, uint32_t& k,
+                                       uint32_t blk, bool mark, uint8_t* __restrict__ mcu_rst, uint32_t& flags)
+{
+    const uint32_t remain = seg_end > cur.p ? seg_end - cur.p : 0u;
+    if (len == 0 && remain >= 16) {
+        // No code matches although a whole code could still fit: a corrupt stream (the reference skips one bit
+        // and reports it, :1178-1186) -- or simply a speculative walk that is not synchronised yet.
+        if (WRITE && blk < im.total_blocks) flags |= F_BAD_CODE;
+        cur_skip(cur, 1);
+        return true;
+    }
+    if (seg + 1 < nseg) {
+        if (WRITE) {
+            if (k != 0 || c != 0 || remain >= 8) flags |= F_RST_MISALIGN;   // well-formed: < 8 pad bits, on an MCU boundary
+            if (mark && blk < im.total_blocks) mcu_rst[blk / im.blk_per_mcu] = 1;
+        }
+        seg++; const uint32_t np = seg_end; seg_end = st[seg + 1] * 8; c = 0; k = 0;
+        if (WRITE && seg_end == np && seg + 1 < nseg) flags |= F_RST_MISALIGN;       // back-to-back RSTn
+        cur_init(cur, words, np);
+        return true;
+    }
+    if (WRITE && blk < im.total_blocks) flags |= F_SHORT;
+    cur.p = P_END; c = 0; k = 0; seg = 0;
+    return false;
+}
+
+// SYNC flavour: state only.  Walks the symbols that start inside [entry position, own_end).
+__device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, const uint32_t* __restrict__ words, const uint32_t* __restrict__ st,
+                                          uint32_t nseg, uint32_t total_bits, uint32_t own_end, uint32_t& p_io, uint32_t& s_io, uint32_t& nblk_out)
+{
+    uint32_t seg = ST_SEG(s_io), c = ST_C(s_io), k = ST_K(s_io), nblk = 0, fl = 0;
+    if (p_io == P_END || (p_io >= total_bits && seg + 1 >= nseg)) { p_io = P_END; s_io = 0; nblk_out = 0; return; }
+    uint32_t seg_end = st[seg + 1] * 8;
+    Cursor cur; cur_init(cur, words, p_io);
+    uint32_t rp = rows_of(T, comp_of(T, c));
+    while (cur.p < own_end) {
+        const uint32_t win = cur_peek(cur);
+        const uint32_t e = sym_lookup(T, win, rp, k);
+        const uint32_t len = (e >> 8) & 31u, run = (e >> 4) & 15u, size = e & 15u;
+        if (__builtin_expect(len == 0 || cur.p + len > seg_end, 0)) {
+            if (!walk_slow<false>(im, words, st, nseg, cur, len, seg, seg_end, c, k, 0, false, nullptr, fl)) break;
+            rp = rows_of(T, comp_of(T, c));
+            continue;
+        }
+        cur_skip(cur, len + size);
+        const bool isdc = k == 0;
+        const uint32_t k2 = isdc ? 1u : k + run + 1u;
+        const bool done = !isdc && ((e & 255u) == 0 || k2 >= 64u);
+        k = done ? 0u : k2;
+        if (done) { c = c + 1 == T.nb ? 0u : c + 1; nblk++; rp = rows_of(T, comp_of(T, c)); }
+    }
+    p_io = cur.p; s_io = cur.p == P_END ? 0u : ST_MAKE(seg, c, k); nblk_out = nblk;
+}
+
 // WRITE flavour: every 8x8 block is written by exactly one thread -- the one that decodes its DC symbol.
 // A thread entering mid-block (k > 0) parses the rest of that block without output; a thread whose last
 // block is unfinished at own_end keeps decoding past it until the block completes.  Coefficients are
 // gathered in a thread-private LDS block buffer and leave as one full 128-byte block (16 x 8-byte stores
 // back to back), so HBM sees whole lines instead of scattered 2-byte read-modify-writes -- and no memset
 // of the coefficient arena is needed.  The exit state / block count reported back are those at own_end.
-template <bool WRITE>
-__device__ __forceinline__ void walk_subseq(const JsImage& im, const SubTabs& T, const uint32_t* __restrict__ words, const uint32_t* __restrict__ st,
-                                            uint32_t nseg, uint32_t total_bits, uint32_t own_end, uint32_t& p_io, uint32_t& s_io, uint32_t& nblk_out,
-                                            int16_t* __restrict__ cbase, int16_t* __restrict__ dbase, uint8_t* __restrict__ mcu_rst, uint32_t blk0, uint32_t& flags,
-                                            int16_t* lbuf)
+__device__ __forceinline__ void walk_write(const JsImage& im, const SubTabs T, const uint32_t* __restrict__ words, const uint32_t* __restrict__ st,
+                                           uint32_t nseg, uint32_t total_bits, uint32_t own_end, uint32_t& p_io, uint32_t& s_io, uint32_t& nblk_out,
+                                           int16_t* __restrict__ cbase, int16_t* __restrict__ dbase, uint8_t* __restrict__ mcu_rst, uint32_t blk0, uint32_t& flags,
+                                           int16_t* lbuf)
 {
-    uint32_t p = p_io, seg = ST_SEG(s_io), c = ST_C(s_io), k = ST_K(s_io), nblk = 0;
-    if (p == P_END || (p >= total_bits && seg + 1 >= nseg)) { p_io = P_END; s_io = 0; nblk_out = 0; return; }
+    uint32_t seg = ST_SEG(s_io), c = ST_C(s_io), k = ST_K(s_io), nblk = 0;
+    if (p_io == P_END || (p_io >= total_bits && seg + 1 >= nseg)) { p_io = P_END; s_io = 0; nblk_out = 0; return; }
     uint32_t seg_end = st[seg + 1] * 8;
-    const uint32_t nb = im.blk_per_mcu, prec_shift = im.precision >= 8 ? ((im.precision - 8) & 31) : 0;
-    Cursor cur; cur_init(cur, words, p);
-    uint32_t blk = blk0;                                   // WRITE: index of the block in progress / next to start
-    bool skip = WRITE && k != 0;                           // the block in progress belongs to an earlier thread
+    const uint32_t prec_shift = im.precision >= 8 ? ((im.precision - 8) & 31) : 0, nblocks = im.total_blocks, decode_ac = im.decode_ac;
+    Cursor cur; cur_init(cur, words, p_io);
+    uint32_t blk = blk0;                                   // index of the block in progress / next to start
+    bool skip = k != 0;                                    // the block in progress belongs to an earlier thread
     bool captured = false; int16_t dq0 = 0;
+    uint32_t comp = comp_of(T, c), rp = rows_of(T, comp);
     for (;;) {
-        if (cur.p >= own_end && !captured) { captured = true; p_io = cur.p; s_io = ST_MAKE(seg, c, k); nblk_out = nblk; }
-        if (cur.p >= own_end && (!WRITE || k == 0 || skip)) break;
-        cur_refill(cur);
-        const uint32_t slot = T.slot_dc[c] + (k ? 1u : 0u);
-        uint32_t e = T.lut1[slot][cur.buf >> 55];
-        if (e & 0x8000u) { const uint32_t nbx = (e >> 12) & 7u; e = T.lut2[(e & 0xFFFu) + ((uint32_t)(cur.buf >> (55 - nbx)) & ((1u << nbx) - 1u))]; }
-        const uint32_t len = (e >> 8) & 31u, sym = e & 255u, size = sym & 15u, run = sym >> 4;
-        const uint32_t remain = seg_end > cur.p ? seg_end - cur.p : 0u;   // bits left in this restart interval
-        if (len == 0 && remain >= 16) {
-            // No code matches although a whole code could still fit: a corrupt stream (the reference skips one bit
-            // and reports it, :1178-1186) -- or simply a speculative walk that is not synchronised yet.
-            if (WRITE && blk < im.total_blocks) flags |= F_BAD_CODE;
-            cur_skip(cur, 1);
+        if (cur.p >= own_end) {
+            if (!captured) { captured = true; p_io = cur.p; s_io = ST_MAKE(seg, c, k); nblk_out = nblk; }
+            if (k == 0 || skip) break;                       // else: finish the block this thread started
+        }
+        const uint32_t win = cur_peek(cur);
+        const uint32_t e = sym_lookup(T, win, rp, k);
+        const uint32_t len = (e >> 8) & 31u, run = (e >> 4) & 15u, size = e & 15u;
+        if (__builtin_expect(len == 0 || cur.p + len > seg_end, 0)) {
+            const bool more = walk_slow<true>(im, words, st, nseg, cur, len, seg, seg_end, c, k, blk, !captured, mcu_rst, flags);
+            if (!more) { if (!captured) { captured = true; p_io = P_END; s_io = 0; nblk_out = nblk; } break; }
+            comp = comp_of(T, c); rp = rows_of(T, comp);
             continue;
         }
-        if (len == 0 || len > remain) {
-            // No code fits in what is left of the interval: what the reference sees as RSV_RST_TERM
-            // (:1167-1176) when an RSTn follows, or the end of the entropy data otherwise.
-            if (seg + 1 < nseg) {
-                if (WRITE) {
-                    if (k != 0 || c != 0 || remain >= 8) flags |= F_RST_MISALIGN;   // well-formed: < 8 pad bits, on an MCU boundary
-                    if (blk < im.total_blocks && !captured) mcu_rst[blk / nb] = 1;
-                }
-                seg++; const uint32_t np = seg_end; seg_end = st[seg + 1] * 8; c = 0; k = 0;
-                if (WRITE && seg_end == np && seg + 1 < nseg) flags |= F_RST_MISALIGN;       // back-to-back RSTn
-                cur_init(cur, words, np);
-                continue;
-            }
-            if (WRITE && blk < im.total_blocks) flags |= F_SHORT;
-            cur.p = P_END; c = 0; k = 0; seg = 0;
-            if (!captured) { captured = true; p_io = P_END; s_io = 0; nblk_out = nblk; }
-            break;
-        }
-        if (len + size > remain) { if (WRITE && blk < im.total_blocks) flags |= F_OVERRUN; }
-        if (WRITE && !skip && (k == 0 || im.decode_ac)) {
+        if (__builtin_expect(cur.p + len + size > seg_end, 0)) { if (blk < nblocks) flags |= F_OVERRUN; }
+        const bool isdc = k == 0;
+        if (!skip && (isdc || (decode_ac && size))) {
             // value bits: EXTEND (HuffmanDc2Signed :859), precision divide (:1234-1238), dequantise (:2278)
             int32_t val = 0;
             if (size) {
-                const uint32_t v = (uint32_t)((cur.buf << len) >> (64 - size));
+                const uint32_t v = (win << len) >> (32 - size);
                 val = v >= (1u << (size - 1)) ? (int32_t)v : (int32_t)(v - ((1u << size) - 1u));
                 if (prec_shift) val /= (int32_t)(1u << prec_shift);
             }
-            const uint32_t ind = k == 0 ? 0u : k + run;
-            if (ind < 64 && (k == 0 || size)) {
-                const int16_t dq = (int16_t)((int32_t)(int16_t)val * (int32_t)T.qzz[T.slot_dc[c] >> 1][ind]);
+            const uint32_t ind = isdc ? 0u : k + run;
+            if (ind < 64) {
+                const int16_t dq = (int16_t)((int32_t)(int16_t)val * (int32_t)T.qzz[comp * 64 + ind]);
                 lbuf[T.zz[ind]] = dq;
-                if (k == 0) dq0 = dq;
+                if (isdc) dq0 = dq;
             }
         }
         cur_skip(cur, len + size);
-        bool done;
-        if (k == 0) { k = 1; done = false; }
-        else if (sym == 0) done = true;                         // EOB
-        else { k += run + 1; done = k >= 64; if (WRITE && k > 64 && blk < im.total_blocks) flags |= F_COEF_OVERFLOW; }
+        const uint32_t k2 = isdc ? 1u : k + run + 1u;
+        const bool done = !isdc && ((e & 255u) == 0 || k2 >= 64u);
+        if (__builtin_expect(k2 > 64u && blk < nblocks, 0)) flags |= F_COEF_OVERFLOW;
+        k = done ? 0u : k2;
         if (done) {
-            k = 0; c = c + 1 == nb ? 0 : c + 1;
+            c = c + 1 == T.nb ? 0u : c + 1; comp = comp_of(T, c); rp = rows_of(T, comp);
             if (!captured) nblk++;
-            if (WRITE) {
-                if (!skip && blk < im.total_blocks) {               // one whole block leaves as 16 back-to-back 8-byte stores
-                    uint2* dst = reinterpret_cast<uint2*>(cbase + (size_t)blk * 64);
-                    uint2* src = reinterpret_cast<uint2*>(lbuf);
-                    #pragma unroll
-                    for (int j = 0; j < 16; j++) { dst[j] = src[j]; src[j] = make_uint2(0u, 0u); }
-                    dbase[blk] = dq0;
-                }
-                skip = false; blk++;
+            if (!skip && blk < nblocks) {                     // one whole block leaves as 16 back-to-back 8-byte stores
+                uint2* dst = reinterpret_cast<uint2*>(cbase + (size_t)blk * 64);
+                uint2* src = reinterpret_cast<uint2*>(lbuf);
+                #pragma unroll
+                for (int j = 0; j < 16; j++) { dst[j] = src[j]; src[j] = make_uint2(0u, 0u); }
+                dbase[blk] = dq0;
             }
+            skip = false; blk++;
         }
     }
     if (!captured) { p_io = cur.p; s_io = cur.p == P_END ? 0u : ST_MAKE(seg, c, k); nblk_out = nblk; }
 }
 
-__device__ __forceinline__ void load_subtabs(SubTabs& T, const JsImage& im, const JsTableSet& ts, uint32_t tid, uint32_t nthreads)
-{
-    for (uint32_t i = tid; i < 6 * (1u << JS_FAST_BITS); i += nthreads) (&T.lut1[0][0])[i] = (&ts.lut1[0][0])[i];
-    for (uint32_t i = tid; i < JS_LUT2_MAX; i += nthreads) T.lut2[i] = ts.lut2[i];
-    for (uint32_t i = tid; i < 3 * 64; i += nthreads) (&T.qzz[0][0])[i] = (&ts.qzz[0][0])[i];
-    if (tid < JS_MAX_BLK_PER_MCU) T.slot_dc[tid] = tid < im.blk_per_mcu ? (uint8_t)((im.blk_comp[tid] - 1) * 2) : 0;
-    if (tid < 64) T.zz[tid] = c_zigzag[tid];
-}
 // upper_bound(seg table, byte) - 1 : the interval a speculative start position lies in
 __device__ __forceinline__ uint32_t find_interval(const uint32_t* __restrict__ st, uint32_t nseg, uint32_t byte)
 {
@@ -798,55 +865,71 @@ struct SubArrays { uint32_t *out_p, *out_s, *in_p, *in_s, *nblk, *base; };
 
 __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sy_base, uint32_t nimg,
                                                      const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr,
-                                                     const uint32_t* __restrict__ seg_tab, const uint32_t* __restrict__ side, SubArrays A, int first_pass)
+                                                     const uint32_t* __restrict__ seg_tab, const uint32_t* __restrict__ side, SubArrays A, int first_pass,
+                                                     uint32_t tab_rows, uint32_t tab_lut2)
 {
-    __shared__ SubTabs T;
-    __shared__ uint32_t s_p[SY_THREADS], s_s[SY_THREADS];
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    __shared__ uint32_t s_inp[SY_THREADS], s_ins[SY_THREADS], s_outp[SY_THREADS], s_outs[SY_THREADS], s_nblk[SY_THREADS];
+    __shared__ uint16_t s_act[SY_THREADS];
+    __shared__ uint32_t s_wcount[SY_THREADS / 64];
     __shared__ int s_changed;
     const uint32_t img = find_image(sy_base, nimg, blockIdx.x);
     const JsImage& im = imgs[img];
     if (!tables[im.tableset].lut_ok) return;
     const uint32_t* sd = side + im.side_off;
     const uint32_t total_bits = sd[10] * 8, nseg = min(sd[11], im.seg_cap - 1);
-    const uint32_t sub0 = (blockIdx.x - sy_base[img]) * SY_THREADS, i = sub0 + threadIdx.x;
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t sub0 = (blockIdx.x - sy_base[img]) * SY_THREADS;
     if (sub0 * SUB_BITS >= total_bits && sub0) return;          // whole workgroup lies past the end of the data
-    load_subtabs(T, im, tables[im.tableset], threadIdx.x, SY_THREADS);
+    SubTabs T; load_subtabs(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, t, SY_THREADS);
     const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);
     const uint32_t* st = seg_tab + im.seg_off;
-    const size_t g = im.subseq_off + i;
-    const uint32_t own_end = min((i + 1) * SUB_BITS, total_bits);
-    uint32_t my_in_p, my_in_s, out_p, out_s, nblk = 0, dummy = 0;
-    if (first_pass) { my_in_p = 0xFFFFFFFEu; my_in_s = 0; out_p = 0; out_s = 0; }
-    else { my_in_p = A.in_p[g]; my_in_s = A.in_s[g]; out_p = A.out_p[g]; out_s = A.out_s[g]; nblk = A.nblk[g]; }
-    s_p[threadIdx.x] = out_p; s_s[threadIdx.x] = out_s;
+    const size_t g0 = im.subseq_off + sub0;
+    if (first_pass) { s_inp[t] = 0xFFFFFFFEu; s_ins[t] = 0; s_outp[t] = 0; s_outs[t] = 0; s_nblk[t] = 0; }
+    else { s_inp[t] = A.in_p[g0 + t]; s_ins[t] = A.in_s[g0 + t]; s_outp[t] = A.out_p[g0 + t]; s_outs[t] = A.out_s[g0 + t]; s_nblk[t] = A.nblk[g0 + t]; }
+    // the exit state of the sub-sequence left of this workgroup, as of the previous launch (speculative start in the first pass)
+    uint32_t left_p = 0, left_s = 0;
+    if (t == 0 && sub0 && !first_pass) { left_p = A.out_p[g0 - 1]; left_s = A.out_s[g0 - 1]; }
     __syncthreads();
     for (int it = 0; it < SY_THREADS + 2; it++) {
+        // ---- phase A: which sub-sequences see a new entry state?  (reads last iteration's exit states only)
+        const uint32_t i = sub0 + t;
         uint32_t ip, is;
-        if (first_pass && it == 0) {                             // speculative start at the first bit of the sub-sequence
-            ip = i * SUB_BITS; is = i * SUB_BITS < total_bits ? ST_MAKE(find_interval(st, nseg, i * (SUB_BITS / 8)), 0u, 0u) : 0u;
-            if (i * SUB_BITS >= total_bits) ip = P_END;
+        if ((first_pass && (it == 0 || t == 0)) && i != 0) {     // speculative start at the first bit of the sub-sequence
+            ip = i * SUB_BITS < total_bits ? i * SUB_BITS : P_END;
+            is = i * SUB_BITS < total_bits ? ST_MAKE(find_interval(st, nseg, i * (SUB_BITS / 8)), 0u, 0u) : 0u;
         } else if (i == 0) { ip = 0; is = 0; }                   // true start of the scan: interval 0, block 0, DC
-        else if (threadIdx.x == 0) {
-            if (first_pass) { ip = my_in_p; is = my_in_s; }      // left neighbour lives in another workgroup: keep the speculative start
-            else { ip = A.out_p[g - 1]; is = A.out_s[g - 1]; }   // ... its exit state as of the previous launch
+        else if (t == 0) { ip = left_p; is = left_s; }
+        else { ip = s_outp[t - 1]; is = s_outs[t - 1]; }
+        const bool active = ip != s_inp[t] || is != s_ins[t];
+        if (t == 0) s_changed = 0;
+        const uint64_t bal = __ballot(active);
+        if (lane == 0) s_wcount[wave] = (uint32_t)__builtin_popcountll(bal);
+        __syncthreads();                                         // everybody has read the old exit states
+        if (active) {
+            s_inp[t] = ip; s_ins[t] = is;
+            uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            for (uint32_t w = 0; w < wave; w++) r += s_wcount[w];
+            s_act[r] = (uint16_t)t;                              // compacted list of sub-sequences to walk again
         }
-        else { ip = s_p[threadIdx.x - 1]; is = s_s[threadIdx.x - 1]; }
-        if (threadIdx.x == 0) s_changed = 0;
+        uint32_t nact = 0;
+        for (uint32_t w = 0; w < SY_THREADS / 64; w++) nact += s_wcount[w];
         __syncthreads();
-        if (ip != my_in_p || is != my_in_s) {
-            my_in_p = ip; my_in_s = is;
-            uint32_t p = ip, s = is;
-            if (p != P_END && p >= own_end) { nblk = 0; }        // owns no symbol: state passes through
-            else walk_subseq<false>(im, T, words, st, nseg, total_bits, own_end, p, s, nblk, nullptr, nullptr, nullptr, 0, dummy, nullptr);
-            if (p != out_p || s != out_s) { out_p = p; out_s = s; s_changed = 1; }
+        // ---- phase B: the first `nact` threads each walk one of them (whole waves drop out as the chain converges)
+        if (t < nact) {
+            const uint32_t u = s_act[t], iu = sub0 + u;
+            uint32_t p = s_inp[u], s = s_ins[u], nblk = 0;
+            const uint32_t own_end = min((iu + 1) * SUB_BITS, total_bits);
+            if (!(p != P_END && p >= own_end))                   // else: owns no symbol, the state passes through
+                walk_sync(im, T, words, st, nseg, total_bits, own_end, p, s, nblk);
+            if (p != s_outp[u] || s != s_outs[u]) { s_outp[u] = p; s_outs[u] = s; s_changed = 1; }
+            s_nblk[u] = nblk;
         }
         __syncthreads();
-        s_p[threadIdx.x] = out_p; s_s[threadIdx.x] = out_s;
-        const int ch = s_changed;
+        if (!s_changed) break;
         __syncthreads();
-        if (!ch && !(first_pass && it == 0)) break;
     }
-    A.out_p[g] = out_p; A.out_s[g] = out_s; A.in_p[g] = my_in_p; A.in_s[g] = my_in_s; A.nblk[g] = nblk;
+    A.out_p[g0 + t] = s_outp[t]; A.out_s[g0 + t] = s_outs[t]; A.in_p[g0 + t] = s_inp[t]; A.in_s[g0 + t] = s_ins[t]; A.nblk[g0 + t] = s_nblk[t];
 }
 
 // One workgroup per image: exclusive scan of blocks-per-sub-sequence.
@@ -875,9 +958,10 @@ __global__ void __launch_bounds__(256) k_block_scan(const JsImage* __restrict__ 
 __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sy_base, uint32_t nimg,
                                                       const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr,
                                                       const uint32_t* __restrict__ seg_tab, const uint32_t* __restrict__ side, SubArrays A,
-                                                      int16_t* __restrict__ coef, int16_t* __restrict__ dccum, uint8_t* __restrict__ mcu_rst, uint32_t* __restrict__ flags)
+                                                      int16_t* __restrict__ coef, int16_t* __restrict__ dccum, uint8_t* __restrict__ mcu_rst, uint32_t* __restrict__ flags,
+                                                      uint32_t tab_rows, uint32_t tab_lut2)
 {
-    __shared__ SubTabs T;
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     __shared__ __attribute__((aligned(16))) int16_t s_blk[SY_THREADS][WR_STRIDE];
     const uint32_t img = find_image(sy_base, nimg, blockIdx.x);
     const JsImage& im = imgs[img];
@@ -886,7 +970,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
     const uint32_t total_bits = sd[10] * 8, nseg = min(sd[11], im.seg_cap - 1);
     const uint32_t sub0 = (blockIdx.x - sy_base[img]) * SY_THREADS, i = sub0 + threadIdx.x;
     if (sub0 * SUB_BITS >= total_bits) return;
-    load_subtabs(T, im, tables[im.tableset], threadIdx.x, SY_THREADS);
+    SubTabs T; load_subtabs(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, threadIdx.x, SY_THREADS);
     { uint2* z = reinterpret_cast<uint2*>(s_blk[threadIdx.x]); for (int j = 0; j < WR_STRIDE / 4; j++) z[j] = make_uint2(0u, 0u); }
     __syncthreads();
     if (i * SUB_BITS >= total_bits) return;
@@ -897,8 +981,8 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
     if (!(p != P_END && p >= own_end)) {
         walked = true;
         if (blk0 < im.total_blocks || p == P_END)
-            walk_subseq<true>(im, T, reinterpret_cast<const uint32_t*>(ustr + im.ustr_off), seg_tab + im.seg_off, nseg, total_bits, own_end, p, s, nblk,
-                              coef + im.coef_off * 64, dccum + im.coef_off, mcu_rst + im.mcu_off, blk0, fl, s_blk[threadIdx.x]);
+            walk_write(im, T, reinterpret_cast<const uint32_t*>(ustr + im.ustr_off), seg_tab + im.seg_off, nseg, total_bits, own_end, p, s, nblk,
+                       coef + im.coef_off * 64, dccum + im.coef_off, mcu_rst + im.mcu_off, blk0, fl, s_blk[threadIdx.x]);
         else { p = A.out_p[g]; s = A.out_s[g]; walked = false; } // everything this thread owns lies past the last MCU
     }
     // the chain must be at its fixed point, and the block count that fed the prefix sum must be the real one
@@ -950,20 +1034,24 @@ void js_launch_unstuff(hipStream_t st, const JsImage* imgs, const uint32_t* us_b
     hipLaunchKernelGGL(k_unstuff_write, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, ustr, seg_tab);
 }
 static SubArrays sub_arrays(uint32_t* sub, uint64_t n) { SubArrays a; a.out_p = sub; a.out_s = sub + n; a.in_p = sub + 2 * n; a.in_s = sub + 3 * n; a.nblk = sub + 4 * n; a.base = sub + 5 * n; return a; }
-void js_launch_sync(hipStream_t st, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
+static size_t subtabs_bytes_host(uint32_t tab_rows, uint32_t tab_lut2)
+{ return (size_t)tab_rows * (2u << JS_L1_BITS) + (((size_t)tab_lut2 * 2 + 15) & ~15ull) + 3 * 64 * 2 + 64; }
+void js_launch_sync(hipStream_t st, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
                     const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub, int first_pass)
 {
     if (!total_wgs) return;
-    hipLaunchKernelGGL(k_sync, dim3(total_wgs), dim3(SY_THREADS), 0, st, imgs, sy_base, nimg, tables, ustr, seg_tab, side, sub_arrays(sub, nsub), first_pass);
+    hipLaunchKernelGGL(k_sync, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                       sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2);
 }
 void js_launch_block_scan(hipStream_t st, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, uint32_t* sub, uint64_t nsub, uint32_t* side, uint32_t* flags)
 { if (nimg) hipLaunchKernelGGL(k_block_scan, dim3(nimg), dim3(256), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags); }
-void js_launch_write(hipStream_t st, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
+void js_launch_write(hipStream_t st, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
                      const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub,
                      int16_t* coef, int16_t* dccum, uint8_t* mcu_rst, uint32_t* flags)
 {
     if (!total_wgs) return;
-    hipLaunchKernelGGL(k_write, dim3(total_wgs), dim3(SY_THREADS), 0, st, imgs, sy_base, nimg, tables, ustr, seg_tab, side, sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags);
+    hipLaunchKernelGGL(k_write, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                       sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2);
 }
 void js_launch_dc_scan(hipStream_t st, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, int16_t* dccum, const uint8_t* mcu_rst)
 { if (nimg) hipLaunchKernelGGL(k_dc_scan, dim3(nimg), dim3(256), 0, st, imgs, tables, dccum, mcu_rst); }

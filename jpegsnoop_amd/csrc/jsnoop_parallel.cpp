@@ -15,8 +15,8 @@
 // well-formed canonical prefix code whose symbols the fast path can interpret.
 void js_build_parallel_luts(JsTableSet* ts, uint32_t ncomp)
 {
-    ts->lut_ok = 0;
-    memset(ts->lut1, 0, sizeof ts->lut1); memset(ts->lut2, 0, sizeof ts->lut2);
+    ts->lut_ok = 0; ts->n_rows = 0; ts->lut2_used = 0;
+    memset(ts->lut1, 0, sizeof ts->lut1); memset(ts->lut2, 0, sizeof ts->lut2); memset(ts->slot_row, 0, sizeof ts->slot_row);
     uint32_t l2_used = 0;
     for (uint32_t slot = 0; slot < ncomp * 2; slot++) {
         const uint32_t n = ts->size[slot]; const bool is_dc = (slot & 1) == 0;
@@ -32,30 +32,37 @@ void js_build_parallel_luts(JsTableSet* ts, uint32_t ncomp)
             if (is_dc && (sym >> 4)) return;                       // a DC category with a run nibble: exact path mirrors the quirk
             next_code++; prev_len = len;
         }
-        // first level: codes of <= 9 bits
-        for (uint32_t i = 0; i < n; i++) {
-            const uint32_t len = ts->bitlen[slot][i], top = ts->bits[slot][i] >> (32 - JS_FAST_BITS), sym = ts->code[slot][i];
-            if (len <= JS_FAST_BITS) for (uint32_t k = 0; k < (1u << (JS_FAST_BITS - len)); k++) ts->lut1[slot][top + k] = (uint16_t)((len << 8) | sym);
+        // identical code list as an earlier slot of the same class? share its row
+        int shared = -1;
+        for (uint32_t q = slot & 1; q < slot && shared < 0; q += 2)
+            if (ts->size[q] == n && !memcmp(ts->bitlen[q], ts->bitlen[slot], n * 4) && !memcmp(ts->bits[q], ts->bits[slot], n * 4) &&
+                !memcmp(ts->code[q], ts->code[slot], n * 4)) shared = (int)ts->slot_row[q];
+        if (shared >= 0) { ts->slot_row[slot] = (uint32_t)shared; continue; }
+        const uint32_t row = ts->n_rows++; ts->slot_row[slot] = row;
+        uint16_t* l1 = ts->lut1[row];
+        for (uint32_t i = 0; i < n; i++) {                        // first level: codes of <= JS_L1_BITS bits
+            const uint32_t len = ts->bitlen[slot][i], top = ts->bits[slot][i] >> (32 - JS_L1_BITS), sym = ts->code[slot][i];
+            if (len <= JS_L1_BITS) for (uint32_t k = 0; k < (1u << (JS_L1_BITS - len)); k++) l1[top + k] = (uint16_t)((len << 8) | sym);
         }
-        // second level: group the longer codes by their 9-bit prefix
-        for (uint32_t i = 0; i < n; ) {
+        for (uint32_t i = 0; i < n; ) {                           // second level: longer codes grouped by their first-level prefix
             const uint32_t len = ts->bitlen[slot][i];
-            if (len <= JS_FAST_BITS) { i++; continue; }
-            const uint32_t prefix = ts->bits[slot][i] >> (32 - JS_FAST_BITS);
+            if (len <= JS_L1_BITS) { i++; continue; }
+            const uint32_t prefix = ts->bits[slot][i] >> (32 - JS_L1_BITS);
             uint32_t j = i, maxlen = len;
-            while (j < n && (ts->bits[slot][j] >> (32 - JS_FAST_BITS)) == prefix) { maxlen = ts->bitlen[slot][j]; j++; }
-            const uint32_t nb = maxlen - JS_FAST_BITS;             // 1..7 extra index bits
+            while (j < n && (ts->bits[slot][j] >> (32 - JS_L1_BITS)) == prefix) { maxlen = ts->bitlen[slot][j]; j++; }
+            const uint32_t nb = maxlen - JS_L1_BITS;              // 1..5 extra index bits
             if (l2_used + (1u << nb) > JS_LUT2_MAX) return;
-            ts->lut1[slot][prefix] = (uint16_t)(0x8000u | (nb << 12) | l2_used);
+            l1[prefix] = (uint16_t)(0x8000u | (nb << 12) | l2_used);
             for (uint32_t k = i; k < j; k++) {
                 const uint32_t l = ts->bitlen[slot][k], sym = ts->code[slot][k];
-                const uint32_t sub = (ts->bits[slot][k] >> (32 - JS_FAST_BITS - nb)) & ((1u << nb) - 1);
-                for (uint32_t q = 0; q < (1u << (JS_FAST_BITS + nb - l)); q++) ts->lut2[l2_used + sub + q] = (uint16_t)((l << 8) | sym);
+                const uint32_t sub = (ts->bits[slot][k] >> (32 - JS_L1_BITS - nb)) & ((1u << nb) - 1);
+                for (uint32_t q = 0; q < (1u << (JS_L1_BITS + nb - l)); q++) ts->lut2[l2_used + sub + q] = (uint16_t)((l << 8) | sym);
             }
             l2_used += 1u << nb;
             i = j;
         }
     }
+    ts->lut2_used = l2_used;
     ts->lut_ok = 1;
 }
 
@@ -71,11 +78,11 @@ int js_parallel_entropy(JsnoopBatch* b, bool timed)
                       b->dev.ustr, b->dev.seg, b->dev.side, b->dev.flags);
     if (timed) HIP_TRY(hipEventRecord(b->ev[2], b->stream));
     for (int l = 0; l < b->sync_launches; l++)
-        js_launch_sync(b->stream, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, l == 0);
+        js_launch_sync(b->stream, b->tab_rows, b->tab_lut2, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, l == 0);
     if (timed) HIP_TRY(hipEventRecord(b->ev[3], b->stream));
     js_launch_block_scan(b->stream, b->dev.imgs, n, b->dev.tables, sub, b->total_subseq, b->dev.side, b->dev.flags);
     if (timed) HIP_TRY(hipEventRecord(b->ev[4], b->stream));
-    js_launch_write(b->stream, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
+    js_launch_write(b->stream, b->tab_rows, b->tab_lut2, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
                     b->dev.coef, b->dev.dccum, b->dev.mcu_rst, b->dev.flags);
     if (timed) HIP_TRY(hipEventRecord(b->ev[5], b->stream));
     js_launch_dc_scan(b->stream, b->dev.imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst);
@@ -115,9 +122,9 @@ static int js_parallel_resume(JsnoopBatch* b, int extra_launches)
     HIP_TRY(hipMemsetAsync(b->dev.flags, 0, (size_t)n * 4, b->stream));
     for (uint32_t i = 0; i < n; i++) HIP_TRY(hipMemsetAsync(b->dev.side + b->imgs[i].side_off + 12, 0, 16, b->stream));
     for (int l = 0; l < extra_launches; l++)
-        js_launch_sync(b->stream, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, 0);
+        js_launch_sync(b->stream, b->tab_rows, b->tab_lut2, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, 0);
     js_launch_block_scan(b->stream, b->dev.imgs, n, b->dev.tables, sub, b->total_subseq, b->dev.side, b->dev.flags);
-    js_launch_write(b->stream, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
+    js_launch_write(b->stream, b->tab_rows, b->tab_lut2, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
                     b->dev.coef, b->dev.dccum, b->dev.mcu_rst, b->dev.flags);
     js_launch_dc_scan(b->stream, b->dev.imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst);
     js_launch_idct_color(b->stream, b->dev.imgs, b->dev.wg_base, n, b->total_wgs, b->max_mcu_w, b->max_mcu_h, b->d_lut, b->dev.coef, b->dev.dccum, b->dev.dib, b->dev.planes, b->dev.side);
