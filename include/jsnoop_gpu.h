@@ -71,6 +71,13 @@ void jsnoop_set_precision(JsnoopDecoder*, unsigned precision);
 void jsnoop_set_image_details(JsnoopDecoder*, unsigned dim_x, unsigned dim_y, unsigned comps_sof, unsigned comps_sos,
                               int rst_en, unsigned rst_interval);
 
+/* ---- minimal JFIF front end: walks SOI/DQT/SOF0-1/DHT/DRI up to the first SOS and
+ *      issues the setter calls above exactly as CjfifDecode::DecodeMarker does (source/JfifDecode.cpp:3581,
+ *      :3600, :4648, :5008-5025, :5161, :5291).  On success *scan_start is the nStart to pass to
+ *      jsnoop_decode_scan_img.  Returns 0, or -1 with jsnoop_last_error() (e.g. SOF2: the reference
+ *      refuses progressive files, :4827-4833).                                                    */
+int  jsnoop_jfif_walk(JsnoopDecoder*, const uint8_t* file, size_t len, unsigned* scan_start);
+
 /* ---- decode: DecodeScanImg(nStart,bDisplay,bQuiet) :2723 ------------------------
  * `file`/`len` is the whole file image that the reference reads through
  * CwindowBuf::Buf (source/WindowBuf.cpp:639; bytes past `len` read as 0).  The bytes are

@@ -38,6 +38,7 @@ SIGNATURES = {
     "jsnoop_set_sof_samp_factors": (None, [_p, _u, _u, _u]),
     "jsnoop_set_precision": (None, [_p, _u]),
     "jsnoop_set_image_details": (None, [_p, _u, _u, _u, _u, _i, _u]),
+    "jsnoop_jfif_walk": (_i, [_p, _p, _sz, _PU]),
     "jsnoop_decode_scan_img": (None, [_p, _p, _sz, _u, _i, _i]),
     "jsnoop_is_preview_ready": (_i, [_p]),
     "jsnoop_get_image_size": (None, [_p, _PU, _PU]),

@@ -1,0 +1,131 @@
+// ImgDecodeGpu.h -- the reference's scan-decoder interface on top of the C ABI (include/jsnoop_gpu.h).
+//
+// `CimgDecodeGpu` keeps the public method names, argument meaning and return conventions of the
+// reference's `CimgDecode` (reference source/ImgDecode.h:286-356, :384-385, :407-425) for the
+// scan-decode path, so that `CjfifDecode` / `CJPEGsnoopCore` code that drives a `CimgDecode*` can be
+// pointed at this class (INTEGRATION.md shows the two-line change).  `CJPEGsnoopCoreGpu` carries the
+// `I_*` pass-throughs of `CJPEGsnoopCore` (source/JPEGsnoopCore.h:79-117) that belong to this path,
+// plus the batched submit that replaces the sequential DoBatchFileProcess loop
+// (source/JPEGsnoopCore.cpp:765-845).
+//
+// Header-only, no MFC: CString/CDocLog/CwindowBuf are replaced by std::string, a log callback and a
+// (pointer, length) view of the file bytes.  Everything below is a thin forwarding layer; the work
+// happens in libjsnoop_gpu.so on the GPU.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/jsnoop_gpu.h"
+
+// What CwindowBuf hands the decoder: the whole file image (overlays already applied by the caller).
+struct CwindowBufView {
+    const uint8_t* pData = nullptr; size_t nLen = 0;
+    uint8_t Buf(size_t nOffset) const { return nOffset < nLen ? pData[nOffset] : 0; }     // WindowBuf.cpp:639
+};
+
+class CimgDecodeGpu {
+public:
+    using LogFn = std::function<void(int /*0 info, 1 warn, 2 err*/, const std::string&)>;
+
+    explicit CimgDecodeGpu(LogFn pLog = nullptr, const CwindowBufView* pWBuf = nullptr) : m_pWBuf(pWBuf), m_log(std::move(pLog))
+    {
+        m_h = jsnoop_create();                                   // CimgDecode ctor (ImgDecode.cpp:142)
+        if (!m_h) throw std::runtime_error(std::string("jsnoop_create: ") + jsnoop_last_error());
+        if (m_log) jsnoop_set_log_callback(m_h, &CimgDecodeGpu::LogThunk, this);
+    }
+    ~CimgDecodeGpu() { jsnoop_destroy(m_h); }
+    CimgDecodeGpu(const CimgDecodeGpu&) = delete;
+    CimgDecodeGpu& operator=(const CimgDecodeGpu&) = delete;
+
+    void SetWindowBuf(const CwindowBufView* pWBuf) { m_pWBuf = pWBuf; }
+
+    // ---- lifecycle ------------------------------------------------------------------------------
+    void Reset() { jsnoop_reset(m_h); }                         // :49
+    void ResetState() { jsnoop_reset_state(m_h); }              // :286
+
+    // ---- options: the CSnoopConfig fields DecodeScanImg reads (:2730-2741) -------------------------
+    void SetConfig(bool bDecodeScanImgAc, bool bHistoEn = false, bool bStatClipEn = false, unsigned nErrMaxDecodeScan = 20)
+    { jsnoop_set_options(m_h, bDecodeScanImgAc, bHistoEn, bStatClipEn, nErrMaxDecodeScan); }
+
+    // ---- tables / geometry (same names, same bool returns) -------------------------------------------
+    bool SetDqtEntry(unsigned nTblDestId, unsigned nCoeffInd, unsigned nCoeffIndZz, unsigned short nCoeffVal)
+    { return jsnoop_set_dqt_entry(m_h, nTblDestId, nCoeffInd, nCoeffIndZz, nCoeffVal) != 0; }                 // :424
+    bool SetDqtTables(unsigned nCompInd, unsigned nTbl) { return jsnoop_set_dqt_tables(m_h, nCompInd, nTbl) != 0; }          // :505
+    unsigned GetDqtEntry(unsigned nTblDestId, unsigned nCoeffInd) { return jsnoop_get_dqt_entry(m_h, nTblDestId, nCoeffInd); } // :466
+    bool SetDhtTables(unsigned nCompInd, unsigned nTblDc, unsigned nTblAc) { return jsnoop_set_dht_tables(m_h, nCompInd, nTblDc, nTblAc) != 0; } // :536
+    bool SetDhtEntry(unsigned nDestId, unsigned nClass, unsigned nInd, unsigned nLen, unsigned nBits, unsigned nMask, unsigned nCode)
+    { return jsnoop_set_dht_entry(m_h, nDestId, nClass, nInd, nLen, nBits, nMask, nCode) != 0; }                // :748
+    bool SetDhtSize(unsigned nDestId, unsigned nClass, unsigned nSize) { return jsnoop_set_dht_size(m_h, nDestId, nClass, nSize) != 0; } // :834
+    void SetPrecision(unsigned nPrecision) { jsnoop_set_precision(m_h, nPrecision); }                           // :564
+    void SetSofSampFactors(unsigned nCompInd, unsigned nSampFactH, unsigned nSampFactV) { jsnoop_set_sof_samp_factors(m_h, nCompInd, nSampFactH, nSampFactV); } // :619
+    void SetImageDetails(unsigned nDimX, unsigned nDimY, unsigned nCompsSOF, unsigned nCompsSOS, bool bRstEn, unsigned nRstInterval)
+    { jsnoop_set_image_details(m_h, nDimX, nDimY, nCompsSOF, nCompsSOS, bRstEn, nRstInterval); }                // :590
+
+    // ---- minimal header walk: the subset of CjfifDecode::DecodeMarker that feeds this object --------------
+    bool WalkJfifHeader(unsigned& nPosScanStart)
+    { return m_pWBuf && jsnoop_jfif_walk(m_h, m_pWBuf->pData, m_pWBuf->nLen, &nPosScanStart) == 0; }
+
+    // ---- the hot path -----------------------------------------------------------------------------------
+    void DecodeScanImg(unsigned nStart, bool bDisplay, bool bQuiet)                                              // :2723
+    {
+        if (!m_pWBuf || !m_pWBuf->pData) { if (m_log) m_log(2, "*** ERROR: DecodeScanImg without a file buffer ***"); return; }
+        jsnoop_decode_scan_img(m_h, m_pWBuf->pData, m_pWBuf->nLen, nStart, bDisplay, bQuiet);
+    }
+
+    // ---- results (owned by the decoder, valid until the next Reset / DecodeScanImg / destruction) ------------
+    bool IsPreviewReady() { return jsnoop_is_preview_ready(m_h) != 0; }                                          // :3753
+    void GetImageSize(unsigned& nX, unsigned& nY) { jsnoop_get_image_size(m_h, &nX, &nY); }                      // :4929
+    void GetBitmapPtr(unsigned char*& pBitmap) { pBitmap = const_cast<unsigned char*>(jsnoop_get_bitmap_ptr(m_h)); } // :4940
+    const void* GetBitmapDevicePtr() { return jsnoop_get_bitmap_dev(m_h); }                                      // HBM copy of the DIB
+    void GetPixMapPtrs(short*& pMapY, short*& pMapCb, short*& pMapCr)                                            // :4913
+    {
+        const int16_t *y, *cb, *cr; jsnoop_get_pixmap_ptrs(m_h, &y, &cb, &cr);
+        pMapY = const_cast<short*>(y); pMapCb = const_cast<short*>(cb); pMapCr = const_cast<short*>(cr);
+    }
+    void LookupFilePosPix(unsigned nPixX, unsigned nPixY, unsigned& nByte, unsigned& nBit) { jsnoop_lookup_file_pos_pix(m_h, nPixX, nPixY, &nByte, &nBit); } // :5001
+    void LookupFilePosMcu(unsigned nMcuX, unsigned nMcuY, unsigned& nByte, unsigned& nBit) { jsnoop_lookup_file_pos_mcu(m_h, nMcuX, nMcuY, &nByte, &nBit); } // :5020
+    void LookupBlkYCC(unsigned nBlkX, unsigned nBlkY, int& nY, int& nCb, int& nCr) { jsnoop_lookup_blk_ycc(m_h, nBlkX, nBlkY, &nY, &nCb, &nCr); }            // :5037
+    unsigned PackFileOffset(unsigned nByte, unsigned nBit) const { return (nByte << 4) + nBit; }                 // :5104
+    void UnpackFileOffset(unsigned nPacked, unsigned& nByte, unsigned& nBit) const { nBit = nPacked & 0x7; nByte = nPacked >> 4; } // :5123
+
+    // ---- preview re-render on the retained data --------------------------------------------------------------
+    void SetPreviewMode(unsigned nMode) { jsnoop_set_preview_mode(m_h, nMode); }                                 // :633
+    unsigned GetPreviewMode() { return jsnoop_get_preview_mode(m_h); }
+    void SetPreviewYccOffset(unsigned nMcuX, unsigned nMcuY, int nY, int nCb, int nCr) { jsnoop_set_preview_ycc_offset(m_h, nMcuX, nMcuY, nY, nCb, nCr); } // :650
+
+    JsnoopDecoder* Handle() { return m_h; }
+
+private:
+    static void LogThunk(void* user, int level, const char* text) { auto* self = static_cast<CimgDecodeGpu*>(user); if (self->m_log) self->m_log(level, text); }
+    JsnoopDecoder* m_h = nullptr;
+    const CwindowBufView* m_pWBuf;
+    LogFn m_log;
+};
+
+// The slice of CJPEGsnoopCore that belongs to the scan-decode path: I_* pass-throughs and a batched
+// replacement for the per-file loop.  AnalyzeBuffer() walks the JFIF header with the built-in front
+// end (the subset of CjfifDecode::DecodeMarker that feeds CimgDecode) and decodes the first scan.
+class CJPEGsnoopCoreGpu {
+public:
+    CJPEGsnoopCoreGpu() { m_b = jsnoop_batch_create(nullptr); if (!m_b) throw std::runtime_error(std::string("jsnoop_batch_create: ") + jsnoop_last_error()); }
+    ~CJPEGsnoopCoreGpu() { jsnoop_batch_destroy(m_b); }
+
+    // batch: N files -> N DIBs resident in HBM (per-file semantics of DoBatchFileProcess preserved)
+    void     BatchClear() { jsnoop_batch_clear(m_b); }
+    int      BatchAddFile(const uint8_t* pFile, size_t nLen) { return jsnoop_batch_add_jpeg(m_b, pFile, nLen); }
+    unsigned GetBatchFileCount() const { return (unsigned)jsnoop_batch_count(m_b); }
+    bool     DoBatchProcess() { return jsnoop_batch_upload(m_b) == 0 && jsnoop_batch_decode(m_b) == 0 && jsnoop_batch_sync(m_b) == 0; }
+    const void* I_GetBitmapDevicePtr(int nFileInd) const { return jsnoop_batch_dib_dev(m_b, nFileInd); }
+    bool     I_GetBitmap(int nFileInd, std::vector<uint8_t>& dib, unsigned& nX, unsigned& nY)
+    {
+        unsigned info[16]; if (jsnoop_batch_image_info(m_b, nFileInd, info)) return false;
+        nX = info[2]; nY = info[3]; dib.resize((size_t)nX * nY * 4);
+        return jsnoop_batch_read_dib(m_b, nFileInd, dib.data()) == 0;
+    }
+    JsnoopBatch* Handle() { return m_b; }
+private:
+    JsnoopBatch* m_b = nullptr;
+};

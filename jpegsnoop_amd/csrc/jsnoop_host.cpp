@@ -394,6 +394,8 @@ void jsnoop_set_precision(JsnoopDecoder* d, unsigned p) { d->t.precision = p; }
 void jsnoop_set_image_details(JsnoopDecoder* d, unsigned x, unsigned y, unsigned nf, unsigned ns, int rst_en, unsigned rst_int)
 { JsTables& t = d->t; t.details_set = 1; t.dim_x = x; t.dim_y = y; t.num_sof = nf; t.num_sos = ns; t.rst_en = rst_en != 0; t.rst_interval = rst_int; }
 
+int jsnoop_jfif_walk(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned* scan_start) { return js_jfif_walk(d, file, len, scan_start); }
+
 void jsnoop_decode_scan_img(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned start, int display, int quiet)
 {
     (void)quiet;
