@@ -780,78 +780,6 @@ __device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, co
     p_io = cur.p; s_io = cur.p == P_END ? 0u : ST_MAKE(seg, c, k); nblk_out = nblk;
 }
 
-// WRITE flavour: every 8x8 block is written by exactly one thread -- the one that decodes its DC symbol.
-// A thread entering mid-block (k > 0) parses the rest of that block without output; a thread whose last
-// block is unfinished at own_end keeps decoding past it until the block completes.  Coefficients are
-// gathered in a thread-private LDS block buffer and leave as one full 128-byte block (16 x 8-byte stores
-// back to back), so HBM sees whole lines instead of scattered 2-byte read-modify-writes -- and no memset
-// of the coefficient arena is needed.  The exit state / block count reported back are those at own_end.
-__device__ __forceinline__ void walk_write(const JsImage& im, const SubTabs T, const uint32_t* __restrict__ words, const uint32_t* __restrict__ st,
-                                           uint32_t nseg, uint32_t total_bits, uint32_t own_end, uint32_t& p_io, uint32_t& s_io, uint32_t& nblk_out,
-                                           int16_t* __restrict__ cbase, int16_t* __restrict__ dbase, uint8_t* __restrict__ mcu_rst, uint32_t blk0, uint32_t& flags,
-                                           int16_t* lbuf)
-{
-    uint32_t seg = ST_SEG(s_io), c = ST_C(s_io), k = ST_K(s_io), nblk = 0;
-    if (p_io == P_END || (p_io >= total_bits && seg + 1 >= nseg)) { p_io = P_END; s_io = 0; nblk_out = 0; return; }
-    uint32_t seg_end = st[seg + 1] * 8;
-    const uint32_t prec_shift = im.precision >= 8 ? ((im.precision - 8) & 31) : 0, nblocks = im.total_blocks, decode_ac = im.decode_ac;
-    Cursor cur; cur_init(cur, words, p_io);
-    uint32_t blk = blk0;                                   // index of the block in progress / next to start
-    bool skip = k != 0;                                    // the block in progress belongs to an earlier thread
-    bool captured = false; int16_t dq0 = 0;
-    uint32_t comp = comp_of(T, c), rp = rows_of(T, comp);
-    for (;;) {
-        if (cur.p >= own_end) {
-            if (!captured) { captured = true; p_io = cur.p; s_io = ST_MAKE(seg, c, k); nblk_out = nblk; }
-            if (k == 0 || skip) break;                       // else: finish the block this thread started
-        }
-        const uint32_t win = cur_peek(cur);
-        const uint32_t e = sym_lookup(T, win, rp, k);
-        const uint32_t len = (e >> 8) & 31u, run = (e >> 4) & 15u, size = e & 15u;
-        if (__builtin_expect(len == 0 || cur.p + len > seg_end, 0)) {
-            const bool more = walk_slow<true>(im, words, st, nseg, cur, len, seg, seg_end, c, k, blk, !captured, mcu_rst, flags);
-            if (!more) { if (!captured) { captured = true; p_io = P_END; s_io = 0; nblk_out = nblk; } break; }
-            comp = comp_of(T, c); rp = rows_of(T, comp);
-            continue;
-        }
-        if (__builtin_expect(cur.p + len + size > seg_end, 0)) { if (blk < nblocks) flags |= F_OVERRUN; }
-        const bool isdc = k == 0;
-        if (!skip && (isdc || (decode_ac && size))) {
-            // value bits: EXTEND (HuffmanDc2Signed :859), precision divide (:1234-1238), dequantise (:2278)
-            int32_t val = 0;
-            if (size) {
-                const uint32_t v = (win << len) >> (32 - size);
-                val = v >= (1u << (size - 1)) ? (int32_t)v : (int32_t)(v - ((1u << size) - 1u));
-                if (prec_shift) val /= (int32_t)(1u << prec_shift);
-            }
-            const uint32_t ind = isdc ? 0u : k + run;
-            if (ind < 64) {
-                const int16_t dq = (int16_t)((int32_t)(int16_t)val * (int32_t)T.qzz[comp * 64 + ind]);
-                lbuf[T.zz[ind]] = dq;
-                if (isdc) dq0 = dq;
-            }
-        }
-        cur_skip(cur, len + size);
-        const uint32_t k2 = isdc ? 1u : k + run + 1u;
-        const bool done = !isdc && ((e & 255u) == 0 || k2 >= 64u);
-        if (__builtin_expect(k2 > 64u && blk < nblocks, 0)) flags |= F_COEF_OVERFLOW;
-        k = done ? 0u : k2;
-        if (done) {
-            c = c + 1 == T.nb ? 0u : c + 1; comp = comp_of(T, c); rp = rows_of(T, comp);
-            if (!captured) nblk++;
-            if (!skip && blk < nblocks) {                     // one whole block leaves as 16 back-to-back 8-byte stores
-                uint2* dst = reinterpret_cast<uint2*>(cbase + (size_t)blk * 64);
-                uint2* src = reinterpret_cast<uint2*>(lbuf);
-                #pragma unroll
-                for (int j = 0; j < 16; j++) { dst[j] = src[j]; src[j] = make_uint2(0u, 0u); }
-                dbase[blk] = dq0;
-            }
-            skip = false; blk++;
-        }
-    }
-    if (!captured) { p_io = cur.p; s_io = cur.p == P_END ? 0u : ST_MAKE(seg, c, k); nblk_out = nblk; }
-}
-
 // upper_bound(seg table, byte) - 1 : the interval a speculative start position lies in
 __device__ __forceinline__ uint32_t find_interval(const uint32_t* __restrict__ st, uint32_t nseg, uint32_t byte)
 {
@@ -955,6 +883,13 @@ __global__ void __launch_bounds__(256) k_block_scan(const JsImage* __restrict__ 
     if (threadIdx.x == 0) { side[im.side_off + 14] = run; if (run < im.total_blocks) atomicOr(&flags[img], F_SHORT); }
 }
 
+// WRITE pass.  Every 8x8 block is written by exactly one lane -- the one that decodes its DC symbol.  A lane entering
+// mid-block (k > 0) parses the rest of that block without output; a lane whose last block is unfinished at the end
+// of its sub-sequence keeps decoding past it until the block completes.  Coefficients are dequantised
+// (DecodeIdctSet :2270-2303) and de-zigzagged into a lane-private LDS block.  The symbol loop is wave-uniform
+// (it runs while any lane is active), so that when some lanes complete a block in an iteration the WHOLE wave
+// moves each finished block out: 64 lanes x 2 bytes = one coalesced 128-byte line per block.  HBM therefore sees
+// whole lines (no scattered 2-byte read-modify-writes) and the coefficient arena needs no memset.
 __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sy_base, uint32_t nimg,
                                                       const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr,
                                                       const uint32_t* __restrict__ seg_tab, const uint32_t* __restrict__ side, SubArrays A,
@@ -968,25 +903,98 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
     if (!tables[im.tableset].lut_ok) return;
     const uint32_t* sd = side + im.side_off;
     const uint32_t total_bits = sd[10] * 8, nseg = min(sd[11], im.seg_cap - 1);
+    const uint32_t lane = threadIdx.x & 63, wave0 = threadIdx.x & ~63u;
     const uint32_t sub0 = (blockIdx.x - sy_base[img]) * SY_THREADS, i = sub0 + threadIdx.x;
     if (sub0 * SUB_BITS >= total_bits) return;
     SubTabs T; load_subtabs(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, threadIdx.x, SY_THREADS);
     { uint2* z = reinterpret_cast<uint2*>(s_blk[threadIdx.x]); for (int j = 0; j < WR_STRIDE / 4; j++) z[j] = make_uint2(0u, 0u); }
     __syncthreads();
-    if (i * SUB_BITS >= total_bits) return;
+
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);
+    const uint32_t* st = seg_tab + im.seg_off;
+    int16_t* cbase = coef + im.coef_off * 64; int16_t* dbase = dccum + im.coef_off; uint8_t* rstf = mcu_rst + im.mcu_off;
+    int16_t* lbuf = s_blk[threadIdx.x];
+    const uint32_t nblocks = im.total_blocks, decode_ac = im.decode_ac, prec_shift = im.precision >= 8 ? ((im.precision - 8) & 31) : 0;
+    const bool in_data = i * SUB_BITS < total_bits;
     const size_t g = im.subseq_off + i;
-    uint32_t p = i ? A.out_p[g - 1] : 0u, s = i ? A.out_s[g - 1] : 0u, nblk = 0, fl = 0;
-    const uint32_t own_end = min((i + 1) * SUB_BITS, total_bits), blk0 = A.base[g];
-    bool walked = false;
-    if (!(p != P_END && p >= own_end)) {
-        walked = true;
-        if (blk0 < im.total_blocks || p == P_END)
-            walk_write(im, T, reinterpret_cast<const uint32_t*>(ustr + im.ustr_off), seg_tab + im.seg_off, nseg, total_bits, own_end, p, s, nblk,
-                       coef + im.coef_off * 64, dccum + im.coef_off, mcu_rst + im.mcu_off, blk0, fl, s_blk[threadIdx.x]);
-        else { p = A.out_p[g]; s = A.out_s[g]; walked = false; } // everything this thread owns lies past the last MCU
+    uint32_t fl = 0, nblk = 0, seg = 0, c = 0, k = 0, seg_end = 0, blk = 0;
+    uint32_t res_p = 0, res_s = 0, res_n = 0;                // what this lane reports for verification
+    bool verify = false, check_n = false, active = false, captured = false, skip = false;
+    const uint32_t own_end = min((i + 1) * SUB_BITS, total_bits);
+    Cursor cur; cur.words = words; cur.widx = 0; cur.w0 = cur.w1 = cur.nxt = 0; cur.off = 0; cur.p = 0;
+    if (in_data) {
+        const uint32_t p0 = i ? A.out_p[g - 1] : 0u, s0 = i ? A.out_s[g - 1] : 0u;
+        blk = A.base[g]; seg = ST_SEG(s0); c = ST_C(s0); k = ST_K(s0);
+        verify = true;
+        if (p0 != P_END && p0 >= own_end) { res_p = p0; res_s = s0; }                          // owns no symbol: passes through
+        else if (p0 == P_END || (p0 >= total_bits && seg + 1 >= nseg)) { res_p = P_END; res_s = 0; check_n = true; }
+        else if (blk >= nblocks) verify = false;                                                // everything owned lies past the last MCU
+        else { active = true; check_n = true; seg_end = st[seg + 1] * 8; skip = k != 0; cur_init(cur, words, p0); }
     }
-    // the chain must be at its fixed point, and the block count that fed the prefix sum must be the real one
-    if (p != A.out_p[g] || s != A.out_s[g] || (walked && nblk != A.nblk[g])) fl |= F_NOSYNC;
+    int16_t dq0 = 0;
+    uint32_t comp = comp_of(T, c), rp = rows_of(T, comp);
+    for (;;) {
+        // ---- end of the owned range: report the state there; keep going only to finish a block this lane started
+        const bool at_end = active && cur.p >= own_end;
+        const bool cap = at_end && !captured;
+        res_p = cap ? cur.p : res_p; res_s = cap ? ST_MAKE(seg, c, k) : res_s; res_n = cap ? nblk : res_n; captured = captured || cap;
+        active = active && !(at_end && (k == 0 || skip));
+        if (!__ballot(active)) break;
+        // ---- one symbol per lane: straight-line select code on the common path
+        const uint32_t win = cur_peek(cur);
+        uint32_t e = T.lut1[((((k ? rp >> 8 : rp) & 255u)) << JS_L1_BITS) + (win >> (32 - JS_L1_BITS))];
+        if (__ballot(active && (e & 0x8000u))) {                 // some lane holds a code longer than 11 bits (< 0.5 % of symbols)
+            if (e & 0x8000u) { const uint32_t nbx = (e >> 12) & 7u; e = T.lut2[(e & 0xFFFu) + ((win >> (32 - JS_L1_BITS - nbx)) & ((1u << nbx) - 1u))]; }
+        }
+        const uint32_t len = (e >> 8) & 31u, run = (e >> 4) & 15u, size = e & 15u;
+        const bool bad = active && (len == 0 || cur.p + len > seg_end);
+        if (__ballot(bad)) {                                     // interval / stream end, or a code that matches nothing: rare
+            if (bad) {
+                const bool more = walk_slow<true>(im, words, st, nseg, cur, len, seg, seg_end, c, k, blk, !captured, rstf, fl);
+                if (!more) { if (!captured) { captured = true; res_p = P_END; res_s = 0; res_n = nblk; } active = false; }
+                comp = comp_of(T, c); rp = rows_of(T, comp);
+            }
+        }
+        const bool norm = active && !bad;
+        if (__ballot(norm && cur.p + len + size > seg_end)) { if (norm && cur.p + len + size > seg_end && blk < nblocks) fl |= F_OVERRUN; }
+        const bool isdc = k == 0;
+        // value bits: EXTEND (HuffmanDc2Signed :859), precision divide (:1234-1238), dequantise (:2278)
+        const uint32_t vraw = size ? (win << len) >> (32 - size) : 0u;
+        int32_t val = (size && vraw < (1u << ((size - 1) & 31))) ? (int32_t)(vraw - ((1u << size) - 1u)) : (int32_t)vraw;
+        if (prec_shift) val /= (int32_t)(1u << prec_shift);
+        const uint32_t ind = isdc ? 0u : k + run;
+        const int16_t dq = (int16_t)((int32_t)(int16_t)val * (int32_t)T.qzz[comp * 64 + (ind & 63u)]);
+        if (norm && !skip && (isdc || (decode_ac && size)) && ind < 64) lbuf[T.zz[ind]] = dq;
+        dq0 = (norm && isdc) ? dq : dq0;
+        const uint32_t tot = norm ? len + size : 0u;
+        cur.off += tot; cur.p += tot;
+        if (cur.off >= 32u) { cur.off -= 32u; cur.w0 = cur.w1; cur.w1 = bswap32(cur.nxt); cur.nxt = words[phys_word(cur.widx++)]; }
+        const uint32_t k2 = isdc ? 1u : k + run + 1u;
+        const bool done = norm && !isdc && ((e & 255u) == 0 || k2 >= 64u);
+        if (__ballot(norm && k2 > 64u)) { if (norm && k2 > 64u && blk < nblocks) fl |= F_COEF_OVERFLOW; }
+        k = norm ? (done ? 0u : k2) : k;
+        const uint32_t c1 = c + 1 == T.nb ? 0u : c + 1;
+        c = done ? c1 : c; comp = comp_of(T, c); rp = rows_of(T, comp);
+        nblk += (done && !captured) ? 1u : 0u;
+        const bool flush = done && !skip && blk < nblocks;
+        const uint32_t fblk = blk;
+        if (flush) dbase[blk] = dq0;
+        skip = done ? false : skip; blk += done ? 1u : 0u;
+        // ---- the whole wave moves every block that completed in this iteration: one 128-byte line each ----
+        uint64_t fm = __ballot(flush);
+        while (fm) {
+            const uint32_t src = (uint32_t)__builtin_ctzll(fm); fm &= fm - 1;
+            const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)fblk, src);
+            int16_t* sb = s_blk[wave0 + src];
+            cbase[(size_t)b * 64 + lane] = sb[lane];
+            sb[lane] = 0;
+        }
+    }
+    if (verify) {
+        if (check_n && !captured && res_p != P_END) { res_p = cur.p; res_s = cur.p == P_END ? 0u : ST_MAKE(seg, c, k); res_n = nblk; }
+        // the chain must be at its fixed point, and the block count that fed the prefix sum must be the real one
+        if (res_p != A.out_p[g] || res_s != A.out_s[g] || (check_n && res_n != A.nblk[g])) fl |= F_NOSYNC;
+    }
     if (fl) atomicOr(&flags[img], fl);
 }
 
