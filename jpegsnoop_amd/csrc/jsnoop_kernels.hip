@@ -809,10 +809,16 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t sub0 = (blockIdx.x - sy_base[img]) * SY_THREADS;
     if (sub0 * SUB_BITS >= total_bits && sub0) return;          // whole workgroup lies past the end of the data
+    const size_t g0 = im.subseq_off + sub0;
+    // Later launches only carry exit states across workgroup boundaries: if the state entering this workgroup is the
+    // one its first sub-sequence was last walked from, the whole workgroup is already at its fixed point.
+    if (!first_pass) {
+        const uint32_t lp = sub0 ? A.out_p[g0 - 1] : 0u, ls = sub0 ? A.out_s[g0 - 1] : 0u;
+        if (lp == A.in_p[g0] && ls == A.in_s[g0]) return;
+    }
     SubTabs T; load_subtabs(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, t, SY_THREADS);
     const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);
     const uint32_t* st = seg_tab + im.seg_off;
-    const size_t g0 = im.subseq_off + sub0;
     if (first_pass) { s_inp[t] = 0xFFFFFFFEu; s_ins[t] = 0; s_outp[t] = 0; s_outs[t] = 0; s_nblk[t] = 0; }
     else { s_inp[t] = A.in_p[g0 + t]; s_ins[t] = A.in_s[g0 + t]; s_outp[t] = A.out_p[g0 + t]; s_outs[t] = A.out_s[g0 + t]; s_nblk[t] = A.nblk[g0 + t]; }
     // the exit state of the sub-sequence left of this workgroup, as of the previous launch (speculative start in the first pass)
@@ -998,37 +1004,48 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
     if (fl) atomicOr(&flags[img], fl);
 }
 
-// One workgroup per image: DC differences (in dccum, decode order) -> cumulative DC per block.
-__global__ void __launch_bounds__(256) k_dc_scan(const JsImage* __restrict__ imgs, const JsTableSet* __restrict__ tables,
-                                                 int16_t* __restrict__ dccum, const uint8_t* __restrict__ mcu_rst)
+// One workgroup (1024 lanes) per image: DC differences (in dccum, decode order) -> cumulative DC per block.
+// int16 wrapping sums per component (m_nDcLum += ..., :3280/:3355/:3386), reset at every MCU the write pass marked as
+// the first of a restart interval (DecodeRestartDcState :2693).  Each lane owns a run of MCUs: local sums, a
+// block-wide segmented carry, then the rewrite in place.
+#define DC_THREADS 1024
+__global__ void __launch_bounds__(DC_THREADS) k_dc_scan(const JsImage* __restrict__ imgs, const JsTableSet* __restrict__ tables,
+                                                        int16_t* __restrict__ dccum, const uint8_t* __restrict__ mcu_rst)
 {
     const uint32_t img = blockIdx.x; const JsImage& im = imgs[img];
     if (!tables[im.tableset].lut_ok) return;
-    const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax, nb = im.blk_per_mcu, per = (nmcu + 255) / 256;
+    const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax, nb = im.blk_per_mcu, per = (nmcu + DC_THREADS - 1) / DC_THREADS;
+    const uint32_t n1 = im.samp_h[1] * im.samp_v[1], n2 = im.ncomp == 3 ? n1 + im.samp_h[2] * im.samp_v[2] : nb;
     const uint32_t m0 = min(threadIdx.x * per, nmcu), m1 = min(m0 + per, nmcu);
     int16_t* d = dccum + im.coef_off; const uint8_t* rf = mcu_rst + im.mcu_off;
-    // pass 1: per-thread (sum since last reset, saw reset) per component
-    int16_t sum[3] = {0, 0, 0}; bool rst = false;
+    int16_t sum0 = 0, sum1 = 0, sum2 = 0; bool rst = false;
     for (uint32_t m = m0; m < m1; m++) {
-        if (rf[m]) { sum[0] = sum[1] = sum[2] = 0; rst = true; }
-        for (uint32_t c = 0; c < nb; c++) { const uint32_t comp = im.blk_comp[c] - 1; sum[comp] = (int16_t)(sum[comp] + d[(size_t)m * nb + c]); }
-    }
-    __shared__ int16_t s_sum[256][3]; __shared__ uint8_t s_rst[256];
-    s_sum[threadIdx.x][0] = sum[0]; s_sum[threadIdx.x][1] = sum[1]; s_sum[threadIdx.x][2] = sum[2]; s_rst[threadIdx.x] = rst;
-    __syncthreads();
-    // carry-in = combination of all earlier threads, stopping at the nearest reset (serial over <=255 entries per thread is
-    // cheap next to the decode; done by walking backwards)
-    int16_t carry[3] = {0, 0, 0};
-    for (int t = (int)threadIdx.x - 1; t >= 0; t--) {
-        carry[0] = (int16_t)(carry[0] + s_sum[t][0]); carry[1] = (int16_t)(carry[1] + s_sum[t][1]); carry[2] = (int16_t)(carry[2] + s_sum[t][2]);
-        if (s_rst[t]) break;
-    }
-    // pass 2: rewrite in place
-    for (uint32_t m = m0; m < m1; m++) {
-        if (rf[m]) carry[0] = carry[1] = carry[2] = 0;
+        if (rf[m]) { sum0 = sum1 = sum2 = 0; rst = true; }
         for (uint32_t c = 0; c < nb; c++) {
-            const uint32_t comp = im.blk_comp[c] - 1; const size_t b = (size_t)m * nb + c;
-            carry[comp] = (int16_t)(carry[comp] + d[b]); d[b] = carry[comp];
+            const int16_t v = d[(size_t)m * nb + c];
+            if (c < n1) sum0 = (int16_t)(sum0 + v); else if (c < n2) sum1 = (int16_t)(sum1 + v); else sum2 = (int16_t)(sum2 + v);
+        }
+    }
+    // segmented inclusive scan over lanes of (sum since last reset, saw reset): combine(a, b) = b.rst ? b : (a.sum + b.sum, a.rst)
+    __shared__ int16_t s_sum[DC_THREADS][3]; __shared__ uint8_t s_rst[DC_THREADS];
+    s_sum[threadIdx.x][0] = sum0; s_sum[threadIdx.x][1] = sum1; s_sum[threadIdx.x][2] = sum2; s_rst[threadIdx.x] = rst;
+    __syncthreads();
+    for (uint32_t dd = 1; dd < DC_THREADS; dd <<= 1) {
+        int16_t a0 = 0, a1 = 0, a2 = 0; bool ar = false; const bool has = threadIdx.x >= dd;
+        if (has) { a0 = s_sum[threadIdx.x - dd][0]; a1 = s_sum[threadIdx.x - dd][1]; a2 = s_sum[threadIdx.x - dd][2]; ar = s_rst[threadIdx.x - dd]; }
+        const bool br = s_rst[threadIdx.x];
+        __syncthreads();
+        if (has && !br) { s_sum[threadIdx.x][0] = (int16_t)(s_sum[threadIdx.x][0] + a0); s_sum[threadIdx.x][1] = (int16_t)(s_sum[threadIdx.x][1] + a1);
+                          s_sum[threadIdx.x][2] = (int16_t)(s_sum[threadIdx.x][2] + a2); s_rst[threadIdx.x] = ar; }
+        __syncthreads();
+    }
+    int16_t c0 = 0, c1 = 0, c2 = 0;                              // carry-in = inclusive result of the lane to the left
+    if (threadIdx.x) { c0 = s_sum[threadIdx.x - 1][0]; c1 = s_sum[threadIdx.x - 1][1]; c2 = s_sum[threadIdx.x - 1][2]; }
+    for (uint32_t m = m0; m < m1; m++) {
+        if (rf[m]) c0 = c1 = c2 = 0;
+        for (uint32_t c = 0; c < nb; c++) {
+            const size_t b = (size_t)m * nb + c; const int16_t v = d[b];
+            if (c < n1) { c0 = (int16_t)(c0 + v); d[b] = c0; } else if (c < n2) { c1 = (int16_t)(c1 + v); d[b] = c1; } else { c2 = (int16_t)(c2 + v); d[b] = c2; }
         }
     }
 }
@@ -1062,4 +1079,4 @@ void js_launch_write(hipStream_t st, uint32_t tab_rows, uint32_t tab_lut2, const
                        sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2);
 }
 void js_launch_dc_scan(hipStream_t st, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, int16_t* dccum, const uint8_t* mcu_rst)
-{ if (nimg) hipLaunchKernelGGL(k_dc_scan, dim3(nimg), dim3(256), 0, st, imgs, tables, dccum, mcu_rst); }
+{ if (nimg) hipLaunchKernelGGL(k_dc_scan, dim3(nimg), dim3(DC_THREADS), 0, st, imgs, tables, dccum, mcu_rst); }
