@@ -171,7 +171,7 @@ JsnoopBatch::~JsnoopBatch()
     for (void** p : { (void**)&dev.raw, (void**)&dev.ustr, (void**)&dev.coef, (void**)&dev.dccum, (void**)&dev.dib, (void**)&dev.planes,
                       (void**)&dev.side, (void**)&dev.imgs, (void**)&dev.tables, (void**)&dev.wg_base, (void**)&dev.sel, (void**)&dev.sums,
                       (void**)&dev.sub, (void**)&dev.probe, (void**)&dev.seg, (void**)&dev.chunk_keep, (void**)&dev.chunk_rst, (void**)&dev.us_base,
-                      (void**)&dev.sy_base, (void**)&dev.mcu_rst, (void**)&dev.flags }) if (*p) hipFree(*p);
+                      (void**)&dev.sy_base, (void**)&dev.mcu_rst, (void**)&dev.flags, (void**)&dev.ustr_lin }) if (*p) hipFree(*p);
     if (d_lut) hipFree(d_lut);
     if (pinned) hipHostFree(pinned);
     for (auto& e : ev) if (e) hipEventDestroy(e);
@@ -245,6 +245,11 @@ int JsnoopBatch::upload()
     uint64_t segw = 0, mcub = 0; uint32_t usc = 0, syw = 0;
     strips_per_wg = 0; uint64_t total_mcus = 0; for (const JsImage& im : imgs) total_mcus += (uint64_t)im.mcu_xmax * im.mcu_ymax;
     const uint32_t mcus_per_wave = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, total_mcus / (8 * 4096)));
+    // sub-sequence length: long (512 B) when the batch still yields plenty of lanes, short (128 B) for small jobs
+    uint64_t scan_total = 0; for (const JsImage& im : imgs) scan_total += im.scan_len;
+    sub_wl = scan_total >= (96ull << 20) ? 7 : 5;
+    if (const char* e = getenv("JSNOOP_SUB_WL")) sub_wl = atoi(e) == 7 ? 7 : 5;
+    const uint32_t sub_bytes = 4u << sub_wl;
     uint32_t wgs = 0; max_mcu_h = 8; max_mcu_w = 8;
     for (size_t i = 0; i < n; i++) {
         JsImage& im = imgs[i];
@@ -253,8 +258,8 @@ int JsnoopBatch::upload()
         im.dib_off = dibb; dibb += align_up((uint64_t)im.img_x * im.img_y * 4, 256);
         im.plane_off = plane; if (opt_want_planes) plane += align_up((uint64_t)im.blk_xmax * 8 * im.blk_ymax * 8 * 3, 64);
         im.side_off = side; side += align_up(js_side_words(im.mcu_xmax * im.mcu_ymax, im.blk_xmax * im.blk_ymax), 4);
-        im.ustr_off = ustr; im.ustr_cap = (uint32_t)align_up((uint64_t)im.scan_len + 64, 8192); ustr += im.ustr_cap;   // whole 64-sub-sequence groups
-        im.n_subseq = (im.ustr_cap + JS_SUBSEQ_BYTES - 1) / JS_SUBSEQ_BYTES; im.subseq_off = subs; subs += align_up(im.n_subseq, 256);
+        im.ustr_off = ustr; im.ustr_cap = (uint32_t)align_up((uint64_t)im.scan_len + 64, 64ull * sub_bytes); ustr += im.ustr_cap;   // whole 64-sub-sequence groups
+        im.n_subseq = (im.ustr_cap + sub_bytes - 1) / sub_bytes; im.subseq_off = subs; subs += align_up(im.n_subseq, 256);
         const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax;
         const uint64_t want_seg = im.rst_interval ? (uint64_t)nmcu / im.rst_interval + 2 : 1;
         im.seg_cap = (uint32_t)std::min<uint64_t>(65535, want_seg * 2 + 16); im.seg_off = segw; segw += align_up(im.seg_cap, 4);
@@ -273,7 +278,7 @@ int JsnoopBatch::upload()
         grow(&dev.sub, &cap.sub, subs * 24 + 64) || grow(&dev.probe, &cap.probe, 1024) || grow(&dev.seg, &cap.seg, segw * 4 + 64) ||
         grow(&dev.chunk_keep, &cap.chunk_keep, (size_t)usc * 4 + 64) || grow(&dev.chunk_rst, &cap.chunk_rst, (size_t)usc * 4 + 64) ||
         grow(&dev.us_base, &cap.us_base, (n + 1) * 4) || grow(&dev.sy_base, &cap.sy_base, (n + 1) * 4) ||
-        grow(&dev.mcu_rst, &cap.mcu_rst, mcub + 64) || grow(&dev.flags, &cap.flags, n * 4 + 64)) return -1;
+        grow(&dev.mcu_rst, &cap.mcu_rst, mcub + 64) || grow(&dev.ustr_lin, &cap.ustr_lin, ustr + 64) || grow(&dev.flags, &cap.flags, n * 4 + 64)) return -1;
     if (opt_want_planes && grow(&dev.planes, &cap.planes, plane * 2)) return -1;
     tab_rows = 1; tab_lut2 = 0; for (const JsTableSet& t : tables) { tab_rows = std::max(tab_rows, t.n_rows); tab_lut2 = std::max(tab_lut2, t.lut2_used); }
     HIP_TRY(hipMemcpyAsync(dev.raw, pinned, raw_bytes, hipMemcpyHostToDevice, stream));

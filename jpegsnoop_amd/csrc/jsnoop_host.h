@@ -44,10 +44,10 @@ struct JsnoopDecoder {
 struct JsDeviceArenas {
     uint8_t* raw; uint8_t* ustr; int16_t* coef; int16_t* dccum; uint8_t* dib; int16_t* planes; uint32_t* side;
     JsImage* imgs; JsTableSet* tables; uint32_t* wg_base; uint32_t* sel; uint64_t* sums; uint8_t* sub; uint8_t* probe;
-    uint32_t* seg; uint32_t* chunk_keep; uint32_t* chunk_rst; uint32_t* us_base; uint32_t* sy_base; uint8_t* mcu_rst; uint32_t* flags;
+    uint32_t* seg; uint32_t* chunk_keep; uint32_t* chunk_rst; uint32_t* us_base; uint32_t* sy_base; uint8_t* mcu_rst; uint32_t* flags; uint8_t* ustr_lin;
 };
 struct JsArenaCaps { size_t raw, ustr, coef, dccum, dib, planes, side, imgs, tables, wg_base, sel, sums, sub, probe,
-                            seg, chunk_keep, chunk_rst, us_base, sy_base, mcu_rst, flags; };
+                            seg, chunk_keep, chunk_rst, us_base, sy_base, mcu_rst, flags, ustr_lin; };
 
 struct JsnoopBatch {
     int device; hipStream_t stream; bool own_stream;
@@ -58,7 +58,8 @@ struct JsnoopBatch {
     JsDeviceArenas dev; JsArenaCaps cap;
     bool uploaded;
     uint64_t total_blocks, dib_bytes, side_words, total_subseq, ustr_bytes, seg_words, mcu_bytes; uint32_t total_wgs, strips_per_wg, us_chunks, sy_wgs, max_mcu_h, max_mcu_w;
-    int sync_launches; uint32_t tab_rows, tab_lut2;     // largest decode-table footprint in the batch (sizes the kernels' LDS)
+    int sync_launches; int sub_wl;   // log2(words per sub-sequence): 5 = 128-byte, 7 = 512-byte sub-sequences (chosen per batch)
+    uint32_t tab_rows, tab_lut2;     // largest decode-table footprint in the batch (sizes the kernels' LDS)
     hipEvent_t ev[JSNOOP_NUM_STAGES + 1];
     float lut[64][64]; float* d_lut;
     explicit JsnoopBatch(void* user_stream);

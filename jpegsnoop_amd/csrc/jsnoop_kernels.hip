@@ -522,7 +522,8 @@ void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, 
 #define US_THREADS 256
 #define US_CHUNK   (US_THREADS * 16)
 #define SY_THREADS 256
-#define SUB_BITS   (JS_SUBSEQ_BYTES * 8)
+// sub-sequence length is a per-batch choice: WL = log2(32-bit words per sub-sequence) = 5 (128 B) or 7 (512 B)
+#define SUB_BITS   (32u << WL)
 
 #define F_BAD_CODE      0x0001u
 #define F_OVERRUN       0x0002u
@@ -531,12 +532,12 @@ void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, 
 #define F_SHORT         0x0010u
 #define F_NOSYNC        0x0080u
 
-// Physical layout of the compacted stream: 64 consecutive sub-sequences (64 x 128 B = 8 KiB) form a group
+// Physical layout of the compacted stream: 64 consecutive sub-sequences (64 x 128 B = 8 KiB, or 64 x 512 B = 32 KiB) form a group
 // stored word-interleaved -- word w of sub-sequence l sits at 32-bit index (group*32 + w)*64 + l -- so that
 // the 64 lanes of a wave, each walking its own sub-sequence at roughly the same pace, read one coalesced
 // 256-byte row per refill instead of 64 different cache lines.
-__device__ __forceinline__ uint32_t phys_word(uint32_t W) { return (W & ~2047u) | ((W & 31u) << 6) | ((W >> 5) & 63u); }
-__device__ __forceinline__ uint32_t phys_byte(uint32_t B) { return (phys_word(B >> 2) << 2) | (B & 3u); }
+template <int WL> __device__ __forceinline__ uint32_t phys_word(uint32_t W) { return (W & ~((64u << WL) - 1u)) | ((W & ((1u << WL) - 1u)) << 6) | ((W >> WL) & 63u); }
+template <int WL> __device__ __forceinline__ uint32_t phys_byte(uint32_t B) { return (phys_word<WL>(B >> 2) << 2) | (B & 3u); }
 
 struct UsBytes { uint32_t keep_mask, rst_mask; };
 
@@ -645,8 +646,30 @@ __global__ void __launch_bounds__(US_THREADS) k_unstuff_write(const JsImage* __r
     #pragma unroll
     for (int j = 0; j < 16; j++) {
         if (c.rst_mask & (1u << j)) { seg++; if (seg + 1 < im.seg_cap) st[seg] = out; }     // interval `seg` starts at the next kept byte
-        if (c.keep_mask & (1u << j)) dst[phys_byte(out++)] = (uint8_t)(w4[j >> 2] >> ((j & 3) * 8));
+        if (c.keep_mask & (1u << j)) dst[out++] = (uint8_t)(w4[j >> 2] >> ((j & 3) * 8));
     }
+}
+
+// Linear compacted stream -> word-interleaved sub-sequence layout (see phys_word).  One workgroup per group of 64
+// sub-sequences: the group's bytes are read linearly (coalesced) into LDS and leave as 256-byte rows (word w of the
+// 64 sub-sequences), so both sides of the permutation stream at full line width.
+template <int WL>
+__global__ void __launch_bounds__(256) k_interleave(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sy_base, uint32_t nimg,
+                                                    const uint32_t* __restrict__ side, const uint8_t* __restrict__ lin, uint8_t* __restrict__ ustr)
+{
+    constexpr uint32_t WPS = 1u << WL, GW = 64u * WPS;               // words per sub-sequence / per group
+    __shared__ uint32_t s_w[64 * (WPS + 1)];                          // +1: the transposed read walks a column without bank conflicts
+    const uint32_t img = find_image(sy_base, nimg, blockIdx.x / 4);
+    const JsImage& im = imgs[img];
+    const uint32_t g = blockIdx.x - sy_base[img] * 4;                 // group index inside the image (4 groups per 256 sub-sequences)
+    if (g * 64 >= im.n_subseq) return;
+    const uint32_t len_words = (side[im.side_off + 10] + 3) / 4 + 4;  // un-stuffed length (+ cursor look-ahead)
+    if (g * GW >= len_words) return;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(lin + im.ustr_off) + (size_t)g * GW;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(ustr + im.ustr_off) + (size_t)g * GW;
+    for (uint32_t i = threadIdx.x; i < GW; i += 256) s_w[(i >> WL) * (WPS + 1) + (i & (WPS - 1))] = src[i];   // i = l*WPS + w
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < GW; i += 256) dst[i] = s_w[(i & 63u) * (WPS + 1) + (i >> 6)];          // i = w*64 + l
 }
 
 // ---- Huffman symbol walk shared by the sync and write passes ------------------------------
@@ -684,18 +707,18 @@ struct Cursor {                        // MSB-first bit cursor: two byte-swapped
     const uint32_t* words; uint32_t widx, w0, w1, nxt, off, p;
 };
 __device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
-__device__ __forceinline__ void cur_init(Cursor& c, const uint32_t* words, uint32_t p)
+template <int WL> __device__ __forceinline__ void cur_init(Cursor& c, const uint32_t* words, uint32_t p)
 {
     c.words = words; c.p = p; c.widx = p >> 5; c.off = p & 31u;
-    c.w0 = bswap32(words[phys_word(c.widx)]); c.w1 = bswap32(words[phys_word(c.widx + 1)]);
-    c.nxt = words[phys_word(c.widx + 2)]; c.widx += 3;
+    c.w0 = bswap32(words[phys_word<WL>(c.widx)]); c.w1 = bswap32(words[phys_word<WL>(c.widx + 1)]);
+    c.nxt = words[phys_word<WL>(c.widx + 2)]; c.widx += 3;
 }
 // the next 32 bits of the stream (one v_alignbit_b32)
 __device__ __forceinline__ uint32_t cur_peek(const Cursor& c) { return __funnelshift_l(c.w1, c.w0, c.off); }
-__device__ __forceinline__ void cur_skip(Cursor& c, uint32_t n)      // n <= 32
+template <int WL> __device__ __forceinline__ void cur_skip(Cursor& c, uint32_t n)      // n <= 32
 {
     c.off += n; c.p += n;
-    if (c.off >= 32u) { c.off -= 32u; c.w0 = c.w1; c.w1 = bswap32(c.nxt); c.nxt = c.words[phys_word(c.widx++)]; }
+    if (c.off >= 32u) { c.off -= 32u; c.w0 = c.w1; c.w1 = bswap32(c.nxt); c.nxt = c.words[phys_word<WL>(c.widx++)]; }
 }
 
 // state word: [31:16] interval index, [15:8] block-in-MCU, [7:0] next coefficient index (0 = DC)
@@ -724,7 +747,7 @@ __device__ __forceinline__ uint32_t sym_lookup(const SubTabs& T, uint32_t win, u
 
 // What the reference sees as RSV_RST_TERM (:1167-1176) -- no code fits in what is left of the interval --
 // or a code that matches nothing.  Returns false when the walk is over (end of the entropy data).
-template <bool WRITE>
+template <bool WRITE, int WL>
 __device__ __forceinline__ bool walk_slow(const JsImage& im, const uint32_t* __restrict__ words, const uint32_t* __restrict__ st, uint32_t nseg,
                                        Cursor& cur, uint32_t len, uint32_t& seg, uint32_t& seg_end, uint32_t& c, uint32_t& k,
                                        uint32_t blk, bool mark, uint8_t* __restrict__ mcu_rst, uint32_t& flags)
@@ -734,7 +757,7 @@ __device__ __forceinline__ bool walk_slow(const JsImage& im, const uint32_t* __r
         // No code matches although a whole code could still fit: a corrupt stream (the reference skips one bit
         // and reports it, :1178-1186) -- or simply a speculative walk that is not synchronised yet.
         if (WRITE && blk < im.total_blocks) flags |= F_BAD_CODE;
-        cur_skip(cur, 1);
+        cur_skip<WL>(cur, 1);
         return true;
     }
     if (seg + 1 < nseg) {
@@ -744,7 +767,7 @@ __device__ __forceinline__ bool walk_slow(const JsImage& im, const uint32_t* __r
         }
         seg++; const uint32_t np = seg_end; seg_end = st[seg + 1] * 8; c = 0; k = 0;
         if (WRITE && seg_end == np && seg + 1 < nseg) flags |= F_RST_MISALIGN;       // back-to-back RSTn
-        cur_init(cur, words, np);
+        cur_init<WL>(cur, words, np);
         return true;
     }
     if (WRITE && blk < im.total_blocks) flags |= F_SHORT;
@@ -753,24 +776,25 @@ __device__ __forceinline__ bool walk_slow(const JsImage& im, const uint32_t* __r
 }
 
 // SYNC flavour: state only.  Walks the symbols that start inside [entry position, own_end).
+template <int WL>
 __device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, const uint32_t* __restrict__ words, const uint32_t* __restrict__ st,
                                           uint32_t nseg, uint32_t total_bits, uint32_t own_end, uint32_t& p_io, uint32_t& s_io, uint32_t& nblk_out)
 {
     uint32_t seg = ST_SEG(s_io), c = ST_C(s_io), k = ST_K(s_io), nblk = 0, fl = 0;
     if (p_io == P_END || (p_io >= total_bits && seg + 1 >= nseg)) { p_io = P_END; s_io = 0; nblk_out = 0; return; }
     uint32_t seg_end = st[seg + 1] * 8;
-    Cursor cur; cur_init(cur, words, p_io);
+    Cursor cur; cur_init<WL>(cur, words, p_io);
     uint32_t rp = rows_of(T, comp_of(T, c));
     while (cur.p < own_end) {
         const uint32_t win = cur_peek(cur);
         const uint32_t e = sym_lookup(T, win, rp, k);
         const uint32_t len = (e >> 8) & 31u, run = (e >> 4) & 15u, size = e & 15u;
         if (__builtin_expect(len == 0 || cur.p + len > seg_end, 0)) {
-            if (!walk_slow<false>(im, words, st, nseg, cur, len, seg, seg_end, c, k, 0, false, nullptr, fl)) break;
+            if (!walk_slow<false, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, 0, false, nullptr, fl)) break;
             rp = rows_of(T, comp_of(T, c));
             continue;
         }
-        cur_skip(cur, len + size);
+        cur_skip<WL>(cur, len + size);
         const bool isdc = k == 0;
         const uint32_t k2 = isdc ? 1u : k + run + 1u;
         const bool done = !isdc && ((e & 255u) == 0 || k2 >= 64u);
@@ -791,6 +815,7 @@ __device__ __forceinline__ uint32_t find_interval(const uint32_t* __restrict__ s
 // sub-sequence state arrays (SoA, one u32 each per sub-sequence slot)
 struct SubArrays { uint32_t *out_p, *out_s, *in_p, *in_s, *nblk, *base; };
 
+template <int WL>
 __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sy_base, uint32_t nimg,
                                                      const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr,
                                                      const uint32_t* __restrict__ seg_tab, const uint32_t* __restrict__ side, SubArrays A, int first_pass,
@@ -855,7 +880,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
             uint32_t p = s_inp[u], s = s_ins[u], nblk = 0;
             const uint32_t own_end = min((iu + 1) * SUB_BITS, total_bits);
             if (!(p != P_END && p >= own_end))                   // else: owns no symbol, the state passes through
-                walk_sync(im, T, words, st, nseg, total_bits, own_end, p, s, nblk);
+                walk_sync<WL>(im, T, words, st, nseg, total_bits, own_end, p, s, nblk);
             if (p != s_outp[u] || s != s_outs[u]) { s_outp[u] = p; s_outs[u] = s; s_changed = 1; }
             s_nblk[u] = nblk;
         }
@@ -867,6 +892,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
 }
 
 // One workgroup per image: exclusive scan of blocks-per-sub-sequence.
+template <int WL>
 __global__ void __launch_bounds__(256) k_block_scan(const JsImage* __restrict__ imgs, const JsTableSet* __restrict__ tables,
                                                     SubArrays A, uint32_t* side, uint32_t* __restrict__ flags)
 {
@@ -896,6 +922,7 @@ __global__ void __launch_bounds__(256) k_block_scan(const JsImage* __restrict__ 
 // (it runs while any lane is active), so that when some lanes complete a block in an iteration the WHOLE wave
 // moves each finished block out: 64 lanes x 2 bytes = one coalesced 128-byte line per block.  HBM therefore sees
 // whole lines (no scattered 2-byte read-modify-writes) and the coefficient arena needs no memset.
+template <int WL>
 __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sy_base, uint32_t nimg,
                                                       const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr,
                                                       const uint32_t* __restrict__ seg_tab, const uint32_t* __restrict__ side, SubArrays A,
@@ -935,7 +962,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         if (p0 != P_END && p0 >= own_end) { res_p = p0; res_s = s0; }                          // owns no symbol: passes through
         else if (p0 == P_END || (p0 >= total_bits && seg + 1 >= nseg)) { res_p = P_END; res_s = 0; check_n = true; }
         else if (blk >= nblocks) verify = false;                                                // everything owned lies past the last MCU
-        else { active = true; check_n = true; seg_end = st[seg + 1] * 8; skip = k != 0; cur_init(cur, words, p0); }
+        else { active = true; check_n = true; seg_end = st[seg + 1] * 8; skip = k != 0; cur_init<WL>(cur, words, p0); }
     }
     int16_t dq0 = 0;
     uint32_t comp = comp_of(T, c), rp = rows_of(T, comp);
@@ -956,7 +983,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         const bool bad = active && (len == 0 || cur.p + len > seg_end);
         if (__ballot(bad)) {                                     // interval / stream end, or a code that matches nothing: rare
             if (bad) {
-                const bool more = walk_slow<true>(im, words, st, nseg, cur, len, seg, seg_end, c, k, blk, !captured, rstf, fl);
+                const bool more = walk_slow<true, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, blk, !captured, rstf, fl);
                 if (!more) { if (!captured) { captured = true; res_p = P_END; res_s = 0; res_n = nblk; } active = false; }
                 comp = comp_of(T, c); rp = rows_of(T, comp);
             }
@@ -974,7 +1001,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         dq0 = (norm && isdc) ? dq : dq0;
         const uint32_t tot = norm ? len + size : 0u;
         cur.off += tot; cur.p += tot;
-        if (cur.off >= 32u) { cur.off -= 32u; cur.w0 = cur.w1; cur.w1 = bswap32(cur.nxt); cur.nxt = words[phys_word(cur.widx++)]; }
+        if (cur.off >= 32u) { cur.off -= 32u; cur.w0 = cur.w1; cur.w1 = bswap32(cur.nxt); cur.nxt = words[phys_word<WL>(cur.widx++)]; }
         const uint32_t k2 = isdc ? 1u : k + run + 1u;
         const bool done = norm && !isdc && ((e & 255u) == 0 || k2 >= 64u);
         if (__ballot(norm && k2 > 64u)) { if (norm && k2 > 64u && blk < nblocks) fl |= F_COEF_OVERFLOW; }
@@ -1050,32 +1077,43 @@ __global__ void __launch_bounds__(DC_THREADS) k_dc_scan(const JsImage* __restric
     }
 }
 
-void js_launch_unstuff(hipStream_t st, const JsImage* imgs, const uint32_t* us_base, uint32_t nimg, uint32_t total_chunks, const uint8_t* raw,
-                       uint32_t* chunk_keep, uint32_t* chunk_rst, uint8_t* ustr, uint32_t* seg_tab, uint32_t* side, uint32_t* flags)
+void js_launch_unstuff(hipStream_t st, int wl, const JsImage* imgs, const uint32_t* us_base, uint32_t nimg, uint32_t total_chunks, const uint8_t* raw,
+                       uint32_t* chunk_keep, uint32_t* chunk_rst, uint8_t* ustr_lin, uint8_t* ustr, uint32_t* seg_tab, uint32_t* side, uint32_t* flags,
+                       const uint32_t* sy_base, uint32_t sy_wgs)
 {
     if (!total_chunks) return;
     hipLaunchKernelGGL(k_unstuff_count, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst);
     hipLaunchKernelGGL(k_unstuff_scan, dim3(nimg), dim3(256), 0, st, imgs, us_base, chunk_keep, chunk_rst, seg_tab, side, flags);
-    hipLaunchKernelGGL(k_unstuff_write, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, ustr, seg_tab);
+    hipLaunchKernelGGL(k_unstuff_write, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, ustr_lin, seg_tab);
+    if (wl == 7) hipLaunchKernelGGL(k_interleave<7>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
+    else hipLaunchKernelGGL(k_interleave<5>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
 }
 static SubArrays sub_arrays(uint32_t* sub, uint64_t n) { SubArrays a; a.out_p = sub; a.out_s = sub + n; a.in_p = sub + 2 * n; a.in_s = sub + 3 * n; a.nblk = sub + 4 * n; a.base = sub + 5 * n; return a; }
 static size_t subtabs_bytes_host(uint32_t tab_rows, uint32_t tab_lut2)
 { return (size_t)tab_rows * (2u << JS_L1_BITS) + (((size_t)tab_lut2 * 2 + 15) & ~15ull) + 3 * 64 * 2 + 64; }
-void js_launch_sync(hipStream_t st, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
+void js_launch_sync(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
                     const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub, int first_pass)
 {
     if (!total_wgs) return;
-    hipLaunchKernelGGL(k_sync, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+    if (wl == 7) hipLaunchKernelGGL(k_sync<7>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                       sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2);
+    else hipLaunchKernelGGL(k_sync<5>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2);
 }
-void js_launch_block_scan(hipStream_t st, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, uint32_t* sub, uint64_t nsub, uint32_t* side, uint32_t* flags)
-{ if (nimg) hipLaunchKernelGGL(k_block_scan, dim3(nimg), dim3(256), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags); }
-void js_launch_write(hipStream_t st, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
+void js_launch_block_scan(hipStream_t st, int wl, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, uint32_t* sub, uint64_t nsub, uint32_t* side, uint32_t* flags)
+{
+    if (!nimg) return;
+    if (wl == 7) hipLaunchKernelGGL(k_block_scan<7>, dim3(nimg), dim3(256), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
+    else hipLaunchKernelGGL(k_block_scan<5>, dim3(nimg), dim3(256), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
+}
+void js_launch_write(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
                      const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub,
                      int16_t* coef, int16_t* dccum, uint8_t* mcu_rst, uint32_t* flags)
 {
     if (!total_wgs) return;
-    hipLaunchKernelGGL(k_write, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+    if (wl == 7) hipLaunchKernelGGL(k_write<7>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                       sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2);
+    else hipLaunchKernelGGL(k_write<5>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2);
 }
 void js_launch_dc_scan(hipStream_t st, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, int16_t* dccum, const uint8_t* mcu_rst)

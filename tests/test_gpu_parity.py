@@ -105,21 +105,22 @@ def test_corrupt_streams_exact_path(harness, oracle, gpu):
     assert paths.get(2, 0) > 0, "some malformed scans must have been routed to the exact-mirror kernel"
 
 
-@pytest.mark.parametrize("force_exact", [False, True])
-def test_batch_api(harness, oracle, force_exact):
+@pytest.mark.parametrize("force_exact,sub_wl", [(False, 5), (False, 7), (True, 5)])
+def test_batch_api(harness, oracle, force_exact, sub_wl, monkeypatch):
     import jpegsnoop_amd as J
+    monkeypatch.setenv("JSNOOP_SUB_WL", str(sub_wl))        # 128-byte or 512-byte sub-sequences
     kws = [dict(width=320, height=240), dict(width=333, height=217, hs=1, vs=1), dict(width=160, height=120, gray=1),
-           dict(width=640, height=360, hs=2, vs=1, restart_interval=40)]
+           dict(width=640, height=360, hs=2, vs=1, restart_interval=40), dict(width=1280, height=720, quality=92)]
     files = [harness.synth_jpeg(seed=20 + i, **kw) for i, kw in enumerate(kws)]
     b = J.JpegBatch(want_planes=True, force_exact=force_exact)
     for f in files:
         b.add_jpeg(f)
-    b.tile(8)
+    b.tile(10)
     b.upload(); b.decode(); b.sync()
     sums = b.dib_checksums()
-    assert all(b.info(i)['path'] == (2 if force_exact else 1) for i in range(8))
-    for i in range(8):
-        harness.drive(oracle, files[i % 4])
+    assert all(b.info(i)['path'] == (2 if force_exact else 1) for i in range(10))
+    for i in range(10):
+        harness.drive(oracle, files[i % 5])
         assert np.array_equal(b.dib(i), oracle.dib())
         for pa, pb in zip(oracle.planes(), b.planes(i)):
             if pa is not None:
