@@ -53,6 +53,12 @@ def main():
     if not (os.path.exists(J.LIB_PATH) and os.path.exists(H.ORC_SO) and os.path.exists(H.SYNTH_SO)):
         if local_rank == 0:
             G.build()
+        else:                                        # other ranks wait for rank 0's build instead of racing it
+            for _ in range(600):
+                if os.path.exists(J.LIB_PATH) and os.path.exists(H.ORC_SO) and os.path.exists(H.SYNTH_SO):
+                    break
+                time.sleep(0.5)
+            time.sleep(1.0)
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -70,7 +76,13 @@ def main():
     for f in files:
         batch.add_jpeg(f)
     batch.tile(args.images)
+    t0 = time.perf_counter()
     batch.upload()                                   # pinned host -> HBM, outside the timed region
+    t_upload_first = time.perf_counter() - t0        # includes the one-time hipMalloc of the arenas
+    lib.jsnoop_batch_set_options(batch._h, 1, 0, 0)  # marks the batch dirty: the next upload() repeats only the H2D copies
+    t0 = time.perf_counter()
+    batch.upload()
+    t_upload = time.perf_counter() - t0
     pixels = batch.pixels()
     alg_bytes = batch.algorithmic_bytes()
 
@@ -144,7 +156,7 @@ def main():
     if rank == 0:
         value = tot_px / max_el / 1e6 if tot_err == 0 else 0.0
         out = {
-            "metric": "Mpixels/sec decoded (baseline 4:2:0 JPEG), bit-exact vs CPU CimgDecode",
+            "metric": "Mpixels/sec decoded (baseline 4:2:0 JPEG) at 1/2/4/8 GPUs; bit-exact vs ref",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(max_el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/i16 entropy+DIB, f32 IDCT+colour", "data": "synthetic",
@@ -164,7 +176,20 @@ def main():
             out["cpu_baseline"] = {"value": round(n_cpu * args.width * args.height / cpu_time / 1e6, 2), "unit": "Mpixels/s", "cores": 1,
                                    "kind": "port", "sample": f"{n_cpu} x {args.width}x{args.height} 4:2:0 images of this workload, oracle/oracle_imgdecode.c, "
                                                              f"1 thread, {cpu_time:.1f} s" + (f"; compiled reference on 2 images: {ref_rate:.2f} Mpixels/s" if ref_rate else "")}
-        out["setup_s"] = {"synth": round(t_gen, 1)}
+        # measured HBM traffic of the dominant kernel (rocprofv3 PMC passes of this same workload, tools/pmc_collect.sh)
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                tj = json.load(open(tf))
+                if tj.get("kernel") == dom and tj.get("images_per_launch"):
+                    out["roofline"]["traffic"] = int(tj["hbm_bytes_per_launch"] * args.images / tj["images_per_launch"])
+                    out["roofline"]["traffic_source"] = tj.get("source")
+            except Exception:
+                pass
+        out["setup_s"] = {"synth": round(t_gen, 1), "first_upload_with_alloc": round(t_upload_first, 3)}
+        out["pcie_inclusive_T2"] = {"h2d_ms": round(t_upload * 1e3, 3), "compressed_bytes": int(sum(len(f) for f in files) * (args.images / args.distinct)),
+                                    "mpix_per_s": round(pixels / (t_upload + max_el / args.steps) / 1e6, 1),
+                                    "note": "timing scope T2: pinned H2D of the compressed batch + decode; reported beside, never as, value"}
         out.update(extra)
         print(json.dumps(out))
     batch.close()
