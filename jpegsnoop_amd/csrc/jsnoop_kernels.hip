@@ -368,6 +368,11 @@ __global__ void __launch_bounds__(BK_THREADS) k_idct_color(const JsImage* __rest
     const bool want_planes = im.want_planes != 0;
     uint64_t bright = 0; uint32_t sum_y = 0;
     if (ncomp == 1) for (uint32_t i = lane; i < 2 * plane_elems; i += 64) tile[plane_elems + i] = 0;   // Cb = Cr = 0 for grayscale (:4709-4715)
+    // A component with 1 < H < Hmax (or V) does not cover its share of the MCU: SetFullRes places its blocks 8 samples
+    // apart but replicates each Hmax/H times (:2498-2557), so part of the MCU keeps the zeros of ClrFullRes (:2443).
+    bool partial = false;
+    for (uint32_t cc = 1; cc <= ncomp; cc++)
+        partial = partial || (im.samp_h[cc] > 1 && im.expand_h[cc] > 1) || (im.samp_v[cc] > 1 && im.expand_v[cc] > 1);
 
     int cv[BK_CHUNK]; int16_t dcv[BK_CHUNK];
     auto load_chunk = [&](uint32_t m, uint32_t base) {
@@ -382,6 +387,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_idct_color(const JsImage* __rest
     uint32_t m = wg_in_img * BK_WAVES + wave;
     if (m < nmcu) load_chunk(m, 0);
     for (; m < nmcu; m += wstride) {
+        if (partial) { for (uint32_t i = lane; i < ncomp * plane_elems; i += 64) tile[i] = 0; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); }
         // ---- IDCT of the MCU's blocks, decode order ---------------------------------------------------
         for (uint32_t base = 0; base < nb; base += BK_CHUNK) {
             if (base) load_chunk(m, base);

@@ -182,3 +182,52 @@ def test_preview_modes_and_shift(harness, oracle, gpu):
     assert np.array_equal(gpu.dib(), expect(1, 160, -80, 40, 3, 2))
     gpu.set_preview_ycc_offset(0, 0, 0, 0, 0)
     assert np.array_equal(gpu.dib(), base)
+
+
+def test_header_variations(harness, oracle, gpu):
+    """Sampling factors the encoder cannot produce (up to 4x4, self-overlapping replication): rewrite the SOF of a valid
+    file.  The scan then decodes to garbage, deterministically -- the geometry / replication arithmetic of the back end and
+    the exact-mirror kernel must still match the reference semantics bit for bit."""
+    data = harness.synth_jpeg(width=160, height=96, seed=4)
+    p = harness.parse_jpeg(data)
+    for samp in ([(4, 1), (1, 1), (1, 1)], [(1, 4), (1, 1), (1, 1)], [(4, 2), (2, 1), (1, 2)], [(2, 2), (2, 1), (1, 1)],
+                 [(1, 1), (2, 2), (2, 2)], [(3, 1), (1, 1), (1, 1)], [(2, 2), (2, 2), (2, 2)], [(4, 4), (1, 1), (2, 2)]):
+        q = harness.parse_jpeg(data)
+        q.comps = [(c[0], h, v, c[3]) for c, (h, v) in zip(p.comps, samp)]
+        harness.drive(oracle, data, q)
+        harness.drive(gpu, data, q)
+        compare(harness, oracle, gpu)
+
+
+def test_config2_single_4k(harness, oracle):
+    """BASELINE config 2: one 3840x2160 4:2:0 image end to end through the parallel path."""
+    import jpegsnoop_amd as J
+    data = harness.synth_jpeg(width=3840, height=2160, seed=21)
+    b = J.JpegBatch(want_planes=True)
+    b.add_jpeg(data); b.upload(); b.decode(); b.sync()
+    assert b.info(0)["path"] == 1 and b.info(0)["flags"] == 0
+    harness.drive(oracle, data)
+    assert np.array_equal(b.dib(0), oracle.dib())
+    for pa, pb in zip(oracle.planes(), b.planes(0)):
+        assert np.array_equal(pa, pb)
+    b.close()
+
+
+def test_config5_baseline_422_restart(harness, oracle):
+    """The reference-decodable form of BASELINE config 5: 1920x1080 4:2:2 with a restart marker every MCU row
+    (the reference refuses SOF2, source/JfifDecode.cpp:4827-4833, so its progressive form has no reference answer)."""
+    import jpegsnoop_amd as J
+    data = harness.synth_jpeg(width=1920, height=1080, hs=2, vs=1, restart_interval=120, seed=22)
+    b = J.JpegBatch()
+    b.add_jpeg(data); b.upload(); b.decode(); b.sync()
+    assert b.info(0)["path"] == 1 and b.info(0)["flags"] == 0
+    harness.drive(oracle, data)
+    assert oracle.status()["restart_read"] == 134
+    assert np.array_equal(b.dib(0), oracle.dib())
+    b.close()
+    # the same pixels without restart markers decode to the same DIB (RST invariance, SURVEY.md Appendix B)
+    plain = harness.synth_jpeg(width=1920, height=1080, hs=2, vs=1, restart_interval=0, seed=22)
+    harness.drive(oracle, plain)
+    b2 = J.JpegBatch(); b2.add_jpeg(plain); b2.upload(); b2.decode(); b2.sync()
+    assert np.array_equal(b2.dib(0), oracle.dib())
+    b2.close()

@@ -1,30 +1,24 @@
-import sys, os, ctypes as C, subprocess
+import sys, os
 sys.path.insert(0, '.')
 import numpy as np
 from oracle import harness as H
 import jpegsnoop_amd as J
 H.build(["oracle", "synth"])
-subprocess.check_call("gcc -O2 -Ioracle tools/syncdist.c oracle/jpeg_synth.c -lm -o /tmp/syncdist && /tmp/syncdist 2 2 1024 0 /tmp/truth.bin", shell=True)
-truth = np.fromfile('/tmp/truth.bin', np.uint32).reshape(-1, 3)
-lib = J.load()
-lib.jsnoop_batch_debug_copy.restype = C.c_uint64
-lib.jsnoop_batch_debug_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
-data = H.synth_jpeg(seed=11, width=1920, height=1080)
-for nl in (1, 2, 3):
-    os.environ['JSNOOP_SYNC_LAUNCHES'] = str(nl)
-    b = J.JpegBatch(want_planes=False)
-    b.add_jpeg(data); b.upload(); b.decode()
-    buf = np.zeros(1 << 22, np.uint32)
-    n = lib.jsnoop_batch_debug_copy(b._h, 0, buf.ctypes.data, buf.nbytes) // 4
-    c = buf[:n].reshape(6, -1).copy()
-    ns = len(truth)
-    gp, gs = c[0][:ns], c[1][:ns]
-    gc, gk = (gs >> 8) & 255, gs & 255
-    ok = (gp == truth[:, 0]) & (gc == truth[:, 1]) & (gk == truth[:, 2])
-    bad = np.nonzero(~ok)[0]
-    print('launches', nl, 'nsub', ns, 'mismatching out states', len(bad), 'first', bad[:12], 'per WG', np.bincount(bad // 256, minlength=18) if len(bad) else '')
-    if len(bad):
-        i = bad[0]
-        for j in range(max(0, i - 2), i + 3):
-            print('  i', j, 'gpu out', gp[j], gc[j], gk[j], 'truth', truth[j], 'gpu in', c[2][j], (c[3][j] >> 8) & 255, c[3][j] & 255, 'nblk', c[4][j])
-    b.sync(); b.close()
+o = H.oracle_backend()
+g = H.Backend(J.load(), "jsnoop_", "hip")
+data = H.synth_jpeg(width=160, height=96, seed=4)
+p = H.parse_jpeg(data)
+for samp in ([(4, 1), (1, 1), (1, 1)], [(1, 4), (1, 1), (1, 1)], [(4, 2), (2, 1), (1, 2)], [(2, 2), (2, 1), (1, 1)],
+             [(1, 1), (2, 2), (2, 2)], [(3, 1), (1, 1), (1, 1)], [(2, 2), (2, 2), (2, 2)], [(4, 4), (1, 1), (2, 2)]):
+    q = H.parse_jpeg(data)
+    q.comps = [(c[0], h, v, c[3]) for c, (h, v) in zip(p.comps, samp)]
+    H.drive(o, data, q); H.drive(g, data, q)
+    path, fl = g.lib.jsnoop_last_path(g.h), g.lib.jsnoop_last_flags(g.h)
+    do, dg = o.dib(), g.dib()
+    po, pg = o.planes(), g.planes()
+    pe = [bool(np.array_equal(a, b)) for a, b in zip(po, pg)]
+    bad = np.argwhere((do != dg).any(axis=2))
+    print(samp, 'path', path, 'flags %#x' % fl, 'dib eq', np.array_equal(do, dg), 'planes eq', pe, 'geom', g.geometry(), 'status', o.status() == g.status(),
+          'first bad px', bad[:3].tolist(), 'nbad', len(bad))
+    if not pe[0]:
+        bp = np.argwhere(po[0] != pg[0]); print('   Y plane bad', bp[:5].tolist(), len(bp), po[0][tuple(bp[0])], pg[0][tuple(bp[0])])
