@@ -118,6 +118,9 @@ void            jsnoop_bright_avg(JsnoopDecoder*, int* out10);         /* bright
 const float*    jsnoop_idct_lut(JsnoopDecoder*);                       /* m_afIdctLookup [64][64] as uploaded to the device */
 const uint32_t* jsnoop_dht_lookupfast(JsnoopDecoder*);                 /* m_anDhtLookupfast [2][4][1024] */
 void            jsnoop_idct_block(JsnoopDecoder*, const int16_t* coef64, float* out64);   /* one block through the device IDCT */
+/* every (Y, Cb, Cr) in [-128,127]^3 through the device ConvertYCCtoRGBFastFloat (ImgDecode.cpp:4086):
+ * out_bgra[(Y+128)<<16 | (Cb+128)<<8 | (Cr+128)] = B | G<<8 | R<<16; 2^24 words; 0 on success */
+int             jsnoop_color_sweep(JsnoopDecoder*, uint32_t* out_bgra);
 /* which device path decoded the last image: 1 = parallel (self-synchronising) entropy
  * decode, 2 = sequential exact-mirror entropy kernel (taken for streams the parallel
  * path flags as malformed), 0 = nothing decoded */

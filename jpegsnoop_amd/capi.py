@@ -60,6 +60,7 @@ SIGNATURES = {
     "jsnoop_idct_lut": (_p, [_p]),
     "jsnoop_dht_lookupfast": (_p, [_p]),
     "jsnoop_idct_block": (None, [_p, _p, _p]),
+    "jsnoop_color_sweep": (C.c_int, [_p, _p]),
     "jsnoop_last_path": (_i, [_p]),
     "jsnoop_last_flags": (C.c_uint32, [_p]),
     "jsnoop_batch_create": (_p, [_p]),

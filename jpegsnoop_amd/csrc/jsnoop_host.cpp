@@ -506,6 +506,18 @@ void jsnoop_idct_block(JsnoopDecoder* d, const int16_t* coef64, float* out64)
     hipMemcpyAsync(out64, b->dev.probe + 256, 256, hipMemcpyDeviceToHost, b->stream);
     hipStreamSynchronize(b->stream);
 }
+int jsnoop_color_sweep(JsnoopDecoder* d, uint32_t* out_bgra)
+{
+    JsnoopBatch* b = d->batch; hipSetDevice(b->device);
+    uint32_t* tmp = nullptr;
+    if (hipMalloc(&tmp, (size_t)4 << 24) != hipSuccess) { js_set_error("jsnoop_color_sweep: hipMalloc failed"); return -1; }
+    js_launch_color_sweep(b->stream, tmp);
+    hipError_t e = hipMemcpyAsync(out_bgra, tmp, (size_t)4 << 24, hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    hipFree(tmp);
+    if (e != hipSuccess) { js_set_error("jsnoop_color_sweep: device error"); return -1; }
+    return 0;
+}
 int jsnoop_last_path(JsnoopDecoder* d) { return d->last_path; }
 uint32_t jsnoop_last_flags(JsnoopDecoder* d) { return d->last_flags; }
 

@@ -260,41 +260,83 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
 #define BK_ROW 144                      // int16 per LDS plane row: 128 + padding so the 8 rows of a block fall in distinct banks
 #define BK_MAX_MCU_H 32
 
-__device__ __forceinline__ void ycc_to_rgb(int py, int pcb, int pcr, uint32_t mode, uint32_t& out_bgra, uint32_t& final_y)
-{   // ConvertYCCtoRGBFastFloat :4086-4139 then ChannelExtract :4832-4872
+// ConvertYCCtoRGBFastFloat :4086-4139.  The reference divides by 0.587f (IEEE).  The quotient is formed here as
+// q0 = x * RN(1/0.587f) followed by ONE fused correction step; for every numerator this function can produce
+// (y, cb, cr in [-128, 127] after the clamp: 2^24 cases) that is bit-identical to the IEEE quotient -- checked
+// exhaustively on the device against the oracle's true division (tests/test_gpu_parity.py::test_color_sweep).
+__device__ __forceinline__ void ycc_core(int py, int pcb, int pcr, uint32_t& R, uint32_t& G, uint32_t& B, uint32_t& FY, uint32_t& FCB, uint32_t& FCR)
+{
     int y = py >> 3, cb = pcb >> 3, cr = pcr >> 3;
-    y = y < -128 ? -128 : y > 127 ? 127 : y; cb = cb < -128 ? -128 : cb > 127 ? 127 : cb; cr = cr < -128 ? -128 : cr > 127 ? 127 : cr;
+    y = min(max(y, -128), 127); cb = min(max(cb, -128), 127); cr = min(max(cr, -128), 127);
     const float kr = 0.299f, kg = 0.587f, kb = 0.114f;
     const float cr_mul = 2 - 2 * kr, cb_mul = 2 - 2 * kb;       // folded in fp32 exactly as the reference's expression
-    float fy = (float)y;
+    const float rkg = 1.0f / kg;
+    const float fy = (float)y;
     float r = __fadd_rn(__fmul_rn((float)cr, cr_mul), fy);
     float b = __fadd_rn(__fmul_rn((float)cb, cb_mul), fy);
-    float g = __fdiv_rn(__fsub_rn(__fsub_rn(fy, __fmul_rn(kb, b)), __fmul_rn(kr, r)), kg);
+    const float x = __fsub_rn(__fsub_rn(fy, __fmul_rn(kb, b)), __fmul_rn(kr, r));
+    const float q0 = __fmul_rn(x, rkg);
+    float g = __fmaf_rn(__fmaf_rn(-kg, q0, x), rkg, q0);        // == x / kg, see above
     r = __fadd_rn(r, 128.0f); b = __fadd_rn(b, 128.0f); g = __fadd_rn(g, 128.0f);
-    uint32_t R = r < 0 ? 0u : r > 255 ? 255u : (uint32_t)(int)r;
-    uint32_t G = g < 0 ? 0u : g > 255 ? 255u : (uint32_t)(int)g;
-    uint32_t B = b < 0 ? 0u : b > 255 ? 255u : (uint32_t)(int)b;
-    uint32_t FY = (uint32_t)(y + 128), FCB = (uint32_t)(cb + 128), FCR = (uint32_t)(cr + 128);
+    R = (uint32_t)(int)__builtin_amdgcn_fmed3f(r, 0.0f, 255.0f);   // <0 -> 0, >255 -> 255, else truncate (:4128-4136)
+    G = (uint32_t)(int)__builtin_amdgcn_fmed3f(g, 0.0f, 255.0f);
+    B = (uint32_t)(int)__builtin_amdgcn_fmed3f(b, 0.0f, 255.0f);
+    FY = (uint32_t)(y + 128); FCB = (uint32_t)(cb + 128); FCR = (uint32_t)(cr + 128);
+}
+// ... then ChannelExtract :4832-4872.  RGB_ONLY: the default preview mode (PREVIEW_RGB), no per-pixel mode dispatch.
+template <bool RGB_ONLY>
+__device__ __forceinline__ void ycc_to_rgb(int py, int pcb, int pcr, uint32_t mode, uint32_t& out_bgra, uint32_t& final_y)
+{
+    uint32_t R, G, B, FY, FCB, FCR;
+    ycc_core(py, pcb, pcr, R, G, B, FY, FCB, FCR);
     final_y = FY;
-    switch (mode) {
-    case 2: R = FCR; G = FY; B = FCB; break;      // PREVIEW_YCC
-    case 3: G = B = R; break;                     // PREVIEW_R
-    case 4: R = B = G; break;                     // PREVIEW_G
-    case 5: R = G = B; break;                     // PREVIEW_B
-    case 6: R = G = B = FY; break;                // PREVIEW_Y
-    case 7: R = G = B = FCB; break;               // PREVIEW_CB
-    case 8: R = G = B = FCR; break;               // PREVIEW_CR
-    default: break;
+    if (!RGB_ONLY) {
+        switch (mode) {
+        case 2: R = FCR; G = FY; B = FCB; break;      // PREVIEW_YCC
+        case 3: G = B = R; break;                     // PREVIEW_R
+        case 4: R = B = G; break;                     // PREVIEW_G
+        case 5: R = G = B; break;                     // PREVIEW_B
+        case 6: R = G = B = FY; break;                // PREVIEW_Y
+        case 7: R = G = B = FCB; break;               // PREVIEW_CB
+        case 8: R = G = B = FCR; break;               // PREVIEW_CR
+        default: break;
+        }
     }
     out_bgra = B | (G << 8) | (R << 16);          // bytes B,G,R,0 (:4786-4789)
 }
 
-// DecodeIdctCalcFloat(64) :2372-2392 on one block held one coefficient per lane.  Only non-zero
-// coefficients are visited, in ascending natural order.  The wave first compacts them into a small LDS
-// list (row offset of the cosine table, coefficient as fp32) with one ballot + mbcnt, padded to a
-// multiple of four with (DC row, 0.0f) entries whose products are exact +-0 and leave the fp32 sum
-// unchanged; the accumulation loop then needs no scalar bit-twiddling: four broadcast list reads and
-// four table reads in flight per trip, then four dependent mul/add pairs in the reference's order.
+// Lane I of every 16-lane row, broadcast to the whole row: folds into the consuming VALU instruction as a DPP
+// operand (row_newbcast), so a value every lane needs costs neither an LDS broadcast read nor a scalar round trip.
+template <int I> __device__ __forceinline__ uint32_t row_bc(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + I, 0xF, 0xF, true); }
+
+// Four terms of the sum: entries I..I+3 of the list registers E (x = byte offset of the table row, y = coefficient).
+#define IDCT_G4(E, I)                                                                                                   \
+    {                                                                                                                   \
+        const float l0 = *reinterpret_cast<const float*>(lut_b + (row_bc<I>(E.x) + lane4));                           \
+        const float l1 = *reinterpret_cast<const float*>(lut_b + (row_bc<I + 1>(E.x) + lane4));                       \
+        const float l2 = *reinterpret_cast<const float*>(lut_b + (row_bc<I + 2>(E.x) + lane4));                       \
+        const float l3 = *reinterpret_cast<const float*>(lut_b + (row_bc<I + 3>(E.x) + lane4));                       \
+        acc = __fadd_rn(acc, __fmul_rn(__uint_as_float(row_bc<I>(E.y)), l0));                                          \
+        acc = __fadd_rn(acc, __fmul_rn(__uint_as_float(row_bc<I + 1>(E.y)), l1));                                      \
+        acc = __fadd_rn(acc, __fmul_rn(__uint_as_float(row_bc<I + 2>(E.y)), l2));                                      \
+        acc = __fadd_rn(acc, __fmul_rn(__uint_as_float(row_bc<I + 3>(E.y)), l3));                                      \
+    }
+#define IDCT_G16(R)                                                                                                     \
+    {                                                                                                                   \
+        const uint2 e = s_list[(R) * 16 + li];                                                                          \
+        IDCT_G4(e, 0)  if (n <= (R) * 16 + 4) break;                                                                    \
+        IDCT_G4(e, 4)  if (n <= (R) * 16 + 8) break;                                                                    \
+        IDCT_G4(e, 8)  if (n <= (R) * 16 + 12) break;                                                                   \
+        IDCT_G4(e, 12)                                                                                                  \
+    }
+
+// DecodeIdctCalcFloat(64) :2372-2392 on one block held one coefficient per lane.  Only non-zero coefficients are
+// visited, in ascending natural order (separate multiply and add, the reference's summation order).  The wave
+// compacts them with one ballot + mbcnt through a small LDS list (row offset of the cosine table, coefficient as
+// fp32), padded to a multiple of four with (DC row, 0.0f) entries whose products are exact +-0 and leave the fp32
+// sum unchanged.  Every 16-lane row then holds 16 list entries in registers (entry i in lane i of the row); the
+// accumulation reads them as DPP row-broadcast operands: per term one address add, one table read, one multiply,
+// one add -- no list traffic in the loop.
 __device__ __forceinline__ float idct_sparse(int cv16, const float* s_lut, uint2* s_list /*this wave's 68 slots*/, uint32_t lane)
 {
     const bool nz = cv16 != 0 && lane != 0;                      // DC is excluded from the sum (:2381)
@@ -305,29 +347,85 @@ __device__ __forceinline__ float idct_sparse(int cv16, const float* s_lut, uint2
     if (lane < 4) s_list[n + lane] = make_uint2(0u, 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     float acc = 0.0f;
-    const uint32_t lane4 = lane * 4u;
+    const uint32_t lane4 = lane * 4u, li = lane & 15u;
     const char* lut_b = reinterpret_cast<const char*>(s_lut);
-    for (uint32_t j = 0; j < n; j += 4) {
-        uint2 e[4]; float l[4];
-        #pragma unroll
-        for (int q = 0; q < 4; q++) e[q] = s_list[j + q];
-        #pragma unroll
-        for (int q = 0; q < 4; q++) l[q] = *reinterpret_cast<const float*>(lut_b + e[q].x + lane4);
-        #pragma unroll
-        for (int q = 0; q < 4; q++) acc = __fadd_rn(acc, __fmul_rn(l[q], __uint_as_float(e[q].y)));   // separate mul and add
-    }
+    do {
+        if (n == 0) break;
+        IDCT_G16(0) if (n <= 16) break;
+        IDCT_G16(1) if (n <= 32) break;
+        IDCT_G16(2) if (n <= 48) break;
+        IDCT_G16(3)
+    } while (0);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     return __fmul_rn(acc, 0.25f);
 }
 // SetFullRes :2468-2561 into the wave's LDS MCU tile (replicated eH x eV times).
 // meta = comp-1 | eh<<4 | ev<<8 | (blk_ch*8)<<12 | (blk_cv*8)<<20 of the block's slot in the MCU.
-__device__ __forceinline__ void sample_to_lds(uint32_t meta, float idct, int16_t dc, int16_t* tile, uint32_t plane_elems, uint32_t rs, uint32_t lane)
+__device__ __forceinline__ uint32_t tile_offset(uint32_t meta, uint32_t plane_elems, uint32_t rs, uint32_t lane)
 {
-    const int16_t smp = (int16_t)((int16_t)(int)__fmul_rn(idct, 8.0f) + dc);   // :2517-2519
     const uint32_t comp0 = meta & 15u, eh = (meta >> 4) & 15u, ev = (meta >> 8) & 15u;
     const uint32_t x0 = ((meta >> 12) & 255u) + (lane & 7) * eh, y0 = ((meta >> 20) & 255u) + (lane >> 3) * ev;
-    int16_t* pl = tile + comp0 * plane_elems + y0 * rs + x0;
-    for (uint32_t jy = 0; jy < ev; jy++) for (uint32_t ix = 0; ix < eh; ix++) pl[jy * rs + ix] = smp;
+    return comp0 * plane_elems + y0 * rs + x0;
+}
+__device__ __forceinline__ void sample_to_lds(uint32_t meta /*wave-uniform*/, float idct, int16_t dc, int16_t* pl, uint32_t rs)
+{
+    const int16_t smp = (int16_t)((int16_t)(int)__fmul_rn(idct, 8.0f) + dc);   // :2517-2519
+    const uint32_t eh = (meta >> 4) & 15u, ev = (meta >> 8) & 15u;
+    if (eh == 1 && ev == 1) pl[0] = smp;
+    else if (eh == 2 && ev <= 2) {                               // 4:2:2 / 4:2:0 chroma: one or two 32-bit stores
+        const uint32_t two = (uint32_t)(uint16_t)smp * 0x10001u;
+        *reinterpret_cast<uint32_t*>(pl) = two;
+        if (ev == 2) *reinterpret_cast<uint32_t*>(pl + rs) = two;
+    } else
+        for (uint32_t jy = 0; jy < ev; jy++) for (uint32_t ix = 0; ix < eh; ix++) pl[jy * rs + ix] = smp;
+}
+
+// Colour conversion + DIB rows of one MCU: 4 pixels (16 bytes) per lane and trip.
+template <bool RGB_ONLY>
+__device__ __forceinline__ void mcu_to_dib(const JsImage& im, const int16_t* tile, uint32_t plane_elems, uint32_t rs, uint32_t quads, uint32_t total,
+                                           uint32_t lane, uint32_t ly0, uint32_t lq0, uint32_t my, uint32_t mx, uint32_t mw, uint32_t mh, bool shifted,
+                                           uint8_t* __restrict__ dibp, int16_t* __restrict__ planes, uint32_t pw, bool want_planes,
+                                           uint64_t& bright, int& best_y, uint32_t& sum_y)
+{
+    const uint32_t img_x = im.img_x, img_y = im.img_y, mode = im.preview_mode, ncomp = im.ncomp;
+    const int sh_y = im.shift_y, sh_cb = im.shift_cb, sh_cr = im.shift_cr;
+    const uint32_t dq = 64u % quads, dy = 64u / quads;
+    uint32_t y = ly0, q = lq0;
+    for (uint32_t p = lane; p < total; p += 64) {
+        const uint32_t x = q * 4, py = my * mh + y, px = mx * mw + x;
+        const uint2 qy = *reinterpret_cast<const uint2*>(tile + y * rs + x);
+        const uint2 qcb = *reinterpret_cast<const uint2*>(tile + plane_elems + y * rs + x);
+        const uint2 qcr = *reinterpret_cast<const uint2*>(tile + 2 * plane_elems + y * rs + x);
+        int vy[4] = { (int)(int16_t)qy.x, (int)qy.x >> 16, (int)(int16_t)qy.y, (int)qy.y >> 16 };
+        int vcb[4] = { (int)(int16_t)qcb.x, (int)qcb.x >> 16, (int)(int16_t)qcb.y, (int)qcb.y >> 16 };
+        int vcr[4] = { (int)(int16_t)qcr.x, (int)qcr.x >> 16, (int)(int16_t)qcr.y, (int)qcr.y >> 16 };
+        // brightest-pixel search (:4722-4730): larger Y wins, earlier raster position breaks ties.  The 64-bit key
+        // is only formed when one of the four pixels can beat (or tie with) what this lane has seen so far.
+        if (max(max(vy[0], vy[1]), max(vy[2], vy[3])) >= best_y) {
+            #pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint64_t key = ((uint64_t)(uint32_t)(vy[k] + 32768) << 32) | (0xFFFFFFFFu - (py * img_x + px + k));
+                bright = key > bright ? key : bright;
+            }
+            best_y = (int)(uint32_t)(bright >> 32) - 32768;
+        }
+        uint32_t o[4];
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (shifted) { vy[k] += sh_y; vcb[k] += sh_cb; vcr[k] += sh_cr; }   // nMcuInd >= nMcuShiftInd (:4735-4739)
+            uint32_t fy; ycc_to_rgb<RGB_ONLY>(vy[k], vcb[k], vcr[k], mode, o[k], fy);
+            sum_y += fy;                                       // nSumY += nFinalY (:4751), wraps mod 2^32 like the reference
+        }
+        uint4 v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
+        *reinterpret_cast<uint4*>(dibp + ((size_t)(img_y - 1 - py) * img_x + px) * 4) = v;
+        if (want_planes) {
+            int16_t* pb = planes + im.plane_off;
+            const size_t pi = (size_t)py * pw + px, psz = (size_t)pw * im.blk_ymax * 8;
+            *reinterpret_cast<uint2*>(pb + pi) = qy;
+            if (ncomp == 3) { *reinterpret_cast<uint2*>(pb + psz + pi) = qcb; *reinterpret_cast<uint2*>(pb + 2 * psz + pi) = qcr; }
+        }
+        q += dq; y += dy; if (q >= quads) { q -= quads; y++; }
+    }
 }
 
 // One WAVE owns one MCU at a time: IDCT of its blocks in decode order (so self-overlapping replication,
@@ -364,9 +462,9 @@ __global__ void __launch_bounds__(BK_THREADS) k_idct_color(const JsImage* __rest
     const int16_t* dbase = dccum + im.coef_off;
     uint8_t* dibp = dib + im.dib_off;
     const uint32_t mcus_across = im.img_x / mw, shift_ind = im.shift_mcu_y * mcus_across + im.shift_mcu_x;
-    const uint32_t img_x = im.img_x, img_y = im.img_y, mode = im.preview_mode; const int sh_y = im.shift_y, sh_cb = im.shift_cb, sh_cr = im.shift_cr;
-    const bool want_planes = im.want_planes != 0;
-    uint64_t bright = 0; uint32_t sum_y = 0;
+    const bool want_planes = im.want_planes != 0, rgb_only = im.preview_mode == 1;
+    const uint32_t quads = mw / 4, total = quads * mh, ly0 = lane / quads, lq0 = lane % quads;
+    uint64_t bright = 0; uint32_t sum_y = 0; int best_y = -0x7FFFFFFF;
     if (ncomp == 1) for (uint32_t i = lane; i < 2 * plane_elems; i += 64) tile[plane_elems + i] = 0;   // Cb = Cr = 0 for grayscale (:4709-4715)
     // A component with 1 < H < Hmax (or V) does not cover its share of the MCU: SetFullRes places its blocks 8 samples
     // apart but replicates each Hmax/H times (:2498-2557), so part of the MCU keeps the zeros of ClrFullRes (:2443).
@@ -375,6 +473,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_idct_color(const JsImage* __rest
         partial = partial || (im.samp_h[cc] > 1 && im.expand_h[cc] > 1) || (im.samp_v[cc] > 1 && im.expand_v[cc] > 1);
 
     int cv[BK_CHUNK]; int16_t dcv[BK_CHUNK];
+    uint32_t meta[BK_CHUNK], toff[BK_CHUNK];                     // placement word (wave-uniform) and this lane's tile offset per block slot
     auto load_chunk = [&](uint32_t m, uint32_t base) {
         #pragma unroll
         for (int j = 0; j < BK_CHUNK; j++) {
@@ -383,6 +482,14 @@ __global__ void __launch_bounds__(BK_THREADS) k_idct_color(const JsImage* __rest
             dcv[j] = c < nb ? dbase[(size_t)m * nb + c] : (int16_t)0;
         }
     };
+    auto place_chunk = [&](uint32_t base) {
+        #pragma unroll
+        for (int j = 0; j < BK_CHUNK; j++) {
+            meta[j] = base + j < nb ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_meta[base + j]) : 0u;
+            toff[j] = tile_offset(meta[j], plane_elems, rs, lane);
+        }
+    };
+    place_chunk(0);
     const uint32_t wstride = wgs_in_img * BK_WAVES;
     uint32_t m = wg_in_img * BK_WAVES + wave;
     if (m < nmcu) load_chunk(m, 0);
@@ -391,43 +498,17 @@ __global__ void __launch_bounds__(BK_THREADS) k_idct_color(const JsImage* __rest
         // ---- IDCT of the MCU's blocks, decode order ---------------------------------------------------
         for (uint32_t base = 0; base < nb; base += BK_CHUNK) {
             if (base) load_chunk(m, base);
+            if (nb > BK_CHUNK) place_chunk(base);
             #pragma unroll
             for (int j = 0; j < BK_CHUNK; j++)
-                if (base + j < nb) sample_to_lds(s_meta[base + j], idct_sparse(cv[j], s_lut, s_list, lane), dcv[j], tile, plane_elems, rs, lane);
+                if (base + j < nb) sample_to_lds(meta[j], idct_sparse(cv[j], s_lut, s_list, lane), dcv[j], tile + toff[j], rs);
         }
         if (m + wstride < nmcu) load_chunk(m + wstride, 0);           // next MCU's rows fly during the colour phase
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        // ---- colour conversion + DIB rows: 4 pixels (16 bytes) per lane ---------------------------------
-        const uint32_t mx = m % im.mcu_xmax, my = m / im.mcu_xmax, quads = mw / 4, total = quads * mh;
+        const uint32_t mx = m % im.mcu_xmax, my = m / im.mcu_xmax;
         const bool shifted = my * mcus_across + mx >= shift_ind;
-        for (uint32_t p = lane; p < total; p += 64) {
-            const uint32_t y = p / quads, x = (p % quads) * 4;
-            const uint32_t py = my * mh + y, px = mx * mw + x;
-            const uint2 qy = *reinterpret_cast<const uint2*>(tile + y * rs + x);
-            const uint2 qcb = *reinterpret_cast<const uint2*>(tile + plane_elems + y * rs + x);
-            const uint2 qcr = *reinterpret_cast<const uint2*>(tile + 2 * plane_elems + y * rs + x);
-            uint32_t o[4];
-            #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                int vy  = (int)(int16_t)((k < 2 ? qy.x  : qy.y)  >> ((k & 1) * 16));
-                int vcb = (int)(int16_t)((k < 2 ? qcb.x : qcb.y) >> ((k & 1) * 16));
-                int vcr = (int)(int16_t)((k < 2 ? qcr.x : qcr.y) >> ((k & 1) * 16));
-                // brightest-pixel search (:4722-4730): larger Y wins, earlier raster position breaks ties
-                const uint64_t key = ((uint64_t)(uint32_t)(vy + 32768) << 32) | (0xFFFFFFFFu - (py * img_x + px + k));
-                bright = key > bright ? key : bright;
-                if (shifted) { vy += sh_y; vcb += sh_cb; vcr += sh_cr; }       // nMcuInd >= nMcuShiftInd (:4735-4739)
-                uint32_t fy; ycc_to_rgb(vy, vcb, vcr, mode, o[k], fy);
-                sum_y += fy;                                   // nSumY += nFinalY (:4751), wraps mod 2^32 like the reference
-            }
-            uint4 v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
-            *reinterpret_cast<uint4*>(dibp + ((size_t)(img_y - 1 - py) * img_x + px) * 4) = v;
-            if (want_planes) {
-                int16_t* pb = planes + im.plane_off;
-                const size_t pi = (size_t)py * pw + px, psz = (size_t)pw * im.blk_ymax * 8;
-                *reinterpret_cast<uint2*>(pb + pi) = qy;
-                if (ncomp == 3) { *reinterpret_cast<uint2*>(pb + psz + pi) = qcb; *reinterpret_cast<uint2*>(pb + 2 * psz + pi) = qcr; }
-            }
-        }
+        if (rgb_only) mcu_to_dib<true>(im, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, shifted, dibp, planes, pw, want_planes, bright, best_y, sum_y);
+        else          mcu_to_dib<false>(im, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, shifted, dibp, planes, pw, want_planes, bright, best_y, sum_y);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -442,22 +523,25 @@ __global__ void __launch_bounds__(BK_THREADS) k_idct_color(const JsImage* __rest
 }
 
 // One block through the device IDCT (known-answer probe for jsnoop_idct_block).
-__global__ void k_idct_probe(const float* __restrict__ lut_t, const int16_t* __restrict__ coef64, float* __restrict__ out64)
+__global__ void __launch_bounds__(64) k_idct_probe(const float* __restrict__ lut_t, const int16_t* __restrict__ coef64, float* __restrict__ out64)
 {
+    __shared__ float s_lut[64 * 64]; __shared__ uint2 s_list[68];
     const uint32_t lane = threadIdx.x;
-    const int cv16 = coef64[lane]; const float cf = (float)cv16;
-    uint64_t mask = __ballot(cv16 != 0) & ~1ull; float acc = 0.0f;
-    while (mask) {
-        const uint32_t vu = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask)); mask &= mask - 1;
-        const float cvu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cf), vu));
-        acc = __fadd_rn(acc, __fmul_rn(lut_t[vu * 64 + lane], cvu));
-    }
-    out64[lane] = __fmul_rn(acc, 0.25f);
+    for (uint32_t i = lane; i < 64 * 64; i += 64) s_lut[i] = lut_t[i];
+    __syncthreads();
+    out64[lane] = idct_sparse((int)coef64[lane], s_lut, s_list, lane);      // the production routine of k_idct_color
 }
 
 // ConvertYCCtoRGBFastFloat on one triple (the RGB of the brightest pixel, :4805-4811).
 __global__ void k_color_probe(int y, int cb, int cr, uint32_t* out)
-{ uint32_t bgra, fy; ycc_to_rgb(y, cb, cr, 1, bgra, fy); out[0] = bgra; }
+{ uint32_t bgra, fy; ycc_to_rgb<true>(y, cb, cr, 1, bgra, fy); out[0] = bgra; }
+// Every (y, cb, cr) in [-128, 127]^3 through the device colour conversion: out[(y+128)<<16 | (cb+128)<<8 | (cr+128)] = BGRA.
+__global__ void __launch_bounds__(256) k_color_sweep(uint32_t* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint32_t bgra, fy; ycc_to_rgb<true>(((int)(i >> 16) - 128) * 8, ((int)((i >> 8) & 255u) - 128) * 8, ((int)(i & 255u) - 128) * 8, 1, bgra, fy);
+    out[i] = bgra;
+}
 
 // Position-keyed 64-bit checksum of every DIB: sum over 32-bit pixels of mix64(index<<32 | pixel).
 // Order independent, so it reduces in parallel; tests recompute it with numpy from the oracle's DIB.
@@ -498,6 +582,8 @@ void js_launch_idct_probe(hipStream_t st, const float* lut_t, const int16_t* coe
 { hipLaunchKernelGGL(k_idct_probe, dim3(1), dim3(64), 0, st, lut_t, coef64, out64); }
 void js_launch_color_probe(hipStream_t st, int y, int cb, int cr, uint32_t* out)
 { hipLaunchKernelGGL(k_color_probe, dim3(1), dim3(1), 0, st, y, cb, cr, out); }
+void js_launch_color_sweep(hipStream_t st, uint32_t* out)
+{ hipLaunchKernelGGL(k_color_sweep, dim3(1u << 16), dim3(256), 0, st, out); }
 void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, const uint8_t* dib, unsigned long long* sums)
 {
     if (!nimg) return;

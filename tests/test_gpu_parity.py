@@ -148,6 +148,22 @@ def test_golden_fixtures(harness, gpu):
     assert harness.hash_bytes(gpu.idct_lut()) == M["kat"]["idct_lut_sha256"]
 
 
+def test_color_sweep(harness, oracle, gpu):
+    """All 2^24 clamped (Y, Cb, Cr) triples through the device colour conversion against the oracle's
+    ConvertYCCtoRGBFastFloat (true IEEE division by 0.587f): pins the FMA-corrected reciprocal form used on the device."""
+    import ctypes as C
+    out = np.zeros(1 << 24, np.uint32)
+    assert gpu.lib.jsnoop_color_sweep(gpu.h, out.ctypes.data_as(C.c_void_p)) == 0
+    cb, cr = np.meshgrid(np.arange(-128, 128, dtype=np.int32), np.arange(-128, 128, dtype=np.int32), indexing="ij")
+    for y in range(-128, 128):
+        ycc = np.stack([np.full(cb.size, y * 8, np.int32), cb.ravel() * 8, cr.ravel() * 8], -1).copy()
+        rgb = np.zeros((ycc.shape[0], 3), np.uint8)
+        oracle.lib.orc_color_fast(ycc.ctypes.data_as(C.c_void_p), rgb.ctypes.data_as(C.c_void_p), C.c_size_t(ycc.shape[0]))
+        want = rgb[:, 2].astype(np.uint32) | (rgb[:, 1].astype(np.uint32) << 8) | (rgb[:, 0].astype(np.uint32) << 16)
+        got = out[(y + 128) << 16:(y + 129) << 16]
+        assert np.array_equal(got, want), f"Y={y}: {int((got != want).sum())} triples differ"
+
+
 def test_preview_modes_and_shift(harness, oracle, gpu):
     """SetPreviewMode / SetPreviewYccOffset re-render (reference :633-659): colour kernel only, on the retained data."""
     data = harness.synth_jpeg(width=160, height=96, seed=8)
