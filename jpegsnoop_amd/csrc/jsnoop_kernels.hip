@@ -264,10 +264,8 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
 // q0 = x * RN(1/0.587f) followed by ONE fused correction step; for every numerator this function can produce
 // (y, cb, cr in [-128, 127] after the clamp: 2^24 cases) that is bit-identical to the IEEE quotient -- checked
 // exhaustively on the device against the oracle's true division (tests/test_gpu_parity.py::test_color_sweep).
-__device__ __forceinline__ void ycc_core(int py, int pcb, int pcr, uint32_t& R, uint32_t& G, uint32_t& B, uint32_t& FY, uint32_t& FCB, uint32_t& FCR)
+__device__ __forceinline__ void ycc_core(int y, int cb, int cr /*already clamped to [-128,127]*/, uint32_t& R, uint32_t& G, uint32_t& B)
 {
-    int y = py >> 3, cb = pcb >> 3, cr = pcr >> 3;
-    y = min(max(y, -128), 127); cb = min(max(cb, -128), 127); cr = min(max(cr, -128), 127);
     const float kr = 0.299f, kg = 0.587f, kb = 0.114f;
     const float cr_mul = 2 - 2 * kr, cb_mul = 2 - 2 * kb;       // folded in fp32 exactly as the reference's expression
     const float rkg = 1.0f / kg;
@@ -281,16 +279,15 @@ __device__ __forceinline__ void ycc_core(int py, int pcb, int pcr, uint32_t& R, 
     R = (uint32_t)(int)__builtin_amdgcn_fmed3f(r, 0.0f, 255.0f);   // <0 -> 0, >255 -> 255, else truncate (:4128-4136)
     G = (uint32_t)(int)__builtin_amdgcn_fmed3f(g, 0.0f, 255.0f);
     B = (uint32_t)(int)__builtin_amdgcn_fmed3f(b, 0.0f, 255.0f);
-    FY = (uint32_t)(y + 128); FCB = (uint32_t)(cb + 128); FCR = (uint32_t)(cr + 128);
 }
-// ... then ChannelExtract :4832-4872.  RGB_ONLY: the default preview mode (PREVIEW_RGB), no per-pixel mode dispatch.
+// ... then ChannelExtract :4832-4872 on clamped values.  RGB_ONLY: the default preview mode (PREVIEW_RGB), no mode dispatch.
 template <bool RGB_ONLY>
-__device__ __forceinline__ void ycc_to_rgb(int py, int pcb, int pcr, uint32_t mode, uint32_t& out_bgra, uint32_t& final_y)
+__device__ __forceinline__ uint32_t ycc_pixel(int y, int cb, int cr, uint32_t mode)
 {
-    uint32_t R, G, B, FY, FCB, FCR;
-    ycc_core(py, pcb, pcr, R, G, B, FY, FCB, FCR);
-    final_y = FY;
+    uint32_t R, G, B;
+    ycc_core(y, cb, cr, R, G, B);
     if (!RGB_ONLY) {
+        const uint32_t FY = (uint32_t)(y + 128), FCB = (uint32_t)(cb + 128), FCR = (uint32_t)(cr + 128);
         switch (mode) {
         case 2: R = FCR; G = FY; B = FCB; break;      // PREVIEW_YCC
         case 3: G = B = R; break;                     // PREVIEW_R
@@ -302,7 +299,23 @@ __device__ __forceinline__ void ycc_to_rgb(int py, int pcb, int pcr, uint32_t mo
         default: break;
         }
     }
-    out_bgra = B | (G << 8) | (R << 16);          // bytes B,G,R,0 (:4786-4789)
+    return B | (G << 8) | (R << 16);              // bytes B,G,R,0 (:4786-4789)
+}
+__device__ __forceinline__ int clamp_s8(int v) { return min(max(v, -128), 127); }
+template <bool RGB_ONLY>
+__device__ __forceinline__ void ycc_to_rgb(int py, int pcb, int pcr, uint32_t mode, uint32_t& out_bgra, uint32_t& final_y)
+{
+    const int y = clamp_s8(py >> 3), cb = clamp_s8(pcb >> 3), cr = clamp_s8(pcr >> 3);   // :4096-4104
+    out_bgra = ycc_pixel<RGB_ONLY>(y, cb, cr, mode); final_y = (uint32_t)(y + 128);
+}
+// two int16 samples at a time: >> 3, clamp to [-128, 127] (packed 16-bit VALU ops)
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { union { uint32_t u; s16x2 s; } c; c.u = v; return c.s; }
+__device__ __forceinline__ s16x2 clamp_s8x2(uint32_t packed)
+{
+    s16x2 v = as_s16x2(packed) >> (s16x2){3, 3};
+    v = __builtin_elementwise_max(v, (s16x2){-128, -128});
+    return __builtin_elementwise_min(v, (s16x2){127, 127});
 }
 
 // Lane I of every 16-lane row, broadcast to the whole row: folds into the consuming VALU instruction as a DPP
@@ -396,12 +409,11 @@ __device__ __forceinline__ void mcu_to_dib(const JsImage& im, const int16_t* til
         const uint2 qy = *reinterpret_cast<const uint2*>(tile + y * rs + x);
         const uint2 qcb = *reinterpret_cast<const uint2*>(tile + plane_elems + y * rs + x);
         const uint2 qcr = *reinterpret_cast<const uint2*>(tile + 2 * plane_elems + y * rs + x);
-        int vy[4] = { (int)(int16_t)qy.x, (int)qy.x >> 16, (int)(int16_t)qy.y, (int)qy.y >> 16 };
-        int vcb[4] = { (int)(int16_t)qcb.x, (int)qcb.x >> 16, (int)(int16_t)qcb.y, (int)qcb.y >> 16 };
-        int vcr[4] = { (int)(int16_t)qcr.x, (int)qcr.x >> 16, (int)(int16_t)qcr.y, (int)qcr.y >> 16 };
         // brightest-pixel search (:4722-4730): larger Y wins, earlier raster position breaks ties.  The 64-bit key
         // is only formed when one of the four pixels can beat (or tie with) what this lane has seen so far.
-        if (max(max(vy[0], vy[1]), max(vy[2], vy[3])) >= best_y) {
+        const s16x2 m2 = __builtin_elementwise_max(as_s16x2(qy.x), as_s16x2(qy.y));
+        if (max((int)m2.x, (int)m2.y) >= best_y) {
+            const int vy[4] = { (int)(int16_t)qy.x, (int)qy.x >> 16, (int)(int16_t)qy.y, (int)qy.y >> 16 };
             #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint64_t key = ((uint64_t)(uint32_t)(vy[k] + 32768) << 32) | (0xFFFFFFFFu - (py * img_x + px + k));
@@ -409,13 +421,23 @@ __device__ __forceinline__ void mcu_to_dib(const JsImage& im, const int16_t* til
             }
             best_y = (int)(uint32_t)(bright >> 32) - 32768;
         }
+        int cy[4], ccb[4], ccr[4];                             // clamped Y, Cb, Cr of the four pixels (:4096-4104)
+        if (!shifted) {
+            const s16x2 a0 = clamp_s8x2(qy.x), a1 = clamp_s8x2(qy.y), b0 = clamp_s8x2(qcb.x), b1 = clamp_s8x2(qcb.y), c0 = clamp_s8x2(qcr.x), c1 = clamp_s8x2(qcr.y);
+            cy[0] = a0.x; cy[1] = a0.y; cy[2] = a1.x; cy[3] = a1.y;
+            ccb[0] = b0.x; ccb[1] = b0.y; ccb[2] = b1.x; ccb[3] = b1.y;
+            ccr[0] = c0.x; ccr[1] = c0.y; ccr[2] = c1.x; ccr[3] = c1.y;
+        } else {                                               // nMcuInd >= nMcuShiftInd (:4735-4739): offsets added in int before the >> 3
+            const int vy[4] = { (int)(int16_t)qy.x, (int)qy.x >> 16, (int)(int16_t)qy.y, (int)qy.y >> 16 };
+            const int vcb[4] = { (int)(int16_t)qcb.x, (int)qcb.x >> 16, (int)(int16_t)qcb.y, (int)qcb.y >> 16 };
+            const int vcr[4] = { (int)(int16_t)qcr.x, (int)qcr.x >> 16, (int)(int16_t)qcr.y, (int)qcr.y >> 16 };
+            #pragma unroll
+            for (int k = 0; k < 4; k++) { cy[k] = clamp_s8((vy[k] + sh_y) >> 3); ccb[k] = clamp_s8((vcb[k] + sh_cb) >> 3); ccr[k] = clamp_s8((vcr[k] + sh_cr) >> 3); }
+        }
         uint32_t o[4];
         #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (shifted) { vy[k] += sh_y; vcb[k] += sh_cb; vcr[k] += sh_cr; }   // nMcuInd >= nMcuShiftInd (:4735-4739)
-            uint32_t fy; ycc_to_rgb<RGB_ONLY>(vy[k], vcb[k], vcr[k], mode, o[k], fy);
-            sum_y += fy;                                       // nSumY += nFinalY (:4751), wraps mod 2^32 like the reference
-        }
+        for (int k = 0; k < 4; k++) o[k] = ycc_pixel<RGB_ONLY>(cy[k], ccb[k], ccr[k], mode);
+        sum_y += (uint32_t)(cy[0] + cy[1] + cy[2] + cy[3] + 512);   // nSumY += nFinalY (:4751), wraps mod 2^32 like the reference
         uint4 v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
         *reinterpret_cast<uint4*>(dibp + ((size_t)(img_y - 1 - py) * img_x + px) * 4) = v;
         if (want_planes) {
@@ -433,7 +455,7 @@ __device__ __forceinline__ void mcu_to_dib(const JsImage& im, const int16_t* til
 // samples staged in a wave-private LDS tile, then colour conversion and the MCU's DIB rows.  No
 // workgroup barrier in the loop; the next MCU's coefficient rows are prefetched into registers while
 // the current MCU is converted.
-__global__ void __launch_bounds__(BK_THREADS) k_idct_color(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ wg_base, uint32_t nimg,
+__global__ void __launch_bounds__(BK_THREADS, 6) k_idct_color(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ wg_base, uint32_t nimg,
                                                            uint32_t tile_bytes, const float* __restrict__ lut_t /*[vu][yx]*/,
                                                            const int16_t* __restrict__ coef, const int16_t* __restrict__ dccum,
                                                            uint8_t* __restrict__ dib, int16_t* __restrict__ planes, uint32_t* __restrict__ side)
@@ -462,7 +484,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_idct_color(const JsImage* __rest
     const int16_t* dbase = dccum + im.coef_off;
     uint8_t* dibp = dib + im.dib_off;
     const uint32_t mcus_across = im.img_x / mw, shift_ind = im.shift_mcu_y * mcus_across + im.shift_mcu_x;
-    const bool want_planes = im.want_planes != 0, rgb_only = im.preview_mode == 1;
+    const bool want_planes = im.want_planes != 0, rgb_only = im.preview_mode == 1, any_shift = (im.shift_y | im.shift_cb | im.shift_cr) != 0;
     const uint32_t quads = mw / 4, total = quads * mh, ly0 = lane / quads, lq0 = lane % quads;
     uint64_t bright = 0; uint32_t sum_y = 0; int best_y = -0x7FFFFFFF;
     if (ncomp == 1) for (uint32_t i = lane; i < 2 * plane_elems; i += 64) tile[plane_elems + i] = 0;   // Cb = Cr = 0 for grayscale (:4709-4715)
@@ -506,7 +528,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_idct_color(const JsImage* __rest
         if (m + wstride < nmcu) load_chunk(m + wstride, 0);           // next MCU's rows fly during the colour phase
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         const uint32_t mx = m % im.mcu_xmax, my = m / im.mcu_xmax;
-        const bool shifted = my * mcus_across + mx >= shift_ind;
+        const bool shifted = any_shift && my * mcus_across + mx >= shift_ind;
         if (rgb_only) mcu_to_dib<true>(im, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, shifted, dibp, planes, pw, want_planes, bright, best_y, sum_y);
         else          mcu_to_dib<false>(im, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, shifted, dibp, planes, pw, want_planes, bright, best_y, sum_y);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -178,6 +178,9 @@ def parse_jpeg(data: bytes) -> ParsedJpeg:
 
 
 # ------------------------------------------------------------------------- backends
+STATS_WORDS = 2482      # 37 PixelCcHisto + 13 PixelCcClip + 3 x 128 RGB bins + 2048 Y bins
+
+
 class Backend:
     """ctypes view of one implementation of the shared entry-point set."""
 
@@ -211,9 +214,9 @@ class Backend:
             f(fn).restype = C.c_void_p
             f(fn).argtypes = [C.c_void_p]
         f("idct_block").argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        if prefix == "jsnoop_":
-            f("set_preview_mode").argtypes = [C.c_void_p, C.c_uint]
-            f("set_preview_ycc_offset").argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int]
+        f("set_preview_mode").argtypes = [C.c_void_p, C.c_uint]
+        f("set_preview_ycc_offset").argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int]
+        f("get_color_stats" if prefix == "jsnoop_" else "color_stats").argtypes = [C.c_void_p, C.c_void_p]
         self.h = f("create")()
 
     def _f(self, name):
@@ -288,6 +291,13 @@ class Backend:
         s = (C.c_int * 10)()
         self._f("bright_avg")(self.h, s)
         return list(s)
+
+    def color_stats(self):
+        """bHistoEn / bStatClipEn statistics: dict of the PixelCcHisto ints, the PixelCcClip counters and the histograms."""
+        o = np.zeros(STATS_WORDS, np.uint32)
+        self._f("get_color_stats" if self.prefix == "jsnoop_" else "color_stats")(self.h, o.ctypes.data)
+        return {"histo": o[:36].view(np.int32).copy(), "count": int(o[36]), "clip": o[37:50].copy(),
+                "rgb": o[50:434].reshape(3, 128).copy(), "yfull": o[434:2482].copy()}
 
     def idct_lut(self):
         p = self._f("idct_lut")(self.h)

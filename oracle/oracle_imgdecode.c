@@ -69,6 +69,9 @@ struct OrcDecoder {
     /* stats (:579-590) */
     int      bright_valid, bright_y, bright_cb, bright_cr; unsigned bright_r, bright_g, bright_b;
     int      bright_mx, bright_my; long avg_y; int avg_valid;
+    /* bHistoEn / bStatClipEn colour path (m_sHisto, m_sStatClip, m_anCcHisto_*, m_anHistoYFull, m_nWarnYccClipNum) */
+    int      hist_en, stat_clip_en; unsigned warn_ycc_clip;
+    int32_t  cc_histo[36]; unsigned cc_count, cc_clip[13], cc_rgb[3][128], cc_yfull[2048];
     /* test instrumentation: every decoded coefficient block, in decode order */
     int16_t* coef; size_t coef_blocks, coef_cap;
 };
@@ -123,7 +126,7 @@ void orc_reset(OrcDecoder* d)                                             /* Res
     d->avg_valid = 0; d->avg_y = 0;
     if (d->dib_ready) { free(d->dib); d->dib = NULL; d->dib_ready = 0; }
     free_outputs(d);
-    d->warn_bad = 0;
+    d->warn_bad = 0; d->warn_ycc_clip = 0;                                /* :130 */
 }
 static void reset_dqt(OrcDecoder* d)                                      /* ResetDqtTables :343-360 */
 {
@@ -403,6 +406,49 @@ static void ycc_to_rgb_fast_float(PixCc* p)                                     
     p->g = (g < 0) ? 0 : (g > 255) ? 255 : (uint8_t)g;
     p->b = (b < 0) ? 0 : (b > 255) ? 255 : (uint8_t)b;
 }
+/* min / max / sum triplet of PixelCcHisto (ints; the sums wrap like the reference's int adds do in practice) */
+static void mms(int32_t* t, int v) { if (v < t[0]) t[0] = v; if (v > t[1]) t[1] = v; t[2] = (int32_t)((uint32_t)t[2] + (uint32_t)v); }
+enum { CL_Y_UNDER, CL_Y_OVER, CL_CB_UNDER, CL_CB_OVER, CL_CR_UNDER, CL_CR_OVER, CL_R_UNDER, CL_R_OVER, CL_G_UNDER, CL_G_OVER, CL_B_UNDER, CL_B_OVER, CL_WHITE };
+enum { H_PRE_Y = 0, H_PRE_CB = 3, H_PRE_CR = 6, H_CLIP_Y = 9, H_CLIP_CB = 12, H_CLIP_CR = 15, H_CLIP_R = 18, H_CLIP_G = 21, H_CLIP_B = 24,
+       H_PRE_R = 27, H_PRE_G = 30, H_PRE_B = 33 };
+/* one YCC range check of CapYccRange: the counter only moves while fewer than YCC_CLIP_REPORT_MAX (10) warnings
+ * have been issued since Reset() (:4372-4378) -- the clip itself always happens */
+static int cap_ycc(OrcDecoder* d, int v, int under_ix, int over_ix)
+{
+    if (v > 255) { if (d->warn_ycc_clip < 10) { d->warn_ycc_clip++; d->cc_clip[over_ix]++; } v = 255; }
+    if (v < 0)   { if (d->warn_ycc_clip < 10) { d->warn_ycc_clip++; d->cc_clip[under_ix]++; } v = 0; }
+    return v;
+}
+static void ycc_to_rgb_histo(OrcDecoder* d, PixCc* p)      /* ConvertYCCtoRGB :4229-4326, CapYccRange :4341-4475, CapRgbRange :4495-4601 */
+{
+    int32_t* H = d->cc_histo;
+    if (d->hist_en) {
+        mms(H + H_PRE_Y, p->pre_y); mms(H + H_PRE_CB, p->pre_cb); mms(H + H_PRE_CR, p->pre_cr);
+        int hi = p->pre_y; if (hi < -1024) hi = -1024; if (hi > 1023) hi = 1023;
+        d->cc_yfull[hi + 1024]++;
+    }
+    int cy = (p->pre_y + 1024) / 8, ccb = (p->pre_cb + 1024) / 8, ccr = (p->pre_cr + 1024) / 8;   /* C division: truncates toward zero */
+    if (d->hist_en) { mms(H + H_CLIP_Y, cy); mms(H + H_CLIP_CB, ccb); mms(H + H_CLIP_CR, ccr); d->cc_count++; }
+    cy = cap_ycc(d, cy, CL_Y_UNDER, CL_Y_OVER); ccb = cap_ycc(d, ccb, CL_CB_UNDER, CL_CB_OVER); ccr = cap_ycc(d, ccr, CL_CR_UNDER, CL_CR_OVER);
+    p->fy = (uint8_t)cy; p->fcb = (uint8_t)ccb; p->fcr = (uint8_t)ccr;
+    const int vy = cy - 128, vcb = ccb - 128, vcr = ccr - 128;
+    const float kr = 0.299f, kg = 0.587f, kb = 0.114f;
+    float r = vcr * (2 - 2 * kr) + vy;
+    float b = vcb * (2 - 2 * kb) + vy;
+    float g = (vy - kb * b - kr * r) / kg;
+    r += 128; b += 128; g += 128;
+    int lr = (int)r, lg = (int)g, lb = (int)b;                                                     /* truncate first, then range-check */
+    if (d->hist_en) { mms(H + H_PRE_R, lr); mms(H + H_PRE_G, lg); mms(H + H_PRE_B, lb); }
+    if (lr < 0) { d->cc_clip[CL_R_UNDER]++; lr = 0; }
+    if (lg < 0) { d->cc_clip[CL_G_UNDER]++; lg = 0; }
+    if (lb < 0) { d->cc_clip[CL_B_UNDER]++; lb = 0; }
+    if (lr > 255) { d->cc_clip[CL_R_OVER]++; lr = 255; }
+    if (lg > 255) { d->cc_clip[CL_G_OVER]++; lg = 255; }
+    if (lb > 255) { d->cc_clip[CL_B_OVER]++; lb = 255; }
+    if (d->hist_en) { mms(H + H_CLIP_R, lr); mms(H + H_CLIP_G, lg); mms(H + H_CLIP_B, lb); }
+    p->r = (uint8_t)lr; p->g = (uint8_t)lg; p->b = (uint8_t)lb;
+    if (d->hist_en) { d->cc_rgb[0][p->r / 2]++; d->cc_rgb[1][p->g / 2]++; d->cc_rgb[2][p->b / 2]++; }   /* 256 / HISTO_BINS = 2 */
+}
 static void channel_extract(unsigned mode, const PixCc* s, uint8_t* r, uint8_t* g, uint8_t* b)  /* ChannelExtract :4832-4872 */
 {
     switch (mode) {
@@ -432,7 +478,7 @@ static void calc_channel_preview(OrcDecoder* d)                                 
             PixCc s; s.pre_y = ty; s.pre_cb = tcb; s.pre_cr = tcr;
             if (ty > d->bright_y) { d->bright_y = ty; d->bright_cb = tcb; d->bright_cr = tcr; d->bright_mx = (int)mx; d->bright_my = (int)my; }
             if (mi >= shift_ind) { s.pre_y += d->shift_y; s.pre_cb += d->shift_cb; s.pre_cr += d->shift_cr; }
-            ycc_to_rgb_fast_float(&s);
+            if (d->hist_en || d->stat_clip_en) ycc_to_rgb_histo(d, &s); else ycc_to_rgb_fast_float(&s);   /* :4742-4747 */
             sum_y += s.fy;
             uint8_t r, g, b; channel_extract(d->preview_mode, &s, &r, &g, &b);
             uint8_t* o = d->dib + (size_t)px * 4 + (size_t)inv * row;
@@ -452,6 +498,7 @@ void orc_decode_scan_img(OrcDecoder* d, const uint8_t* file, size_t len, unsigne
     (void)quiet;
     d->file = file; d->flen = len; d->coef_blocks = 0;
     int want_ac = display ? d->opt_decode_ac : 0;
+    d->hist_en = d->opt_histo_en; d->stat_clip_en = d->opt_stat_clip_en;                          /* :2740-2741 */
     orc_reset(d);
     d->decode_ac = want_ac;
     if (!d->details_set) return;
@@ -487,6 +534,10 @@ void orc_decode_scan_img(OrcDecoder* d, const uint8_t* file, size_t len, unsigne
     }
     free(d->dib); d->dib = NULL; d->dib_ready = 0; d->preview_is_jpeg = 0;
     if (display) d->dib = (uint8_t*)calloc((size_t)d->img_x * d->img_y, 4);       /* CDIB::CreateDIB, Dib.cpp:53-88 */
+    if (display) {                                                                /* :3145-3155 */
+        memset(d->cc_histo, 0, sizeof d->cc_histo); d->cc_count = 0; memset(d->cc_clip, 0, sizeof d->cc_clip);
+        memset(d->cc_rgb, 0, sizeof d->cc_rgb); memset(d->cc_yfull, 0, sizeof d->cc_yfull);
+    }
 
     restart_dc_state(d);
     restart_scan_buf(d, start, 0);
@@ -549,6 +600,10 @@ void orc_decode_scan_img(OrcDecoder* d, const uint8_t* file, size_t len, unsigne
 
 /* ------------------------------------------------------------------ getters */
 int  orc_is_preview_ready(OrcDecoder* d) { return d->preview_is_jpeg; }
+void orc_set_preview_mode(OrcDecoder* d, unsigned mode) { d->preview_mode = mode; calc_channel_preview(d); }              /* SetPreviewMode :633-639 */
+unsigned orc_get_preview_mode(OrcDecoder* d) { return d->preview_mode; }
+void orc_set_preview_ycc_offset(OrcDecoder* d, unsigned mx, unsigned my, int y, int cb, int cr)                        /* SetPreviewYccOffset :650-659 */
+{ d->shift_y = y; d->shift_cb = cb; d->shift_cr = cr; d->shift_mcu_x = mx; d->shift_mcu_y = my; calc_channel_preview(d); }
 void orc_get_image_size(OrcDecoder* d, unsigned* x, unsigned* y) { *x = d->img_x; *y = d->img_y; }
 const uint8_t* orc_get_bitmap_ptr(OrcDecoder* d) { return d->dib; }
 void orc_get_pixmap_ptrs(OrcDecoder* d, const int16_t** y, const int16_t** cb, const int16_t** cr)
@@ -572,6 +627,12 @@ void orc_scan_status(OrcDecoder* d, unsigned* o)
 void orc_bright_avg(OrcDecoder* d, int* o)
 { o[0] = d->bright_valid; o[1] = d->bright_y; o[2] = d->bright_cb; o[3] = d->bright_cr; o[4] = (int)d->bright_r;
   o[5] = (int)d->bright_g; o[6] = (int)d->bright_b; o[7] = d->bright_mx; o[8] = d->bright_my; o[9] = (int)d->avg_y; }
+/* [0..36] PixelCcHisto (36 ints + nCount), [37..49] PixelCcClip, [50..433] R,G,B 128-bin histograms, [434..2481] full Y histogram */
+void orc_color_stats(OrcDecoder* d, unsigned* o)
+{
+    memcpy(o, d->cc_histo, 36 * 4); o[36] = d->cc_count; memcpy(o + 37, d->cc_clip, 13 * 4);
+    memcpy(o + 50, d->cc_rgb, 3 * 128 * 4); memcpy(o + 434, d->cc_yfull, 2048 * 4);
+}
 const float* orc_idct_lut(OrcDecoder* d) { return &d->lut[0][0]; }
 const uint32_t* orc_dht_lookupfast(OrcDecoder* d) { return &d->dht_fast[0][0][0]; }
 const int16_t* orc_coef_ptr(OrcDecoder* d) { return d->coef; }

@@ -64,6 +64,10 @@ void     orc_blk_dc_ptrs(OrcDecoder*, const int16_t** y, const int16_t** cb, con
 const uint32_t* orc_dht_histo(OrcDecoder*);               /* [2][4][17] */
 void     orc_scan_status(OrcDecoder*, unsigned* out8);
 void     orc_bright_avg(OrcDecoder*, int* out10);
+void     orc_set_preview_mode(OrcDecoder*, unsigned mode);                                          /* :633 */
+unsigned orc_get_preview_mode(OrcDecoder*);
+void     orc_set_preview_ycc_offset(OrcDecoder*, unsigned mcu_x, unsigned mcu_y, int y, int cb, int cr); /* :650 */
+void     orc_color_stats(OrcDecoder*, unsigned* out2482);   /* bHistoEn / bStatClipEn statistics, layout of jsnoop_get_color_stats */
 const float* orc_idct_lut(OrcDecoder*);                   /* [64][64] */
 const uint32_t* orc_dht_lookupfast(OrcDecoder*);          /* [2][4][1024] */
 const int16_t* orc_coef_ptr(OrcDecoder*);                 /* dequantised natural-order coefficients, decode order, 64/block */

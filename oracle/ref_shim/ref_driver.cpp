@@ -9,6 +9,7 @@
 // (c) the HIP path.  `#define private public` exposes the decoder's internal maps
 // and per-function probes (IDCT, colour) for known-answer tests only.
 #include "stdafx.h"
+#include <cstring>
 #define private public
 #include "ImgDecode.h"
 #undef private
@@ -115,6 +116,19 @@ void jsref_bright_avg(void* h, int* out10)
     out10[0] = d->m_bBrightValid; out10[1] = d->m_nBrightY; out10[2] = d->m_nBrightCb; out10[3] = d->m_nBrightCr;
     out10[4] = (int)d->m_nBrightR; out10[5] = (int)d->m_nBrightG; out10[6] = (int)d->m_nBrightB;
     out10[7] = d->m_ptBrightMcu.x; out10[8] = d->m_ptBrightMcu.y; out10[9] = (int)d->m_nAvgY;
+}
+void jsref_set_preview_mode(void* h, unsigned mode) { ((JsRef*)h)->dec->SetPreviewMode(mode); }                       // :633
+unsigned jsref_get_preview_mode(void* h) { return ((JsRef*)h)->dec->GetPreviewMode(); }
+void jsref_set_preview_ycc_offset(void* h, unsigned mx, unsigned my, int y, int cb, int cr)                                // :650
+{ ((JsRef*)h)->dec->SetPreviewYccOffset(mx, my, y, cb, cr); }
+// Colour statistics of the bHistoEn / bStatClipEn path (ConvertYCCtoRGB :4229, CapYccRange :4341, CapRgbRange :4495):
+// out[0..36] PixelCcHisto, [37..49] PixelCcClip, [50..433] m_anCcHisto_r/g/b[128], [434..2481] m_anHistoYFull[2048]
+void jsref_color_stats(void* h, unsigned* out2482)
+{
+    CimgDecode* d = ((JsRef*)h)->dec;
+    memcpy(out2482, &d->m_sHisto, 37 * 4); memcpy(out2482 + 37, &d->m_sStatClip, 13 * 4);
+    memcpy(out2482 + 50, d->m_anCcHisto_r, 128 * 4); memcpy(out2482 + 178, d->m_anCcHisto_g, 128 * 4); memcpy(out2482 + 306, d->m_anCcHisto_b, 128 * 4);
+    memcpy(out2482 + 434, d->m_anHistoYFull, 2048 * 4);
 }
 const float* jsref_idct_lut(void* h) { return &((JsRef*)h)->dec->m_afIdctLookup[0][0]; }       // [64][64]
 const unsigned* jsref_dht_lookupfast(void* h) { return &((JsRef*)h)->dec->m_anDhtLookupfast[0][0][0]; } // [2][4][1024]

@@ -7,7 +7,8 @@ fixtures committed here are what travels to machines without /root/reference (th
 For every case the manifest stores sha256 of: DIB bytes, the three int16 planes, the MCU file map,
 the block-DC maps, the Huffman code-length histogram, plus the status words, brightest-pixel /
 average-Y record and image size, all as produced by reference CimgDecode::DecodeScanImg in
-Full-IDCT mode (bDecodeScanImgAc=true, bHistoEn=false) -- and a second record for DC-only mode.
+Full-IDCT mode (bDecodeScanImgAc=true, bHistoEn=false) -- a second record for DC-only mode -- and a third
+for the bHistoEn colour path (statistics after the decode and after two preview re-renders).
 """
 import json
 import os
@@ -31,6 +32,31 @@ def record(b):
     r["histo"] = H.hash_bytes(b.dht_histo())
     r["status"] = {k: int(v) for k, v in b.status().items()}
     r["bright_avg"] = [int(v) for v in b.bright_avg()]
+    return r
+
+
+def stats_record(b):
+    """bHistoEn statistics (ConvertYCCtoRGB / CapYccRange / CapRgbRange, reference :4229-4601)."""
+    st = b.color_stats()
+    words = np.concatenate([st["histo"].view(np.uint32), np.array([st["count"]], np.uint32), st["clip"], st["rgb"].ravel(), st["yfull"]])
+    return {"sha256": H.hash_bytes(words), "count": st["count"], "clip": [int(v) for v in st["clip"]], "histo": [int(v) for v in st["histo"]]}
+
+
+def histo_record(b, data):
+    """Decode with bHistoEn, then two re-renders (the reference keeps accumulating, it only clears in DecodeScanImg)."""
+    b.set_options(decode_ac=1, histo_en=1)
+    H.drive(b, data)
+    if b.dib() is None:
+        b.set_options(decode_ac=1)
+        return {"preview": False}
+    r = {"preview": True, "dib": H.hash_bytes(b.dib()), "stats": stats_record(b)}
+    b.set_preview_mode(6)
+    b.set_preview_ycc_offset(1, 1, 500, -200, 100)
+    r["dib_rerender"] = H.hash_bytes(b.dib())
+    r["stats_rerender"] = stats_record(b)
+    b.set_preview_ycc_offset(0, 0, 0, 0, 0)
+    b.set_preview_mode(1)
+    b.set_options(decode_ac=1)
     return r
 
 
@@ -88,6 +114,7 @@ def main():
             H.drive(ref, data)
             entry[mode] = record(ref)
         ref.set_options(decode_ac=1)
+        entry["histo_en"] = histo_record(ref, data)
         manifest["cases"][name] = entry
     # known-answer values of the two fp32 stages, straight from the compiled reference
     lut = ref.idct_lut()

@@ -29,3 +29,29 @@ def record(H, b, side=True):
         r["status"] = {k: int(v) for k, v in b.status().items()}
         r["bright_avg"] = [int(v) for v in b.bright_avg()]
     return r
+
+
+def stats_record(H, b):
+    import numpy as np
+    st = b.color_stats()
+    words = np.concatenate([st["histo"].view(np.uint32), np.array([st["count"]], np.uint32), st["clip"], st["rgb"].ravel(), st["yfull"]])
+    return {"sha256": H.hash_bytes(words), "count": st["count"], "clip": [int(v) for v in st["clip"]], "histo": [int(v) for v in st["histo"]]}
+
+
+def histo_record(H, b, data):
+    """Same bHistoEn record tests/golden/make_golden.py stores, taken from any backend."""
+    b.set_options(decode_ac=1, histo_en=1)
+    try:
+        H.drive(b, data)
+        if b.dib() is None:
+            return {"preview": False}
+        r = {"preview": True, "dib": H.hash_bytes(b.dib()), "stats": stats_record(H, b)}
+        b.set_preview_mode(6)
+        b.set_preview_ycc_offset(1, 1, 500, -200, 100)
+        r["dib_rerender"] = H.hash_bytes(b.dib())
+        r["stats_rerender"] = stats_record(H, b)
+        b.set_preview_ycc_offset(0, 0, 0, 0, 0)
+        b.set_preview_mode(1)
+        return r
+    finally:
+        b.set_options(decode_ac=1)

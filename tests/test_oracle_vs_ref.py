@@ -96,3 +96,43 @@ def test_fuzz_corrupt_scans(harness, oracle, ref):
         harness.drive(ref, d, p)
         harness.drive(oracle, d, p)
         assert same(harness, ref, oracle), (it, mode)
+
+
+def stats_equal(a, b):
+    sa, sb = a.color_stats(), b.color_stats()
+    return all((sa[k] == sb[k]) if k == "count" else np.array_equal(sa[k], sb[k]) for k in sa)
+
+
+def test_histogram_path(harness, oracle, ref):
+    """bHistoEn / bStatClipEn colour path: min/max/sum records, clip counters (the YCC ones stop at 10 warnings),
+    the 128-bin RGB and 2048-bin Y histograms -- after the decode and after preview re-renders (the reference keeps
+    accumulating) -- for well-formed and corrupted streams."""
+    rng = np.random.default_rng(77)
+    files = [harness.synth_jpeg(width=160, height=96, seed=3), harness.synth_jpeg(width=200, height=120, hs=2, vs=1, restart_interval=5, seed=4),
+             harness.synth_jpeg(width=96, height=64, gray=1, seed=5)]
+    for base in list(files):
+        p = harness.parse_jpeg(base)
+        for _ in range(6):
+            d = bytearray(base)
+            for _ in range(int(rng.integers(1, 6))):
+                d[int(rng.integers(p.scan_start, p.scan_end))] ^= 1 << int(rng.integers(0, 8))
+            files.append(bytes(d))
+    try:
+        for data in files:
+            for opt in (dict(histo_en=1), dict(stat_clip_en=1), dict(histo_en=1, stat_clip_en=1, decode_ac=0)):
+                for b in (oracle, ref):
+                    b.set_options(**opt)
+                    harness.drive(b, data)
+                assert same(harness, ref, oracle) and stats_equal(ref, oracle), opt
+                if ref.dib() is None:
+                    continue
+                for b in (oracle, ref):
+                    b.set_preview_mode(4)
+                    b.set_preview_ycc_offset(2, 1, 700, -250, 90)
+                assert np.array_equal(ref.dib(), oracle.dib()) and stats_equal(ref, oracle), opt
+                for b in (oracle, ref):
+                    b.set_preview_ycc_offset(0, 0, 0, 0, 0)
+                    b.set_preview_mode(1)
+    finally:
+        for b in (oracle, ref):
+            b.set_options()
