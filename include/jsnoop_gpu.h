@@ -115,6 +115,14 @@ void            jsnoop_blk_dc_ptrs(JsnoopDecoder*, const int16_t** y, const int1
 const uint32_t* jsnoop_dht_histo(JsnoopDecoder*);                      /* m_anDhtHisto [2][4][17] */
 void            jsnoop_scan_status(JsnoopDecoder*, unsigned* out8);    /* scan_bad, scan_end, #RST, num_pixels, pos0, align, warn_bad, first */
 void            jsnoop_bright_avg(JsnoopDecoder*, int* out10);         /* brightest pixel + average Y (:4722-4730, :4802-4819) */
+/* Statistics of the bHistoEn / bStatClipEn colour path (ConvertYCCtoRGB :4229, CapYccRange :4341, CapRgbRange :4495;
+ * enable with jsnoop_set_options before DecodeScanImg).  As in the reference they are cleared by DecodeScanImg
+ * (:3145-3155) and accumulated by every CalcChannelPreview, i.e. also by the preview re-renders below.  Layout,
+ * JSNOOP_STATS_WORDS 32-bit words: [0..35] PixelCcHisto (ImgDecode.h:238-279: min,max,sum as int for PreclipY/Cb/Cr,
+ * ClipY/Cb/Cr, ClipR/G/B, PreclipR/G/B), [36] nCount, [37..49] PixelCcClip (ImgDecode.h:220-234), [50..433]
+ * m_anCcHisto_r/g/b[128], [434..2481] m_anHistoYFull[2048].                                                      */
+#define JSNOOP_STATS_WORDS 2482
+void            jsnoop_get_color_stats(JsnoopDecoder*, uint32_t* out);
 const float*    jsnoop_idct_lut(JsnoopDecoder*);                       /* m_afIdctLookup [64][64] as uploaded to the device */
 const uint32_t* jsnoop_dht_lookupfast(JsnoopDecoder*);                 /* m_anDhtLookupfast [2][4][1024] */
 void            jsnoop_idct_block(JsnoopDecoder*, const int16_t* coef64, float* out64);   /* one block through the device IDCT */
@@ -175,6 +183,9 @@ int          jsnoop_batch_read_planes(JsnoopBatch*, int i, int16_t* y, int16_t* 
 int          jsnoop_batch_read_coefs(JsnoopBatch*, int i, int16_t* dst, size_t max_blocks); /* dequantised blocks, decode order */
 /* 64-bit FNV-1a of every DIB computed on the device (one word per image), for
  * whole-batch parity checks without moving 8 GB over PCIe.                          */
+/* the same statistics for image i of a decoded batch (needs want_planes): one fresh pass, as a DecodeScanImg with
+ * bHistoEn (histo_en != 0) or only bStatClipEn (histo_en == 0) would leave them */
+int          jsnoop_batch_color_stats(JsnoopBatch*, int i, int histo_en, uint32_t* out);
 int          jsnoop_batch_dib_hashes(JsnoopBatch*, uint64_t* host_dst);
 uint64_t     jsnoop_batch_algorithmic_bytes(const JsnoopBatch*);                   /* sum(scan bytes + DIB bytes), SURVEY.md 8(d) */
 uint64_t     jsnoop_batch_pixels(const JsnoopBatch*);                              /* sum(SOF X*Y) */

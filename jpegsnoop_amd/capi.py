@@ -57,6 +57,7 @@ SIGNATURES = {
     "jsnoop_dht_histo": (_p, [_p]),
     "jsnoop_scan_status": (None, [_p, _PU]),
     "jsnoop_bright_avg": (None, [_p, _PI]),
+    "jsnoop_get_color_stats": (None, [_p, _p]),
     "jsnoop_idct_lut": (_p, [_p]),
     "jsnoop_dht_lookupfast": (_p, [_p]),
     "jsnoop_idct_block": (None, [_p, _p, _p]),
@@ -81,6 +82,7 @@ SIGNATURES = {
     "jsnoop_batch_read_dib": (_i, [_p, _i, _p]),
     "jsnoop_batch_read_planes": (_i, [_p, _i, _p, _p, _p]),
     "jsnoop_batch_read_coefs": (_i, [_p, _i, _p, _sz]),
+    "jsnoop_batch_color_stats": (_i, [_p, _i, _i, _p]),
     "jsnoop_batch_dib_hashes": (_i, [_p, _p]),
     "jsnoop_batch_algorithmic_bytes": (C.c_uint64, [_p]),
     "jsnoop_batch_pixels": (C.c_uint64, [_p]),

@@ -88,6 +88,9 @@ public:
     void LookupFilePosPix(unsigned nPixX, unsigned nPixY, unsigned& nByte, unsigned& nBit) { jsnoop_lookup_file_pos_pix(m_h, nPixX, nPixY, &nByte, &nBit); } // :5001
     void LookupFilePosMcu(unsigned nMcuX, unsigned nMcuY, unsigned& nByte, unsigned& nBit) { jsnoop_lookup_file_pos_mcu(m_h, nMcuX, nMcuY, &nByte, &nBit); } // :5020
     void LookupBlkYCC(unsigned nBlkX, unsigned nBlkY, int& nY, int& nCb, int& nCr) { jsnoop_lookup_blk_ycc(m_h, nBlkX, nBlkY, &nY, &nCb, &nCr); }            // :5037
+    // bHistoEn / bStatClipEn statistics (m_sHisto, m_sStatClip, m_anCcHisto_r/g/b, m_anHistoYFull; ImgDecode.h:220-279, :656-661)
+    // as one JSNOOP_STATS_WORDS record, see include/jsnoop_gpu.h
+    void GetColorStats(uint32_t* pStats) { jsnoop_get_color_stats(m_h, pStats); }
     unsigned PackFileOffset(unsigned nByte, unsigned nBit) const { return (nByte << 4) + nBit; }                 // :5104
     void UnpackFileOffset(unsigned nPacked, unsigned& nByte, unsigned& nBit) const { nBit = nPacked & 0x7; nByte = nPacked >> 4; } // :5123
 

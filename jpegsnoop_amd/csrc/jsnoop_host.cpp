@@ -41,6 +41,7 @@ JsnoopDecoder::JsnoopDecoder()
     preview_mode = 1; shift_y = shift_cb = shift_cr = 0; shift_mcu_x = shift_mcu_y = 0;
     preview_is_jpeg = false; have_image = false; host_valid = 0; last_path = 0; last_flags = 0; side_ready = false;
     memset(geom, 0, sizeof geom);
+    memset(stats, 0, sizeof stats); warn_ycc_clip = 0; hist_latched = clip_latched = false;
     reset_state();
 }
 void JsnoopDecoder::log(int level, const char* fmt, ...)
@@ -350,7 +351,7 @@ JsnoopDecoder* jsnoop_create(void)
 }
 void jsnoop_destroy(JsnoopDecoder* d) { if (!d) return; delete d->batch; delete d; }
 void jsnoop_reset(JsnoopDecoder* d)                                             // Reset :49-138
-{ d->have_image = false; d->host_valid = 0; memset(d->geom, 0, sizeof d->geom); d->geom[0] = d->geom[1] = 1; }
+{ d->have_image = false; d->host_valid = 0; memset(d->geom, 0, sizeof d->geom); d->geom[0] = d->geom[1] = 1; d->warn_ycc_clip = 0; }
 void jsnoop_reset_state(JsnoopDecoder* d) { d->reset_state(); }
 void jsnoop_set_log_callback(JsnoopDecoder* d, jsnoop_log_fn fn, void* user) { d->log_fn = fn; d->log_user = user; }
 void jsnoop_set_options(JsnoopDecoder* d, int ac, int histo, int clip, unsigned err_max)
@@ -404,6 +405,7 @@ int jsnoop_jfif_walk(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned
 void jsnoop_decode_scan_img(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned start, int display, int quiet)
 {
     (void)quiet;
+    d->hist_latched = d->opt_histo_en != 0; d->clip_latched = d->opt_stat_clip_en != 0;      // :2740-2741
     jsnoop_reset(d);
     JsnoopBatch* b = d->batch;
     b->clear();
@@ -411,12 +413,14 @@ void jsnoop_decode_scan_img(JsnoopDecoder* d, const uint8_t* file, size_t len, u
     d->last_path = 0; d->last_flags = 0;
     if (b->add(d, file, len, start, display) < 0) return;          // early returns of DecodeScanImg: no preview
     d->preview_is_jpeg = false;                                     // :2978
+    if (display) memset(d->stats, 0, sizeof d->stats);              // :3145-3155
     if (b->upload() || b->decode(false) || b->sync()) { d->log(2, "*** ERROR: device decode failed: %s", g_err.c_str()); return; }
     d->have_image = true; d->host_valid = 0;
     if (display) d->preview_is_jpeg = true;
     d->last_path = (int)b->host_path[0]; d->last_flags = b->host_flags[0];
     d->side_ready = d->last_path == 2;          // the exact-mirror kernel fills the side block as it goes
     d->fetch_side();
+    if (display) d->stats_pass();
 }
 
 int  jsnoop_is_preview_ready(JsnoopDecoder* d) { return d->preview_is_jpeg; }
@@ -660,4 +664,49 @@ void JsnoopDecoder::rerender()                                  // CalcChannelPr
     js_launch_idct_color(b->stream, b->dev.imgs, b->dev.wg_base, 1, b->total_wgs, b->max_mcu_w, b->max_mcu_h, b->d_lut, b->dev.coef, b->dev.dccum, b->dev.dib, b->dev.planes, b->dev.side);
     hipStreamSynchronize(b->stream);
     host_valid = 0; fetch_side();
+    stats_pass();
+}
+
+// ConvertYCCtoRGB (:4229) instead of ConvertYCCtoRGBFastFloat when bHistoEn or bStatClipEn (:4742-4747): same pixels,
+// plus the statistics -- one reduction kernel over the retained planes per CalcChannelPreview.
+void JsnoopDecoder::stats_pass()
+{
+    if (!have_image || !preview_is_jpeg || !(hist_latched || clip_latched)) return;   // CalcChannelPreview needs the DIB (:4971-4974)
+    if (batch->color_stats_pass(0, hist_latched, stats, &warn_ycc_clip)) log(2, "*** ERROR: colour statistics pass failed: %s", g_err.c_str());
+}
+int JsnoopBatch::color_stats_pass(int i, bool hist_en, uint32_t* acc, unsigned* warn_used)
+{
+    if (i < 0 || (size_t)i >= imgs.size() || !opt_want_planes || !uploaded) { js_set_error("colour statistics need a decoded image with planes"); return -1; }
+    HIP_TRY(hipSetDevice(device));
+    size_t c = cap.probe; if (grow(&dev.probe, &c, JS_STATS_DEV_WORDS * 4 + 64)) return -1; cap.probe = c;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(dev.probe);
+    std::vector<uint32_t> h(JS_STATS_DEV_WORDS);
+    HIP_TRY(hipMemsetAsync(dst, 0, JS_STATS_DEV_WORDS * 4, stream));
+    js_launch_color_stats(stream, dev.imgs, (uint32_t)i, dev.planes, hist_en, dst);
+    HIP_TRY(hipMemcpyAsync(h.data(), dst, JS_STATS_DEV_WORDS * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    int32_t* ai = reinterpret_cast<int32_t*>(acc); const int32_t* hi = reinterpret_cast<const int32_t*>(h.data());
+    for (int k = 0; k < 36; k += 3) { ai[k] = std::min(ai[k], hi[k]); ai[k + 1] = std::max(ai[k + 1], hi[k + 1]); acc[k + 2] += h[k + 2]; }
+    acc[36] += h[36];
+    for (int k = 43; k < 50; k++) acc[k] += h[k];                                 // RGB clip counters
+    for (int k = 50; k < JS_STATS_WORDS; k++) acc[k] += h[k];                     // histograms
+    // YCC range events: counted only while fewer than YCC_CLIP_REPORT_MAX (10) warnings were issued (:4372-4378)
+    uint32_t total = 0; for (int k = 0; k < 6; k++) total += h[2482 + k];
+    const unsigned left = *warn_used < 10 ? 10 - *warn_used : 0;
+    if (total <= left) { for (int k = 0; k < 6; k++) acc[37 + k] += h[2482 + k]; *warn_used += total; }
+    else if (left) {
+        js_launch_clip_order(stream, dev.imgs, (uint32_t)i, dev.planes, left, dst);
+        uint32_t first[6];
+        HIP_TRY(hipMemcpyAsync(first, dst, sizeof first, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (int k = 0; k < 6; k++) acc[37 + k] += first[k];
+        *warn_used = 10;
+    }
+    return 0;
+}
+void jsnoop_get_color_stats(JsnoopDecoder* d, uint32_t* out) { memcpy(out, d->stats, sizeof d->stats); }
+int jsnoop_batch_color_stats(JsnoopBatch* b, int i, int histo_en, uint32_t* out)
+{
+    memset(out, 0, JS_STATS_WORDS * 4); unsigned used = 0;
+    return b->color_stats_pass(i, histo_en != 0, out, &used);
 }

@@ -39,6 +39,10 @@ struct JsnoopDecoder {
     void ensure_side();      // side outputs are produced on first request when the parallel path decoded the image
     bool side_ready;
     void rerender();
+    // bHistoEn / bStatClipEn statistics (m_sHisto, m_sStatClip, m_anCcHisto_*, m_anHistoYFull): cleared by DecodeScanImg
+    // (:3145-3155), accumulated by every CalcChannelPreview; m_nWarnYccClipNum only restarts in Reset() (:130)
+    uint32_t stats[2482]; unsigned warn_ycc_clip; bool hist_latched, clip_latched;
+    void stats_pass();
 };
 
 struct JsDeviceArenas {
@@ -51,6 +55,7 @@ struct JsArenaCaps { size_t raw, ustr, coef, dccum, dib, planes, side, imgs, tab
 
 struct JsnoopBatch {
     int device; hipStream_t stream; bool own_stream;
+    int color_stats_pass(int i, bool hist_en, uint32_t* acc /*2482 words, accumulated into*/, unsigned* warn_used);
     int opt_decode_ac, opt_want_planes, opt_force_exact;
     std::vector<JsImage> imgs; std::vector<JsTableSet> tables;
     std::vector<uint32_t> host_flags, host_path;

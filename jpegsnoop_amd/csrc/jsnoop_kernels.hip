@@ -585,6 +585,134 @@ __global__ void __launch_bounds__(256) k_dib_checksum(const JsImage* __restrict_
     if (threadIdx.x == 0) atomicAdd(&sums[blockIdx.y], (unsigned long long)(s[0] + s[1] + s[2] + s[3]));
 }
 
+// =====================================================================================
+//  bHistoEn / bStatClipEn statistics: ConvertYCCtoRGB :4229-4326, CapYccRange :4341-4475,
+//  CapRgbRange :4495-4601 evaluated over the retained int16 planes.  The pixels this path produces are the ones
+//  ConvertYCCtoRGBFastFloat produces (the DIB comes from k_idct_color either way); what it adds is a set of
+//  reductions: min / max / sum records (PixelCcHisto), clip counters (PixelCcClip), a 2048-bin histogram of the
+//  raw Y samples and 128-bin histograms of the final R, G, B.
+//  stats block (u32): [0..36] PixelCcHisto (36 ints + nCount), [37..49] PixelCcClip, [50..433] R,G,B bins,
+//  [434..2481] Y bins, [2482..2487] how many YCC range events the image has in all (Y<0, Y>255, Cb<0, Cb>255,
+//  Cr<0, Cr>255): the reference only counts those while fewer than 10 warnings were issued (:4372-4378), which
+//  the host resolves from these totals -- or, when the budget is exceeded, with k_clip_order below.
+// =====================================================================================
+struct StatPix { int pre[3]; int clipv[3]; int fin[3]; int lim[3]; int rgb[3]; };
+__device__ __forceinline__ void stat_pixel(const JsImage& im, const int16_t* __restrict__ pl, uint32_t p, uint32_t shift_ind, StatPix& o)
+{
+    const uint32_t W = im.img_x, pw = im.blk_xmax * 8, py = p / W, px = p - py * W;
+    const size_t pi = (size_t)py * pw + px, psz = (size_t)pw * im.blk_ymax * 8;
+    o.pre[0] = pl[pi]; o.pre[1] = im.ncomp == 3 ? pl[psz + pi] : 0; o.pre[2] = im.ncomp == 3 ? pl[2 * psz + pi] : 0;   // :4683-4693
+    const uint32_t mi = (py / im.mcu_h) * (W / im.mcu_w) + px / im.mcu_w;
+    if (mi >= shift_ind) { o.pre[0] += im.shift_y; o.pre[1] += im.shift_cb; o.pre[2] += im.shift_cr; }                   // :4735-4739
+    #pragma unroll
+    for (int c = 0; c < 3; c++) {
+        o.clipv[c] = (o.pre[c] + 1024) / 8;                      // C division, truncates toward zero (:4265-4267)
+        o.fin[c] = min(max(o.clipv[c], 0), 255);                 // CapYccRange
+    }
+    const float kr = 0.299f, kg = 0.587f, kb = 0.114f;
+    const float cr_mul = 2 - 2 * kr, cb_mul = 2 - 2 * kb;
+    const float fy = (float)(o.fin[0] - 128);
+    float r = __fadd_rn(__fmul_rn((float)(o.fin[2] - 128), cr_mul), fy);
+    float b = __fadd_rn(__fmul_rn((float)(o.fin[1] - 128), cb_mul), fy);
+    float g = __fdiv_rn(__fsub_rn(__fsub_rn(fy, __fmul_rn(kb, b)), __fmul_rn(kr, r)), kg);
+    r = __fadd_rn(r, 128.0f); b = __fadd_rn(b, 128.0f); g = __fadd_rn(g, 128.0f);
+    o.lim[0] = (int)r; o.lim[1] = (int)g; o.lim[2] = (int)b;      // CapRgbRange truncates first, then range-checks the ints
+    #pragma unroll
+    for (int c = 0; c < 3; c++) o.rgb[c] = min(max(o.lim[c], 0), 255);
+}
+
+#define ST_THREADS 256
+__global__ void __launch_bounds__(ST_THREADS) k_color_stats(const JsImage* __restrict__ imgs, uint32_t img, const int16_t* __restrict__ planes,
+                                                            uint32_t hist_en, uint32_t* __restrict__ stats)
+{
+    __shared__ int s_mm[36]; __shared__ uint32_t s_cnt[24]; __shared__ uint32_t s_bins[3 * 128 + 2048];
+    const JsImage& im = imgs[img];
+    const int16_t* pl = planes + im.plane_off;
+    const uint32_t npix = im.img_x * im.img_y, shift_ind = im.shift_mcu_y * (im.img_x / im.mcu_w) + im.shift_mcu_x;
+    const uint32_t t = threadIdx.x;
+    if (t < 36) s_mm[t] = 0;                                    // the reference's records start from memset(0) (:3146-3147)
+    if (t < 24) s_cnt[t] = 0;
+    for (uint32_t i = t; i < 3 * 128 + 2048; i += ST_THREADS) s_bins[i] = 0;
+    __syncthreads();
+    int mn[12], mx[12]; uint32_t sm[12], clip[12], tot[6], n = 0;
+    #pragma unroll
+    for (int i = 0; i < 12; i++) { mn[i] = 0; mx[i] = 0; sm[i] = 0; clip[i] = 0; }
+    #pragma unroll
+    for (int i = 0; i < 6; i++) tot[i] = 0;
+    for (uint32_t p = blockIdx.x * ST_THREADS + t; p < npix; p += gridDim.x * ST_THREADS) {
+        StatPix q; stat_pixel(im, pl, p, shift_ind, q);
+        #pragma unroll
+        for (int c = 0; c < 3; c++) {
+            tot[2 * c] += q.clipv[c] < 0; tot[2 * c + 1] += q.clipv[c] > 255;
+            clip[6 + 2 * c] += q.lim[c] < 0; clip[7 + 2 * c] += q.lim[c] > 255;
+        }
+        if (hist_en) {
+            #pragma unroll
+            for (int c = 0; c < 3; c++) {                          // PixelCcHisto groups: PreclipYCC 0-2, ClipYCC 3-5, ClipRGB 6-8, PreclipRGB 9-11
+                mn[c] = min(mn[c], q.pre[c]); mx[c] = max(mx[c], q.pre[c]); sm[c] += (uint32_t)q.pre[c];
+                mn[3 + c] = min(mn[3 + c], q.clipv[c]); mx[3 + c] = max(mx[3 + c], q.clipv[c]); sm[3 + c] += (uint32_t)q.clipv[c];
+                mn[6 + c] = min(mn[6 + c], q.rgb[c]); mx[6 + c] = max(mx[6 + c], q.rgb[c]); sm[6 + c] += (uint32_t)q.rgb[c];
+                mn[9 + c] = min(mn[9 + c], q.lim[c]); mx[9 + c] = max(mx[9 + c], q.lim[c]); sm[9 + c] += (uint32_t)q.lim[c];
+                atomicAdd(&s_bins[c * 128 + (uint32_t)q.rgb[c] / 2u], 1u);        // 256 / HISTO_BINS = 2 (:4313-4317)
+            }
+            atomicAdd(&s_bins[384 + (uint32_t)(min(max(q.pre[0], -1024), 1023) + 1024)], 1u);   // m_anHistoYFull (:4254-4259)
+            n++;
+        }
+    }
+    #pragma unroll
+    for (int i = 0; i < 12; i++) {
+        if (hist_en) { atomicMin(&s_mm[3 * i], mn[i]); atomicMax(&s_mm[3 * i + 1], mx[i]); atomicAdd(reinterpret_cast<uint32_t*>(&s_mm[3 * i + 2]), sm[i]); }
+        if (i >= 6) atomicAdd(&s_cnt[i], clip[i]);
+    }
+    #pragma unroll
+    for (int i = 0; i < 6; i++) atomicAdd(&s_cnt[12 + i], tot[i]);
+    atomicAdd(&s_cnt[18], n);
+    __syncthreads();
+    if (hist_en && t < 36) {
+        int* g = reinterpret_cast<int*>(stats);
+        if (t % 3 == 0) atomicMin(&g[t], s_mm[t]); else if (t % 3 == 1) atomicMax(&g[t], s_mm[t]); else atomicAdd(&stats[t], (uint32_t)s_mm[t]);
+    }
+    if (t == 36) atomicAdd(&stats[36], s_cnt[18]);
+    if (t >= 6 && t < 12) atomicAdd(&stats[37 + t], s_cnt[t]);               // RGB clip counters are unconditional (:4532-4586)
+    if (t < 6) atomicAdd(&stats[2482 + t], s_cnt[12 + t]);
+    if (hist_en) for (uint32_t i = t; i < 3 * 128 + 2048; i += ST_THREADS) { const uint32_t v = s_bins[i]; if (v) atomicAdd(&stats[50 + i], v); }
+}
+
+// The first `budget` YCC range events of the image in the reference's visiting order: pixels in raster order, within
+// a pixel Y over, Y under, Cb over, Cb under, Cr over, Cr under (:4370-4462).  One workgroup, 1024 pixels per
+// step, stops as soon as the budget is used up.  out6 is indexed like PixelCcClip (Y<0, Y>255, Cb<0, Cb>255, Cr<0, Cr>255).
+__global__ void __launch_bounds__(1024) k_clip_order(const JsImage* __restrict__ imgs, uint32_t img, const int16_t* __restrict__ planes,
+                                                     uint32_t budget, uint32_t* __restrict__ out6)
+{
+    __shared__ uint32_t s_scan[1024]; __shared__ uint32_t s_out[6]; __shared__ uint32_t s_run;
+    const JsImage& im = imgs[img];
+    const int16_t* pl = planes + im.plane_off;
+    const uint32_t npix = im.img_x * im.img_y, shift_ind = im.shift_mcu_y * (im.img_x / im.mcu_w) + im.shift_mcu_x;
+    const uint32_t t = threadIdx.x;
+    if (t < 6) s_out[t] = 0;
+    if (t == 0) s_run = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < npix; base += 1024) {
+        uint32_t ev = 0;                                         // bit 2c: component c over, bit 2c+1: component c under
+        if (base + t < npix) {
+            StatPix q; stat_pixel(im, pl, base + t, shift_ind, q);
+            for (int c = 0; c < 3; c++) ev |= (q.clipv[c] > 255 ? 1u : 0u) << (2 * c) | (q.clipv[c] < 0 ? 2u : 0u) << (2 * c);
+        }
+        const uint32_t cnt = (uint32_t)__builtin_popcount(ev);
+        s_scan[t] = cnt; __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) { const uint32_t a = t >= d ? s_scan[t - d] : 0; __syncthreads(); s_scan[t] += a; __syncthreads(); }
+        uint32_t ord = s_run + s_scan[t] - cnt;
+        for (uint32_t e = ev; e; e &= e - 1, ord++)
+            if (ord < budget) { const uint32_t bit = (uint32_t)__builtin_ctz(e); atomicAdd(&s_out[(bit >> 1) * 2 + ((bit & 1) ? 0 : 1)], 1u); }
+        __syncthreads();
+        if (t == 1023) s_run += s_scan[1023];
+        __syncthreads();
+        if (s_run >= budget) break;
+    }
+    __syncthreads();
+    if (t < 6) out6[t] = s_out[t];
+}
+
 // ------------------------------------------------------------------------------ launch wrappers
 void js_launch_entropy_exact(hipStream_t st, const JsImage* imgs, const uint32_t* sel, uint32_t nsel, const JsTableSet* tables,
                              const uint8_t* raw, int16_t* coef, int16_t* dccum, uint32_t* side, int side_only)
@@ -606,6 +734,10 @@ void js_launch_color_probe(hipStream_t st, int y, int cb, int cr, uint32_t* out)
 { hipLaunchKernelGGL(k_color_probe, dim3(1), dim3(1), 0, st, y, cb, cr, out); }
 void js_launch_color_sweep(hipStream_t st, uint32_t* out)
 { hipLaunchKernelGGL(k_color_sweep, dim3(1u << 16), dim3(256), 0, st, out); }
+void js_launch_color_stats(hipStream_t st, const JsImage* imgs, uint32_t img, const int16_t* planes, int hist_en, uint32_t* stats)
+{ hipLaunchKernelGGL(k_color_stats, dim3(512), dim3(ST_THREADS), 0, st, imgs, img, planes, (uint32_t)(hist_en != 0), stats); }
+void js_launch_clip_order(hipStream_t st, const JsImage* imgs, uint32_t img, const int16_t* planes, uint32_t budget, uint32_t* out6)
+{ hipLaunchKernelGGL(k_clip_order, dim3(1), dim3(1024), 0, st, imgs, img, planes, budget, out6); }
 void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, const uint8_t* dib, unsigned long long* sums)
 {
     if (!nimg) return;

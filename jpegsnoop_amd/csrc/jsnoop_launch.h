@@ -11,6 +11,10 @@ void js_launch_idct_color(hipStream_t st, const JsImage* imgs, const uint32_t* w
 void js_launch_idct_probe(hipStream_t st, const float* lut_t, const int16_t* coef64, float* out64);
 void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, const uint8_t* dib, unsigned long long* sums);
 void js_launch_color_probe(hipStream_t st, int y, int cb, int cr, uint32_t* out);
+#define JS_STATS_WORDS 2482          /* public layout, include/jsnoop_gpu.h JSNOOP_STATS_WORDS */
+#define JS_STATS_DEV_WORDS 2496      /* + the six uncapped YCC range-event totals, padded */
+void js_launch_color_stats(hipStream_t st, const JsImage* imgs, uint32_t img, const int16_t* planes, int hist_en, uint32_t* stats);
+void js_launch_clip_order(hipStream_t st, const JsImage* imgs, uint32_t img, const int16_t* planes, uint32_t budget, uint32_t* out6);
 void js_launch_color_sweep(hipStream_t st, uint32_t* out /*2^24 words*/);
 void js_launch_unstuff(hipStream_t st, int wl, const JsImage* imgs, const uint32_t* us_base, uint32_t nimg, uint32_t total_chunks, const uint8_t* raw,
                        uint32_t* chunk_keep, uint32_t* chunk_rst, uint8_t* ustr_lin, uint8_t* ustr, uint32_t* seg_tab, uint32_t* side, uint32_t* flags,

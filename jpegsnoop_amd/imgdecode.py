@@ -162,6 +162,12 @@ class JpegBatch:
         self._chk(self._lib.jsnoop_batch_read_dib(self._h, i, out.ctypes.data), "batch_read_dib")
         return out
 
+    def color_stats(self, i, histo_en=True):
+        """bHistoEn (or only bStatClipEn) statistics of image i: the JSNOOP_STATS_WORDS record of include/jsnoop_gpu.h."""
+        out = np.zeros(2482, np.uint32)
+        self._chk(self._lib.jsnoop_batch_color_stats(self._h, i, int(histo_en), out.ctypes.data), "batch_color_stats")
+        return out
+
     def planes(self, i):
         inf = self.info(i)
         shp = (inf["blk_ymax"] * 8, inf["blk_xmax"] * 8)

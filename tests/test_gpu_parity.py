@@ -148,6 +148,67 @@ def test_golden_fixtures(harness, gpu):
     assert harness.hash_bytes(gpu.idct_lut()) == M["kat"]["idct_lut_sha256"]
 
 
+def test_histogram_path(harness, oracle, gpu):
+    """bHistoEn / bStatClipEn colour statistics: the committed records of the compiled reference,
+    then the oracle on fresh streams (incl. corrupted ones whose DC drift trips the YCC range checks and their
+    10-warning budget), after the decode and after preview re-renders; and the batch form of the same statistics."""
+    import jpegsnoop_amd as J
+    from golden_util import histo_record, load_case, manifest
+    M = manifest()
+    for name in sorted(M["cases"]):
+        assert histo_record(harness, gpu, load_case(name)) == M["cases"][name]["histo_en"], name
+
+    def stats_equal(a, b):
+        sa, sb = a.color_stats(), b.color_stats()
+        return all((sa[k] == sb[k]) if k == "count" else np.array_equal(sa[k], sb[k]) for k in sa)
+
+    rng = np.random.default_rng(123)
+    files = [harness.synth_jpeg(width=333, height=217, seed=21), harness.synth_jpeg(width=200, height=120, hs=2, vs=1, restart_interval=5, seed=22),
+             harness.synth_jpeg(width=97, height=61, gray=1, seed=23)]
+    for base in list(files):
+        p = harness.parse_jpeg(base)
+        for _ in range(4):
+            d = bytearray(base)
+            for _ in range(int(rng.integers(1, 6))):
+                d[int(rng.integers(p.scan_start, p.scan_end))] ^= 1 << int(rng.integers(0, 8))
+            files.append(bytes(d))
+    try:
+        for data in files:
+            for opt in (dict(histo_en=1), dict(stat_clip_en=1), dict(histo_en=1, stat_clip_en=1, decode_ac=0)):
+                for b in (oracle, gpu):
+                    b.set_options(**opt)
+                    harness.drive(b, data)
+                if oracle.dib() is None:
+                    assert gpu.dib() is None
+                    continue
+                assert np.array_equal(oracle.dib(), gpu.dib()) and stats_equal(oracle, gpu), opt
+                for b in (oracle, gpu):
+                    b.set_preview_mode(4)
+                    b.set_preview_ycc_offset(2, 1, 700, -250, 90)
+                assert np.array_equal(oracle.dib(), gpu.dib()) and stats_equal(oracle, gpu), opt
+                for b in (oracle, gpu):
+                    b.set_preview_ycc_offset(0, 0, 0, 0, 0)
+                    b.set_preview_mode(1)
+    finally:
+        for b in (oracle, gpu):
+            b.set_options()
+    # batch API: one fresh pass per image
+    batch = J.JpegBatch(want_planes=True)
+    for data in files[:6]:
+        batch.add_jpeg(data)
+    batch.upload(); batch.decode(); batch.sync()
+    oracle.set_options(histo_en=1)
+    try:
+        for i, data in enumerate(files[:6]):
+            harness.drive(oracle, data)
+            st = oracle.color_stats()
+            want = np.concatenate([st["histo"].view(np.uint32), np.array([st["count"]], np.uint32), st["clip"], st["rgb"].ravel(), st["yfull"]])
+            assert np.array_equal(batch.color_stats(i), want), i
+    finally:
+        oracle.set_options()
+        batch.close()
+
+
 def test_color_sweep(harness, oracle, gpu):
     """All 2^24 clamped (Y, Cb, Cr) triples through the device colour conversion against the oracle's
     ConvertYCCtoRGBFastFloat (true IEEE division by 0.587f): pins the FMA-corrected reciprocal form used on the device."""
