@@ -174,6 +174,7 @@ JsnoopBatch::~JsnoopBatch()
                       (void**)&dev.sub, (void**)&dev.probe, (void**)&dev.seg, (void**)&dev.chunk_keep, (void**)&dev.chunk_rst, (void**)&dev.us_base,
                       (void**)&dev.sy_base, (void**)&dev.mcu_rst, (void**)&dev.flags, (void**)&dev.ustr_lin }) if (*p) hipFree(*p);
     if (d_lut) hipFree(d_lut);
+    if (d_side_tmp) hipFree(d_side_tmp);
     if (pinned) hipHostFree(pinned);
     for (auto& e : ev) if (e) hipEventDestroy(e);
     if (own_stream && stream) hipStreamDestroy(stream);
@@ -289,6 +290,7 @@ int JsnoopBatch::upload()
     HIP_TRY(hipMemcpyAsync(dev.us_base, usb.data(), (n + 1) * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(dev.sy_base, syb.data(), (n + 1) * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));          // host vectors above may go out of scope
+    h_us_base = usb; h_sy_base = syb;
     uploaded = true;
     return 0;
 }

@@ -58,7 +58,8 @@ struct JsnoopBatch {
     int color_stats_pass(int i, bool hist_en, uint32_t* acc /*2482 words, accumulated into*/, unsigned* warn_used);
     int opt_decode_ac, opt_want_planes, opt_force_exact;
     std::vector<JsImage> imgs; std::vector<JsTableSet> tables;
-    std::vector<uint32_t> host_flags, host_path;
+    std::vector<uint32_t> host_flags, host_path, h_us_base, h_sy_base;
+    uint32_t* d_side_tmp = nullptr; size_t side_tmp_cap = 0;      // scratch of the side-output pass (one image at a time)
     uint8_t* pinned; size_t pinned_cap; uint64_t raw_bytes;
     JsDeviceArenas dev; JsArenaCaps cap;
     bool uploaded;

@@ -867,14 +867,19 @@ __global__ void __launch_bounds__(256) k_unstuff_scan(const JsImage* __restrict_
     }
 }
 
+// Side-output pass (us_out != nullptr, grid = the chunks of one image starting at workgroup wg0): instead of writing the
+// stream again, every thread records the compacted-stream index of its first kept byte -- the inverse map
+// "compacted byte -> file offset" that the MCU file map needs (k_side_maps).
 __global__ void __launch_bounds__(US_THREADS) k_unstuff_write(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ us_base, uint32_t nimg,
                                                               const uint8_t* __restrict__ raw, const uint32_t* __restrict__ chunk_keep,
-                                                              const uint32_t* __restrict__ chunk_rst, uint8_t* __restrict__ ustr, uint32_t* __restrict__ seg_tab)
+                                                              const uint32_t* __restrict__ chunk_rst, uint8_t* __restrict__ ustr, uint32_t* __restrict__ seg_tab,
+                                                              uint32_t wg0, uint32_t* __restrict__ us_out)
 {
-    const uint32_t img = find_image(us_base, nimg, blockIdx.x);
+    const uint32_t wg = blockIdx.x + wg0;
+    const uint32_t img = find_image(us_base, nimg, wg);
     const JsImage& im = imgs[img];
     const uint64_t s = im.file_off + im.scan_start, e = s + im.scan_len;
-    const uint64_t o16 = (s & ~15ull) + (uint64_t)(blockIdx.x - us_base[img]) * US_CHUNK + threadIdx.x * 16;
+    const uint64_t o16 = (s & ~15ull) + (uint64_t)(wg - us_base[img]) * US_CHUNK + threadIdx.x * 16;
     const UsBytes c = us_classify(raw, o16, s, e);
     const uint32_t nk = __popc(c.keep_mask), nr = __popc(c.rst_mask), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t pk = nk, pr = nr;                                             // inclusive wave scans
@@ -882,9 +887,10 @@ __global__ void __launch_bounds__(US_THREADS) k_unstuff_write(const JsImage* __r
     __shared__ uint32_t wk[US_THREADS / 64], wr[US_THREADS / 64];
     if (lane == 63) { wk[wave] = pk; wr[wave] = pr; }
     __syncthreads();
-    uint32_t bk = chunk_keep[blockIdx.x], br = chunk_rst[blockIdx.x];
+    uint32_t bk = chunk_keep[wg], br = chunk_rst[wg];
     for (uint32_t w = 0; w < wave; w++) { bk += wk[w]; br += wr[w]; }
     uint32_t out = bk + pk - nk, seg = br + pr - nr;                       // exclusive prefixes of this thread
+    if (us_out) { us_out[blockIdx.x * US_THREADS + threadIdx.x] = out; return; }
     if (!(c.keep_mask | c.rst_mask)) return;
     uint8_t* dst = ustr + im.ustr_off; uint32_t* st = seg_tab + im.seg_off;
     const uint4 v = *reinterpret_cast<const uint4*>(raw + o16);
@@ -1168,23 +1174,32 @@ __global__ void __launch_bounds__(256) k_block_scan(const JsImage* __restrict__ 
 // (it runs while any lane is active), so that when some lanes complete a block in an iteration the WHOLE wave
 // moves each finished block out: 64 lanes x 2 bytes = one coalesced 128-byte line per block.  HBM therefore sees
 // whole lines (no scattered 2-byte read-modify-writes) and the coefficient arena needs no memset.
-template <int WL>
+// SIDE variant (side-output pass over one already decoded image, grid = its workgroups starting at wg0): the same
+// walk, but instead of coefficients it produces what the reference records while it decodes -- the bit position at
+// which every MCU starts (-> m_pMcuFileMap :3229) and the Huffman code-length histogram (m_anDhtHisto :1190).  A
+// symbol is counted by the lane in whose own range it starts; an MCU start is recorded by the lane that completes
+// the last block of the MCU before it.
+template <int WL, bool SIDE>
 __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sy_base, uint32_t nimg,
                                                       const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr,
-                                                      const uint32_t* __restrict__ seg_tab, const uint32_t* __restrict__ side, SubArrays A,
+                                                      const uint32_t* __restrict__ seg_tab, uint32_t* __restrict__ side, SubArrays A,
                                                       int16_t* __restrict__ coef, int16_t* __restrict__ dccum, uint8_t* __restrict__ mcu_rst, uint32_t* __restrict__ flags,
-                                                      uint32_t tab_rows, uint32_t tab_lut2)
+                                                      uint32_t tab_rows, uint32_t tab_lut2, uint32_t wg0, uint32_t* __restrict__ mcu_pos)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     __shared__ __attribute__((aligned(16))) int16_t s_blk[SY_THREADS][WR_STRIDE];
-    const uint32_t img = find_image(sy_base, nimg, blockIdx.x);
+    __shared__ uint32_t s_histo[SIDE ? 2 * 4 * 17 : 1];
+    const uint32_t wg = blockIdx.x + wg0;
+    const uint32_t img = find_image(sy_base, nimg, wg);
     const JsImage& im = imgs[img];
     if (!tables[im.tableset].lut_ok) return;
     const uint32_t* sd = side + im.side_off;
     const uint32_t total_bits = sd[10] * 8, nseg = min(sd[11], im.seg_cap - 1);
     const uint32_t lane = threadIdx.x & 63, wave0 = threadIdx.x & ~63u;
-    const uint32_t sub0 = (blockIdx.x - sy_base[img]) * SY_THREADS, i = sub0 + threadIdx.x;
+    const uint32_t sub0 = (wg - sy_base[img]) * SY_THREADS, i = sub0 + threadIdx.x;
     if (sub0 * SUB_BITS >= total_bits) return;
+    if (SIDE) for (uint32_t q = threadIdx.x; q < 2 * 4 * 17; q += SY_THREADS) s_histo[q] = 0;
+    const JsTableSet& tset = tables[im.tableset];
     SubTabs T; load_subtabs(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, threadIdx.x, SY_THREADS);
     { uint2* z = reinterpret_cast<uint2*>(s_blk[threadIdx.x]); for (int j = 0; j < WR_STRIDE / 4; j++) z[j] = make_uint2(0u, 0u); }
     __syncthreads();
@@ -1243,7 +1258,8 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         if (prec_shift) val /= (int32_t)(1u << prec_shift);
         const uint32_t ind = isdc ? 0u : k + run;
         const int16_t dq = (int16_t)((int32_t)(int16_t)val * (int32_t)T.qzz[comp * 64 + (ind & 63u)]);
-        if (norm && !skip && (isdc || (decode_ac && size)) && ind < 64) lbuf[T.zz[ind]] = dq;
+        if (!SIDE && norm && !skip && (isdc || (decode_ac && size)) && ind < 64) lbuf[T.zz[ind]] = dq;
+        if (SIDE && norm && !captured && blk < nblocks) atomicAdd(&s_histo[((isdc ? 0u : 4u) + tset.dest_id[comp * 2 + (isdc ? 0u : 1u)]) * 17u + len], 1u);
         dq0 = (norm && isdc) ? dq : dq0;
         const uint32_t tot = norm ? len + size : 0u;
         cur.off += tot; cur.p += tot;
@@ -1257,10 +1273,11 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         nblk += (done && !captured) ? 1u : 0u;
         const bool flush = done && !skip && blk < nblocks;
         const uint32_t fblk = blk;
-        if (flush) dbase[blk] = dq0;
+        if (!SIDE && flush) dbase[blk] = dq0;
+        if (SIDE && flush && c == 0) mcu_pos[(blk + 1) / T.nb] = cur.p;      // the next MCU starts here (before any restart handling)
         skip = done ? false : skip; blk += done ? 1u : 0u;
         // ---- the whole wave moves every block that completed in this iteration: one 128-byte line each ----
-        uint64_t fm = __ballot(flush);
+        uint64_t fm = SIDE ? 0ull : __ballot(flush);
         while (fm) {
             const uint32_t src = (uint32_t)__builtin_ctzll(fm); fm &= fm - 1;
             const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)fblk, src);
@@ -1274,7 +1291,11 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         // the chain must be at its fixed point, and the block count that fed the prefix sum must be the real one
         if (res_p != A.out_p[g] || res_s != A.out_s[g] || (check_n && res_n != A.nblk[g])) fl |= F_NOSYNC;
     }
-    if (fl) atomicOr(&flags[img], fl);
+    if (SIDE) {
+        __syncthreads();
+        uint32_t* ho = side + im.side_off + JS_SIDE_HISTO;
+        for (uint32_t q = threadIdx.x; q < 2 * 4 * 17; q += SY_THREADS) { const uint32_t v = s_histo[q]; if (v) atomicAdd(&ho[q], v); }
+    } else if (fl) atomicOr(&flags[img], fl);
 }
 
 // One workgroup (1024 lanes) per image: DC differences (in dccum, decode order) -> cumulative DC per block.
@@ -1330,7 +1351,7 @@ void js_launch_unstuff(hipStream_t st, int wl, const JsImage* imgs, const uint32
     if (!total_chunks) return;
     hipLaunchKernelGGL(k_unstuff_count, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst);
     hipLaunchKernelGGL(k_unstuff_scan, dim3(nimg), dim3(256), 0, st, imgs, us_base, chunk_keep, chunk_rst, seg_tab, side, flags);
-    hipLaunchKernelGGL(k_unstuff_write, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, ustr_lin, seg_tab);
+    hipLaunchKernelGGL(k_unstuff_write, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, ustr_lin, seg_tab, 0u, (uint32_t*)nullptr);
     if (wl == 7) hipLaunchKernelGGL(k_interleave<7>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
     else hipLaunchKernelGGL(k_interleave<5>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
 }
@@ -1353,14 +1374,143 @@ void js_launch_block_scan(hipStream_t st, int wl, const JsImage* imgs, uint32_t 
     else hipLaunchKernelGGL(k_block_scan<5>, dim3(nimg), dim3(256), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
 }
 void js_launch_write(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
-                     const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub,
+                     const uint8_t* ustr, const uint32_t* seg_tab, uint32_t* side, uint32_t* sub, uint64_t nsub,
                      int16_t* coef, int16_t* dccum, uint8_t* mcu_rst, uint32_t* flags)
 {
     if (!total_wgs) return;
-    if (wl == 7) hipLaunchKernelGGL(k_write<7>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
-                       sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2);
-    else hipLaunchKernelGGL(k_write<5>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
-                       sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2);
+    if (wl == 7) hipLaunchKernelGGL((k_write<7, false>), dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                       sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2, 0u, (uint32_t*)nullptr);
+    else hipLaunchKernelGGL((k_write<5, false>), dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                       sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2, 0u, (uint32_t*)nullptr);
+}
+// =====================================================================================
+//  Side outputs of an image the parallel path decoded, without the sequential kernel:
+//   * k_unstuff_write (side mode)  -> compacted-byte index of every 16-byte group of the scan  (inverse map)
+//   * k_write<WL, true>            -> bit position at which every MCU starts, Huffman code-length histogram
+//   * k_side_maps                  -> m_pMcuFileMap (:3229, PackFileOffset :5104), the three block-DC maps (:3524-3608) and the
+//                                     status words the reference is left with after the last MCU.  Where the answer depends on
+//                                     the register's bookkeeping rather than on the bit position alone (register run empty in
+//                                     front of an RSTn; end of the scan) the exact-mirror reader is run over the few MCUs before.
+// =====================================================================================
+// File offset (relative to the file start) of byte `u` of the compacted stream of image `im`.
+__device__ uint32_t raw_of_compacted(const JsImage& im, const uint8_t* __restrict__ raw, const uint32_t* __restrict__ us_out, uint32_t nthreads, uint32_t u)
+{
+    uint32_t lo = 0, hi = nthreads;                                // last group whose first kept byte has index <= u
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (us_out[mid] <= u) lo = mid; else hi = mid; }
+    const uint64_t s = im.file_off + im.scan_start, e = s + im.scan_len;
+    const uint64_t o16 = (s & ~15ull) + (uint64_t)lo * 16;
+    const UsBytes c = us_classify(raw, o16, s, e);
+    uint32_t m = c.keep_mask;
+    for (uint32_t k = u - us_out[lo]; k && m; k--) m &= m - 1;       // drop the k lowest kept bytes
+    if (!m) return im.scan_start + im.scan_len;                     // past the end of the scan data
+    return (uint32_t)(o16 + (uint32_t)__builtin_ctz(m) - im.file_off);
+}
+
+// Brings an exact-mirror reader to the state the reference's reader has when its MCU loop reaches MCU `m_top` (m_top ==
+// number of MCUs: after the last one).  The register state at an MCU top is a function of the bit position alone --
+// four bytes buffered from byte(p), p & 7 bits of the first consumed -- PROVIDED the refill that follows was not cut
+// short by a restart marker; otherwise slots of the position array keep older values that can surface later (the
+// register's bookkeeping shifts them down when it runs empty, ScanBuffConsume :921-955).  The walk therefore starts at
+// the closest earlier MCU top that either begins a restart interval (freshly restarted buffer, DecodeRestartScanBuf
+// :4038) or lies at least 5 bytes before the next RSTn, and decodes forward from there with the mirror itself.
+// Returns the number of RSTn markers the reference has seen before the point the walk started from.
+__device__ uint32_t mirror_to_mcu_top(const JsImage& im, const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ raw, const uint32_t* __restrict__ st,
+                                      uint32_t nseg, uint32_t total_bytes, const uint8_t* __restrict__ mcu_rst, const uint32_t* __restrict__ mcu_pos,
+                                      const uint32_t* __restrict__ us_out, uint32_t us_threads, uint32_t m_top, ExactReader& r, uint32_t* dummy_histo, int16_t* scratch)
+{
+    r.file = raw + im.file_off; r.flen = im.file_len; r.ts = tables + im.tableset; r.histo = dummy_histo;
+    r.rst_interval = im.rst_interval; r.precision = im.precision; r.err_max = im.err_max; r.warn_bad = 0;
+    r.rst_count = 0; r.rst_last = 0; r.rst_expect = 0; r.rst_handled = 0;
+    uint32_t m0 = m_top ? m_top - 1 : 0, rst_before = 0;
+    for (;; m0--) {
+        if (m0 == 0) { ex_restart_scan_buf(r, im.scan_start, false); ex_topup(r); break; }
+        const uint32_t p = mcu_pos[m0];
+        if (mcu_rst[im.mcu_off + m0]) {                             // first MCU of an interval: the RSTn in front of it has been handled (:1644-1680)
+            const uint32_t u1 = (p + 7) >> 3;                       //   fewer than 8 pad bits, else the parallel path had flagged the image
+            rst_before = find_interval(st, nseg, min(u1, total_bytes ? total_bytes - 1 : 0));
+            ex_restart_scan_buf(r, raw_of_compacted(im, raw, us_out, us_threads, u1), true); ex_topup(r);
+            break;
+        }
+        const uint32_t sg = find_interval(st, nseg, p >> 3);
+        if (sg + 1 >= nseg || st[sg + 1] * 8 >= p + 40) {           // the refill at this MCU top is not cut short by an RSTn
+            rst_before = sg;
+            ex_restart_scan_buf(r, raw_of_compacted(im, raw, us_out, us_threads, p >> 3), true); ex_topup(r); ex_consume(r, p & 7u);
+            break;
+        }
+    }
+    r.ptr_first = im.scan_start;
+    int16_t dc_y = 0, dc_cb = 0, dc_cr = 0;
+    for (uint32_t mi = m0; mi < m_top; mi++) {
+        for (uint32_t c = 0; c < im.blk_per_mcu; c++) {
+            ex_decode_block(r, im.blk_comp[c], im.decode_ac, scratch, dc_y, dc_cb, dc_cr);
+            if (r.cur_err) { if (r.warn_bad < r.err_max) r.warn_bad++; r.cur_err = 0; }   // CheckScanErrors :2605
+        }
+        if (im.rst_en) r.mcus_left--;
+    }
+    return rst_before;
+}
+
+__global__ void __launch_bounds__(256) k_side_maps(const JsImage* __restrict__ imgs, uint32_t img, const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ raw,
+                                                   const uint32_t* __restrict__ seg_tab, const int16_t* __restrict__ dccum, const uint8_t* __restrict__ mcu_rst,
+                                                   const uint32_t* __restrict__ mcu_pos, const uint32_t* __restrict__ us_out, uint32_t us_threads,
+                                                   uint32_t* __restrict__ side)
+{
+    const JsImage& im = imgs[img];
+    uint32_t* sd = side + im.side_off;
+    const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax, nblk = im.blk_xmax * im.blk_ymax, nseg = min(sd[11], im.seg_cap - 1);
+    const uint32_t* st = seg_tab + im.seg_off;
+    uint32_t* mcu_map = sd + JS_SIDE_MCUMAP;
+    int16_t* bdc0 = reinterpret_cast<int16_t*>(mcu_map + nmcu);
+    const uint32_t stride = 2 * ((nblk + 1) / 2);
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
+    // ---- MCU file map: position of the first buffered byte and the bit alignment when the MCU loop reaches MCU m (:3229)
+    for (uint32_t m = gid; m <= nmcu; m += gsz) {
+        const uint32_t p = m ? mcu_pos[m] : 0u, ub = p >> 3, a = p & 7u;
+        bool empty = false;                                         // the previous interval was consumed to its last bit: the register is empty
+        if (m && m < nmcu && a == 0) { const uint32_t sg = find_interval(st, nseg, ub); empty = sg >= 1 && st[sg] == ub; }
+        if (m == nmcu || empty) {
+            // what an empty register still shows depends on how its last bytes were loaded, and the end of the scan is where the
+            // look-ahead meets EOI / trailing bytes: take both from the mirror reader itself
+            uint32_t dummy_histo[2 * 4 * 17]; int16_t scratch[64]; ExactReader r;
+            const uint32_t before = mirror_to_mcu_top(im, tables, raw, st, nseg, sd[10], mcu_rst, mcu_pos, us_out, us_threads, m, r, dummy_histo, scratch);
+            if (m < nmcu) mcu_map[m] = (r.pos0 << 4) + r.align;
+            else {                                                  // status words after the last MCU
+                sd[0] = r.scan_bad; sd[1] = r.scan_end; sd[2] = before + r.rst_count; sd[3] = nmcu * im.samp_h[1] * im.samp_v[1] * 64u;
+                sd[4] = r.pos0; sd[5] = r.align; sd[6] = r.warn_bad; sd[7] = im.scan_start;
+            }
+        } else mcu_map[m] = (raw_of_compacted(im, raw, us_out, us_threads, ub) << 4) + a;
+    }
+    // ---- block-DC maps: the cumulative DC of the block that wrote the cell last (MCU raster order, :3524-3608)
+    const int16_t* dc = dccum + im.coef_off;
+    for (uint32_t q = gid; q < im.ncomp * nblk; q += gsz) {
+        const uint32_t comp = q / nblk + 1, cell = q % nblk, bx = cell % im.blk_xmax, by = cell / im.blk_xmax;
+        const uint32_t eh = im.expand_h[comp], ev = im.expand_v[comp];
+        int best = -1; uint32_t best_blk = 0;
+        for (uint32_t c = 0; c < im.blk_per_mcu; c++) {
+            if (im.blk_comp[c] != comp || !eh || !ev) continue;
+            const uint32_t ch = im.blk_ch[c], cv = im.blk_cv[c];
+            if (bx < ch || by < cv || (bx - ch) % eh || (by - cv) % ev) continue;
+            const uint32_t mx = (bx - ch) / eh, my = (by - cv) / ev;
+            if (mx >= im.mcu_xmax || my >= im.mcu_ymax) continue;
+            const int mi = (int)(my * im.mcu_xmax + mx);
+            if (mi > best) { best = mi; best_blk = (uint32_t)mi * im.blk_per_mcu + c; }
+        }
+        if (best >= 0) bdc0[(comp - 1) * stride + cell] = dc[best_blk];
+    }
+}
+
+void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* us_base, const uint32_t* sy_base, uint32_t nimg,
+                         uint32_t img, uint32_t us_wg0, uint32_t us_wgs, uint32_t sy_wg0, uint32_t sy_wgs, const JsTableSet* tables, const uint8_t* raw,
+                         const uint32_t* chunk_keep, const uint32_t* chunk_rst, const uint8_t* ustr, uint32_t* seg_tab, uint32_t* side, uint32_t* sub, uint64_t nsub,
+                         const int16_t* dccum, uint8_t* mcu_rst, uint32_t* mcu_pos, uint32_t* us_out)
+{
+    if (!us_wgs || !sy_wgs) return;
+    hipLaunchKernelGGL(k_unstuff_write, dim3(us_wgs), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, (uint8_t*)nullptr, seg_tab, us_wg0, us_out);
+    if (wl == 7) hipLaunchKernelGGL((k_write<7, true>), dim3(sy_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                       sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos);
+    else hipLaunchKernelGGL((k_write<5, true>), dim3(sy_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                       sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos);
+    hipLaunchKernelGGL(k_side_maps, dim3(64), dim3(256), 0, st, imgs, img, tables, raw, seg_tab, dccum, mcu_rst, mcu_pos, us_out, us_wgs * US_THREADS, side);
 }
 void js_launch_dc_scan(hipStream_t st, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, int16_t* dccum, const uint8_t* mcu_rst)
 { if (nimg) hipLaunchKernelGGL(k_dc_scan, dim3(nimg), dim3(DC_THREADS), 0, st, imgs, tables, dccum, mcu_rst); }

@@ -1,6 +1,7 @@
 // jsnoop_parallel.cpp -- host side of the parallel (self-synchronising) entropy path:
 // LUT construction from the DHT code lists, stage launches, and the re-decode of flagged
 // images on the sequential exact-mirror kernel (all on the device; no CPU decode).
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include "jsnoop_host.h"
@@ -158,17 +159,38 @@ int js_parallel_fixup(JsnoopBatch* b)
     return b->run_exact(bad);
 }
 
-// Side outputs (MCU file map, block-DC maps, Huffman code-length histogram, status words) of image i,
-// recomputed by the exact-mirror kernel without touching the coefficient / pixel data.
+// Side outputs (MCU file map, block-DC maps, Huffman code-length histogram, status words) of image i, produced on
+// request without touching the coefficient / pixel data.  Images the parallel path decoded get them from the
+// parallel side pass (k_write<.., true> + k_side_maps + k_side_tail); images that went through the exact-mirror
+// kernel already have them, and that kernel remains the producer for anything flagged.
 int js_side_only(JsnoopBatch* b, uint32_t i)
 {
     HIP_TRY(hipSetDevice(b->device));
     const JsImage& im = b->imgs[i];
-    const size_t words = js_side_words(im.mcu_xmax * im.mcu_ymax, im.blk_xmax * im.blk_ymax);
+    const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax;
+    const size_t words = js_side_words(nmcu, im.blk_xmax * im.blk_ymax);
     HIP_TRY(hipMemsetAsync(b->dev.side + im.side_off, 0, 8 * 4, b->stream));
     HIP_TRY(hipMemsetAsync(b->dev.side + im.side_off + JS_SIDE_HISTO, 0, (words - JS_SIDE_HISTO) * 4, b->stream));
-    HIP_TRY(hipMemcpyAsync(b->dev.sel, &i, 4, hipMemcpyHostToDevice, b->stream));
-    js_launch_entropy_exact(b->stream, b->dev.imgs, b->dev.sel, 1, b->dev.tables, b->dev.raw, b->dev.coef, b->dev.dccum, b->dev.side, 1);
+    const bool parallel = i < b->host_path.size() && b->host_path[i] == 1 && b->host_flags[i] == 0 && !getenv("JSNOOP_SIDE_EXACT");
+    if (parallel) {
+        const uint32_t us0 = b->h_us_base[i], usn = b->h_us_base[i + 1] - us0, sy0 = b->h_sy_base[i], syn = b->h_sy_base[i + 1] - sy0;
+        const size_t need = ((size_t)nmcu + 1 + (size_t)usn * 256 + 64) * 4;
+        if (need > b->side_tmp_cap) {
+            if (b->d_side_tmp) hipFree(b->d_side_tmp);
+            b->d_side_tmp = nullptr; b->side_tmp_cap = 0;
+            HIP_TRY(hipMalloc((void**)&b->d_side_tmp, need + need / 8));
+            b->side_tmp_cap = need + need / 8;
+        }
+        uint32_t* mcu_pos = b->d_side_tmp; uint32_t* us_out = mcu_pos + (((size_t)nmcu + 1 + 15) & ~(size_t)15);
+        HIP_TRY(hipMemsetAsync(mcu_pos, 0, ((size_t)nmcu + 1) * 4, b->stream));
+        js_launch_side_pass(b->stream, b->sub_wl, b->tab_rows, b->tab_lut2, b->dev.imgs, b->dev.us_base, b->dev.sy_base, (uint32_t)b->imgs.size(), i, us0, usn, sy0, syn,
+                            b->dev.tables, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst, b->dev.ustr, b->dev.seg, b->dev.side, (uint32_t*)b->dev.sub, b->total_subseq,
+                            b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out);
+    } else {
+        HIP_TRY(hipMemcpyAsync(b->dev.sel, &i, 4, hipMemcpyHostToDevice, b->stream));
+        js_launch_entropy_exact(b->stream, b->dev.imgs, b->dev.sel, 1, b->dev.tables, b->dev.raw, b->dev.coef, b->dev.dccum, b->dev.side, 1);
+    }
     HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipGetLastError());
     return 0;
 }

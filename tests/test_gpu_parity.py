@@ -148,6 +148,29 @@ def test_golden_fixtures(harness, gpu):
     assert harness.hash_bytes(gpu.idct_lut()) == M["kat"]["idct_lut_sha256"]
 
 
+def test_parallel_side_outputs(harness, oracle, gpu):
+    """MCU file map, block-DC maps, code-length histogram and status words of images the parallel path decoded come from
+    the parallel side pass (no sequential kernel): restart intervals of every length (byte-aligned interval ends
+    included), what follows the scan (EOI, nothing, trailing bytes, a second marker), tiny and single-MCU images."""
+    cases = []
+    for i, kw in enumerate([dict(width=320, height=240, restart_interval=1), dict(width=320, height=240, restart_interval=3, hs=2, vs=1),
+                            dict(width=333, height=217, restart_interval=7, hs=1, vs=1), dict(width=161, height=97, gray=1, restart_interval=2),
+                            dict(width=16, height=16), dict(width=8, height=8, hs=1, vs=1), dict(width=40, height=24, restart_interval=1, quality=5, noise_sigma=0),
+                            dict(width=640, height=480, quality=97, optimize_huffman=1), dict(width=96, height=80, hs=1, vs=2, restart_interval=5)]):
+        cases.append(harness.synth_jpeg(seed=40 + i, **kw))
+    base = cases[1]
+    assert base[-2:] == b"\xff\xd9"
+    cases += [base[:-2], base[:-1], base + b"\x00" * 7, base + b"\xff\xd9\xff\xe1\x00\x04ab", base[:-2] + b"\xff\xc4\x00\x02", base + b"\xff" * 5]
+    for k, data in enumerate(cases):
+        harness.drive(oracle, data)
+        harness.drive(gpu, data)
+        assert gpu.lib.jsnoop_last_path(gpu.h) == 1 and gpu.lib.jsnoop_last_flags(gpu.h) == 0, k
+        try:
+            compare(harness, oracle, gpu)
+        except AssertionError as e:
+            raise AssertionError(f"case {k}: {e}")
+
+
 def test_histogram_path(harness, oracle, gpu):
     """bHistoEn / bStatClipEn colour statistics: the committed records of the compiled reference,
     then the oracle on fresh streams (incl. corrupted ones whose DC drift trips the YCC range checks and their
