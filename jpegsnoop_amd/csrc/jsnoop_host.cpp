@@ -66,7 +66,7 @@ void JsnoopDecoder::reset_state()                                              /
 
 // The geometry and readiness checks DecodeScanImg performs before its MCU loop (:2755-3123),
 // restated on the table state.  Returns false (with a log line) exactly where the reference returns early.
-bool js_describe_image(JsnoopDecoder* d, JsImage* im, JsTableSet* ts, uint32_t file_len, uint32_t scan_start, int display)
+bool js_describe_image(JsnoopDecoder* d, JsImage* im, JsTableSet* ts, uint32_t file_len, uint32_t scan_start, int display, int quiet)
 {
     JsTables& t = d->t;
     memset(im, 0, sizeof *im);
@@ -99,6 +99,7 @@ bool js_describe_image(JsnoopDecoder* d, JsImage* im, JsTableSet* ts, uint32_t f
     im->total_blocks = im->mcu_xmax * im->mcu_ymax * nb;
     d->geom[0] = im->mcu_w; d->geom[1] = im->mcu_h; d->geom[2] = im->mcu_xmax; d->geom[3] = im->mcu_ymax;
     d->geom[4] = im->blk_xmax; d->geom[5] = im->blk_ymax; d->geom[6] = im->img_x; d->geom[7] = im->img_y;
+    if (!quiet) { d->log(0, "*** Decoding SCAN Data ***"); d->log(0, "  OFFSET: 0x%08X", scan_start); }            // :3021-3025
     if (t.num_sof != 1 && t.num_sof != 3) { d->log(1, "  NOTE: Number of Image Components not supported [%u]", t.num_sof); return false; }
     for (uint32_t i = 1; i <= t.num_sos; i++) if (t.dqt_sel[i] < 0) {
         d->log(2, "*** ERROR: Decoding image before DQT Table Selection via JFIF_SOF ***"); return false; }
@@ -108,6 +109,12 @@ bool js_describe_image(JsnoopDecoder* d, JsImage* im, JsTableSet* ts, uint32_t f
         if (sel < 0 || sel >= 4 || t.dht_size[cls][sel] == 0) ready = false;
     }
     if (!ready) { d->log(2, "*** ERROR: Decoding image before DHT Table Selection via JFIF_SOS ***"); return false; }
+    if (!quiet) {                                                                                                       // :3126-3135
+        if (display && d->opt_decode_ac) d->log(0, "  Scan Decode Mode: Full IDCT (AC + DC)");
+        else { d->log(0, "  Scan Decode Mode: No IDCT (DC only)");
+               d->log(1, "    NOTE: Low-resolution DC component shown. Can decode full-res with [Options->Scan Segment->Full IDCT]"); }
+        d->log(0, "");
+    }
 
     im->precision = t.precision; im->rst_en = t.rst_en; im->rst_interval = t.rst_interval;
     im->decode_ac = display ? (uint32_t)d->opt_decode_ac : 0; im->err_max = d->opt_err_max;
@@ -172,7 +179,7 @@ JsnoopBatch::~JsnoopBatch()
     for (void** p : { (void**)&dev.raw, (void**)&dev.ustr, (void**)&dev.coef, (void**)&dev.dccum, (void**)&dev.dib, (void**)&dev.planes,
                       (void**)&dev.side, (void**)&dev.imgs, (void**)&dev.tables, (void**)&dev.wg_base, (void**)&dev.sel, (void**)&dev.sums,
                       (void**)&dev.sub, (void**)&dev.probe, (void**)&dev.seg, (void**)&dev.chunk_keep, (void**)&dev.chunk_rst, (void**)&dev.us_base,
-                      (void**)&dev.sy_base, (void**)&dev.mcu_rst, (void**)&dev.flags, (void**)&dev.ustr_lin }) if (*p) hipFree(*p);
+                      (void**)&dev.sy_base, (void**)&dev.mcu_rst, (void**)&dev.flags, (void**)&dev.ustr_lin, (void**)&dev.events }) if (*p) hipFree(*p);
     if (d_lut) hipFree(d_lut);
     if (d_side_tmp) hipFree(d_side_tmp);
     if (pinned) hipHostFree(pinned);
@@ -193,11 +200,11 @@ int JsnoopBatch::reserve_pinned(size_t need)
     pinned = np; pinned_cap = ncap;
     return 0;
 }
-int JsnoopBatch::add(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned scan_start, int display)
+int JsnoopBatch::add(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned scan_start, int display, int quiet)
 {
     if (len >= (1ull << 32) - 64) { js_set_error("file too large for the 32-bit offsets of the reference format"); return -1; }
     JsImage im; JsTableSet* ts = new JsTableSet;
-    if (!js_describe_image(d, &im, ts, (uint32_t)len, scan_start, display)) { delete ts; js_set_error("image not decodable (see log callback)"); return -1; }
+    if (!js_describe_image(d, &im, ts, (uint32_t)len, scan_start, display, quiet)) { delete ts; js_set_error("image not decodable (see log callback)"); return -1; }
     im.decode_ac = display ? (uint32_t)(d->batch == this ? d->opt_decode_ac : opt_decode_ac) : 0;
     // scan length: up to the first marker that is neither stuffing nor RSTn (what pass 1 of the SOS
     // handler skips over, source/JfifDecode.cpp:5207-5265); bytes past `len` read as zero.
@@ -266,6 +273,7 @@ int JsnoopBatch::upload()
         const uint64_t want_seg = im.rst_interval ? (uint64_t)nmcu / im.rst_interval + 2 : 1;
         im.seg_cap = (uint32_t)std::min<uint64_t>(65535, want_seg * 2 + 16); im.seg_off = segw; segw += align_up(im.seg_cap, 4);
         im.mcu_off = mcub; mcub += align_up(nmcu, 16);
+        im.ev_cap = opt_events ? JS_EV_MAX : 0; im.ev_off = (uint64_t)i * (1 + JS_EV_WORDS * JS_EV_MAX);
         usb[i] = usc; usc += (uint32_t)(((im.scan_start & 15) + (uint64_t)im.scan_len + JS_US_CHUNK - 1) / JS_US_CHUNK);
         syb[i] = syw; syw += (im.n_subseq + JS_SY_THREADS - 1) / JS_SY_THREADS;
         max_mcu_h = std::max(max_mcu_h, im.mcu_h); max_mcu_w = std::max(max_mcu_w, im.mcu_w);
@@ -282,6 +290,8 @@ int JsnoopBatch::upload()
         grow(&dev.us_base, &cap.us_base, (n + 1) * 4) || grow(&dev.sy_base, &cap.sy_base, (n + 1) * 4) ||
         grow(&dev.mcu_rst, &cap.mcu_rst, mcub + 64) || grow(&dev.ustr_lin, &cap.ustr_lin, ustr + 64) || grow(&dev.flags, &cap.flags, n * 4 + 64)) return -1;
     if (opt_want_planes && grow(&dev.planes, &cap.planes, plane * 2)) return -1;
+    event_words = opt_events ? (uint64_t)n * (1 + JS_EV_WORDS * JS_EV_MAX) : 0;
+    if (event_words && grow(&dev.events, &cap.events, event_words * 4)) return -1;
     tab_rows = 1; tab_lut2 = 0; for (const JsTableSet& t : tables) { tab_rows = std::max(tab_rows, t.n_rows); tab_lut2 = std::max(tab_lut2, t.lut2_used); }
     HIP_TRY(hipMemcpyAsync(dev.raw, pinned, raw_bytes, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(dev.imgs, imgs.data(), n * sizeof(JsImage), hipMemcpyHostToDevice, stream));
@@ -310,12 +320,13 @@ int JsnoopBatch::decode(bool timed)
     HIP_TRY(hipMemsetAsync(dev.side, 0, side_words * 4, stream));
     HIP_TRY(hipMemsetAsync(dev.mcu_rst, 0, mcu_bytes, stream));
     HIP_TRY(hipMemsetAsync(dev.flags, 0, (size_t)n * 4, stream));
+    if (event_words) HIP_TRY(hipMemsetAsync(dev.events, 0, event_words * 4, stream));
     if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
     // parallel path stages 1..5 (k_unstuff .. k_dc_scan) are launched by js_parallel_entropy
     int used_parallel = opt_force_exact ? 0 : js_parallel_entropy(this, timed);
     if (used_parallel < 0) return -1;
     if (timed && !used_parallel) for (int s = 2; s <= 6; s++) HIP_TRY(hipEventRecord(ev[s], stream));
-    if (!used_parallel) js_launch_entropy_exact(stream, dev.imgs, nullptr, n, dev.tables, dev.raw, dev.coef, dev.dccum, dev.side, 0);
+    if (!used_parallel) js_launch_entropy_exact(stream, dev.imgs, nullptr, n, dev.tables, dev.raw, dev.coef, dev.dccum, dev.side, 0, event_words ? dev.events : nullptr);
     if (timed) HIP_TRY(hipEventRecord(ev[7], stream));
     js_launch_idct_color(stream, dev.imgs, dev.wg_base, n, total_wgs, max_mcu_w, max_mcu_h, d_lut, dev.coef, dev.dccum, dev.dib, dev.planes, dev.side);
     if (timed) HIP_TRY(hipEventRecord(ev[8], stream));
@@ -349,6 +360,7 @@ JsnoopDecoder* jsnoop_create(void)
     d->batch = new JsnoopBatch(nullptr);
     if (d->batch->init()) { delete d->batch; delete d; return nullptr; }
     d->batch->opt_want_planes = 1;        // the reference always keeps m_pPixValY/Cb/Cr
+    d->batch->opt_events = 1;             // ... and writes its messages to CDocLog as it goes
     return d;
 }
 void jsnoop_destroy(JsnoopDecoder* d) { if (!d) return; delete d->batch; delete d; }
@@ -406,14 +418,13 @@ int jsnoop_jfif_walk(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned
 
 void jsnoop_decode_scan_img(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned start, int display, int quiet)
 {
-    (void)quiet;
     d->hist_latched = d->opt_histo_en != 0; d->clip_latched = d->opt_stat_clip_en != 0;      // :2740-2741
     jsnoop_reset(d);
     JsnoopBatch* b = d->batch;
     b->clear();
     b->opt_decode_ac = d->opt_decode_ac;
     d->last_path = 0; d->last_flags = 0;
-    if (b->add(d, file, len, start, display) < 0) return;          // early returns of DecodeScanImg: no preview
+    if (b->add(d, file, len, start, display, quiet) < 0) return;   // early returns of DecodeScanImg: no preview
     d->preview_is_jpeg = false;                                     // :2978
     if (display) memset(d->stats, 0, sizeof d->stats);              // :3145-3155
     if (b->upload() || b->decode(false) || b->sync()) { d->log(2, "*** ERROR: device decode failed: %s", g_err.c_str()); return; }
@@ -422,7 +433,15 @@ void jsnoop_decode_scan_img(JsnoopDecoder* d, const uint8_t* file, size_t len, u
     d->last_path = (int)b->host_path[0]; d->last_flags = b->host_flags[0];
     d->side_ready = d->last_path == 2;          // the exact-mirror kernel fills the side block as it goes
     d->fetch_side();
+    d->pending_log.clear();
     if (display) d->stats_pass();
+    if (d->log_fn) {                        // the reference's log text (messages of the decode loop, then the report)
+        d->ensure_side();
+        js_emit_decode_events(d);
+        if (!quiet) d->log(0, "");                                  // :3630-3632
+        d->flush_pending_log();                                     // CalcChannelPreview's warnings (:3643)
+        js_emit_report(d, display != 0, quiet != 0);
+    }
 }
 
 int  jsnoop_is_preview_ready(JsnoopDecoder* d) { return d->preview_is_jpeg; }
@@ -666,7 +685,7 @@ void JsnoopDecoder::rerender()                                  // CalcChannelPr
     js_launch_idct_color(b->stream, b->dev.imgs, b->dev.wg_base, 1, b->total_wgs, b->max_mcu_w, b->max_mcu_h, b->d_lut, b->dev.coef, b->dev.dccum, b->dev.dib, b->dev.planes, b->dev.side);
     hipStreamSynchronize(b->stream);
     host_valid = 0; fetch_side();
-    stats_pass();
+    stats_pass(); flush_pending_log();
 }
 
 // ConvertYCCtoRGB (:4229) instead of ConvertYCCtoRGBFastFloat when bHistoEn or bStatClipEn (:4742-4747): same pixels,
@@ -674,9 +693,17 @@ void JsnoopDecoder::rerender()                                  // CalcChannelPr
 void JsnoopDecoder::stats_pass()
 {
     if (!have_image || !preview_is_jpeg || !(hist_latched || clip_latched)) return;   // CalcChannelPreview needs the DIB (:4971-4974)
-    if (batch->color_stats_pass(0, hist_latched, stats, &warn_ycc_clip)) log(2, "*** ERROR: colour statistics pass failed: %s", g_err.c_str());
+    const bool want_notes = log_fn != nullptr;
+    if (want_notes) ensure_side();                                  // the warning text quotes the reader's final position (GetScanBufPos)
+    if (batch->color_stats_pass(0, hist_latched, stats, &warn_ycc_clip, want_notes ? &pending_log : nullptr, want_notes ? h_side[4] : 0, want_notes ? h_side[5] : 0))
+        log(2, "*** ERROR: colour statistics pass failed: %s", g_err.c_str());
 }
-int JsnoopBatch::color_stats_pass(int i, bool hist_en, uint32_t* acc, unsigned* warn_used)
+void JsnoopDecoder::flush_pending_log()
+{
+    for (auto& l : pending_log) if (log_fn) log_fn(log_user, l.first, l.second.c_str());
+    pending_log.clear();
+}
+int JsnoopBatch::color_stats_pass(int i, bool hist_en, uint32_t* acc, unsigned* warn_used, std::vector<std::pair<int, std::string>>* notes, uint32_t pos0, uint32_t align)
 {
     if (i < 0 || (size_t)i >= imgs.size() || !opt_want_planes || !uploaded) { js_set_error("colour statistics need a decoded image with planes"); return -1; }
     HIP_TRY(hipSetDevice(device));
@@ -692,17 +719,29 @@ int JsnoopBatch::color_stats_pass(int i, bool hist_en, uint32_t* acc, unsigned* 
     acc[36] += h[36];
     for (int k = 43; k < 50; k++) acc[k] += h[k];                                 // RGB clip counters
     for (int k = 50; k < JS_STATS_WORDS; k++) acc[k] += h[k];                     // histograms
-    // YCC range events: counted only while fewer than YCC_CLIP_REPORT_MAX (10) warnings were issued (:4372-4378)
+    // YCC range events: counted -- and reported -- only while fewer than YCC_CLIP_REPORT_MAX (10) warnings were issued (:4372-4378)
     uint32_t total = 0; for (int k = 0; k < 6; k++) total += h[2482 + k];
     const unsigned left = *warn_used < 10 ? 10 - *warn_used : 0;
-    if (total <= left) { for (int k = 0; k < 6; k++) acc[37 + k] += h[2482 + k]; *warn_used += total; }
+    if (total <= left && !(notes && total)) { for (int k = 0; k < 6; k++) acc[37 + k] += h[2482 + k]; *warn_used += total; }
     else if (left) {
-        js_launch_clip_order(stream, dev.imgs, (uint32_t)i, dev.planes, left, dst);
-        uint32_t first[6];
+        const unsigned take = std::min<uint32_t>(left, total);
+        js_launch_clip_order(stream, dev.imgs, (uint32_t)i, dev.planes, take, dst);
+        uint32_t first[6 + 5 * 10];
         HIP_TRY(hipMemcpyAsync(first, dst, sizeof first, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         for (int k = 0; k < 6; k++) acc[37 + k] += first[k];
-        *warn_used = 10;
+        if (notes) {
+            static const char* kKind[6] = { "Y Overflow", "Y Underflow", "Cb Overflow", "Cb Underflow", "Cr Overflow", "Cr Underflow" };
+            char buf[256];
+            for (unsigned k = 0; k < take; k++) {
+                const uint32_t* r = first + 6 + 5 * k;
+                snprintf(buf, sizeof buf, "*** NOTE: YCC Clipped. MCU=(%4u,%4u) YCC=(%5d,%5d,%5d) %s @ Offset 0x%08X.%u", r[0] & 0xFFFF, r[0] >> 16,
+                         (int)r[2], (int)r[3], (int)r[4], kKind[r[1] % 6], pos0, align);
+                notes->emplace_back(1, buf);
+                if (*warn_used + k + 1 == 10) notes->emplace_back(1, "    Only reported first 10 instances of this message...");
+            }
+        }
+        *warn_used += take;
     }
     return 0;
 }

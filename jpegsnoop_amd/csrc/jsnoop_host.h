@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string>
+#include <utility>
 #include <vector>
 #include "../../include/jsnoop_gpu.h"
 #include "jsnoop_types.h"
@@ -43,20 +45,25 @@ struct JsnoopDecoder {
     // (:3145-3155), accumulated by every CalcChannelPreview; m_nWarnYccClipNum only restarts in Reset() (:130)
     uint32_t stats[2482]; unsigned warn_ycc_clip; bool hist_latched, clip_latched;
     void stats_pass();
+    std::vector<std::pair<int, std::string>> pending_log;          // CapYccRange warnings of the current CalcChannelPreview
+    void flush_pending_log();
 };
 
 struct JsDeviceArenas {
     uint8_t* raw; uint8_t* ustr; int16_t* coef; int16_t* dccum; uint8_t* dib; int16_t* planes; uint32_t* side;
     JsImage* imgs; JsTableSet* tables; uint32_t* wg_base; uint32_t* sel; uint64_t* sums; uint8_t* sub; uint8_t* probe;
     uint32_t* seg; uint32_t* chunk_keep; uint32_t* chunk_rst; uint32_t* us_base; uint32_t* sy_base; uint8_t* mcu_rst; uint32_t* flags; uint8_t* ustr_lin;
+    uint32_t* events;
 };
 struct JsArenaCaps { size_t raw, ustr, coef, dccum, dib, planes, side, imgs, tables, wg_base, sel, sums, sub, probe,
-                            seg, chunk_keep, chunk_rst, us_base, sy_base, mcu_rst, flags, ustr_lin; };
+                            seg, chunk_keep, chunk_rst, us_base, sy_base, mcu_rst, flags, ustr_lin, events; };
 
 struct JsnoopBatch {
     int device; hipStream_t stream; bool own_stream;
-    int color_stats_pass(int i, bool hist_en, uint32_t* acc /*2482 words, accumulated into*/, unsigned* warn_used);
-    int opt_decode_ac, opt_want_planes, opt_force_exact;
+    int color_stats_pass(int i, bool hist_en, uint32_t* acc /*2482 words, accumulated into*/, unsigned* warn_used,
+                         std::vector<std::pair<int, std::string>>* notes = nullptr, uint32_t pos0 = 0, uint32_t align = 0);
+    int opt_decode_ac, opt_want_planes, opt_force_exact, opt_events = 0;   // opt_events: keep the decoder's event log (single-image API)
+    uint64_t event_words = 0;
     std::vector<JsImage> imgs; std::vector<JsTableSet> tables;
     std::vector<uint32_t> host_flags, host_path, h_us_base, h_sy_base;
     uint32_t* d_side_tmp = nullptr; size_t side_tmp_cap = 0;      // scratch of the side-output pass (one image at a time)
@@ -73,7 +80,7 @@ struct JsnoopBatch {
     int  init();
     void clear();
     int  reserve_pinned(size_t need);
-    int  add(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned scan_start, int display);
+    int  add(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned scan_start, int display, int quiet = 1);
     int  tile(int total);
     int  upload();
     int  decode(bool timed);
@@ -84,7 +91,9 @@ struct JsnoopBatch {
 };
 
 void js_set_error(const char* fmt, ...);
-bool js_describe_image(JsnoopDecoder* d, JsImage* im, JsTableSet* ts, uint32_t file_len, uint32_t scan_start, int display);
+bool js_describe_image(JsnoopDecoder* d, JsImage* im, JsTableSet* ts, uint32_t file_len, uint32_t scan_start, int display, int quiet);
+void js_emit_decode_events(JsnoopDecoder* d);                      // jsnoop_report.cpp
+void js_emit_report(JsnoopDecoder* d, bool display, bool quiet);
 void js_build_parallel_luts(JsTableSet* ts, uint32_t ncomp);          // jsnoop_parallel.cpp
 int  js_parallel_entropy(JsnoopBatch* b, bool timed);                 // 1 = launched, 0 = not applicable, <0 error
 int  js_parallel_fixup(JsnoopBatch* b);

@@ -44,7 +44,17 @@ struct ExactReader {
     uint32_t scan_end, scan_bad, cur_err, restart_read;
     uint32_t rst_count, rst_last, rst_expect, mcus_left, rst_interval, warn_bad, err_max;
     uint32_t used1, used2, precision, rst_handled;
+    uint32_t* ev; uint32_t ev_cap, ev_only;                    // event log (JS_EV_*): nullptr = off; ev_only != 0: record just that kind
 };
+
+// One line (group) of what the reference writes to its log while decoding; formatted on the host (jsnoop_report.cpp).
+__device__ void ex_event(ExactReader& r, uint32_t kind, uint32_t a0 = 0, uint32_t a1 = 0, uint32_t a2 = 0, uint32_t a3 = 0, uint32_t a4 = 0)
+{
+    if (!r.ev || (r.ev_only && r.ev_only != kind)) return;
+    const uint32_t n = r.ev[0];
+    if (n < r.ev_cap) { uint32_t* e = r.ev + 1 + (size_t)n * JS_EV_WORDS; e[0] = kind; e[1] = a0; e[2] = a1; e[3] = a2; e[4] = a3; e[5] = a4; }
+    r.ev[0] = n + 1;
+}
 
 __device__ __forceinline__ uint32_t ex_byte(const ExactReader& r, uint32_t off) { return off < r.flen ? r.file[off] : 0u; }
 
@@ -82,11 +92,13 @@ __device__ void ex_add_byte(ExactReader& r)                                     
     if (r.restart_read) return;
     uint32_t b0 = ex_byte(r, r.ptr), b1 = ex_byte(r, r.ptr + 1);
     if (b0 == 0xFF && b1 >= 0xD0 && b1 <= 0xD7) {
-        r.rst_count++; r.rst_last = b1 - 0xD0; r.rst_expect = (r.rst_last + 1) & 7; r.restart_read = 1; return;
+        r.rst_count++; r.rst_last = b1 - 0xD0;
+        if (r.rst_last != r.rst_expect) ex_event(r, JS_EV_RST_INDEX, r.rst_expect, r.rst_last, r.ptr);       // :1416-1423
+        r.rst_expect = (r.rst_last + 1) & 7; r.restart_read = 1; return;
     }
     if (b0 == 0xFF && b1 == 0x00)      { ex_add(r, b0, r.ptr, SB_OK); r.ptr += 2; }
     else if (b0 == 0xFF && b1 == 0xFF) { ex_add(r, b0, r.ptr, SB_OK); r.ptr += 1; }
-    else if (b0 == 0xFF)               { if (r.warn_bad < r.err_max) r.warn_bad++; ex_add(r, b0, r.ptr, SB_BADMARK); r.ptr += 1; }
+    else if (b0 == 0xFF)               { if (r.warn_bad < r.err_max) { ex_event(r, JS_EV_MARKER, b1, r.ptr); r.warn_bad++; } ex_add(r, b0, r.ptr, SB_BADMARK); r.ptr += 1; }
     else                               { ex_add(r, b0, r.ptr, SB_OK); r.ptr += 1; }
 }
 __device__ void ex_topup(ExactReader& r)                                                // BuffTopup :1292-1323
@@ -103,7 +115,7 @@ __device__ int ex_read_scan_val(ExactReader& r, uint32_t t, uint32_t& zrl, int32
     uint32_t code = JS_CODE_UNUSED, ind = 0; bool done = false, found = false;
     r.used1 = r.used2 = 0; zrl = 0; val = 0;
     if (r.vacant == 32 && r.restart_read) return RSV_RST_TERM;
-    if (r.vacant >= 32) { if (r.warn_bad < r.err_max) r.warn_bad++; r.scan_end = 1; r.scan_bad = 1; return RSV_UNDERFLOW; }
+    if (r.vacant >= 32) { if (r.warn_bad < r.err_max) { ex_event(r, JS_EV_OVERREAD_BEFORE, r.pos0, r.align); r.warn_bad++; } r.scan_end = 1; r.scan_bad = 1; return RSV_UNDERFLOW; }
     ex_topup(r);
     if ((32 - r.vacant) >= JS_FAST_BITS) {
         uint32_t f = r.ts->fast[t][r.buff >> (32 - JS_FAST_BITS)];
@@ -124,7 +136,7 @@ __device__ int ex_read_scan_val(ExactReader& r, uint32_t t, uint32_t& zrl, int32
     }
     if (r.used1 < 17) r.histo[((t & 1) * 4 + r.ts->dest_id[t]) * 17 + r.used1]++;
     ex_consume(r, r.used1);
-    if (r.vacant > 32) { r.scan_end = 1; r.scan_bad = 1; return RSV_UNDERFLOW; }
+    if (r.vacant > 32) { ex_event(r, JS_EV_OVERREAD_CODE, r.pos0, r.align); r.scan_end = 1; r.scan_bad = 1; return RSV_UNDERFLOW; }
     ex_topup(r);
     if (code != JS_CODE_UNUSED) {
         zrl = (code & 0xF0) >> 4; r.used2 = code & 0x0F;
@@ -134,10 +146,10 @@ __device__ int ex_read_scan_val(ExactReader& r, uint32_t t, uint32_t& zrl, int32
         val = v >= (1u << (r.used2 - 1)) ? (int32_t)v : (int32_t)(v - ((1u << r.used2) - 1));   // HuffmanDc2Signed :859
         if (r.precision >= 8) val /= (int32_t)(1u << ((r.precision - 8) & 31));
         ex_consume(r, r.used2);
-        if (r.vacant > 32) { r.scan_end = 1; r.scan_bad = 1; return RSV_UNDERFLOW; }
+        if (r.vacant > 32) { ex_event(r, JS_EV_OVERREAD_BITS, r.pos0, r.align); r.scan_end = 1; r.scan_bad = 1; return RSV_UNDERFLOW; }
         return RSV_OK;
     }
-    if (r.warn_bad < r.err_max) r.warn_bad++;
+    if (r.warn_bad < r.err_max) { ex_event(r, JS_EV_CANT_FIND, r.pos0, r.align, r.ts->dest_id[t], r.buff); r.warn_bad++; }   // :1266-1277
     r.scan_bad = 1;
     return RSV_UNDERFLOW;
 }
@@ -152,7 +164,7 @@ __device__ int16_t ex_decode_block(ExactReader& r, uint32_t comp, uint32_t decod
     uint32_t zrl, ncoef = 0; int32_t val; bool done = false, is_dc = true, failed = false; int16_t dct0 = 0;
     while (!done) {
         ex_topup(r);
-        uint32_t saved_err = r.latch;
+        const uint32_t saved_err = r.latch, saved_pos = r.pos0, saved_align = r.align;
         int rv = ex_read_scan_val(r, is_dc ? tdc : tac, zrl, val);
         if (rv == RSV_RST_TERM) {                               // marker-driven restart :1644-1680
             dc_y = dc_cb = dc_cr = 0; r.rst_handled++;      // DecodeRestartDcState :2693
@@ -160,12 +172,12 @@ __device__ int16_t ex_decode_block(ExactReader& r, uint32_t comp, uint32_t decod
             ex_topup(r);
             rv = ex_read_scan_val(r, is_dc ? tdc : tac, zrl, val);
         }
-        if (saved_err == SB_BADMARK) { r.cur_err = 1; r.scan_bad = 1; if (r.warn_bad < r.err_max) r.warn_bad++; r.latch = SB_OK; }
+        if (saved_err == SB_BADMARK) { r.cur_err = 1; r.scan_bad = 1; if (r.warn_bad < r.err_max) { ex_event(r, JS_EV_BAD_MARKER, saved_pos, saved_align); r.warn_bad++; } r.latch = SB_OK; }
         int16_t v16 = (int16_t)(val & 0xFFFF);
         bool store = false;
         if (rv == RSV_OK)       { if (is_dc) { store = true; is_dc = false; } else store = decode_ac != 0; }
         else if (rv == RSV_EOB) { if (is_dc) { store = true; is_dc = false; } else done = true; }
-        else if (rv == RSV_UNDERFLOW) { if (r.warn_bad < r.err_max) r.warn_bad++; r.cur_err = 1; failed = true; break; }
+        else if (rv == RSV_UNDERFLOW) { if (r.warn_bad < r.err_max) { ex_event(r, JS_EV_BAD_HUFF, saved_pos, saved_align); r.warn_bad++; } r.cur_err = 1; failed = true; break; }
         if (store) {                                            // DecodeIdctSet :2270-2303
             uint32_t ind = ncoef + zrl;
             if (ind < 64) {
@@ -176,7 +188,7 @@ __device__ int16_t ex_decode_block(ExactReader& r, uint32_t comp, uint32_t decod
         }
         ncoef += 1 + zrl;
         if (ncoef == 64) done = true;
-        else if (ncoef > 64) { if (r.warn_bad < r.err_max) r.warn_bad++; r.cur_err = 1; r.scan_bad = 1; done = true; }
+        else if (ncoef > 64) { if (r.warn_bad < r.err_max) { ex_event(r, JS_EV_NUMCOEF, saved_pos, saved_align, ncoef); r.warn_bad++; } r.cur_err = 1; r.scan_bad = 1; done = true; }
     }
     if (failed) for (int i = 1; i < 64; i++) out[i] = 0;         // IDCT skipped (:1737-1757): AC contributes 0.0f
     out[0] = dct0;
@@ -185,7 +197,8 @@ __device__ int16_t ex_decode_block(ExactReader& r, uint32_t comp, uint32_t decod
 
 __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sel, uint32_t nsel,
                                                       const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ raw,
-                                                      int16_t* __restrict__ coef, int16_t* __restrict__ dccum, uint32_t* __restrict__ side, int side_only)
+                                                      int16_t* __restrict__ coef, int16_t* __restrict__ dccum, uint32_t* __restrict__ side, int side_only,
+                                                      uint32_t* __restrict__ events)
 {
     // side_only: recompute only the decoder's side outputs (MCU file map, block-DC maps, code-length
     // histogram, status words) for an image whose pixels came from the parallel path.
@@ -202,6 +215,7 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
     r.file = raw + im.file_off; r.flen = im.file_len; r.ts = tables + im.tableset; r.histo = sd + JS_SIDE_HISTO;
     r.rst_interval = im.rst_interval; r.precision = im.precision; r.err_max = im.err_max; r.warn_bad = 0;
     r.rst_count = 0; r.rst_last = 0; r.rst_expect = 0; r.rst_handled = 0;
+    r.ev = (im.ev_cap && !side_only) ? events + im.ev_off : nullptr; r.ev_cap = im.ev_cap; r.ev_only = 0;
     ex_restart_scan_buf(r, im.scan_start, false);
     int16_t dc_y = 0, dc_cb = 0, dc_cr = 0;
     int16_t css[3][16];
@@ -215,6 +229,7 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
         bool stop = false;
         for (uint32_t mx = 0; mx < im.mcu_xmax && !stop; mx++) {
             const uint32_t mi = my * im.mcu_xmax + mx;
+            if (im.rst_en && r.mcus_left == 0 && !r.restart_read) ex_event(r, JS_EV_RST_NOT_DETECTED, r.pos0, r.align);   // :3180-3200
             mcu_map[mi] = (r.pos0 << 4) + r.align;                        // PackFileOffset :5104
             for (uint32_t c = 0; c < im.blk_per_mcu; c++) {
                 const uint32_t comp = im.blk_comp[c];
@@ -222,7 +237,9 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
                 const uint32_t rst_before = r.rst_handled;
                 int16_t d0 = ex_decode_block(r, comp, im.decode_ac, side_only ? scratch : cbase + b * 64, dc_y, dc_cb, dc_cr);
                 if (r.rst_handled != rst_before) for (int cc = 0; cc < 3; cc++) for (int i = 0; i < 16; i++) css[cc][i] = 0;
-                if (r.cur_err) { if (r.warn_bad < r.err_max) r.warn_bad++; r.cur_err = 0; }   // CheckScanErrors :2605
+                if (r.cur_err) {                                          // CheckScanErrors :2605
+                    if (r.warn_bad < r.err_max) { ex_event(r, JS_EV_BAD_SCAN_MCU, mx | (my << 16), comp | (im.blk_ch[c] << 8) | (im.blk_cv[c] << 16), r.pos0, r.align); r.warn_bad++; }
+                    r.cur_err = 0; }
                 int16_t* acc = comp == 1 ? &dc_y : comp == 2 ? &dc_cb : &dc_cr;
                 *acc = (int16_t)(*acc + d0);
                 css[comp - 1][im.blk_cv[c] * 4 + im.blk_ch[c]] = *acc;
@@ -678,11 +695,13 @@ __global__ void __launch_bounds__(ST_THREADS) k_color_stats(const JsImage* __res
     if (hist_en) for (uint32_t i = t; i < 3 * 128 + 2048; i += ST_THREADS) { const uint32_t v = s_bins[i]; if (v) atomicAdd(&stats[50 + i], v); }
 }
 
-// The first `budget` YCC range events of the image in the reference's visiting order: pixels in raster order, within
-// a pixel Y over, Y under, Cb over, Cb under, Cr over, Cr under (:4370-4462).  One workgroup, 1024 pixels per
-// step, stops as soon as the budget is used up.  out6 is indexed like PixelCcClip (Y<0, Y>255, Cb<0, Cb>255, Cr<0, Cr>255).
+// The first `budget` (<= 10) YCC range events of the image in the reference's visiting order: pixels in raster order,
+// within a pixel Y over, Y under, Cb over, Cb under, Cr over, Cr under (:4370-4462).  One workgroup, 1024 pixels per
+// step, stops as soon as the budget is used up.  out[0..5] is indexed like PixelCcClip (Y<0, Y>255, Cb<0, Cb>255, Cr<0,
+// Cr>255); out[6 + 5*k ..] describes event k for the warning text: MCU x | y << 16, kind (0 Y over, 1 Y under, 2 Cb
+// over, ...), and the three values as the message prints them (earlier clips of the same pixel already applied).
 __global__ void __launch_bounds__(1024) k_clip_order(const JsImage* __restrict__ imgs, uint32_t img, const int16_t* __restrict__ planes,
-                                                     uint32_t budget, uint32_t* __restrict__ out6)
+                                                     uint32_t budget, uint32_t* __restrict__ out)
 {
     __shared__ uint32_t s_scan[1024]; __shared__ uint32_t s_out[6]; __shared__ uint32_t s_run;
     const JsImage& im = imgs[img];
@@ -694,31 +713,43 @@ __global__ void __launch_bounds__(1024) k_clip_order(const JsImage* __restrict__
     __syncthreads();
     for (uint32_t base = 0; base < npix; base += 1024) {
         uint32_t ev = 0;                                         // bit 2c: component c over, bit 2c+1: component c under
+        StatPix q;
         if (base + t < npix) {
-            StatPix q; stat_pixel(im, pl, base + t, shift_ind, q);
+            stat_pixel(im, pl, base + t, shift_ind, q);
             for (int c = 0; c < 3; c++) ev |= (q.clipv[c] > 255 ? 1u : 0u) << (2 * c) | (q.clipv[c] < 0 ? 2u : 0u) << (2 * c);
         }
         const uint32_t cnt = (uint32_t)__builtin_popcount(ev);
         s_scan[t] = cnt; __syncthreads();
         for (uint32_t d = 1; d < 1024; d <<= 1) { const uint32_t a = t >= d ? s_scan[t - d] : 0; __syncthreads(); s_scan[t] += a; __syncthreads(); }
         uint32_t ord = s_run + s_scan[t] - cnt;
-        for (uint32_t e = ev; e; e &= e - 1, ord++)
-            if (ord < budget) { const uint32_t bit = (uint32_t)__builtin_ctz(e); atomicAdd(&s_out[(bit >> 1) * 2 + ((bit & 1) ? 0 : 1)], 1u); }
+        if (ev) {
+            const uint32_t p = base + t, py = p / im.img_x, px = p - py * im.img_x;
+            int cur[3] = { q.clipv[0], q.clipv[1], q.clipv[2] };
+            for (uint32_t e = ev; e; e &= e - 1, ord++) {
+                const uint32_t bit = (uint32_t)__builtin_ctz(e), c = bit >> 1;
+                if (ord < budget) {
+                    atomicAdd(&s_out[c * 2 + ((bit & 1) ? 0 : 1)], 1u);
+                    uint32_t* r = out + 6 + ord * 5;
+                    r[0] = (px / im.mcu_w) | ((py / im.mcu_h) << 16); r[1] = bit; r[2] = (uint32_t)cur[0]; r[3] = (uint32_t)cur[1]; r[4] = (uint32_t)cur[2];
+                }
+                cur[c] = (bit & 1) ? 0 : 255;
+            }
+        }
         __syncthreads();
         if (t == 1023) s_run += s_scan[1023];
         __syncthreads();
         if (s_run >= budget) break;
     }
     __syncthreads();
-    if (t < 6) out6[t] = s_out[t];
+    if (t < 6) out[t] = s_out[t];
 }
 
 // ------------------------------------------------------------------------------ launch wrappers
 void js_launch_entropy_exact(hipStream_t st, const JsImage* imgs, const uint32_t* sel, uint32_t nsel, const JsTableSet* tables,
-                             const uint8_t* raw, int16_t* coef, int16_t* dccum, uint32_t* side, int side_only)
+                             const uint8_t* raw, int16_t* coef, int16_t* dccum, uint32_t* side, int side_only, uint32_t* events)
 {
     if (!nsel) return;
-    hipLaunchKernelGGL(k_entropy_exact, dim3((nsel + 63) / 64), dim3(64), 0, st, imgs, sel, nsel, tables, raw, coef, dccum, side, side_only);
+    hipLaunchKernelGGL(k_entropy_exact, dim3((nsel + 63) / 64), dim3(64), 0, st, imgs, sel, nsel, tables, raw, coef, dccum, side, side_only, events);
 }
 void js_launch_idct_color(hipStream_t st, const JsImage* imgs, const uint32_t* wg_base, uint32_t nimg, uint32_t total_wgs, uint32_t max_mcu_w, uint32_t max_mcu_h,
                           const float* lut_t, const int16_t* coef, const int16_t* dccum, uint8_t* dib, int16_t* planes, uint32_t* side)
@@ -1416,9 +1447,12 @@ __device__ uint32_t raw_of_compacted(const JsImage& im, const uint8_t* __restric
 // Returns the number of RSTn markers the reference has seen before the point the walk started from.
 __device__ uint32_t mirror_to_mcu_top(const JsImage& im, const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ raw, const uint32_t* __restrict__ st,
                                       uint32_t nseg, uint32_t total_bytes, const uint8_t* __restrict__ mcu_rst, const uint32_t* __restrict__ mcu_pos,
-                                      const uint32_t* __restrict__ us_out, uint32_t us_threads, uint32_t m_top, ExactReader& r, uint32_t* dummy_histo, int16_t* scratch)
+                                      const uint32_t* __restrict__ us_out, uint32_t us_threads, uint32_t m_top, ExactReader& r, uint32_t* dummy_histo, int16_t* scratch,
+                                      uint32_t* events)
 {
     r.file = raw + im.file_off; r.flen = im.file_len; r.ts = tables + im.tableset; r.histo = dummy_histo;
+    // the markers the look-ahead runs into at the end of the scan (":  Scan Data encountered marker", :1536) are logged from here
+    r.ev = (events && im.ev_cap) ? events + im.ev_off : nullptr; r.ev_cap = im.ev_cap; r.ev_only = JS_EV_MARKER;
     r.rst_interval = im.rst_interval; r.precision = im.precision; r.err_max = im.err_max; r.warn_bad = 0;
     r.rst_count = 0; r.rst_last = 0; r.rst_expect = 0; r.rst_handled = 0;
     uint32_t m0 = m_top ? m_top - 1 : 0, rst_before = 0;
@@ -1453,7 +1487,7 @@ __device__ uint32_t mirror_to_mcu_top(const JsImage& im, const JsTableSet* __res
 __global__ void __launch_bounds__(256) k_side_maps(const JsImage* __restrict__ imgs, uint32_t img, const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ raw,
                                                    const uint32_t* __restrict__ seg_tab, const int16_t* __restrict__ dccum, const uint8_t* __restrict__ mcu_rst,
                                                    const uint32_t* __restrict__ mcu_pos, const uint32_t* __restrict__ us_out, uint32_t us_threads,
-                                                   uint32_t* __restrict__ side)
+                                                   uint32_t* __restrict__ side, uint32_t* __restrict__ events)
 {
     const JsImage& im = imgs[img];
     uint32_t* sd = side + im.side_off;
@@ -1472,7 +1506,8 @@ __global__ void __launch_bounds__(256) k_side_maps(const JsImage* __restrict__ i
             // what an empty register still shows depends on how its last bytes were loaded, and the end of the scan is where the
             // look-ahead meets EOI / trailing bytes: take both from the mirror reader itself
             uint32_t dummy_histo[2 * 4 * 17]; int16_t scratch[64]; ExactReader r;
-            const uint32_t before = mirror_to_mcu_top(im, tables, raw, st, nseg, sd[10], mcu_rst, mcu_pos, us_out, us_threads, m, r, dummy_histo, scratch);
+            const uint32_t before = mirror_to_mcu_top(im, tables, raw, st, nseg, sd[10], mcu_rst, mcu_pos, us_out, us_threads, m, r, dummy_histo, scratch,
+                                                      m == nmcu ? events : nullptr);
             if (m < nmcu) mcu_map[m] = (r.pos0 << 4) + r.align;
             else {                                                  // status words after the last MCU
                 sd[0] = r.scan_bad; sd[1] = r.scan_end; sd[2] = before + r.rst_count; sd[3] = nmcu * im.samp_h[1] * im.samp_v[1] * 64u;
@@ -1502,7 +1537,7 @@ __global__ void __launch_bounds__(256) k_side_maps(const JsImage* __restrict__ i
 void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* us_base, const uint32_t* sy_base, uint32_t nimg,
                          uint32_t img, uint32_t us_wg0, uint32_t us_wgs, uint32_t sy_wg0, uint32_t sy_wgs, const JsTableSet* tables, const uint8_t* raw,
                          const uint32_t* chunk_keep, const uint32_t* chunk_rst, const uint8_t* ustr, uint32_t* seg_tab, uint32_t* side, uint32_t* sub, uint64_t nsub,
-                         const int16_t* dccum, uint8_t* mcu_rst, uint32_t* mcu_pos, uint32_t* us_out)
+                         const int16_t* dccum, uint8_t* mcu_rst, uint32_t* mcu_pos, uint32_t* us_out, uint32_t* events)
 {
     if (!us_wgs || !sy_wgs) return;
     hipLaunchKernelGGL(k_unstuff_write, dim3(us_wgs), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, (uint8_t*)nullptr, seg_tab, us_wg0, us_out);
@@ -1510,7 +1545,7 @@ void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab
                        sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos);
     else hipLaunchKernelGGL((k_write<5, true>), dim3(sy_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos);
-    hipLaunchKernelGGL(k_side_maps, dim3(64), dim3(256), 0, st, imgs, img, tables, raw, seg_tab, dccum, mcu_rst, mcu_pos, us_out, us_wgs * US_THREADS, side);
+    hipLaunchKernelGGL(k_side_maps, dim3(64), dim3(256), 0, st, imgs, img, tables, raw, seg_tab, dccum, mcu_rst, mcu_pos, us_out, us_wgs * US_THREADS, side, events);
 }
 void js_launch_dc_scan(hipStream_t st, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, int16_t* dccum, const uint8_t* mcu_rst)
 { if (nimg) hipLaunchKernelGGL(k_dc_scan, dim3(nimg), dim3(DC_THREADS), 0, st, imgs, tables, dccum, mcu_rst); }

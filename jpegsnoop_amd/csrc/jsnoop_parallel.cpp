@@ -104,7 +104,7 @@ int JsnoopBatch::run_exact(const std::vector<uint32_t>& which)
         HIP_TRY(hipMemsetAsync(dev.side + im.side_off, 0, (size_t)js_side_words(im.mcu_xmax * im.mcu_ymax, im.blk_xmax * im.blk_ymax) * 4, stream));
     }
     HIP_TRY(hipMemcpyAsync(dev.sel, which.data(), which.size() * 4, hipMemcpyHostToDevice, stream));
-    js_launch_entropy_exact(stream, dev.imgs, dev.sel, (uint32_t)which.size(), dev.tables, dev.raw, dev.coef, dev.dccum, dev.side, 0);
+    js_launch_entropy_exact(stream, dev.imgs, dev.sel, (uint32_t)which.size(), dev.tables, dev.raw, dev.coef, dev.dccum, dev.side, 0, event_words ? dev.events : nullptr);
     js_launch_idct_color(stream, dev.imgs, dev.wg_base, (uint32_t)imgs.size(), total_wgs, max_mcu_w, max_mcu_h, d_lut, dev.coef, dev.dccum, dev.dib, dev.planes, dev.side);
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipGetLastError());
@@ -185,10 +185,10 @@ int js_side_only(JsnoopBatch* b, uint32_t i)
         HIP_TRY(hipMemsetAsync(mcu_pos, 0, ((size_t)nmcu + 1) * 4, b->stream));
         js_launch_side_pass(b->stream, b->sub_wl, b->tab_rows, b->tab_lut2, b->dev.imgs, b->dev.us_base, b->dev.sy_base, (uint32_t)b->imgs.size(), i, us0, usn, sy0, syn,
                             b->dev.tables, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst, b->dev.ustr, b->dev.seg, b->dev.side, (uint32_t*)b->dev.sub, b->total_subseq,
-                            b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out);
+                            b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out, b->event_words ? b->dev.events : nullptr);
     } else {
         HIP_TRY(hipMemcpyAsync(b->dev.sel, &i, 4, hipMemcpyHostToDevice, b->stream));
-        js_launch_entropy_exact(b->stream, b->dev.imgs, b->dev.sel, 1, b->dev.tables, b->dev.raw, b->dev.coef, b->dev.dccum, b->dev.side, 1);
+        js_launch_entropy_exact(b->stream, b->dev.imgs, b->dev.sel, 1, b->dev.tables, b->dev.raw, b->dev.coef, b->dev.dccum, b->dev.side, 1, nullptr);
     }
     HIP_TRY(hipStreamSynchronize(b->stream));
     HIP_TRY(hipGetLastError());

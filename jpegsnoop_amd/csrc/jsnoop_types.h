@@ -68,7 +68,15 @@ struct JsImage {
     // preview controls (SetPreviewMode :633, SetPreviewYccOffset :650)
     uint32_t preview_mode; int32_t shift_y, shift_cb, shift_cr; uint32_t shift_mcu_x, shift_mcu_y;
     uint32_t err_max;
+    // event log of the exact-mirror reader (what the reference writes to CDocLog while it decodes); 0 capacity = off
+    uint64_t ev_off; uint32_t ev_cap;
 };
+
+// Event records (6 u32 each, preceded by one count word per image): what the reference logs during the scan decode.
+#define JS_EV_WORDS 6
+#define JS_EV_MAX   1024
+enum { JS_EV_OVERREAD_BEFORE = 1, JS_EV_OVERREAD_CODE, JS_EV_OVERREAD_BITS, JS_EV_CANT_FIND, JS_EV_RST_INDEX, JS_EV_MARKER,
+       JS_EV_BAD_MARKER, JS_EV_BAD_HUFF, JS_EV_NUMCOEF, JS_EV_BAD_SCAN_MCU, JS_EV_RST_NOT_DETECTED };
 
 // Per-image side block (u32 words, in this order):
 //   [0..15]   status: 0 scan_bad, 1 scan_end, 2 #RST read, 3 num_pixels, 4 pos0, 5 align, 6 warn_bad, 7 first,

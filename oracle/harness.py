@@ -218,6 +218,16 @@ class Backend:
         f("set_preview_ycc_offset").argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int]
         f("get_color_stats" if prefix == "jsnoop_" else "color_stats").argtypes = [C.c_void_p, C.c_void_p]
         self.h = f("create")()
+        self._log = []
+        if prefix == "jsnoop_":           # CDocLog replacement: collect (level, text) like the shim's ShimLog does for the reference
+            LOGFN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_char_p)
+            self._log_cb = LOGFN(lambda _u, level, text: self._log.append(("", "W:", "E:")[min(max(level, 0), 2)] + text.decode()))
+            f("set_log_callback").argtypes = [C.c_void_p, LOGFN, C.c_void_p]
+            f("set_log_callback")(self.h, self._log_cb, None)
+        elif prefix == "jsref_":
+            lib.jsref_log_count.restype = C.c_size_t
+            lib.jsref_log_line.restype = C.c_char_p
+            lib.jsref_log_line.argtypes = [C.c_size_t]
 
     def _f(self, name):
         return getattr(self.lib, self.prefix + name)
@@ -291,6 +301,15 @@ class Backend:
         s = (C.c_int * 10)()
         self._f("bright_avg")(self.h, s)
         return list(s)
+
+    def log_reset(self):
+        self._log.clear()
+
+    def log_lines(self):
+        """Text written to the log since the last decode: 'W:' / 'E:' prefix AddLineWarn / AddLineErr lines."""
+        if self.prefix == "jsref_":
+            return [self.lib.jsref_log_line(i).decode() for i in range(self.lib.jsref_log_count())]
+        return list(self._log)
 
     def color_stats(self):
         """bHistoEn / bStatClipEn statistics: dict of the PixelCcHisto ints, the PixelCcClip counters and the histograms."""
@@ -370,5 +389,6 @@ def drive(b: Backend, data: bytes, parsed: ParsedJpeg | None = None, display=1, 
     p = parsed or parse_jpeg(data)
     push_tables(b, p)
     buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    b.log_reset()
     b.decode_scan_img(C.cast(buf, C.c_void_p), len(data), p.scan_start, display, quiet)
     return p

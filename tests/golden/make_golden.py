@@ -60,6 +60,23 @@ def histo_record(b, data):
     return r
 
 
+def log_record(b, data):
+    """The text DecodeScanImg(nStart, true, false) writes to CDocLog (shim: 'W:' / 'E:' mark AddLineWarn / AddLineErr),
+    with the histogram path off and on (the second adds the colour-statistics lines and the YCC clip warnings)."""
+    out = {}
+    for key, histo in (("plain", 0), ("histo", 1)):
+        b.set_options(decode_ac=1, histo_en=histo)
+        H.drive(b, data, quiet=0)
+        out[key] = b.log_lines()
+    b.set_options(decode_ac=0)
+    H.drive(b, data, quiet=0)
+    out["dc_only"] = b.log_lines()
+    b.set_options(decode_ac=1)
+    H.drive(b, data, quiet=1)
+    out["quiet"] = b.log_lines()
+    return out
+
+
 def corrupt(data, mode, rng):
     d = bytearray(data)
     p = H.parse_jpeg(data)
@@ -105,6 +122,20 @@ def main():
     for bi, bname in enumerate(base_for_corrupt):
         for mode in ("flip", "trunc", "marker", "ffff", "delete", "stray_rst"):
             files[f"bad_{mode}_{bname}"] = corrupt(files[bname], mode, rng)
+    # restart bookkeeping messages on scans that decode fine: wrong RSTn numbering; a DRI that announces a shorter
+    # interval than the stream uses (markers are honoured where they are, "Restart marker not detected" where they are not)
+    d = bytearray(files["422_rst_row_160x64"])
+    pj = H.parse_jpeg(bytes(d)); k = 0
+    for i in range(pj.scan_start, len(d) - 1):
+        if d[i] == 0xFF and 0xD0 <= d[i + 1] <= 0xD7:
+            k += 1
+            if k in (2, 5): d[i + 1] = 0xD0 + ((d[i + 1] - 0xD0 + 3) & 7)
+    files["rstnum_422_rst_row_160x64"] = bytes(d)
+    d = bytearray(files["422_rst_row_160x64"])
+    i = d.find(b"\xff\xdd\x00\x04")
+    assert i > 0 and d[i + 4:i + 6] == b"\x00\x0a"
+    d[i + 5] = 4
+    files["dri4_422_rst_row_160x64"] = bytes(d)
     for name, data in files.items():
         with open(os.path.join(HERE, name + ".jpg"), "wb") as f:
             f.write(data)
@@ -115,6 +146,7 @@ def main():
             entry[mode] = record(ref)
         ref.set_options(decode_ac=1)
         entry["histo_en"] = histo_record(ref, data)
+        entry["log"] = log_record(ref, data)
         manifest["cases"][name] = entry
     # known-answer values of the two fp32 stages, straight from the compiled reference
     lut = ref.idct_lut()

@@ -171,6 +171,27 @@ def test_parallel_side_outputs(harness, oracle, gpu):
             raise AssertionError(f"case {k}: {e}")
 
 
+def test_decode_log_text(harness, gpu):
+    """The text DecodeScanImg writes to the log (messages of the decode loop, statistics report, YCC clip warnings),
+    line for line against what the compiled reference wrote (tests/golden/manifest.json): Full IDCT, histogram path,
+    DC-only and quiet mode; well-formed, corrupted and restart-bookkeeping cases."""
+    from golden_util import load_case, manifest
+    M = manifest()
+    bad = []
+    for name in sorted(M["cases"]):
+        data = load_case(name)
+        want = M["cases"][name]["log"]
+        for key, opt, quiet in (("plain", dict(decode_ac=1), 0), ("histo", dict(decode_ac=1, histo_en=1), 0), ("dc_only", dict(decode_ac=0), 0), ("quiet", dict(decode_ac=1), 1)):
+            gpu.set_options(**opt)
+            harness.drive(gpu, data, quiet=quiet)
+            got = gpu.log_lines()
+            if got != want[key]:
+                k = next((i for i, (a, b) in enumerate(zip(got, want[key])) if a != b), min(len(got), len(want[key])))
+                bad.append(f"{name} [{key}] line {k}: got {got[k] if k < len(got) else None!r} want {want[key][k] if k < len(want[key]) else None!r} ({len(got)} vs {len(want[key])} lines)")
+    gpu.set_options()
+    assert not bad, "\n".join(bad[:25]) + f"\n... {len(bad)} mismatching logs"
+
+
 def test_histogram_path(harness, oracle, gpu):
     """bHistoEn / bStatClipEn colour statistics: the committed records of the compiled reference,
     then the oracle on fresh streams (incl. corrupted ones whose DC drift trips the YCC range checks and their
