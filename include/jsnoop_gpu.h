@@ -105,6 +105,11 @@ void     jsnoop_set_preview_mode(JsnoopDecoder*, unsigned mode);
 unsigned jsnoop_get_preview_mode(JsnoopDecoder*);
 void     jsnoop_set_preview_ycc_offset(JsnoopDecoder*, unsigned mcu_x, unsigned mcu_y, int y, int cb, int cr);
 
+/* ---- Export to TIFF (CJPEGsnoopDoc::OnToolsExporttiff, source/JPEGsnoopDoc.cpp:2008-2190, FileTiff::WriteFile
+ *      source/FileTiff.cpp:436): mode 0 = RGB 8 bit, 1 = RGB 16 bit, 2 = YCC 8 bit (three-component images); byte-identical
+ *      to the reference's file.  The pixel strip is arranged on the device.  0 on success, -1 + jsnoop_last_error().  */
+int jsnoop_export_tiff(JsnoopDecoder*, const char* path, int mode);
+
 /* ---- decoder internals that the reference keeps in public/inspectable members and
  *      that the log / hover UI consume (side outputs).
  *      Layouts match oracle/ref_shim/ref_driver.cpp so the same parity script runs

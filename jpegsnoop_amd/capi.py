@@ -58,6 +58,7 @@ SIGNATURES = {
     "jsnoop_scan_status": (None, [_p, _PU]),
     "jsnoop_bright_avg": (None, [_p, _PI]),
     "jsnoop_get_color_stats": (None, [_p, _p]),
+    "jsnoop_export_tiff": (_i, [_p, C.c_char_p, _i]),
     "jsnoop_idct_lut": (_p, [_p]),
     "jsnoop_dht_lookupfast": (_p, [_p]),
     "jsnoop_idct_block": (None, [_p, _p, _p]),

@@ -91,6 +91,8 @@ public:
     // bHistoEn / bStatClipEn statistics (m_sHisto, m_sStatClip, m_anCcHisto_r/g/b, m_anHistoYFull; ImgDecode.h:220-279, :656-661)
     // as one JSNOOP_STATS_WORDS record, see include/jsnoop_gpu.h
     void GetColorStats(uint32_t* pStats) { jsnoop_get_color_stats(m_h, pStats); }
+    // Export to TIFF (CJPEGsnoopDoc::OnToolsExporttiff + FileTiff::WriteFile): nMode 0 RGB8, 1 RGB16, 2 YCC8
+    bool ExportTiff(const std::string& strFnameOut, int nMode) { return jsnoop_export_tiff(m_h, strFnameOut.c_str(), nMode) == 0; }
     unsigned PackFileOffset(unsigned nByte, unsigned nBit) const { return (nByte << 4) + nBit; }                 // :5104
     void UnpackFileOffset(unsigned nPacked, unsigned& nByte, unsigned& nBit) const { nBit = nPacked & 0x7; nByte = nPacked >> 4; } // :5123
 

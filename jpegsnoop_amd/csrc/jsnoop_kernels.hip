@@ -744,6 +744,31 @@ __global__ void __launch_bounds__(1024) k_clip_order(const JsImage* __restrict__
     if (t < 6) out[t] = s_out[t];
 }
 
+// TIFF export (OnToolsExporttiff, source/JPEGsnoopDoc.cpp:2110-2180): the pixel strip in file order, top-down.
+//   mode 0: R,G,B bytes from the bottom-up BGRA DIB; mode 1: the same as 16-bit samples v << 8, big-endian (bytes v, 0);
+//   mode 2: Y,Cb,Cr from the int16 planes, clamped to [-1024, 1023], (1024 + v) >> 3.
+__global__ void __launch_bounds__(256) k_tiff_pack(const JsImage* __restrict__ imgs, uint32_t img, const uint8_t* __restrict__ dib,
+                                                   const int16_t* __restrict__ planes, int mode, uint8_t* __restrict__ out)
+{
+    const JsImage& im = imgs[img];
+    const uint32_t W = im.img_x, H = im.img_y, npix = W * H;
+    const uint8_t* src = dib + im.dib_off;
+    const int16_t* pl = planes + im.plane_off;
+    const size_t psz = (size_t)im.blk_xmax * 8 * im.blk_ymax * 8;
+    for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
+        const uint32_t y = p / W, x = p - y * W;
+        if (mode == 2) {
+            uint8_t* o = out + (size_t)p * 3;
+            for (int c = 0; c < 3; c++) { const int v = min(max((int)pl[c * psz + p], -1024), 1023); o[c] = (uint8_t)((1024 + v) >> 3); }
+        } else {
+            const uint32_t bgra = *reinterpret_cast<const uint32_t*>(src + ((size_t)(H - 1 - y) * W + x) * 4);
+            const uint8_t r = (uint8_t)(bgra >> 16), g = (uint8_t)(bgra >> 8), b = (uint8_t)bgra;
+            if (mode == 0) { uint8_t* o = out + (size_t)p * 3; o[0] = r; o[1] = g; o[2] = b; }
+            else { uint8_t* o = out + (size_t)p * 6; o[0] = r; o[1] = 0; o[2] = g; o[3] = 0; o[4] = b; o[5] = 0; }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ launch wrappers
 void js_launch_entropy_exact(hipStream_t st, const JsImage* imgs, const uint32_t* sel, uint32_t nsel, const JsTableSet* tables,
                              const uint8_t* raw, int16_t* coef, int16_t* dccum, uint32_t* side, int side_only, uint32_t* events)
@@ -769,6 +794,8 @@ void js_launch_color_stats(hipStream_t st, const JsImage* imgs, uint32_t img, co
 { hipLaunchKernelGGL(k_color_stats, dim3(512), dim3(ST_THREADS), 0, st, imgs, img, planes, (uint32_t)(hist_en != 0), stats); }
 void js_launch_clip_order(hipStream_t st, const JsImage* imgs, uint32_t img, const int16_t* planes, uint32_t budget, uint32_t* out6)
 { hipLaunchKernelGGL(k_clip_order, dim3(1), dim3(1024), 0, st, imgs, img, planes, budget, out6); }
+void js_launch_tiff_pack(hipStream_t st, const JsImage* imgs, uint32_t img, const uint8_t* dib, const int16_t* planes, int mode, uint8_t* out)
+{ hipLaunchKernelGGL(k_tiff_pack, dim3(1024), dim3(256), 0, st, imgs, img, dib, planes, mode, out); }
 void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, const uint8_t* dib, unsigned long long* sums)
 {
     if (!nimg) return;

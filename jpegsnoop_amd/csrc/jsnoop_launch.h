@@ -15,6 +15,7 @@ void js_launch_color_probe(hipStream_t st, int y, int cb, int cr, uint32_t* out)
 #define JS_STATS_DEV_WORDS 2496      /* + the six uncapped YCC range-event totals, padded */
 void js_launch_color_stats(hipStream_t st, const JsImage* imgs, uint32_t img, const int16_t* planes, int hist_en, uint32_t* stats);
 void js_launch_clip_order(hipStream_t st, const JsImage* imgs, uint32_t img, const int16_t* planes, uint32_t budget, uint32_t* out6);
+void js_launch_tiff_pack(hipStream_t st, const JsImage* imgs, uint32_t img, const uint8_t* dib, const int16_t* planes, int mode, uint8_t* out);
 void js_launch_color_sweep(hipStream_t st, uint32_t* out /*2^24 words*/);
 void js_launch_unstuff(hipStream_t st, int wl, const JsImage* imgs, const uint32_t* us_base, uint32_t nimg, uint32_t total_chunks, const uint8_t* raw,
                        uint32_t* chunk_keep, uint32_t* chunk_rst, uint8_t* ustr_lin, uint8_t* ustr, uint32_t* seg_tab, uint32_t* side, uint32_t* flags,

@@ -302,6 +302,16 @@ class Backend:
         self._f("bright_avg")(self.h, s)
         return list(s)
 
+    def export_tiff(self, mode):
+        """Export-to-TIFF bytes of the decoded image (mode 0 RGB8, 1 RGB16, 2 YCC8), or None when the backend refuses."""
+        import tempfile
+        fn = self._f("export_tiff")
+        fn.argtypes = [C.c_void_p, C.c_char_p, C.c_int]; fn.restype = C.c_int
+        with tempfile.NamedTemporaryFile(suffix=".tif") as t:
+            if fn(self.h, t.name.encode(), int(mode)) != 0:
+                return None
+            return open(t.name, "rb").read()
+
     def log_reset(self):
         self._log.clear()
 

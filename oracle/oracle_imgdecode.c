@@ -11,6 +11,7 @@
  */
 #include "oracle_imgdecode.h"
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -632,6 +633,81 @@ void orc_color_stats(OrcDecoder* d, unsigned* o)
 {
     memcpy(o, d->cc_histo, 36 * 4); o[36] = d->cc_count; memcpy(o + 37, d->cc_clip, 13 * 4);
     memcpy(o + 50, d->cc_rgb, 3 * 128 * 4); memcpy(o + 434, d->cc_yfull, 2048 * 4);
+}
+/* ------------------------------------------------------------------ TIFF export
+ * Pixel re-arrangement of CJPEGsnoopDoc::OnToolsExporttiff (source/JPEGsnoopDoc.cpp:2110-2180) and the container of
+ * FileTiff::WriteFile / WriteIfd (source/FileTiff.cpp:281-433, :436-538): big-endian TIFF, one strip, tags in the
+ * reference's order; values longer than 4 bytes go to an area behind the IFD; width / height / strip offset are
+ * written as SHORT like the reference does.  mode 0 = RGB 8 bit, 1 = RGB 16 bit, 2 = YCC 8 bit. */
+typedef struct { uint8_t* p; size_t n, cap; } TBuf;
+static void tb_put(TBuf* b, const void* src, size_t n)
+{ if (b->n + n > b->cap) { b->cap = (b->n + n) * 2 + 256; b->p = (uint8_t*)realloc(b->p, b->cap); } memcpy(b->p + b->n, src, n); b->n += n; }
+static void tb8(TBuf* b, unsigned v) { uint8_t c = (uint8_t)v; tb_put(b, &c, 1); }
+static void tb16(TBuf* b, unsigned v) { tb8(b, (v >> 8) & 0xFF); tb8(b, v & 0xFF); }
+static void tb32(TBuf* b, unsigned v) { tb16(b, (v >> 16) & 0xFFFF); tb16(b, v & 0xFFFF); }
+enum { TT_SHORT = 3, TT_LONG = 4, TT_RATIONAL = 5 };
+static void tiff_single(TBuf* ifd, unsigned* count, unsigned tag, unsigned type, unsigned v)               /* WriteIfdEntrySingle :120 */
+{ tb16(ifd, tag); tb16(ifd, type); tb32(ifd, 1); if (type == TT_SHORT) { tb16(ifd, v & 0xFFFF); tb16(ifd, 0); } else tb32(ifd, v); (*count)++; }
+static void tiff_mult(TBuf* ifd, TBuf* extra, unsigned extra_ptr, unsigned* count, unsigned tag, unsigned type, unsigned n, const unsigned* vals) /* WriteIfdEntryMult :190 */
+{
+    const unsigned tlen = n * (type == TT_SHORT ? 2u : 4u); const int in_extra = tlen > 4;
+    tb16(ifd, tag); tb16(ifd, type); tb32(ifd, type != TT_RATIONAL ? n : n / 2);
+    if (in_extra) tb32(ifd, extra_ptr + (unsigned)extra->n);
+    (*count)++;
+    for (unsigned i = 0; i < n; i++) { TBuf* dst = in_extra ? extra : ifd; if (type == TT_SHORT) tb16(dst, vals[i] & 0xFFFF); else tb32(dst, vals[i]); }
+    if (!in_extra && tlen < 4) for (unsigned k = 0; k < 4 - tlen; k++) tb8(ifd, 0);
+}
+static void tiff_ifd(TBuf* out, unsigned w, unsigned h, int ycc, int b16, unsigned ptr_img_in, unsigned num_in, unsigned extra_ptr, unsigned* num_out, unsigned* extra_ptr_out)
+{   /* one pass of WriteIfd :281-433: entries, terminator, then the extra area */
+    TBuf ifd = {0, 0, 0}, extra = {0, 0, 0}; unsigned count = 0, v[16];
+    tb16(&ifd, num_in);
+    tiff_single(&ifd, &count, 0x0100, TT_SHORT, w); tiff_single(&ifd, &count, 0x0101, TT_SHORT, h);
+    v[0] = v[1] = v[2] = b16 ? 16 : 8; tiff_mult(&ifd, &extra, extra_ptr, &count, 0x0102, TT_SHORT, 3, v);
+    tiff_single(&ifd, &count, 0x0103, TT_SHORT, 1);
+    tiff_single(&ifd, &count, 0x0106, TT_SHORT, ycc ? 6 : 2);
+    tiff_single(&ifd, &count, 0x0111, TT_SHORT, ptr_img_in);
+    tiff_single(&ifd, &count, 0x0112, TT_SHORT, 1);
+    tiff_single(&ifd, &count, 0x0115, TT_SHORT, 3);
+    tiff_single(&ifd, &count, 0x0116, TT_SHORT, h);
+    tiff_single(&ifd, &count, 0x0117, TT_LONG, h * w * (b16 ? 6u : 3u));
+    v[0] = 72; v[1] = 1; tiff_mult(&ifd, &extra, extra_ptr, &count, 0x011A, TT_RATIONAL, 2, v); tiff_mult(&ifd, &extra, extra_ptr, &count, 0x011B, TT_RATIONAL, 2, v);
+    tiff_single(&ifd, &count, 0x011C, TT_SHORT, 1); tiff_single(&ifd, &count, 0x0128, TT_SHORT, 2);
+    if (ycc) {
+        const unsigned c[6] = {299, 1000, 587, 1000, 114, 1000}; tiff_mult(&ifd, &extra, extra_ptr, &count, 0x0211, TT_RATIONAL, 6, c);
+        v[0] = v[1] = 1; tiff_mult(&ifd, &extra, extra_ptr, &count, 0x0212, TT_SHORT, 2, v);
+        tiff_single(&ifd, &count, 0x0213, TT_SHORT, 1);
+    }
+    { const unsigned bw[12] = {0, 1, 0xFF, 1, 0, 1, 0xFF, 1, 0, 1, 0xFF, 1}; tiff_mult(&ifd, &extra, extra_ptr, &count, 0x0214, TT_RATIONAL, 12, bw); }
+    tb32(&ifd, 0);
+    *num_out = count; *extra_ptr_out = 8 + (unsigned)ifd.n;
+    tb_put(out, ifd.p, ifd.n); tb_put(out, extra.p, extra.n);
+    free(ifd.p); free(extra.p);
+}
+int orc_export_tiff(OrcDecoder* d, const char* path, int mode)
+{
+    const int ycc = mode == 2, b16 = mode == 1;
+    const unsigned W = d->img_x, Hh = d->img_y;
+    if (!d->dib || !W || !Hh || (ycc && !(d->pix[0] && d->pix[1] && d->pix[2]))) return -1;
+    TBuf out = {0, 0, 0};
+    tb32(&out, 0x4D4D002A); tb32(&out, 8);
+    unsigned num = 0, extra_ptr = 0, n1, e1;
+    { TBuf pre = {0, 0, 0}; tiff_ifd(&pre, W, Hh, ycc, b16, 0, 0, 0, &n1, &e1); num = n1; extra_ptr = e1; unsigned end = 8 + (unsigned)pre.n; free(pre.p);
+      tiff_ifd(&out, W, Hh, ycc, b16, end, num, extra_ptr, &n1, &e1); }          /* pass 2 knows the entry count, the extra area and the strip offset */
+    const size_t npx = (size_t)W * Hh;
+    for (unsigned y = 0; y < Hh; y++) for (unsigned x = 0; x < W; x++) {
+        if (!ycc) {
+            const uint8_t* s = d->dib + ((size_t)(Hh - 1 - y) * W + x) * 4;
+            if (!b16) { tb8(&out, s[2]); tb8(&out, s[1]); tb8(&out, s[0]); }
+            else { tb8(&out, s[2]); tb8(&out, 0); tb8(&out, s[1]); tb8(&out, 0); tb8(&out, s[0]); tb8(&out, 0); }   /* Swap16(v << 8) stored little-endian = bytes (v, 0) */
+        } else {
+            const size_t i = (size_t)y * W + x;
+            for (int c = 0; c < 3; c++) { int v = d->pix[c][i]; if (v < -1024) v = -1024; if (v > 1023) v = 1023; tb8(&out, (unsigned)((0x0400 + v) >> 3)); }
+        }
+    }
+    (void)npx;
+    FILE* f = fopen(path, "wb"); if (!f) { free(out.p); return -1; }
+    fwrite(out.p, 1, out.n, f); fclose(f); free(out.p);
+    return 0;
 }
 const float* orc_idct_lut(OrcDecoder* d) { return &d->lut[0][0]; }
 const uint32_t* orc_dht_lookupfast(OrcDecoder* d) { return &d->dht_fast[0][0][0]; }

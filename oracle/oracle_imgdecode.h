@@ -67,6 +67,7 @@ void     orc_bright_avg(OrcDecoder*, int* out10);
 void     orc_set_preview_mode(OrcDecoder*, unsigned mode);                                          /* :633 */
 unsigned orc_get_preview_mode(OrcDecoder*);
 void     orc_set_preview_ycc_offset(OrcDecoder*, unsigned mcu_x, unsigned mcu_y, int y, int cb, int cr); /* :650 */
+int      orc_export_tiff(OrcDecoder*, const char* path, int mode);   /* 0 RGB8, 1 RGB16, 2 YCC8; JPEGsnoopDoc.cpp:2110-2180 + FileTiff.cpp:436 */
 void     orc_color_stats(OrcDecoder*, unsigned* out2482);   /* bHistoEn / bStatClipEn statistics, layout of jsnoop_get_color_stats */
 const float* orc_idct_lut(OrcDecoder*);                   /* [64][64] */
 const uint32_t* orc_dht_lookupfast(OrcDecoder*);          /* [2][4][1024] */

@@ -173,12 +173,20 @@ class CUIntArray { public: std::vector<unsigned> v; int Add(unsigned s) { v.push
 
 // Memory-backed CFile: the reference's CwindowBuf reads its 128 KB windows
 // through Seek/Read/GetLength only.
+class CFileException : public CObject {
+public:
+    BOOL GetErrorMessage(TCHAR* msg, unsigned n) { if (n) msg[0] = 0; return TRUE; }
+    void Delete() { delete this; }
+};
 class CFile : public CObject {
 public:
-    enum { begin = 0, current = 1, end = 2, modeRead = 0, shareDenyNone = 0, typeBinary = 0 };
+    enum { begin = 0, current = 1, end = 2, modeRead = 0, shareDenyNone = 0, typeBinary = 0, modeCreate = 0x1000, modeWrite = 0x0001 };
     const BYTE* m_p = nullptr; ULONGLONG m_n = 0, m_pos = 0;
+    FILE* m_out = nullptr;                                   // write mode (FileTiff): a real file
     CFile() {}
     CFile(const BYTE* p, ULONGLONG n) : m_p(p), m_n(n) {}
+    CFile(CString name, unsigned flags) { if (flags & modeWrite) { m_out = fopen(name.s.c_str(), "wb"); if (!m_out) throw new CFileException(); } }
+    ~CFile() { if (m_out) fclose(m_out); }
     ULONGLONG GetLength() const { return m_n; }
     ULONGLONG Seek(long long off, unsigned from) {
         long long base = from == begin ? 0 : from == current ? (long long)m_pos : (long long)m_n;
@@ -187,8 +195,9 @@ public:
     unsigned Read(void* dst, unsigned n) {
         if (m_pos >= m_n) return 0; ULONGLONG k = m_n - m_pos; if (k > n) k = n;
         memcpy(dst, m_p + m_pos, (size_t)k); m_pos += k; return (unsigned)k; }
+    void Write(const void* src, unsigned n) { if (m_out) fwrite(src, 1, n, m_out); }
     ULONGLONG GetPosition() const { return m_pos; }
-    void Close() {}
+    void Close() { if (m_out) { fclose(m_out); m_out = nullptr; } }
 };
 class CStdioFile : public CFile { public: void WriteString(const char*) {} };
 

@@ -14,6 +14,8 @@
 #include "ImgDecode.h"
 #undef private
 #include "JPEGsnoop.h"
+#include "FileTiff.h"
+#include "General.h"
 
 std::vector<std::string>& ShimLog();
 CSnoopConfig* ShimConfig();
@@ -121,6 +123,38 @@ void jsref_set_preview_mode(void* h, unsigned mode) { ((JsRef*)h)->dec->SetPrevi
 unsigned jsref_get_preview_mode(void* h) { return ((JsRef*)h)->dec->GetPreviewMode(); }
 void jsref_set_preview_ycc_offset(void* h, unsigned mx, unsigned my, int y, int cb, int cr)                                // :650
 { ((JsRef*)h)->dec->SetPreviewYccOffset(mx, my, y, cb, cr); }
+// TIFF export: the container is written by the reference's own FileTiff::WriteFile (source/FileTiff.cpp:436); the pixel
+// re-arrangement in front of it lives in a GUI handler (CJPEGsnoopDoc::OnToolsExporttiff, source/JPEGsnoopDoc.cpp:2110-2180:
+// dialogs + loop) and is restated here.  mode 0 = RGB 8 bit, 1 = RGB 16 bit, 2 = YCC 8 bit.  Returns 0 on success.
+int jsref_export_tiff(void* h, const char* path, int mode)
+{
+    CimgDecode* d = ((JsRef*)h)->dec;
+    unsigned nSizeX = 0, nSizeY = 0; unsigned char* pRgb = NULL; short *pY = NULL, *pCb = NULL, *pCr = NULL;
+    d->GetImageSize(nSizeX, nSizeY); d->GetBitmapPtr(pRgb); d->GetPixMapPtrs(pY, pCb, pCr);
+    const bool bModeYcc = mode == 2, bMode16b = mode == 1;
+    if (!pRgb || !nSizeX || !nSizeY || (bModeYcc && !(pY && pCb && pCr))) return -1;
+    std::vector<unsigned char> sel8; std::vector<unsigned short> sel16;
+    if (bMode16b) sel16.resize((size_t)nSizeX * nSizeY * 3); else sel8.resize((size_t)nSizeX * nSizeY * 3);
+    for (unsigned y = 0; y < nSizeY; y++) for (unsigned x = 0; x < nSizeX; x++) {
+        const size_t dst = ((size_t)y * nSizeX + x) * 3;
+        if (!bModeYcc) {
+            const size_t src = ((size_t)(nSizeY - 1 - y) * nSizeX + x) * 4;            // the DIB is bottom-up
+            const unsigned short r = pRgb[src + 2], g = pRgb[src + 1], b = pRgb[src + 0];
+            if (!bMode16b) { sel8[dst] = r & 0xFF; sel8[dst + 1] = g & 0xFF; sel8[dst + 2] = b & 0xFF; }
+            else { sel16[dst] = Swap16(r << 8); sel16[dst + 1] = Swap16(g << 8); sel16[dst + 2] = Swap16(b << 8); }
+        } else {
+            const size_t src = (size_t)y * nSizeX + x;
+            short vy = pY[src], vcb = pCb[src], vcr = pCr[src];
+            if (vy < -1024) vy = -1024; if (vy > 1023) vy = 1023;
+            if (vcb < -1024) vcb = -1024; if (vcb > 1023) vcb = 1023;
+            if (vcr < -1024) vcr = -1024; if (vcr > 1023) vcr = 1023;
+            sel8[dst] = (unsigned char)((0x0400 + vy) >> 3); sel8[dst + 1] = (unsigned char)((0x0400 + vcb) >> 3); sel8[dst + 2] = (unsigned char)((0x0400 + vcr) >> 3);
+        }
+    }
+    FileTiff t;
+    t.WriteFile(CString(path), bModeYcc, bMode16b, bMode16b ? (void*)sel16.data() : (void*)sel8.data(), nSizeX, nSizeY);
+    return 0;
+}
 // Colour statistics of the bHistoEn / bStatClipEn path (ConvertYCCtoRGB :4229, CapYccRange :4341, CapRgbRange :4495):
 // out[0..36] PixelCcHisto, [37..49] PixelCcClip, [50..433] m_anCcHisto_r/g/b[128], [434..2481] m_anHistoYFull[2048]
 void jsref_color_stats(void* h, unsigned* out2482)

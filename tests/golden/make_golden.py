@@ -147,6 +147,10 @@ def main():
         ref.set_options(decode_ac=1)
         entry["histo_en"] = histo_record(ref, data)
         entry["log"] = log_record(ref, data)
+        H.drive(ref, data)                                     # Export to TIFF of the plain Full-IDCT decode (FileTiff.cpp:436)
+        if ref.dib() is not None:
+            ycc_ok = ref.planes()[1] is not None                   # the reference's handler dereferences the chroma planes
+            entry["tiff"] = {k: H.hash_bytes(ref.export_tiff(m)) if (m != 2 or ycc_ok) else None for k, m in (("rgb8", 0), ("rgb16", 1), ("ycc8", 2))}
         manifest["cases"][name] = entry
     # known-answer values of the two fp32 stages, straight from the compiled reference
     lut = ref.idct_lut()

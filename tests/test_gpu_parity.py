@@ -171,6 +171,27 @@ def test_parallel_side_outputs(harness, oracle, gpu):
             raise AssertionError(f"case {k}: {e}")
 
 
+def test_tiff_export(harness, oracle, gpu):
+    """Export to TIFF (RGB 8 / 16 bit, YCC 8 bit): file bytes against the compiled reference's FileTiff output (golden
+    hashes) and against the oracle's writer on a larger image."""
+    from golden_util import load_case, manifest
+    M = manifest()
+    for name in sorted(M["cases"]):
+        if "tiff" not in M["cases"][name]:
+            continue
+        harness.drive(gpu, load_case(name))
+        for key, mode in (("rgb8", 0), ("rgb16", 1), ("ycc8", 2)):
+            want = M["cases"][name]["tiff"][key]
+            got = gpu.export_tiff(mode)
+            assert (got is None) == (want is None), (name, key)
+            if want is not None:
+                assert harness.hash_bytes(got) == want, (name, key)
+    data = harness.synth_jpeg(width=1920, height=1080, seed=31)
+    harness.drive(oracle, data); harness.drive(gpu, data)
+    for mode in (0, 1, 2):
+        assert gpu.export_tiff(mode) == oracle.export_tiff(mode), mode
+
+
 def test_decode_log_text(harness, gpu):
     """The text DecodeScanImg writes to the log (messages of the decode loop, statistics report, YCC clip warnings),
     line for line against what the compiled reference wrote (tests/golden/manifest.json): Full IDCT, histogram path,
