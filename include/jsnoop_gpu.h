@@ -105,6 +105,14 @@ void     jsnoop_set_preview_mode(JsnoopDecoder*, unsigned mode);
 unsigned jsnoop_get_preview_mode(JsnoopDecoder*);
 void     jsnoop_set_preview_ycc_offset(JsnoopDecoder*, unsigned mcu_x, unsigned mcu_y, int y, int cb, int cr);
 
+/* ---- Progressive (SOF2) files -- beyond the reference, which refuses them (source/JfifDecode.cpp:4827-4833; the two
+ *      entry points above refuse them the same way).  Walks ALL scans of the file (spectral selection and successive
+ *      approximation, T.81 Annex G; tables may change between scans), decodes every restart interval of every scan as an
+ *      independent lane, and hands the coefficient arena to the same back end as the baseline path, so a progressive
+ *      file carrying the coefficients of a baseline file yields that file's DIB.  Results through the getters above
+ *      (jsnoop_last_path() == 3; no MCU file map / block-DC maps).  Returns the number of scans, or -1.            */
+int jsnoop_decode_progressive(JsnoopDecoder*, const uint8_t* file, size_t len);
+
 /* ---- Export to TIFF (CJPEGsnoopDoc::OnToolsExporttiff, source/JPEGsnoopDoc.cpp:2008-2190, FileTiff::WriteFile
  *      source/FileTiff.cpp:436): mode 0 = RGB 8 bit, 1 = RGB 16 bit, 2 = YCC 8 bit (three-component images); byte-identical
  *      to the reference's file.  The pixel strip is arranged on the device.  0 on success, -1 + jsnoop_last_error().  */

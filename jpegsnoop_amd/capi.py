@@ -40,6 +40,7 @@ SIGNATURES = {
     "jsnoop_set_image_details": (None, [_p, _u, _u, _u, _u, _i, _u]),
     "jsnoop_jfif_walk": (_i, [_p, _p, _sz, _PU]),
     "jsnoop_decode_scan_img": (None, [_p, _p, _sz, _u, _i, _i]),
+    "jsnoop_decode_progressive": (_i, [_p, _p, _sz]),
     "jsnoop_is_preview_ready": (_i, [_p]),
     "jsnoop_get_image_size": (None, [_p, _PU, _PU]),
     "jsnoop_get_bitmap_ptr": (_p, [_p]),

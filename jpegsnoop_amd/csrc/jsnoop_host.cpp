@@ -66,7 +66,8 @@ void JsnoopDecoder::reset_state()                                              /
 
 // The geometry and readiness checks DecodeScanImg performs before its MCU loop (:2755-3123),
 // restated on the table state.  Returns false (with a log line) exactly where the reference returns early.
-bool js_describe_image(JsnoopDecoder* d, JsImage* im, JsTableSet* ts, uint32_t file_len, uint32_t scan_start, int display, int quiet)
+// Geometry of the scan as DecodeScanImg derives it (:2753-2872): MCU size, block layout of an MCU, MCU-rounded image size.
+bool js_geometry(JsnoopDecoder* d, JsImage* im)
 {
     JsTables& t = d->t;
     memset(im, 0, sizeof *im);
@@ -99,6 +100,12 @@ bool js_describe_image(JsnoopDecoder* d, JsImage* im, JsTableSet* ts, uint32_t f
     im->total_blocks = im->mcu_xmax * im->mcu_ymax * nb;
     d->geom[0] = im->mcu_w; d->geom[1] = im->mcu_h; d->geom[2] = im->mcu_xmax; d->geom[3] = im->mcu_ymax;
     d->geom[4] = im->blk_xmax; d->geom[5] = im->blk_ymax; d->geom[6] = im->img_x; d->geom[7] = im->img_y;
+    return true;
+}
+bool js_describe_image(JsnoopDecoder* d, JsImage* im, JsTableSet* ts, uint32_t file_len, uint32_t scan_start, int display, int quiet)
+{
+    JsTables& t = d->t;
+    if (!js_geometry(d, im)) return false;
     if (!quiet) { d->log(0, "*** Decoding SCAN Data ***"); d->log(0, "  OFFSET: 0x%08X", scan_start); }            // :3021-3025
     if (t.num_sof != 1 && t.num_sof != 3) { d->log(1, "  NOTE: Number of Image Components not supported [%u]", t.num_sof); return false; }
     for (uint32_t i = 1; i <= t.num_sos; i++) if (t.dqt_sel[i] < 0) {
@@ -224,6 +231,21 @@ int JsnoopBatch::add(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned
     if (tsi == tables.size()) tables.push_back(*ts);
     delete ts;
     im.tableset = tsi;
+    imgs.push_back(im); uploaded = false;
+    return (int)imgs.size() - 1;
+}
+// Stages a file whose image descriptor the caller built itself (progressive path): no scan-length search, no decode tables.
+int JsnoopBatch::add_described(const JsImage& desc, const uint8_t* file, size_t len)
+{
+    if (len >= (1ull << 32) - 64) { js_set_error("file too large for the 32-bit offsets of the reference format"); return -1; }
+    JsImage im = desc;
+    const uint64_t off = align_up(raw_bytes, 16);
+    if (reserve_pinned(off + len + 16)) return -1;
+    memset(pinned + raw_bytes, 0, off - raw_bytes);
+    memcpy(pinned + off, file, len); memset(pinned + off + len, 0, 16);
+    raw_bytes = off + len + 16; im.file_off = off; im.file_len = (uint32_t)len;
+    if (tables.empty()) { JsTableSet* ts = new JsTableSet; memset(ts, 0, sizeof *ts); tables.push_back(*ts); delete ts; }
+    im.tableset = 0;
     imgs.push_back(im); uploaded = false;
     return (int)imgs.size() - 1;
 }

@@ -81,6 +81,7 @@ struct JsnoopBatch {
     void clear();
     int  reserve_pinned(size_t need);
     int  add(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned scan_start, int display, int quiet = 1);
+    int  add_described(const JsImage& desc, const uint8_t* file, size_t len);
     int  tile(int total);
     int  upload();
     int  decode(bool timed);
@@ -91,6 +92,7 @@ struct JsnoopBatch {
 };
 
 void js_set_error(const char* fmt, ...);
+bool js_geometry(JsnoopDecoder* d, JsImage* im);
 bool js_describe_image(JsnoopDecoder* d, JsImage* im, JsTableSet* ts, uint32_t file_len, uint32_t scan_start, int display, int quiet);
 void js_emit_decode_events(JsnoopDecoder* d);                      // jsnoop_report.cpp
 void js_emit_report(JsnoopDecoder* d, bool display, bool quiet);

@@ -1,0 +1,198 @@
+// jsnoop_progressive.hip -- progressive (SOF2) scan decode, SURVEY.md 8(f) rank 4 / BASELINE.json config 5
+// ("progressive multi-scan 4:2:2 JPEG with RSTn restart intervals, per-interval parallel entropy decode").
+//
+// The reference refuses SOF2 (source/JfifDecode.cpp:4827-4833, :5272-5274), so there is no reference answer for these
+// files; the contract is transitive: a progressive file that carries the same quantised coefficients as a baseline
+// file must come out with the baseline file's pixels.  The scans therefore only rebuild the coefficient arena of the
+// baseline path -- `coef` (natural order, one 64-entry row per block in decode order) and `dccum` -- and the unchanged
+// back end (k_idct_color: the reference's fp32 IDCT, replication, colour conversion, DIB) runs on it.
+//
+// Entropy decoding follows ITU-T T.81 Annex G: DC first / refinement scans (G.1.2.1), AC first scans with EOBRUN
+// (G.1.2.2) and AC refinement scans with correction bits (G.1.2.3), spectral selection and successive approximation.
+// Parallelism is what the stream offers without speculation: restart intervals are independent, so every
+// (scan, interval) pair is one lane with its own bit reader; the scans of one image are launched in file order.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "jsnoop_types.h"
+#include "jsnoop_progressive.h"
+
+__device__ __constant__ uint8_t c_zz_nat[64] = {       // zig-zag index -> natural index (T.81 Figure A.6)
+     0, 1, 8,16, 9, 2, 3,10, 17,24,32,25,18,11, 4, 5, 12,19,26,33,40,48,41,34, 27,20,13, 6, 7,14,21,28,
+    35,42,49,56,57,50,43,36, 29,22,15,23,30,37,44,51, 58,59,52,45,38,31,39,46, 53,60,61,54,47,55,62,63 };
+
+namespace {
+
+// MSB-first bit reader over one restart interval of a scan (file bytes, stuffing removed on the fly).
+struct PReader {
+    const uint8_t* p; const uint8_t* end; uint64_t acc; int n; uint32_t over;
+    __device__ void init(const uint8_t* s, const uint8_t* e) { p = s; end = e; acc = 0; n = 0; over = 0; }
+    __device__ void fill()
+    {
+        while (n <= 56) {
+            uint32_t b = 0;
+            if (p < end) { b = *p++; if (b == 0xFF && p < end && *p == 0x00) p++; }    // FF00 -> FF (B.1.1.5)
+            else over++;                                                               // past the interval: zero bits, counted
+            acc |= (uint64_t)b << (56 - n); n += 8;
+        }
+    }
+    __device__ uint32_t peek(int k) { if (n < k) fill(); return (uint32_t)(acc >> (64 - k)); }
+    __device__ void skip(int k) { acc <<= k; n -= k; }
+    __device__ uint32_t bits(int k) { if (!k) return 0; const uint32_t v = peek(k); skip(k); return v; }
+    __device__ uint32_t bit() { return bits(1); }
+    __device__ bool overrun() const { return over * 8 > (uint32_t)(n > 0 ? n : 0); }      // consumed bits that were never in the interval
+};
+
+// Canonical Huffman decode (T.81 F.2.2.3): 8-bit look-ahead table, then bit-serial through MAXCODE.
+__device__ int huff(PReader& r, const JsProgTable& t)
+{
+    const uint32_t la = r.peek(16);
+    const uint32_t e = t.look[la >> 8];
+    if (e) { r.skip((int)(e >> 8)); return (int)(e & 255u); }
+    for (int l = 9; l <= 16; l++) {
+        const int32_t code = (int32_t)(la >> (16 - l));
+        if (code <= t.maxcode[l]) { r.skip(l); return t.sym[(code + t.valoff[l]) & 255]; }
+    }
+    r.skip(16);
+    return -1;                                                   // no code matches
+}
+__device__ int extend(uint32_t v, int s) { return v < (1u << (s - 1)) ? (int)v - (int)((1u << s) - 1) : (int)v; }   // F.2.2.1
+
+// decode-order row of block (bx, by) of frame component `comp` (0-based) in the coefficient arena
+__device__ size_t block_row(const JsImage& im, const JsProgFrame& fr, uint32_t comp, uint32_t bx, uint32_t by)
+{
+    const uint32_t hs = fr.hs[comp], vs = fr.vs[comp];
+    return ((size_t)(by / vs) * im.mcu_xmax + bx / hs) * im.blk_per_mcu + fr.first_blk[comp] + (by % vs) * hs + (bx % hs);
+}
+
+}  // namespace
+
+// One lane per restart interval of one scan.
+__global__ void __launch_bounds__(64) k_prog_scan(const JsImage* __restrict__ imgs, JsProgFrame fr, JsProgScan sc, const JsProgTable* __restrict__ tabs,
+                                                  const JsProgSeg* __restrict__ segs, const uint8_t* __restrict__ raw, int16_t* __restrict__ coef,
+                                                  uint32_t* __restrict__ status)
+{
+    __shared__ JsProgTable s_tab[4];
+    for (uint32_t t = 0; t < sc.ntabs; t++) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(tabs + sc.tab[t]); uint32_t* dst = reinterpret_cast<uint32_t*>(&s_tab[t]);
+        for (uint32_t i = threadIdx.x; i < sizeof(JsProgTable) / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t iv = blockIdx.x * blockDim.x + threadIdx.x;
+    if (iv >= sc.nseg) return;
+    const JsImage& im = imgs[0];
+    const JsProgSeg sg = segs[sc.seg_first + iv];
+    const uint8_t* file = raw + im.file_off;
+    PReader r; r.init(file + sg.start, file + sg.end);
+    int16_t* cbase = coef + im.coef_off * 64;
+    const uint32_t units = sc.ncomp > 1 ? im.mcu_xmax * im.mcu_ymax : sc.nbx * sc.nby;     // MCUs of the scan (A.2.2 / A.2.3)
+    const uint32_t ri = sc.rst_interval ? sc.rst_interval : units;
+    const uint32_t u0 = iv * ri, u1 = min(units, u0 + ri);
+    uint32_t bad = 0;
+    const int al = (int)sc.al;
+
+    if (sc.ss == 0) {
+        // ---- DC scans (G.1.2.1): interleaved or not; first (Ah = 0): DIFF, point transform; refinement: one bit per block
+        int pred[3] = { 0, 0, 0 };
+        for (uint32_t u = u0; u < u1 && !bad; u++) {
+            for (uint32_t ci = 0; ci < sc.ncomp; ci++) {
+                const uint32_t comp = sc.comp[ci];
+                const uint32_t hs = sc.ncomp > 1 ? fr.hs[comp] : 1u, vs = sc.ncomp > 1 ? fr.vs[comp] : 1u;
+                for (uint32_t v = 0; v < vs; v++) for (uint32_t h = 0; h < hs; h++) {
+                    const uint32_t bx = sc.ncomp > 1 ? (u % im.mcu_xmax) * hs + h : u % sc.nbx;
+                    const uint32_t by = sc.ncomp > 1 ? (u / im.mcu_xmax) * vs + v : u / sc.nbx;
+                    int16_t* blk = cbase + block_row(im, fr, comp, bx, by) * 64;
+                    if (sc.ah == 0) {
+                        const int s = huff(r, s_tab[sc.dc_slot[ci]]);
+                        if (s < 0 || s > 15) { bad = 1; break; }
+                        const int diff = s ? extend(r.bits(s), s) : 0;
+                        pred[ci] += diff;
+                        blk[0] = (int16_t)(pred[ci] * (1 << al));
+                    } else if (r.bit()) blk[0] = (int16_t)(blk[0] | (1 << al));
+                }
+            }
+        }
+    } else if (sc.ah == 0) {
+        // ---- AC first scan (G.1.2.2): one component, band Ss..Se, end-of-band runs
+        const uint32_t comp = sc.comp[0]; const JsProgTable& T = s_tab[sc.ac_slot[0]];
+        uint32_t eobrun = 0;
+        for (uint32_t u = u0; u < u1 && !bad; u++) {
+            if (eobrun) { eobrun--; continue; }
+            int16_t* blk = cbase + block_row(im, fr, comp, u % sc.nbx, u / sc.nbx) * 64;
+            for (uint32_t k = sc.ss; k <= sc.se; k++) {
+                const int rs = huff(r, T);
+                if (rs < 0) { bad = 1; break; }
+                const uint32_t run = (uint32_t)rs >> 4, s = (uint32_t)rs & 15u;
+                if (s) {
+                    k += run;
+                    if (k > sc.se) { bad = 1; break; }
+                    blk[c_zz_nat[k]] = (int16_t)(extend(r.bits((int)s), (int)s) * (1 << al));
+                } else if (run == 15) k += 15;                                          // ZRL
+                else { eobrun = (1u << run) + r.bits((int)run) - 1; break; }             // EOBn: this block ends here, eobrun more follow
+            }
+        }
+    } else {
+        // ---- AC refinement scan (G.1.2.3): new coefficients of magnitude 1 << Al, correction bits for the known non-zero ones
+        const uint32_t comp = sc.comp[0]; const JsProgTable& T = s_tab[sc.ac_slot[0]];
+        const int p1 = 1 << al, m1 = -(1 << al);
+        uint32_t eobrun = 0;
+        for (uint32_t u = u0; u < u1 && !bad; u++) {
+            int16_t* blk = cbase + block_row(im, fr, comp, u % sc.nbx, u / sc.nbx) * 64;
+            uint32_t k = sc.ss;
+            if (!eobrun) {
+                for (; k <= sc.se; k++) {
+                    const int rs = huff(r, T);
+                    if (rs < 0) { bad = 1; break; }
+                    int run = rs >> 4; const uint32_t s = (uint32_t)rs & 15u;
+                    int newv = 0;
+                    if (s) { if (s != 1) { bad = 1; break; } newv = r.bit() ? p1 : m1; }
+                    else if (run != 15) { eobrun = (1u << run) + r.bits(run); break; }     // EOBn (this block included)
+                    // skip `run` zero-history coefficients; every non-zero one passed on the way takes a correction bit
+                    for (; k <= sc.se; k++) {
+                        int16_t* c = blk + c_zz_nat[k];
+                        if (*c) { if (r.bit() && !(*c & p1)) *c = (int16_t)(*c + (*c >= 0 ? p1 : m1)); }
+                        else if (--run < 0) break;
+                    }
+                    if (newv && k <= sc.se) blk[c_zz_nat[k]] = (int16_t)newv;
+                }
+            }
+            if (eobrun) {                                          // rest of the band: correction bits only
+                for (; k <= sc.se; k++) {
+                    int16_t* c = blk + c_zz_nat[k];
+                    if (*c && r.bit() && !(*c & p1)) *c = (int16_t)(*c + (*c >= 0 ? p1 : m1));
+                }
+                eobrun--;
+            }
+        }
+    }
+    if (bad) atomicOr(&status[0], 1u);                              // a code that matches nothing / illegal symbol
+    if (r.overrun()) atomicOr(&status[0], 2u);                      // the interval ended before its blocks did
+}
+
+// Quantised, point-transformed coefficients -> what the baseline path leaves behind: dequantised AC terms in place
+// ((short)(val * Q), DecodeIdctSet :2278) and the dequantised DC in `dccum` (the reference's running DC sum equals
+// Q * DC in wrapping int16 arithmetic, :3280); slot 0 of the block is cleared (the back end never reads it).
+__global__ void __launch_bounds__(256) k_prog_finalize(const JsImage* __restrict__ imgs, JsProgFrame fr, int16_t* __restrict__ coef, int16_t* __restrict__ dccum)
+{
+    const JsImage& im = imgs[0];
+    const uint32_t lane = threadIdx.x & 63;
+    int16_t* cbase = coef + im.coef_off * 64; int16_t* dbase = dccum + im.coef_off;
+    for (uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6); b < im.total_blocks; b += gridDim.x * 4) {
+        const uint32_t comp = im.blk_comp[b % im.blk_per_mcu] - 1u;
+        const int16_t v = cbase[(size_t)b * 64 + lane];
+        const int16_t dq = (int16_t)((int32_t)v * (int32_t)fr.qnat[comp][lane]);
+        if (lane == 0) { dbase[b] = dq; cbase[(size_t)b * 64] = 0; }
+        else cbase[(size_t)b * 64 + lane] = dq;
+    }
+}
+
+void js_launch_prog_scan(hipStream_t st, const JsImage* imgs, const JsProgFrame& fr, const JsProgScan& sc, const JsProgTable* tabs, const JsProgSeg* segs,
+                         const uint8_t* raw, int16_t* coef, uint32_t* status)
+{
+    if (!sc.nseg) return;
+    hipLaunchKernelGGL(k_prog_scan, dim3((sc.nseg + 63) / 64), dim3(64), 0, st, imgs, fr, sc, tabs, segs, raw, coef, status);
+}
+void js_launch_prog_finalize(hipStream_t st, const JsImage* imgs, const JsProgFrame& fr, uint32_t total_blocks, int16_t* coef, int16_t* dccum)
+{
+    const uint32_t g = (total_blocks + 3) / 4;
+    hipLaunchKernelGGL(k_prog_finalize, dim3(g < 4096 ? (g ? g : 1) : 4096), dim3(256), 0, st, imgs, fr, coef, dccum);
+}

@@ -312,6 +312,14 @@ class Backend:
                 return None
             return open(t.name, "rb").read()
 
+    def decode_progressive(self, data: bytes) -> int:
+        """HIP path only: decode a progressive (SOF2) file, all scans; returns the number of scans or -1."""
+        fn = self._f("decode_progressive")
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]; fn.restype = C.c_int
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        self.log_reset()
+        return fn(self.h, C.cast(buf, C.c_void_p), len(data))
+
     def log_reset(self):
         self._log.clear()
 

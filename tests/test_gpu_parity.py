@@ -171,6 +171,48 @@ def test_parallel_side_outputs(harness, oracle, gpu):
             raise AssertionError(f"case {k}: {e}")
 
 
+PROGRESSIVE = [
+    dict(width=1920, height=1080, hs=2, vs=1, restart_interval=120),   # BASELINE config 5: 4:2:2, RSTn every MCU row
+    dict(width=320, height=240),                                        # 4:2:0, no restart markers (one lane per scan)
+    dict(width=160, height=96, hs=1, vs=1, restart_interval=7),
+    dict(width=128, height=64, gray=1, restart_interval=3),
+    dict(width=96, height=80, hs=1, vs=2, restart_interval=1, quality=30),
+    dict(width=333, height=217, restart_interval=5),                    # not a multiple of the MCU: compare the visible region
+    dict(width=141, height=93, hs=2, vs=1, optimize_huffman=1),
+]
+
+
+@pytest.mark.parametrize("kw", PROGRESSIVE, ids=lambda k: "-".join(f"{a}{b}" for a, b in k.items()))
+def test_progressive_transitive_parity(harness, oracle, gpu, kw):
+    """BASELINE config 5.  The reference refuses SOF2, so parity is transitive: the generator writes the
+    same quantised coefficients once as a baseline file -- decoded by the oracle -- and once as a progressive multi-scan
+    file with RSTn; the progressive decode must produce the baseline DIB and planes.  Blocks that lie wholly outside the
+    picture are not coded by non-interleaved scans (T.81 A.2.3), so for sizes that are not MCU multiples the comparison
+    covers the visible region."""
+    base = harness.synth_jpeg(seed=61, progressive=0, **kw)
+    prog = harness.synth_jpeg(seed=61, progressive=1, **kw)
+    harness.drive(oracle, base)
+    ncomp = 1 if kw.get("gray") else 3
+    assert gpu.decode_progressive(prog) == 1 + 2 * ncomp, gpu.lib.jsnoop_last_error()
+    assert gpu.lib.jsnoop_last_path(gpu.h) == 3 and gpu.lib.jsnoop_last_flags(gpu.h) == 0
+    assert gpu.image_size() == oracle.image_size()
+    a, b = oracle.dib(), gpu.dib()
+    H, W = kw["height"], kw["width"]
+    assert np.array_equal(a[a.shape[0] - H:, :W], b[b.shape[0] - H:, :W]), "visible DIB differs"
+    for pa, pb in zip(oracle.planes(), gpu.planes()):
+        if pa is not None:
+            assert np.array_equal(pa[:H, :W], pb[:H, :W]), "visible planes differ"
+    mcu_w = 8 if kw.get("gray") else 8 * kw.get("hs", 2); mcu_h = 8 if kw.get("gray") else 8 * kw.get("vs", 2)
+    if W % mcu_w == 0 and H % mcu_h == 0:
+        assert np.array_equal(a, b), "DIB differs"
+        assert gpu.bright_avg() == oracle.bright_avg()
+    # the drop-in entry points keep refusing the file like the reference does
+    import ctypes as C
+    start = C.c_uint(0)
+    buf = (C.c_uint8 * len(prog)).from_buffer_copy(prog)
+    assert gpu.lib.jsnoop_jfif_walk(gpu.h, C.cast(buf, C.c_void_p), len(prog), C.byref(start)) == -1
+
+
 def test_tiff_export(harness, oracle, gpu):
     """Export to TIFF (RGB 8 / 16 bit, YCC 8 bit): file bytes against the compiled reference's FileTiff output (golden
     hashes) and against the oracle's writer on a larger image."""
