@@ -152,6 +152,21 @@ def main():
                                               "bit_exact": bool(int(one.dib_checksums()[0]) == J.dib_checksum_numpy(orc.dib())),
                                               "stages_ms": {k: round(v, 4) for k, v in st1.items()}}
         one.close()
+        # BASELINE config 5: progressive multi-scan 4:2:2 with RSTn every MCU row; parity is transitive (same coefficients as baseline)
+        kw5 = dict(width=1920, height=1080, hs=2, vs=1, restart_interval=120, quality=85, seed=55)
+        base5, prog5 = H.synth_jpeg(progressive=0, **kw5), H.synth_jpeg(progressive=2, **kw5)
+        dec = J.CimgDecode()
+        nsc = dec.DecodeProgressive(prog5)
+        H.drive(orc, base5)
+        ok5 = bool(np.array_equal(dec.GetBitmapPtr(), orc.dib()))
+        t5 = time.perf_counter()
+        for _ in range(10):
+            dec.DecodeProgressive(prog5)
+        ms5 = (time.perf_counter() - t5) * 100.0
+        extra["config5_progressive_1920x1080_422_rst"] = {"scans": nsc, "ms_end_to_end": round(ms5, 3), "mpix_per_s": round(1920 * 1080 / ms5 / 1e3, 1),
+                                                          "bit_exact_vs_baseline_encoding": ok5,
+                                                          "note": "host parse + H2D + 10 scan launches (one lane per restart interval) + back end, per call"}
+        dec.close()
 
     if rank == 0:
         value = tot_px / max_el / 1e6 if tot_err == 0 else 0.0

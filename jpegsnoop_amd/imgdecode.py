@@ -68,6 +68,20 @@ class CimgDecode:
         self._buf = (C.c_uint8 * len(file_bytes)).from_buffer_copy(file_bytes)
         self._lib.jsnoop_decode_scan_img(self._h, C.cast(self._buf, C.c_void_p), len(file_bytes), nStart, int(bDisplay), int(bQuiet))
 
+    def DecodeProgressive(self, file_bytes: bytes) -> int:
+        """Beyond the reference (it refuses SOF2): decode every scan of a progressive file; returns the number of scans."""
+        self._buf = (C.c_uint8 * len(file_bytes)).from_buffer_copy(file_bytes)
+        n = self._lib.jsnoop_decode_progressive(self._h, C.cast(self._buf, C.c_void_p), len(file_bytes))
+        if n < 0:
+            raise RuntimeError("jsnoop_decode_progressive: " + capi.last_error())
+        return n
+    def GetColorStats(self):
+        out = np.zeros(2482, np.uint32)
+        self._lib.jsnoop_get_color_stats(self._h, out.ctypes.data)
+        return out
+    def ExportTiff(self, path: str, nMode: int = 0) -> bool:
+        return self._lib.jsnoop_export_tiff(self._h, path.encode(), nMode) == 0
+
     # --- results ---------------------------------------------------------------------------
     def IsPreviewReady(self): return bool(self._lib.jsnoop_is_preview_ready(self._h))
     def GetImageSize(self):

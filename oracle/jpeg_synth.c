@@ -204,9 +204,8 @@ static void scan_sequential(BitW* w, const JsynthParams* p, Comp* comp, int ncom
     if (!stats) flush_bits(w);
 }
 
-/* Progressive (T.81 Annex G), spectral selection only (Ah = Al = 0):
- * scan 0 = interleaved DC of all components; then per component AC bands. */
-static void prog_dc_scan(BitW* w, const JsynthParams* p, Comp* comp, int ncomp, int mcux, int mcuy, HuffTab* dc, long fdc[2][256], int stats)
+/* Progressive (T.81 Annex G): first and refinement scans of the DC coefficients and of AC bands. */
+static void prog_dc_scan(BitW* w, const JsynthParams* p, Comp* comp, int ncomp, int mcux, int mcuy, HuffTab* dc, long fdc[2][256], int stats, int ah, int al)
 {
     int pred[3] = {0, 0, 0}, left = p->restart_interval, rstn = 0;
     for (int my = 0; my < mcuy; my++) for (int mx = 0; mx < mcux; mx++) {
@@ -217,6 +216,8 @@ static void prog_dc_scan(BitW* w, const JsynthParams* p, Comp* comp, int ncomp, 
         for (int c = 0; c < ncomp; c++) for (int v = 0; v < comp[c].vs; v++) for (int h = 0; h < comp[c].hs; h++) {
             int bx = mx * comp[c].hs + h, by = my * comp[c].vs + v, t = c ? 1 : 0;
             int z = comp[c].coef[((size_t)by * comp[c].bw + bx) * 64];
+            if (ah) { if (!stats) put_bits(w, (unsigned)(z >> al) & 1u, 1); continue; }     /* G.1.2.1 refinement: one bit per block */
+            z >>= al;                                                                      /* point transform: arithmetic shift */
             int d = z - pred[c]; pred[c] = z; int n = bit_size(d);
             if (stats) fdc[t][n]++; else { put_bits(w, dc[t].code[n], dc[t].size[n]); put_bits(w, bit_mag(d, n), n); }
         }
@@ -233,7 +234,8 @@ static void prog_flush_eobrun(BitW* w, int* eobrun, const HuffTab* ac, long* fac
 }
 /* Non-interleaved AC band scan of one component over its un-padded block grid
  * (T.81 A.2.3: ceil(X*Hi/Hmax / 8) x ceil(Y*Vi/Vmax / 8) blocks). */
-static void prog_ac_scan(BitW* w, const JsynthParams* p, const Comp* c, int nbx, int nby, int ss, int se, const HuffTab* ac, long* fac)
+static int pt_ac(int v, int al) { return v < 0 ? -((-v) >> al) : v >> al; }   /* AC point transform: divide by 2^Al toward zero */
+static void prog_ac_scan(BitW* w, const JsynthParams* p, const Comp* c, int nbx, int nby, int ss, int se, const HuffTab* ac, long* fac, int al)
 {
     int eobrun = 0, left = p->restart_interval, rstn = 0;
     for (int by = 0; by < nby; by++) for (int bx = 0; bx < nbx; bx++) {
@@ -245,7 +247,7 @@ static void prog_ac_scan(BitW* w, const JsynthParams* p, const Comp* c, int nbx,
         const int16_t* zz = c->coef + ((size_t)by * c->bw + bx) * 64;
         int run = 0;
         for (int k = ss; k <= se; k++) {
-            int v = zz[k];
+            int v = pt_ac(zz[k], al);
             if (!v) { run++; continue; }
             prog_flush_eobrun(w, &eobrun, ac, fac);
             while (run > 15) { if (fac) fac[0xF0]++; else put_bits(w, ac->code[0xF0], ac->size[0xF0]); run -= 16; }
@@ -257,6 +259,58 @@ static void prog_ac_scan(BitW* w, const JsynthParams* p, const Comp* c, int nbx,
         if (p->restart_interval) left--;
     }
     prog_flush_eobrun(w, &eobrun, ac, fac);
+    if (!fac) flush_bits(w);
+}
+
+/* AC refinement scan (T.81 G.1.2.3): coefficients that become non-zero at this bit position are coded as run/1 + sign,
+ * the already non-zero ones contribute one correction bit each, buffered until the next code is written. */
+typedef struct { unsigned char b[2048]; int n; } BitQ;
+static void refine_flush(BitW* w, int* eobrun, BitQ* be, const HuffTab* ac, long* fac)
+{
+    if (*eobrun) {
+        int n = 0, t = *eobrun; while (t > 1) { n++; t >>= 1; }
+        if (fac) fac[n << 4]++; else { put_bits(w, ac->code[n << 4], ac->size[n << 4]); if (n) put_bits(w, (unsigned)*eobrun & ((1u << n) - 1), n); }
+        *eobrun = 0;
+    }
+    if (!fac) for (int i = 0; i < be->n; i++) put_bits(w, be->b[i], 1);
+    be->n = 0;
+}
+static void prog_ac_refine_scan(BitW* w, const JsynthParams* p, const Comp* c, int nbx, int nby, int ss, int se, const HuffTab* ac, long* fac, int al)
+{
+    int eobrun = 0, left = p->restart_interval, rstn = 0; BitQ be; be.n = 0;
+    for (int by = 0; by < nby; by++) for (int bx = 0; bx < nbx; bx++) {
+        if (p->restart_interval && left == 0) {
+            refine_flush(w, &eobrun, &be, ac, fac);
+            if (!fac) { flush_bits(w); put_u16(w, 0xFFD0 + (rstn & 7)); }
+            rstn++; left = p->restart_interval;
+        }
+        const int16_t* zz = c->coef + ((size_t)by * c->bw + bx) * 64;
+        int av[64], eob = 0;
+        for (int k = ss; k <= se; k++) { int v = zz[k]; av[k] = (v < 0 ? -v : v) >> al; if (av[k] == 1) eob = k; }
+        int run = 0; BitQ br; br.n = 0;
+        for (int k = ss; k <= se; k++) {
+            if (av[k] == 0) { run++; continue; }
+            while (run > 15 && k <= eob) {                       /* ZRL only while a new coefficient is still to come */
+                refine_flush(w, &eobrun, &be, ac, fac);
+                if (fac) fac[0xF0]++; else put_bits(w, ac->code[0xF0], ac->size[0xF0]);
+                run -= 16;
+                if (!fac) for (int i = 0; i < br.n; i++) put_bits(w, br.b[i], 1);
+                br.n = 0;
+            }
+            if (av[k] > 1) { br.b[br.n++] = (unsigned char)(av[k] & 1); continue; }   /* correction bit of a known coefficient */
+            refine_flush(w, &eobrun, &be, ac, fac);
+            if (fac) fac[(run << 4) + 1]++; else { put_bits(w, ac->code[(run << 4) + 1], ac->size[(run << 4) + 1]); put_bits(w, zz[k] < 0 ? 0u : 1u, 1); }
+            if (!fac) for (int i = 0; i < br.n; i++) put_bits(w, br.b[i], 1);
+            br.n = 0; run = 0;
+        }
+        if (run > 0 || br.n > 0) {                                 /* the rest of the block rides on an end-of-band run */
+            eobrun++;
+            for (int i = 0; i < br.n; i++) be.b[be.n++] = br.b[i];
+            if (eobrun == 0x7FFF || be.n > 1900) refine_flush(w, &eobrun, &be, ac, fac);
+        }
+        if (p->restart_interval) left--;
+    }
+    refine_flush(w, &eobrun, &be, ac, fac);
     if (!fac) flush_bits(w);
 }
 
@@ -330,29 +384,52 @@ size_t jsynth_encode_rgb(const JsynthParams* p, const uint8_t* rgb, uint8_t* out
         put_byte(&w, 0); put_byte(&w, 63); put_byte(&w, 0);
         scan_sequential(&w, p, comp, ncomp, mcux, mcuy, dc, ac, NULL, NULL, 0);
     } else {
-        /* DC scan */
-        if (p->optimize_huffman) { long fdc[2][256]; memset(fdc, 0, sizeof fdc);
-            prog_dc_scan(&w, p, comp, ncomp, mcux, mcuy, dc, fdc, 1);
-            for (int t = 0; t < (ncomp == 3 ? 2 : 1); t++) huff_optimal(&dc[t], fdc[t]); }
-        for (int t = 0; t < (ncomp == 3 ? 2 : 1); t++) emit_dht(&w, 0, t, &dc[t]);
-        put_u16(&w, 0xFFDA); put_u16(&w, (unsigned)(6 + 2 * ncomp)); put_byte(&w, (unsigned)ncomp);
-        for (int c = 0; c < ncomp; c++) { put_byte(&w, (unsigned)(c + 1)); put_byte(&w, c ? 0x10 : 0x00); }
-        put_byte(&w, 0); put_byte(&w, 0); put_byte(&w, 0);
-        prog_dc_scan(&w, p, comp, ncomp, mcux, mcuy, dc, NULL, 0);
-        /* AC bands, one component per scan */
-        static const int band[2][2] = {{1, 5}, {6, 63}};
-        for (int c = 0; c < ncomp; c++) for (int b = 0; b < 2; b++) {
-            int t = c ? 1 : 0;
+        /* progressive == 1: spectral selection only (DC, then two AC bands per component);
+         * progressive == 2: spectral selection + successive approximation, a script in the style of the IJG default */
+        typedef struct { int comp, ss, se, ah, al; } ScanDef;     /* comp < 0: all components interleaved (DC scans only) */
+        ScanDef script[16]; int ns = 0;
+        if (p->progressive == 1) {
+            script[ns++] = (ScanDef){-1, 0, 0, 0, 0};
+            for (int c = 0; c < ncomp; c++) { script[ns++] = (ScanDef){c, 1, 5, 0, 0}; script[ns++] = (ScanDef){c, 6, 63, 0, 0}; }
+        } else {
+            script[ns++] = (ScanDef){-1, 0, 0, 0, 1};
+            script[ns++] = (ScanDef){0, 1, 5, 0, 2};
+            if (ncomp == 3) { script[ns++] = (ScanDef){2, 1, 63, 0, 1}; script[ns++] = (ScanDef){1, 1, 63, 0, 1}; }
+            script[ns++] = (ScanDef){0, 6, 63, 0, 2};
+            script[ns++] = (ScanDef){0, 1, 63, 2, 1};
+            script[ns++] = (ScanDef){-1, 0, 0, 1, 0};
+            if (ncomp == 3) { script[ns++] = (ScanDef){2, 1, 63, 1, 0}; script[ns++] = (ScanDef){1, 1, 63, 1, 0}; }
+            script[ns++] = (ScanDef){0, 1, 63, 1, 0};
+        }
+        for (int si = 0; si < ns; si++) {
+            const ScanDef sd = script[si];
+            if (sd.comp < 0) {                                     /* DC scan, interleaved */
+                if (!sd.ah) {
+                    if (p->optimize_huffman) { long fdc[2][256]; memset(fdc, 0, sizeof fdc);
+                        prog_dc_scan(&w, p, comp, ncomp, mcux, mcuy, dc, fdc, 1, 0, sd.al);
+                        for (int t = 0; t < (ncomp == 3 ? 2 : 1); t++) huff_optimal(&dc[t], fdc[t]); }
+                    for (int t = 0; t < (ncomp == 3 ? 2 : 1); t++) emit_dht(&w, 0, t, &dc[t]);
+                }
+                put_u16(&w, 0xFFDA); put_u16(&w, (unsigned)(6 + 2 * ncomp)); put_byte(&w, (unsigned)ncomp);
+                for (int c = 0; c < ncomp; c++) { put_byte(&w, (unsigned)(c + 1)); put_byte(&w, c ? 0x10 : 0x00); }
+                put_byte(&w, 0); put_byte(&w, 0); put_byte(&w, (unsigned)(sd.ah << 4 | sd.al));
+                prog_dc_scan(&w, p, comp, ncomp, mcux, mcuy, dc, NULL, 0, sd.ah, sd.al);
+                continue;
+            }
+            const int c = sd.comp, t = c ? 1 : 0;
             int nbx = ncomp == 1 ? (W + 7) / 8 : ((W * comp[c].hs + hmax - 1) / hmax + 7) / 8;
             int nby = ncomp == 1 ? (H + 7) / 8 : ((H * comp[c].vs + vmax - 1) / vmax + 7) / 8;
             HuffTab a = ac[t];
-            /* EOBn symbols (0x10..0xE0) are absent from Annex K: AC band tables are always per-scan optimal */
+            /* EOBn symbols (0x10..0xE0) are absent from Annex K: AC scan tables are always per-scan optimal */
             { long fac[256]; memset(fac, 0, sizeof fac);
-                prog_ac_scan(&w, p, &comp[c], nbx, nby, band[b][0], band[b][1], &a, fac); huff_optimal(&a, fac); }
+                if (sd.ah) prog_ac_refine_scan(&w, p, &comp[c], nbx, nby, sd.ss, sd.se, &a, fac, sd.al);
+                else prog_ac_scan(&w, p, &comp[c], nbx, nby, sd.ss, sd.se, &a, fac, sd.al);
+                huff_optimal(&a, fac); }
             emit_dht(&w, 1, t, &a);
             put_u16(&w, 0xFFDA); put_u16(&w, 8); put_byte(&w, 1); put_byte(&w, (unsigned)(c + 1)); put_byte(&w, (unsigned)t);
-            put_byte(&w, (unsigned)band[b][0]); put_byte(&w, (unsigned)band[b][1]); put_byte(&w, 0);
-            prog_ac_scan(&w, p, &comp[c], nbx, nby, band[b][0], band[b][1], &a, NULL);
+            put_byte(&w, (unsigned)sd.ss); put_byte(&w, (unsigned)sd.se); put_byte(&w, (unsigned)(sd.ah << 4 | sd.al));
+            if (sd.ah) prog_ac_refine_scan(&w, p, &comp[c], nbx, nby, sd.ss, sd.se, &a, NULL, sd.al);
+            else prog_ac_scan(&w, p, &comp[c], nbx, nby, sd.ss, sd.se, &a, NULL, sd.al);
         }
     }
     put_u16(&w, 0xFFD9);

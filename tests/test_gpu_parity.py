@@ -182,18 +182,22 @@ PROGRESSIVE = [
 ]
 
 
+@pytest.mark.parametrize("mode", [1, 2], ids=["spectral", "successive"])
 @pytest.mark.parametrize("kw", PROGRESSIVE, ids=lambda k: "-".join(f"{a}{b}" for a, b in k.items()))
-def test_progressive_transitive_parity(harness, oracle, gpu, kw):
+def test_progressive_transitive_parity(harness, oracle, gpu, kw, mode):
     """BASELINE config 5.  The reference refuses SOF2, so parity is transitive: the generator writes the
     same quantised coefficients once as a baseline file -- decoded by the oracle -- and once as a progressive multi-scan
     file with RSTn; the progressive decode must produce the baseline DIB and planes.  Blocks that lie wholly outside the
     picture are not coded by non-interleaved scans (T.81 A.2.3), so for sizes that are not MCU multiples the comparison
-    covers the visible region."""
+    covers the visible region.  mode 1: spectral selection only (DC scan + two AC bands per component); mode 2: spectral
+    selection and successive approximation (DC and AC first scans with point transform, two refinement levels for
+    luminance AC, DC refinement) -- a script in the style of the IJG default, cross-checked with libjpeg via PIL here."""
     base = harness.synth_jpeg(seed=61, progressive=0, **kw)
-    prog = harness.synth_jpeg(seed=61, progressive=1, **kw)
+    prog = harness.synth_jpeg(seed=61, progressive=mode, **kw)
     harness.drive(oracle, base)
     ncomp = 1 if kw.get("gray") else 3
-    assert gpu.decode_progressive(prog) == 1 + 2 * ncomp, gpu.lib.jsnoop_last_error()
+    want_scans = 1 + 2 * ncomp if mode == 1 else (6 if ncomp == 1 else 10)
+    assert gpu.decode_progressive(prog) == want_scans, gpu.lib.jsnoop_last_error()
     assert gpu.lib.jsnoop_last_path(gpu.h) == 3 and gpu.lib.jsnoop_last_flags(gpu.h) == 0
     assert gpu.image_size() == oracle.image_size()
     a, b = oracle.dib(), gpu.dib()
