@@ -1358,47 +1358,55 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
 
 // One workgroup (1024 lanes) per image: DC differences (in dccum, decode order) -> cumulative DC per block.
 // int16 wrapping sums per component (m_nDcLum += ..., :3280/:3355/:3386), reset at every MCU the write pass marked as
-// the first of a restart interval (DecodeRestartDcState :2693).  Each lane owns a run of MCUs: local sums, a
-// block-wide segmented carry, then the rewrite in place.
+// the first of a restart interval (DecodeRestartDcState :2693).  One lane per MCU, 1024 MCUs per step: the lanes of a
+// wave read one contiguous stretch of the DC array; a segmented inclusive scan (wave shuffles, then the 16 wave totals)
+// gives every MCU the sums that enter it, and a running carry links the steps.
 #define DC_THREADS 1024
+struct DcSeg { int s0, s1, s2; int r; };                            // sums since the last reset inside the span, reset seen
+__device__ __forceinline__ DcSeg dc_combine(const DcSeg& a, const DcSeg& b) { DcSeg o; if (b.r) o = b; else { o.s0 = a.s0 + b.s0; o.s1 = a.s1 + b.s1; o.s2 = a.s2 + b.s2; o.r = a.r; } return o; }
 __global__ void __launch_bounds__(DC_THREADS) k_dc_scan(const JsImage* __restrict__ imgs, const JsTableSet* __restrict__ tables,
                                                         int16_t* __restrict__ dccum, const uint8_t* __restrict__ mcu_rst)
 {
     const uint32_t img = blockIdx.x; const JsImage& im = imgs[img];
     if (!tables[im.tableset].lut_ok) return;
-    const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax, nb = im.blk_per_mcu, per = (nmcu + DC_THREADS - 1) / DC_THREADS;
+    const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax, nb = im.blk_per_mcu;
     const uint32_t n1 = im.samp_h[1] * im.samp_v[1], n2 = im.ncomp == 3 ? n1 + im.samp_h[2] * im.samp_v[2] : nb;
-    const uint32_t m0 = min(threadIdx.x * per, nmcu), m1 = min(m0 + per, nmcu);
     int16_t* d = dccum + im.coef_off; const uint8_t* rf = mcu_rst + im.mcu_off;
-    int16_t sum0 = 0, sum1 = 0, sum2 = 0; bool rst = false;
-    for (uint32_t m = m0; m < m1; m++) {
-        if (rf[m]) { sum0 = sum1 = sum2 = 0; rst = true; }
-        for (uint32_t c = 0; c < nb; c++) {
-            const int16_t v = d[(size_t)m * nb + c];
-            if (c < n1) sum0 = (int16_t)(sum0 + v); else if (c < n2) sum1 = (int16_t)(sum1 + v); else sum2 = (int16_t)(sum2 + v);
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    __shared__ DcSeg s_w[DC_THREADS / 64];
+    DcSeg carry = { 0, 0, 0, 0 };
+    for (uint32_t base = 0; base < nmcu; base += DC_THREADS) {
+        const uint32_t m = base + t; const bool valid = m < nmcu;
+        int v[JS_MAX_BLK_PER_MCU];
+        DcSeg own = { 0, 0, 0, valid && rf[m] ? 1 : 0 };
+        #pragma unroll
+        for (uint32_t c = 0; c < JS_MAX_BLK_PER_MCU; c++) {
+            v[c] = (valid && c < nb) ? (int)d[(size_t)m * nb + c] : 0;
+            if (c < n1) own.s0 += v[c]; else if (c < n2) own.s1 += v[c]; else own.s2 += v[c];
         }
-    }
-    // segmented inclusive scan over lanes of (sum since last reset, saw reset): combine(a, b) = b.rst ? b : (a.sum + b.sum, a.rst)
-    __shared__ int16_t s_sum[DC_THREADS][3]; __shared__ uint8_t s_rst[DC_THREADS];
-    s_sum[threadIdx.x][0] = sum0; s_sum[threadIdx.x][1] = sum1; s_sum[threadIdx.x][2] = sum2; s_rst[threadIdx.x] = rst;
-    __syncthreads();
-    for (uint32_t dd = 1; dd < DC_THREADS; dd <<= 1) {
-        int16_t a0 = 0, a1 = 0, a2 = 0; bool ar = false; const bool has = threadIdx.x >= dd;
-        if (has) { a0 = s_sum[threadIdx.x - dd][0]; a1 = s_sum[threadIdx.x - dd][1]; a2 = s_sum[threadIdx.x - dd][2]; ar = s_rst[threadIdx.x - dd]; }
-        const bool br = s_rst[threadIdx.x];
-        __syncthreads();
-        if (has && !br) { s_sum[threadIdx.x][0] = (int16_t)(s_sum[threadIdx.x][0] + a0); s_sum[threadIdx.x][1] = (int16_t)(s_sum[threadIdx.x][1] + a1);
-                          s_sum[threadIdx.x][2] = (int16_t)(s_sum[threadIdx.x][2] + a2); s_rst[threadIdx.x] = ar; }
-        __syncthreads();
-    }
-    int16_t c0 = 0, c1 = 0, c2 = 0;                              // carry-in = inclusive result of the lane to the left
-    if (threadIdx.x) { c0 = s_sum[threadIdx.x - 1][0]; c1 = s_sum[threadIdx.x - 1][1]; c2 = s_sum[threadIdx.x - 1][2]; }
-    for (uint32_t m = m0; m < m1; m++) {
-        if (rf[m]) c0 = c1 = c2 = 0;
-        for (uint32_t c = 0; c < nb; c++) {
-            const size_t b = (size_t)m * nb + c; const int16_t v = d[b];
-            if (c < n1) { c0 = (int16_t)(c0 + v); d[b] = c0; } else if (c < n2) { c1 = (int16_t)(c1 + v); d[b] = c1; } else { c2 = (int16_t)(c2 + v); d[b] = c2; }
+        DcSeg inc = own;                                         // inclusive scan over the lanes of the wave
+        #pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            DcSeg a; a.s0 = __shfl_up(inc.s0, off); a.s1 = __shfl_up(inc.s1, off); a.s2 = __shfl_up(inc.s2, off); a.r = __shfl_up(inc.r, off);
+            if (lane >= (uint32_t)off) inc = dc_combine(a, inc);
         }
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        DcSeg pre = carry, tot = carry;                          // what enters this wave / leaves the step
+        for (uint32_t w = 0; w < DC_THREADS / 64; w++) { const DcSeg x = s_w[w]; if (w < wave) pre = dc_combine(pre, x); tot = dc_combine(tot, x); }
+        inc = dc_combine(pre, inc);
+        // sums entering this MCU: nothing after a reset, else the inclusive result minus the MCU's own contribution
+        int c0 = own.r ? 0 : inc.s0 - own.s0, c1 = own.r ? 0 : inc.s1 - own.s1, c2 = own.r ? 0 : inc.s2 - own.s2;
+        if (valid) {
+            #pragma unroll
+            for (uint32_t c = 0; c < JS_MAX_BLK_PER_MCU; c++) if (c < nb) {
+                int16_t o;
+                if (c < n1) { c0 += v[c]; o = (int16_t)c0; } else if (c < n2) { c1 += v[c]; o = (int16_t)c1; } else { c2 += v[c]; o = (int16_t)c2; }
+                d[(size_t)m * nb + c] = o;
+            }
+        }
+        carry = tot; carry.r = 0;
+        __syncthreads();
     }
 }
 
