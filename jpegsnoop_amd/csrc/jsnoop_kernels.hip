@@ -986,7 +986,7 @@ __global__ void __launch_bounds__(256) k_interleave(const JsImage* __restrict__ 
 // Per-workgroup LDS view of one image's decode tables (dynamic shared memory, sized by the batch).
 struct SubTabs {
     const uint16_t* lut1;              // n_rows x 2048 entries
-    const uint16_t* lut2;              // second level (codes longer than 11 bits)
+    const uint16_t* lut2;              // second level (codes longer than JS_L1_BITS bits)
     const uint16_t* qzz;               // 3 x 64 quantiser entries, zig-zag order
     const uint8_t*  zz;                // 64: zig-zag index -> natural index
     uint32_t rows01, rows2;            // per component 16 bits: first-level row of its DC table | AC table << 8
@@ -1048,7 +1048,7 @@ __device__ __forceinline__ uint32_t sym_lookup(const SubTabs& T, uint32_t win, u
 {
     const uint32_t row = (k ? rp >> 8 : rp) & 255u;
     uint32_t e = T.lut1[(row << JS_L1_BITS) + (win >> (32 - JS_L1_BITS))];
-    if (__builtin_expect(e & 0x8000u, 0)) {                      // < 0.5 % of symbols: code longer than 11 bits
+    if (__builtin_expect(e & 0x8000u, 0)) {                      // a few % of symbols: code longer than JS_L1_BITS bits
         const uint32_t nbx = (e >> 12) & 7u;
         e = T.lut2[(e & 0xFFFu) + ((win >> (32 - JS_L1_BITS - nbx)) & ((1u << nbx) - 1u))];
     }
@@ -1295,7 +1295,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         // ---- one symbol per lane: straight-line select code on the common path
         const uint32_t win = cur_peek(cur);
         uint32_t e = T.lut1[((((k ? rp >> 8 : rp) & 255u)) << JS_L1_BITS) + (win >> (32 - JS_L1_BITS))];
-        if (__ballot(active && (e & 0x8000u))) {                 // some lane holds a code longer than 11 bits (< 0.5 % of symbols)
+        if (__ballot(active && (e & 0x8000u))) {                 // some lane holds a code longer than JS_L1_BITS bits (a few % of symbols)
             if (e & 0x8000u) { const uint32_t nbx = (e >> 12) & 7u; e = T.lut2[(e & 0xFFFu) + ((win >> (32 - JS_L1_BITS - nbx)) & ((1u << nbx) - 1u))]; }
         }
         const uint32_t len = (e >> 8) & 31u, run = (e >> 4) & 15u, size = e & 15u;

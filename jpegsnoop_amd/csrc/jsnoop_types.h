@@ -19,8 +19,8 @@
 #define JS_DHT_CODES       260     // MAX_DHT_CODES, ImgDecode.h:68
 #define JS_FAST_BITS       9       // DHT_FAST_SIZE, ImgDecode.h:96
 #define JS_CODE_UNUSED     0xFFFFFFFFu
-#define JS_L1_BITS         11      // first-level index width of the parallel path's decode tables
-#define JS_LUT2_MAX        1024    // second-level entries (all tables together) in the parallel path's LUT form
+#define JS_L1_BITS         9       // first-level index width of the parallel path's decode tables (1 KiB rows: LDS occupancy of the write pass)
+#define JS_LUT2_MAX        2048    // second-level entries (all tables together) in the parallel path's LUT form
 #define JS_SUBSEQ_BYTES    128     // bytes of un-stuffed stream per sub-sequence (parallel entropy path)
 
 // One distinct set of Huffman + quantisation tables, resolved per scan component
@@ -32,7 +32,7 @@ struct JsTableSet {
     uint32_t bitlen[6][JS_DHT_CODES], bits[6][JS_DHT_CODES], mask[6][JS_DHT_CODES], code[6][JS_DHT_CODES];
     uint32_t dest_id[6];                    // DHT destination id behind each slot (histogram index)
     uint16_t qzz[3][64];                    // m_anDqtCoeffZz of the table selected for each component
-    // --- parallel-path form: 11-bit first level + second level for the (rare, < 0.5 % of symbols) longer codes.
+    // --- parallel-path form: JS_L1_BITS-bit first level + second level for the longer codes (a few % of symbols).
     //     Identical tables share one row (Cb and Cr normally do): slot_row[slot] says which.
     //     entry: bit15 = 0 : [12:8] = code length (0 = invalid), [7:0] = symbol (run<<4 | size)
     //            bit15 = 1 : [14:12] = extra index bits nb (1..5), [11:0] = base into lut2
