@@ -1037,7 +1037,8 @@ template <int WL> __device__ __forceinline__ void cur_skip(Cursor& c, uint32_t n
 #define ST_K(s)   ((s) & 255u)
 #define ST_MAKE(seg, c, k) (((seg) << 16) | ((c) << 8) | (k))
 #define P_END 0xFFFFFFFFu
-#define WR_STRIDE 68                   // int16 per thread-private LDS block buffer (64 + pad: 8-byte aligned, banks staggered)
+#define WR_STRIDE 66                   // int16 per thread-private LDS block buffer (64 + pad: 33-dword rows stagger the banks; 33 KiB per
+                                       // workgroup leaves room for the decode tables with FOUR workgroups per CU -- the walk is latency-bound)
 
 // component (0..2) of block-in-MCU index c, without a table lookup
 __device__ __forceinline__ uint32_t comp_of(const SubTabs& T, uint32_t c) { return (c >= T.n1 ? 1u : 0u) + (c >= T.n2 ? 1u : 0u); }
@@ -1259,7 +1260,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
     if (SIDE) for (uint32_t q = threadIdx.x; q < 2 * 4 * 17; q += SY_THREADS) s_histo[q] = 0;
     const JsTableSet& tset = tables[im.tableset];
     SubTabs T; load_subtabs(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, threadIdx.x, SY_THREADS);
-    { uint2* z = reinterpret_cast<uint2*>(s_blk[threadIdx.x]); for (int j = 0; j < WR_STRIDE / 4; j++) z[j] = make_uint2(0u, 0u); }
+    { uint32_t* z = reinterpret_cast<uint32_t*>(s_blk[threadIdx.x]); for (int j = 0; j < WR_STRIDE / 2; j++) z[j] = 0u; }
     __syncthreads();
 
     const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);
