@@ -45,6 +45,11 @@ struct ExactReader {
     uint32_t rst_count, rst_last, rst_expect, mcus_left, rst_interval, warn_bad, err_max;
     uint32_t used1, used2, precision, rst_handled;
     uint32_t* ev; uint32_t ev_cap, ev_only;                    // event log (JS_EV_*): nullptr = off; ev_only != 0: record just that kind
+    uint64_t win; uint32_t win_at;                             // 8 file bytes in registers (file images are 16-byte aligned and zero padded)
+    const uint32_t* fast;                                      // m_anDhtLookupfast of the six slots, [6][1 << JS_FAST_BITS] (LDS copy in k_entropy_exact)
+    const uint32_t* meta;                                      // [0..5] m_anDhtLookupSize per slot, [6..11] DHT destination id per slot
+    const uint16_t* q;                                         // quantiser [3][64], zig-zag order
+    const uint8_t* zz;                                         // zig-zag index -> natural index
 };
 
 // One line (group) of what the reference writes to its log while decoding; formatted on the host (jsnoop_report.cpp).
@@ -56,7 +61,13 @@ __device__ void ex_event(ExactReader& r, uint32_t kind, uint32_t a0 = 0, uint32_
     r.ev[0] = n + 1;
 }
 
-__device__ __forceinline__ uint32_t ex_byte(const ExactReader& r, uint32_t off) { return off < r.flen ? r.file[off] : 0u; }
+__device__ __forceinline__ uint32_t ex_byte(ExactReader& r, uint32_t off)          // CwindowBuf::Buf: 0 past the end of the file
+{
+    if (off >= r.flen) return 0u;
+    const uint32_t a = off & ~7u;
+    if (a != r.win_at) { r.win = *reinterpret_cast<const uint64_t*>(r.file + a); r.win_at = a; }   // one aligned load per 8 bytes instead of one per byte
+    return (uint32_t)(r.win >> ((off & 7u) * 8)) & 255u;
+}
 
 __device__ void ex_restart_scan_buf(ExactReader& r, uint32_t file_pos, bool restart)   // DecodeRestartScanBuf :4038-4075
 {
@@ -118,10 +129,10 @@ __device__ int ex_read_scan_val(ExactReader& r, uint32_t t, uint32_t& zrl, int32
     if (r.vacant >= 32) { if (r.warn_bad < r.err_max) { ex_event(r, JS_EV_OVERREAD_BEFORE, r.pos0, r.align); r.warn_bad++; } r.scan_end = 1; r.scan_bad = 1; return RSV_UNDERFLOW; }
     ex_topup(r);
     if ((32 - r.vacant) >= JS_FAST_BITS) {
-        uint32_t f = r.ts->fast[t][r.buff >> (32 - JS_FAST_BITS)];
+        uint32_t f = r.fast[t * (1u << JS_FAST_BITS) + (r.buff >> (32 - JS_FAST_BITS))];
         if (f != JS_CODE_UNUSED) { r.used1 += f >> 8; code = f & 0xFF; done = true; found = true; }
     }
-    const uint32_t size = r.ts->size[t];
+    const uint32_t size = r.meta[t];
     while (!done) {
         if ((r.buff & r.ts->mask[t][ind]) == r.ts->bits[t][ind]) {
             uint32_t bl = r.ts->bitlen[t][ind];
@@ -134,7 +145,7 @@ __device__ int ex_read_scan_val(ExactReader& r, uint32_t t, uint32_t& zrl, int32
         if (r.restart_read) return RSV_RST_TERM;
         r.used1 = 1; code = JS_CODE_UNUSED;
     }
-    if (r.used1 < 17) r.histo[((t & 1) * 4 + r.ts->dest_id[t]) * 17 + r.used1]++;
+    if (r.used1 < 17) r.histo[((t & 1) * 4 + r.meta[6 + t]) * 17 + r.used1]++;
     ex_consume(r, r.used1);
     if (r.vacant > 32) { ex_event(r, JS_EV_OVERREAD_CODE, r.pos0, r.align); r.scan_end = 1; r.scan_bad = 1; return RSV_UNDERFLOW; }
     ex_topup(r);
@@ -149,7 +160,7 @@ __device__ int ex_read_scan_val(ExactReader& r, uint32_t t, uint32_t& zrl, int32
         if (r.vacant > 32) { ex_event(r, JS_EV_OVERREAD_BITS, r.pos0, r.align); r.scan_end = 1; r.scan_bad = 1; return RSV_UNDERFLOW; }
         return RSV_OK;
     }
-    if (r.warn_bad < r.err_max) { ex_event(r, JS_EV_CANT_FIND, r.pos0, r.align, r.ts->dest_id[t], r.buff); r.warn_bad++; }   // :1266-1277
+    if (r.warn_bad < r.err_max) { ex_event(r, JS_EV_CANT_FIND, r.pos0, r.align, r.meta[6 + t], r.buff); r.warn_bad++; }   // :1266-1277
     r.scan_bad = 1;
     return RSV_UNDERFLOW;
 }
@@ -160,7 +171,7 @@ __device__ int16_t ex_decode_block(ExactReader& r, uint32_t comp, uint32_t decod
                                    int16_t& dc_y, int16_t& dc_cb, int16_t& dc_cr)
 {
     const uint32_t tdc = (comp - 1) * 2, tac = tdc + 1;
-    const uint16_t* q = r.ts->qzz[comp - 1];
+    const uint16_t* q = r.q + (comp - 1) * 64;
     uint32_t zrl, ncoef = 0; int32_t val; bool done = false, is_dc = true, failed = false; int16_t dct0 = 0;
     while (!done) {
         ex_topup(r);
@@ -182,7 +193,7 @@ __device__ int16_t ex_decode_block(ExactReader& r, uint32_t comp, uint32_t decod
             uint32_t ind = ncoef + zrl;
             if (ind < 64) {
                 int16_t dq = (int16_t)((int32_t)v16 * (int32_t)q[ind]);
-                uint32_t nat = c_zigzag[ind];
+                uint32_t nat = r.zz[ind];
                 if (nat == 0) dct0 = dq; else out[nat] = dq;
             }
         }
@@ -202,17 +213,33 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
 {
     // side_only: recompute only the decoder's side outputs (MCU file map, block-DC maps, code-length
     // histogram, status words) for an image whose pixels came from the parallel path.
+    // One workgroup (one wave) per image, lane 0 decodes: the mirror is a sequential program whose every step waits for the
+    // previous one, so what counts is latency -- the 9-bit look-up tables and the histogram live in LDS, and lanes of
+    // different images do not share a wave (their branches would serialise).
+    __shared__ uint32_t s_fast[6 * (1 << JS_FAST_BITS)]; __shared__ uint32_t s_histo[2 * 4 * 17];
+    __shared__ uint32_t s_meta[12]; __shared__ uint16_t s_q[3 * 64]; __shared__ uint8_t s_zz[64];
     int16_t scratch[64];
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = blockIdx.x;
     if (j >= nsel) return;
     const JsImage& im = imgs[sel ? sel[j] : j];
+    {
+        const uint32_t* src = &tables[im.tableset].fast[0][0];
+        for (uint32_t i = threadIdx.x; i < 6 * (1u << JS_FAST_BITS); i += blockDim.x) s_fast[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < 2 * 4 * 17; i += blockDim.x) s_histo[i] = 0;
+        const JsTableSet& tset = tables[im.tableset];
+        if (threadIdx.x < 6) { s_meta[threadIdx.x] = tset.size[threadIdx.x]; s_meta[6 + threadIdx.x] = tset.dest_id[threadIdx.x]; }
+        for (uint32_t i = threadIdx.x; i < 3 * 64; i += blockDim.x) s_q[i] = (&tset.qzz[0][0])[i];
+        if (threadIdx.x < 64) s_zz[threadIdx.x] = c_zigzag[threadIdx.x];
+    }
+    __syncthreads();
+    if (threadIdx.x) return;
     uint32_t* sd = side + im.side_off;
     const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax, nblk = im.blk_xmax * im.blk_ymax;
     uint32_t* mcu_map = sd + JS_SIDE_MCUMAP;
     int16_t* bdc[3]; bdc[0] = (int16_t*)(mcu_map + nmcu); bdc[1] = bdc[0] + 2 * ((nblk + 1) / 2); bdc[2] = bdc[1] + 2 * ((nblk + 1) / 2);
 
     ExactReader r;
-    r.file = raw + im.file_off; r.flen = im.file_len; r.ts = tables + im.tableset; r.histo = sd + JS_SIDE_HISTO;
+    r.file = raw + im.file_off; r.flen = im.file_len; r.ts = tables + im.tableset; r.histo = s_histo; r.fast = s_fast; r.meta = s_meta; r.q = s_q; r.zz = s_zz; r.win_at = 0xFFFFFFFFu; r.win = 0;
     r.rst_interval = im.rst_interval; r.precision = im.precision; r.err_max = im.err_max; r.warn_bad = 0;
     r.rst_count = 0; r.rst_last = 0; r.rst_expect = 0; r.rst_handled = 0;
     r.ev = (im.ev_cap && !side_only) ? events + im.ev_off : nullptr; r.ev_cap = im.ev_cap; r.ev_only = 0;
@@ -261,6 +288,7 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
     }
     sd[0] = r.scan_bad; sd[1] = r.scan_end; sd[2] = r.rst_count; sd[3] = num_pixels;
     sd[4] = r.pos0; sd[5] = r.align; sd[6] = r.warn_bad; sd[7] = r.ptr_first; if (!side_only) sd[9] = 2;
+    for (uint32_t i = 0; i < 2 * 4 * 17; i++) sd[JS_SIDE_HISTO + i] = s_histo[i];
 }
 
 // =====================================================================================
@@ -774,7 +802,7 @@ void js_launch_entropy_exact(hipStream_t st, const JsImage* imgs, const uint32_t
                              const uint8_t* raw, int16_t* coef, int16_t* dccum, uint32_t* side, int side_only, uint32_t* events)
 {
     if (!nsel) return;
-    hipLaunchKernelGGL(k_entropy_exact, dim3((nsel + 63) / 64), dim3(64), 0, st, imgs, sel, nsel, tables, raw, coef, dccum, side, side_only, events);
+    hipLaunchKernelGGL(k_entropy_exact, dim3(nsel), dim3(64), 0, st, imgs, sel, nsel, tables, raw, coef, dccum, side, side_only, events);
 }
 void js_launch_idct_color(hipStream_t st, const JsImage* imgs, const uint32_t* wg_base, uint32_t nimg, uint32_t total_wgs, uint32_t max_mcu_w, uint32_t max_mcu_h,
                           const float* lut_t, const int16_t* coef, const int16_t* dccum, uint8_t* dib, int16_t* planes, uint32_t* side)
@@ -1486,7 +1514,9 @@ __device__ uint32_t mirror_to_mcu_top(const JsImage& im, const JsTableSet* __res
                                       const uint32_t* __restrict__ us_out, uint32_t us_threads, uint32_t m_top, ExactReader& r, uint32_t* dummy_histo, int16_t* scratch,
                                       uint32_t* events)
 {
-    r.file = raw + im.file_off; r.flen = im.file_len; r.ts = tables + im.tableset; r.histo = dummy_histo;
+    uint32_t* meta12 = dummy_histo + 2 * 4 * 17;                  // the caller's scratch has room for the 12 slot words behind the histogram
+    r.file = raw + im.file_off; r.flen = im.file_len; r.ts = tables + im.tableset; r.histo = dummy_histo; r.fast = &r.ts->fast[0][0]; r.meta = meta12; r.q = &r.ts->qzz[0][0]; r.zz = c_zigzag; r.win_at = 0xFFFFFFFFu; r.win = 0;
+    for (int i = 0; i < 6; i++) { meta12[i] = r.ts->size[i]; meta12[6 + i] = r.ts->dest_id[i]; }
     // the markers the look-ahead runs into at the end of the scan (":  Scan Data encountered marker", :1536) are logged from here
     r.ev = (events && im.ev_cap) ? events + im.ev_off : nullptr; r.ev_cap = im.ev_cap; r.ev_only = JS_EV_MARKER;
     r.rst_interval = im.rst_interval; r.precision = im.precision; r.err_max = im.err_max; r.warn_bad = 0;
@@ -1541,7 +1571,7 @@ __global__ void __launch_bounds__(256) k_side_maps(const JsImage* __restrict__ i
         if (m == nmcu || empty) {
             // what an empty register still shows depends on how its last bytes were loaded, and the end of the scan is where the
             // look-ahead meets EOI / trailing bytes: take both from the mirror reader itself
-            uint32_t dummy_histo[2 * 4 * 17]; int16_t scratch[64]; ExactReader r;
+            uint32_t dummy_histo[2 * 4 * 17 + 12]; int16_t scratch[64]; ExactReader r;
             const uint32_t before = mirror_to_mcu_top(im, tables, raw, st, nseg, sd[10], mcu_rst, mcu_pos, us_out, us_threads, m, r, dummy_histo, scratch,
                                                       m == nmcu ? events : nullptr);
             if (m < nmcu) mcu_map[m] = (r.pos0 << 4) + r.align;
