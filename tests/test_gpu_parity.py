@@ -387,6 +387,40 @@ def test_header_variations(harness, oracle, gpu):
         compare(harness, oracle, gpu)
 
 
+def test_precision_divider(harness, oracle, gpu):
+    """SOF precision other than 8 (reference :1234-1238: value /= 1 << (P - 8), truncating; nothing for P < 8), on the
+    parallel path and -- with a corrupted scan -- on the exact-mirror path."""
+    data = harness.synth_jpeg(width=160, height=96, seed=6, restart_interval=4)
+    p = harness.parse_jpeg(data)
+    bad = bytearray(data); bad[p.scan_start + 200] ^= 0x40; bad[p.scan_start + 900] ^= 0x08
+    for prec in (12, 16, 9, 5):
+        for stream in (data, bytes(bad)):
+            q = harness.parse_jpeg(stream)
+            q.precision = prec
+            harness.drive(oracle, stream, q)
+            harness.drive(gpu, stream, q)
+            compare(harness, oracle, gpu)
+        assert True
+
+
+def test_error_limit_option(harness, oracle, gpu):
+    """nErrMaxDecodeScan other than the default 20: warning counter, status words and pixels on the corrupted golden files."""
+    from golden_util import load_case, manifest
+    M = manifest()
+    names = [n for n in sorted(M["cases"]) if n.startswith("bad_")]
+    try:
+        for em in (1, 3, 50):
+            for n in names:
+                data = load_case(n)
+                for b in (oracle, gpu):
+                    b.set_options(err_max=em)
+                    harness.drive(b, data)
+                compare(harness, oracle, gpu)
+    finally:
+        for b in (oracle, gpu):
+            b.set_options()
+
+
 def test_config2_single_4k(harness, oracle):
     """BASELINE config 2: one 3840x2160 4:2:0 image end to end through the parallel path."""
     import jpegsnoop_amd as J

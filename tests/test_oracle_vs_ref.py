@@ -136,3 +136,35 @@ def test_histogram_path(harness, oracle, ref):
     finally:
         for b in (oracle, ref):
             b.set_options()
+
+
+def test_precision_divider(harness, oracle, ref):
+    """SOF precision other than 8: the reference divides every decoded value by 1 << (P - 8) (truncating, :1234-1238) and
+    does nothing for P < 8."""
+    data = harness.synth_jpeg(width=160, height=96, seed=6, restart_interval=4)
+    for prec in (12, 16, 9, 5):
+        q = harness.parse_jpeg(data)
+        q.precision = prec
+        for ac in (1, 0):
+            for b in (oracle, ref):
+                b.set_options(decode_ac=ac)
+                harness.drive(b, data, q)
+            assert same(harness, ref, oracle), (prec, ac)
+    for b in (oracle, ref):
+        b.set_options()
+
+
+def test_error_limit_option(harness, oracle, ref):
+    """nErrMaxDecodeScan (CSnoopConfig, read at :2732): the warning counter saturates there; decoding continues."""
+    from golden_util import load_case, manifest
+    M = manifest()
+    names = [n for n in sorted(M["cases"]) if n.startswith("bad_")][:10]
+    for em in (1, 3, 50):
+        for n in names:
+            data = load_case(n)
+            for b in (oracle, ref):
+                b.set_options(err_max=em)
+                harness.drive(b, data)
+            assert same(harness, ref, oracle), (em, n)
+    for b in (oracle, ref):
+        b.set_options()
