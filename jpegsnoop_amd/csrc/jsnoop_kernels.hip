@@ -977,14 +977,32 @@ __global__ void __launch_bounds__(US_THREADS) k_unstuff_write(const JsImage* __r
     for (uint32_t w = 0; w < wave; w++) { bk += wk[w]; br += wr[w]; }
     uint32_t out = bk + pk - nk, seg = br + pr - nr;                       // exclusive prefixes of this thread
     if (us_out) { us_out[blockIdx.x * US_THREADS + threadIdx.x] = out; return; }
-    if (!(c.keep_mask | c.rst_mask)) return;
-    uint8_t* dst = ustr + im.ustr_off; uint32_t* st = seg_tab + im.seg_off;
-    const uint4 v = *reinterpret_cast<const uint4*>(raw + o16);
-    const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
-    #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        if (c.rst_mask & (1u << j)) { seg++; if (seg + 1 < im.seg_cap) st[seg] = out; }     // interval `seg` starts at the next kept byte
-        if (c.keep_mask & (1u << j)) dst[out++] = (uint8_t)(w4[j >> 2] >> ((j & 3) * 8));
+    // The kept bytes of the chunk are gathered in LDS at the byte phase they have in the output (chunk base & 3), so that
+    // the chunk leaves as whole aligned 32-bit words; only the ragged first / last word goes out byte by byte.
+    __shared__ __attribute__((aligned(4))) uint8_t s_out[US_CHUNK + 8];
+    __shared__ uint32_t s_total;
+    const uint32_t cbase_out = chunk_keep[wg], phase = cbase_out & 3u;     // the image's stream starts 16-byte aligned
+    uint32_t* st = seg_tab + im.seg_off;
+    if (c.keep_mask | c.rst_mask) {
+        const uint4 v = *reinterpret_cast<const uint4*>(raw + o16);
+        const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
+        uint32_t lo = phase + (out - cbase_out);
+        #pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (c.rst_mask & (1u << j)) { seg++; if (seg + 1 < im.seg_cap) st[seg] = cbase_out + (lo - phase); }     // interval `seg` starts at the next kept byte
+            if (c.keep_mask & (1u << j)) s_out[lo++] = (uint8_t)(w4[j >> 2] >> ((j & 3) * 8));
+        }
+    }
+    if (threadIdx.x == US_THREADS - 1) s_total = out + nk - cbase_out;       // bytes this chunk keeps
+    __syncthreads();
+    const uint32_t total = s_total;
+    if (!total) return;
+    uint8_t* dst = ustr + im.ustr_off + (cbase_out - phase);               // 4-byte aligned
+    const uint32_t lo_b = phase, hi_b = phase + total;                     // valid byte range inside s_out / dst
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(s_out);
+    for (uint32_t w = threadIdx.x; w * 4 < hi_b; w += US_THREADS) {
+        if (w * 4 >= lo_b && w * 4 + 4 <= hi_b) reinterpret_cast<uint32_t*>(dst)[w] = s32[w];
+        else for (uint32_t b = max(w * 4, lo_b); b < min(w * 4 + 4, hi_b); b++) dst[b] = s_out[b];
     }
 }
 
