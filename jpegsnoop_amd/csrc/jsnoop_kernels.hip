@@ -535,9 +535,13 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_idct_color(const JsImage* __r
     if (ncomp == 1) for (uint32_t i = lane; i < 2 * plane_elems; i += 64) tile[plane_elems + i] = 0;   // Cb = Cr = 0 for grayscale (:4709-4715)
     // A component with 1 < H < Hmax (or V) does not cover its share of the MCU: SetFullRes places its blocks 8 samples
     // apart but replicates each Hmax/H times (:2498-2557), so part of the MCU keeps the zeros of ClrFullRes (:2443).
+    // The same happens when H does not divide Hmax (expansion = Hmax / H truncates: H = 2 under Hmax = 3 fills 16 of 24 columns).
     bool partial = false;
-    for (uint32_t cc = 1; cc <= ncomp; cc++)
-        partial = partial || (im.samp_h[cc] > 1 && im.expand_h[cc] > 1) || (im.samp_v[cc] > 1 && im.expand_v[cc] > 1);
+    for (uint32_t cc = 1; cc <= ncomp; cc++) {
+        const bool full_h = (im.samp_h[cc] * 8 == mw && im.expand_h[cc] == 1) || (im.samp_h[cc] == 1 && im.expand_h[cc] * 8 == mw);
+        const bool full_v = (im.samp_v[cc] * 8 == mh && im.expand_v[cc] == 1) || (im.samp_v[cc] == 1 && im.expand_v[cc] * 8 == mh);
+        partial = partial || !full_h || !full_v;
+    }
 
     int cv[BK_CHUNK]; int16_t dcv[BK_CHUNK];
     uint32_t meta[BK_CHUNK], toff[BK_CHUNK];                     // placement word (wave-uniform) and this lane's tile offset per block slot

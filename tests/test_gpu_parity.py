@@ -385,6 +385,18 @@ def test_header_variations(harness, oracle, gpu):
         harness.drive(oracle, data, q)
         harness.drive(gpu, data, q)
         compare(harness, oracle, gpu)
+    # random factors 1..4 for every component: H that does not divide Hmax (expansion truncates, part of the MCU stays zero) etc.
+    rng = np.random.default_rng(3)
+    for _ in range(60):
+        f = [int(x) for x in rng.integers(1, 5, 6)]
+        q = harness.parse_jpeg(data)
+        q.comps = [(c[0], f[2 * i], f[2 * i + 1], c[3]) for i, c in enumerate(p.comps)]
+        harness.drive(oracle, data, q)
+        harness.drive(gpu, data, q)
+        try:
+            compare(harness, oracle, gpu)
+        except AssertionError as e:
+            raise AssertionError(f"sampling factors {f}: {e}")
 
 
 def test_precision_divider(harness, oracle, gpu):

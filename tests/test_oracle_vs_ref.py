@@ -64,6 +64,14 @@ def test_header_variations(harness, oracle, ref):
         harness.drive(ref, data, q)
         harness.drive(oracle, data, q)
         assert same(harness, ref, oracle), samp
+    rng = np.random.default_rng(3)                                 # random factors 1..4 (non-dividing ones included)
+    for _ in range(60):
+        f = [int(x) for x in rng.integers(1, 5, 6)]
+        q = harness.parse_jpeg(data)
+        q.comps = [(c[0], f[2 * i], f[2 * i + 1], c[3]) for i, c in enumerate(p.comps)]
+        harness.drive(ref, data, q)
+        harness.drive(oracle, data, q)
+        assert same(harness, ref, oracle), f
 
 
 def test_fuzz_corrupt_scans(harness, oracle, ref):
