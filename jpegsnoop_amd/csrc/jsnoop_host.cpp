@@ -347,6 +347,7 @@ int JsnoopBatch::decode(bool timed)
     // parallel path stages 1..5 (k_unstuff .. k_dc_scan) are launched by js_parallel_entropy
     int used_parallel = opt_force_exact ? 0 : js_parallel_entropy(this, timed);
     if (used_parallel < 0) return -1;
+    last_used_parallel = used_parallel != 0;
     if (timed && !used_parallel) for (int s = 2; s <= 6; s++) HIP_TRY(hipEventRecord(ev[s], stream));
     if (!used_parallel) js_launch_entropy_exact(stream, dev.imgs, nullptr, n, dev.tables, dev.raw, dev.coef, dev.dccum, dev.side, 0, event_words ? dev.events : nullptr);
     if (timed) HIP_TRY(hipEventRecord(ev[7], stream));

@@ -66,6 +66,7 @@ struct JsnoopBatch {
     uint64_t event_words = 0;
     std::vector<JsImage> imgs; std::vector<JsTableSet> tables;
     std::vector<uint32_t> host_flags, host_path, h_us_base, h_sy_base;
+    bool last_used_parallel = false;                              // false: no table set of the batch fits the parallel path, the exact-mirror kernel decoded everything
     uint32_t* d_side_tmp = nullptr; size_t side_tmp_cap = 0;      // scratch of the side-output pass (one image at a time)
     uint8_t* pinned; size_t pinned_cap; uint64_t raw_bytes;
     JsDeviceArenas dev; JsArenaCaps cap;

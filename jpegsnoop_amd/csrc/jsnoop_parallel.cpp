@@ -139,6 +139,10 @@ int js_parallel_fixup(JsnoopBatch* b)
     const uint32_t n = (uint32_t)b->imgs.size();
     b->host_flags.assign(n, 0); b->host_path.assign(n, b->opt_force_exact ? 2u : 1u);
     if (b->opt_force_exact) { for (uint32_t i = 0; i < n; i++) b->host_flags[i] = JSNOOP_FLAG_FORCED; return 0; }
+    if (!b->last_used_parallel) {                                   // every image went through the exact-mirror kernel already (decode tables
+        for (uint32_t i = 0; i < n; i++) { b->host_flags[i] = JSNOOP_FLAG_TABLES; b->host_path[i] = 2; }   // outside the parallel path's LUT form)
+        return 0;
+    }
     HIP_TRY(hipMemcpyAsync(b->host_flags.data(), b->dev.flags, (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     // An unconverged chain is not a malformed stream: give it more synchronisation rounds first.

@@ -433,6 +433,28 @@ def test_error_limit_option(harness, oracle, gpu):
             b.set_options()
 
 
+def test_fuzz_headers_and_scans(harness, oracle, gpu):
+    """tests/fuzz_util.py: 400 hostile variants (corrupted scan bytes, mutated dimensions / sampling factors / precision /
+    restart interval / table selectors / scan start, one-component scans, damaged Huffman tables), every output of the
+    decoder incl. the colour statistics on half of them, HIP path vs oracle.  (tools/fuzz_gpu.py runs larger sweeps.)"""
+    import fuzz_util as F
+    B = F.bases(harness)
+    rng = np.random.default_rng(4242)
+    try:
+        for k in range(400):
+            data, q, mode = F.mutate(harness, rng, B[int(rng.integers(len(B)))])
+            histo = int(rng.integers(2))
+            for b in (oracle, gpu):
+                b.set_options(histo_en=histo)
+            harness.drive(oracle, data, q)
+            harness.drive(gpu, data, q)
+            r = F.differs(oracle, gpu, stats=bool(histo))
+            assert r is None, (k, mode, r)
+    finally:
+        for b in (oracle, gpu):
+            b.set_options()
+
+
 def test_config2_single_4k(harness, oracle):
     """BASELINE config 2: one 3840x2160 4:2:0 image end to end through the parallel path."""
     import jpegsnoop_amd as J

@@ -176,3 +176,17 @@ def test_error_limit_option(harness, oracle, ref):
             assert same(harness, ref, oracle), (em, n)
     for b in (oracle, ref):
         b.set_options()
+
+
+def test_fuzz_headers_and_scans(harness, oracle, ref):
+    """tests/fuzz_util.py: 500 hostile variants -- corrupted scan bytes and mutated header fields (dimensions, sampling
+    factors, precision, restart interval, table selectors, one-component scans of a three-component frame, shifted scan
+    start, damaged Huffman tables) -- oracle vs the compiled reference, every output."""
+    import fuzz_util as F
+    B = F.bases(harness)
+    rng = np.random.default_rng(2025)
+    for k in range(500):
+        data, q, mode = F.mutate(harness, rng, B[int(rng.integers(len(B)))])
+        harness.drive(ref, data, q)
+        harness.drive(oracle, data, q)
+        assert F.differs(ref, oracle) is None, (k, mode, F.differs(ref, oracle))
