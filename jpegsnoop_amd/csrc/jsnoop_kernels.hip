@@ -544,12 +544,15 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_idct_color(const JsImage* __r
     }
 
     int cv[BK_CHUNK]; int16_t dcv[BK_CHUNK];
+    // DC-only mode: the reference does not run the IDCT at all (:1827), whatever sits at the AC positions -- a DC symbol with a run
+    // nibble stores its value there (DecodeIdctSet with ind = zrl, :1713)
+    const bool with_ac = im.decode_ac != 0;
     uint32_t meta[BK_CHUNK], toff[BK_CHUNK];                     // placement word (wave-uniform) and this lane's tile offset per block slot
     auto load_chunk = [&](uint32_t m, uint32_t base) {
         #pragma unroll
         for (int j = 0; j < BK_CHUNK; j++) {
             const uint32_t c = base + j;
-            cv[j] = c < nb ? (int)cbase[((size_t)m * nb + c) * 64 + lane] : 0;
+            cv[j] = (c < nb && with_ac) ? (int)cbase[((size_t)m * nb + c) * 64 + lane] : 0;
             dcv[j] = c < nb ? dbase[(size_t)m * nb + c] : (int16_t)0;
         }
     };

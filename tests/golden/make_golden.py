@@ -97,6 +97,29 @@ def corrupt(data, mode, rng):
     return bytes(d)
 
 
+def header_variant(data, kind):
+    """Valid scan, hostile header: the mutation is written into the file's own marker segments (SOF0, DRI, SOS, DHT)."""
+    d = bytearray(data)
+    sof = d.find(b"\xff\xc0"); sos = d.find(b"\xff\xda"); dri = d.find(b"\xff\xdd"); dht = d.find(b"\xff\xc4")
+    nf = d[sof + 9]
+    if kind == "samp":                                           # H that does not divide Hmax, V > Vmax of the coded data
+        for c, hv in zip(range(nf), (0x32, 0x21, 0x13)): d[sof + 10 + 3 * c + 1] = hv
+    elif kind == "dims":
+        d[sof + 5:sof + 7] = (d[sof + 5] * 256 + d[sof + 6] + 37).to_bytes(2, "big"); d[sof + 7:sof + 9] = max(9, (d[sof + 7] * 256 + d[sof + 8]) // 2 + 3).to_bytes(2, "big")
+    elif kind == "prec":
+        d[sof + 4] = 12
+    elif kind == "dri":
+        assert dri > 0; d[dri + 4:dri + 6] = (4).to_bytes(2, "big")
+    elif kind == "sel" and nf == 3:
+        ns = d[sos + 4]
+        for c in range(ns): d[sos + 5 + 2 * c + 1] = (0x10, 0x01, 0x00)[c % 3]
+    elif kind == "dcsym":                                        # a DC symbol with a run nibble: outside the parallel path's table form
+        d[dht + 5 + 16 + 5] = 0xAF
+    elif kind == "acsym":
+        q = d.find(b"\xff\xc4", dht + 4); d[q + 5 + 16 + 9] = 0x00    # an AC code turned into EOB
+    return bytes(d)
+
+
 def main():
     H.build(["oracle", "synth", "ref"])
     assert H.have_ref(), "needs the compiled reference (oracle/_ref)"
@@ -136,6 +159,9 @@ def main():
     assert i > 0 and d[i + 4:i + 6] == b"\x00\x0a"
     d[i + 5] = 4
     files["dri4_422_rst_row_160x64"] = bytes(d)
+    for kind, bname in (("samp", "420_q50_128x128"), ("dims", "422_rst_row_160x64"), ("prec", "c1_444_160x120"), ("dri", "422_rst_row_160x64"),
+                        ("sel", "420_odd_141x93"), ("dcsym", "420_q50_128x128"), ("acsym", "c1_444_160x120")):
+        files[f"hdr_{kind}_{bname}"] = header_variant(files[bname], kind)
     for name, data in files.items():
         with open(os.path.join(HERE, name + ".jpg"), "wb") as f:
             f.write(data)
