@@ -16,9 +16,9 @@ B = F.bases(H)
 bad = 0; paths = collections.Counter()
 for k in range(n_cases):
     data, q, mode = F.mutate(H, rng, B[int(rng.integers(len(B)))])
-    histo = int(rng.integers(2))
+    histo = int(rng.integers(2)); ac = int(rng.integers(4) != 0); em = int(rng.choice([20, 20, 3, 1]))
     for b in (orc, gpu):
-        b.set_options(histo_en=histo)
+        b.set_options(histo_en=histo, decode_ac=ac, err_max=em)
     try:
         H.drive(orc, data, q); H.drive(gpu, data, q)
     except Exception as ex:
