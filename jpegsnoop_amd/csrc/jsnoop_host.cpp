@@ -293,7 +293,7 @@ int JsnoopBatch::upload()
         im.n_subseq = (im.ustr_cap + sub_bytes - 1) / sub_bytes; im.subseq_off = subs; subs += align_up(im.n_subseq, 256);
         const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax;
         const uint64_t want_seg = im.rst_interval ? (uint64_t)nmcu / im.rst_interval + 2 : 1;
-        im.seg_cap = (uint32_t)std::min<uint64_t>(65535, want_seg * 2 + 16); im.seg_off = segw; segw += align_up(im.seg_cap, 4);
+        im.seg_cap = (uint32_t)std::min<uint64_t>((1u << 20) - 1, want_seg * 2 + 16); im.seg_off = segw; segw += align_up(im.seg_cap, 4);   // 20-bit interval index in the state word
         im.mcu_off = mcub; mcub += align_up(nmcu, 16);
         im.ev_cap = opt_events ? JS_EV_MAX : 0; im.ev_off = (uint64_t)i * (1 + JS_EV_WORDS * JS_EV_MAX);
         usb[i] = usc; usc += (uint32_t)(((im.scan_start & 15) + (uint64_t)im.scan_len + JS_US_CHUNK - 1) / JS_US_CHUNK);

@@ -1084,11 +1084,11 @@ template <int WL> __device__ __forceinline__ void cur_skip(Cursor& c, uint32_t n
     if (c.off >= 32u) { c.off -= 32u; c.w0 = c.w1; c.w1 = bswap32(c.nxt); c.nxt = c.words[phys_word<WL>(c.widx++)]; }
 }
 
-// state word: [31:16] interval index, [15:8] block-in-MCU, [7:0] next coefficient index (0 = DC)
-#define ST_SEG(s) ((s) >> 16)
-#define ST_C(s)   (((s) >> 8) & 255u)
-#define ST_K(s)   ((s) & 255u)
-#define ST_MAKE(seg, c, k) (((seg) << 16) | ((c) << 8) | (k))
+// state word: [31:12] interval index (up to 2^20 - 1 restart intervals), [11:6] block-in-MCU (< 48), [5:0] next coefficient index (0 = DC)
+#define ST_SEG(s) ((s) >> 12)
+#define ST_C(s)   (((s) >> 6) & 63u)
+#define ST_K(s)   ((s) & 63u)
+#define ST_MAKE(seg, c, k) (((seg) << 12) | ((c) << 6) | (k))
 #define P_END 0xFFFFFFFFu
 #define WR_STRIDE 66                   // int16 per thread-private LDS block buffer (64 + pad: 33-dword rows stagger the banks; 33 KiB per
                                        // workgroup leaves room for the decode tables with FOUR workgroups per CU -- the walk is latency-bound)
