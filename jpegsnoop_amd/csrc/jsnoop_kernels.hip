@@ -1040,6 +1040,7 @@ __global__ void __launch_bounds__(256) k_interleave(const JsImage* __restrict__ 
 struct SubTabs {
     const uint16_t* lut1;              // n_rows x 2048 entries
     const uint16_t* lut2;              // second level (codes longer than JS_L1_BITS bits)
+    const uint32_t* lutp;              // state-only pair entries (k_sync only; nullptr elsewhere)
     const uint16_t* qzz;               // 3 x 64 quantiser entries, zig-zag order
     const uint8_t*  zz;                // 64: zig-zag index -> natural index
     uint32_t rows01, rows2;            // per component 16 bits: first-level row of its DC table | AC table << 8
@@ -1048,6 +1049,7 @@ struct SubTabs {
 __device__ __forceinline__ size_t subtabs_bytes(uint32_t tab_rows, uint32_t tab_lut2)
 { return (size_t)tab_rows * (2u << JS_L1_BITS) + (((size_t)tab_lut2 * 2 + 15) & ~15ull) + 3 * 64 * 2 + 64; }
 
+template <bool PAIRS>
 __device__ __forceinline__ void load_subtabs(SubTabs& T, uint8_t* lds, const JsImage& im, const JsTableSet& ts, uint32_t tab_rows, uint32_t tab_lut2,
                                              uint32_t tid, uint32_t nthreads)
 {
@@ -1061,7 +1063,13 @@ __device__ __forceinline__ void load_subtabs(SubTabs& T, uint8_t* lds, const JsI
     for (uint32_t i = tid; i < ts.lut2_used; i += nthreads) l2[i] = ts.lut2[i];
     for (uint32_t i = tid; i < 3 * 64; i += nthreads) q[i] = (&ts.qzz[0][0])[i];
     if (tid < 64) z[tid] = c_zigzag[tid];
-    T.lut1 = l1; T.lut2 = l2; T.qzz = q; T.zz = z;
+    T.lut1 = l1; T.lut2 = l2; T.qzz = q; T.zz = z; T.lutp = nullptr;
+    if (PAIRS) {
+        uint32_t* lp = reinterpret_cast<uint32_t*>(z + 64);
+        const uint32_t* srcp = &ts.lutp[0][0];
+        for (uint32_t i = tid; i < ts.n_rows * (1u << JS_L1_BITS); i += nthreads) lp[i] = srcp[i];
+        T.lutp = lp;
+    }
     T.rows01 = ts.slot_row[0] | (ts.slot_row[1] << 8) | (ts.slot_row[2] << 16) | (ts.slot_row[3] << 24); T.rows2 = ts.slot_row[4] | (ts.slot_row[5] << 8);
     T.nb = im.blk_per_mcu; T.n1 = im.samp_h[1] * im.samp_v[1]; T.n2 = im.ncomp == 3 ? T.n1 + im.samp_h[2] * im.samp_v[2] : T.nb;
 }
@@ -1151,6 +1159,22 @@ __device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, co
     uint32_t rp = rows_of(T, comp_of(T, c));
     while (cur.p < own_end) {
         const uint32_t win = cur_peek(cur);
+        // One table entry describes the symbol at the cursor and, where its code was visible in the same window, the AC symbol
+        // behind it.  Both are taken together when the first one does not end the block, the second one starts inside this
+        // lane's own range, and everything lies inside the restart interval; anything else goes the one-symbol way below.
+        const uint32_t pe = T.lutp[((((k ? rp >> 8 : rp) & 255u)) << JS_L1_BITS) + (win >> (32 - JS_L1_BITS))];
+        const uint32_t bits1 = pe & 31u, k1 = k + ((pe >> 5) & 31u), bits12 = (pe >> 12) & 63u;
+        const bool done1 = k != 0 && (((pe >> 10) & 1u) || k1 >= 64u);
+        const bool two = ((pe >> 11) & 1u) && !done1 && cur.p + bits1 < own_end;
+        const uint32_t adv = two ? bits12 : bits1;
+        if (__builtin_expect(!(pe >> 31) && cur.p + adv <= seg_end, 1)) {
+            cur_skip<WL>(cur, adv);
+            const uint32_t k2 = k + ((pe >> 18) & 63u);
+            const bool done = two ? (((pe >> 24) & 1u) || k2 >= 64u) : done1;
+            k = done ? 0u : (two ? k2 : k1);
+            if (done) { c = c + 1 == T.nb ? 0u : c + 1; nblk++; rp = rows_of(T, comp_of(T, c)); }
+            continue;
+        }
         const uint32_t e = sym_lookup(T, win, rp, k);
         const uint32_t len = (e >> 8) & 31u, run = (e >> 4) & 15u, size = e & 15u;
         if (__builtin_expect(len == 0 || cur.p + len > seg_end, 0)) {
@@ -1205,7 +1229,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
         const uint32_t lp = sub0 ? A.out_p[g0 - 1] : 0u, ls = sub0 ? A.out_s[g0 - 1] : 0u;
         if (lp == A.in_p[g0] && ls == A.in_s[g0]) return;
     }
-    SubTabs T; load_subtabs(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, t, SY_THREADS);
+    SubTabs T; load_subtabs<true>(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, t, SY_THREADS);
     const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);
     const uint32_t* st = seg_tab + im.seg_off;
     if (first_pass) { s_inp[t] = 0xFFFFFFFEu; s_ins[t] = 0; s_outp[t] = 0; s_outs[t] = 0; s_nblk[t] = 0; }
@@ -1312,7 +1336,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
     if (sub0 * SUB_BITS >= total_bits) return;
     if (SIDE) for (uint32_t q = threadIdx.x; q < 2 * 4 * 17; q += SY_THREADS) s_histo[q] = 0;
     const JsTableSet& tset = tables[im.tableset];
-    SubTabs T; load_subtabs(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, threadIdx.x, SY_THREADS);
+    SubTabs T; load_subtabs<false>(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, threadIdx.x, SY_THREADS);
     { uint32_t* z = reinterpret_cast<uint32_t*>(s_blk[threadIdx.x]); for (int j = 0; j < WR_STRIDE / 2; j++) z[j] = 0u; }
     __syncthreads();
 
@@ -1476,15 +1500,15 @@ void js_launch_unstuff(hipStream_t st, int wl, const JsImage* imgs, const uint32
     else hipLaunchKernelGGL(k_interleave<5>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
 }
 static SubArrays sub_arrays(uint32_t* sub, uint64_t n) { SubArrays a; a.out_p = sub; a.out_s = sub + n; a.in_p = sub + 2 * n; a.in_s = sub + 3 * n; a.nblk = sub + 4 * n; a.base = sub + 5 * n; return a; }
-static size_t subtabs_bytes_host(uint32_t tab_rows, uint32_t tab_lut2)
-{ return (size_t)tab_rows * (2u << JS_L1_BITS) + (((size_t)tab_lut2 * 2 + 15) & ~15ull) + 3 * 64 * 2 + 64; }
+static size_t subtabs_bytes_host(uint32_t tab_rows, uint32_t tab_lut2, bool pairs = false)
+{ return (size_t)tab_rows * (2u << JS_L1_BITS) + (((size_t)tab_lut2 * 2 + 15) & ~15ull) + 3 * 64 * 2 + 64 + (pairs ? (size_t)tab_rows * (4u << JS_L1_BITS) : 0); }
 void js_launch_sync(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
                     const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub, int first_pass)
 {
     if (!total_wgs) return;
-    if (wl == 7) hipLaunchKernelGGL(k_sync<7>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+    if (wl == 7) hipLaunchKernelGGL(k_sync<7>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2, true), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2);
-    else hipLaunchKernelGGL(k_sync<5>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+    else hipLaunchKernelGGL(k_sync<5>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2, true), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2);
 }
 void js_launch_block_scan(hipStream_t st, int wl, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, uint32_t* sub, uint64_t nsub, uint32_t* side, uint32_t* flags)
