@@ -644,19 +644,6 @@ int jsnoop_batch_dib_hashes(JsnoopBatch* b, uint64_t* dst)
     HIP_TRY(hipStreamSynchronize(b->stream));
     return 0;
 }
-// debug aid: raw copy of an internal arena (0 = sub-sequence arrays, 1 = side words, 2 = interval table, 3 = flags)
-uint64_t jsnoop_batch_debug_copy(JsnoopBatch* b, int which, void* dst, uint64_t max_bytes)
-{
-    const void* src = nullptr; uint64_t nbytes = 0;
-    if (which == 0) { src = b->dev.sub; nbytes = b->total_subseq * 24; }
-    else if (which == 1) { src = b->dev.side; nbytes = b->side_words * 4; }
-    else if (which == 2) { src = b->dev.seg; nbytes = b->seg_words * 4; }
-    else if (which == 3) { src = b->dev.flags; nbytes = b->imgs.size() * 4; }
-    if (!src) return 0;
-    nbytes = std::min(nbytes, max_bytes);
-    hipSetDevice(b->device); hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, b->stream); hipStreamSynchronize(b->stream);
-    return nbytes;
-}
 uint64_t jsnoop_batch_algorithmic_bytes(const JsnoopBatch* b)
 { uint64_t s = 0; for (const JsImage& im : b->imgs) s += (uint64_t)im.scan_len + (uint64_t)im.img_x * im.img_y * 4; return s; }
 uint64_t jsnoop_batch_pixels(const JsnoopBatch* b)

@@ -30,6 +30,11 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(lib, n), f"{n} declared in include/jsnoop_gpu.h but not exported"
     assert sorted(capi.SIGNATURES) == names, "python binding and header disagree"
     assert lib.jsnoop_abi_version() == 1
+    # ... and nothing jsnoop_* is exported that the header does not declare
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "jpegsnoop_amd", "libjsnoop_gpu.so")]).decode()
+    exported = sorted(set(re.findall(r"\bT (jsnoop_[a-z0-9_]+)", out)))
+    assert exported == names, "exports and header disagree"
 
 
 def test_no_cpu_fallback(lib):
