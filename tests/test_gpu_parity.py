@@ -455,6 +455,47 @@ def test_fuzz_headers_and_scans(harness, oracle, gpu):
             b.set_options()
 
 
+def test_jfif_front_end_variations(harness, oracle, gpu):
+    """The minimal JFIF walk on header layouts the synthetic encoder does not emit: marker padding
+    (FF fill bytes), APPn / COM segments in between, all DQT tables in one segment with 16-bit entries, all DHT tables in one
+    segment, and a Motion-JPEG frame (APP0 'AVI1', no DHT: the standard tables are imported, JfifDecode.cpp:4405-4421)."""
+    import ctypes as C
+    import jpegsnoop_amd as J
+    data = harness.synth_jpeg(width=160, height=96, seed=12)
+    harness.drive(oracle, data)
+    want = oracle.dib().copy()
+
+    def segments(d):
+        out, pos = [], 2
+        while d[pos + 1] != 0xDA:
+            ln = d[pos + 2] * 256 + d[pos + 3]
+            out.append((d[pos + 1], bytes(d[pos + 4:pos + 2 + ln]))); pos += 2 + ln
+        return out, bytes(d[pos:])
+
+    def build(segs, tail, pad=b""):
+        return b"\xff\xd8" + b"".join(pad + bytes([0xFF, m]) + (len(b) + 2).to_bytes(2, "big") + b for m, b in segs) + pad + tail
+
+    segs, tail = segments(data)
+    variants = {}
+    variants["padding_and_comments"] = build([(0xFE, b"hello")] + segs[:2] + [(0xE1, b"Exif\0\0" + b"\0" * 20)] + segs[2:], tail, pad=b"\xff\xff")
+    dqt = b"".join(bytes([0x10 | b[0]]) + b"".join(bytes([0, v]) for v in b[1:65]) for m, b in segs if m == 0xDB)     # Pq = 1: 16-bit entries
+    dht = b"".join(b for m, b in segs if m == 0xC4)
+    merged = [(m, b) for m, b in segs if m not in (0xDB, 0xC4)]
+    merged.insert(1, (0xDB, dqt)); merged.append((0xC4, dht))
+    variants["merged_tables_16bit_dqt"] = build(merged, tail)
+    mj = [(m, (b"AVI1" + b"\0" * 10) if m == 0xE0 else b) for m, b in segs if m != 0xC4]
+    variants["mjpeg_no_dht"] = build(mj, tail)
+    for name, v in variants.items():
+        start = C.c_uint(0)
+        buf = (C.c_uint8 * len(v)).from_buffer_copy(v)
+        assert gpu.lib.jsnoop_jfif_walk(gpu.h, C.cast(buf, C.c_void_p), len(v), C.byref(start)) == 0, (name, gpu.lib.jsnoop_last_error())
+        gpu.decode_scan_img(C.cast(buf, C.c_void_p), len(v), start.value, 1, 1)
+        assert np.array_equal(gpu.dib(), want), name
+        b = J.JpegBatch(); b.add_jpeg(v); b.upload(); b.decode(); b.sync()
+        assert np.array_equal(b.dib(0), want), name
+        b.close()
+
+
 def test_config2_single_4k(harness, oracle):
     """BASELINE config 2: one 3840x2160 4:2:0 image end to end through the parallel path."""
     import jpegsnoop_amd as J
