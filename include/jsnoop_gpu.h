@@ -104,6 +104,10 @@ void           jsnoop_lookup_blk_ycc(JsnoopDecoder*, unsigned blk_x, unsigned bl
 void     jsnoop_set_preview_mode(JsnoopDecoder*, unsigned mode);
 unsigned jsnoop_get_preview_mode(JsnoopDecoder*);
 void     jsnoop_set_preview_ycc_offset(JsnoopDecoder*, unsigned mcu_x, unsigned mcu_y, int y, int cb, int cr);
+void     jsnoop_get_preview_ycc_offset(JsnoopDecoder*, unsigned* mcu_x, unsigned* mcu_y, int* y, int* cb, int* cr);   /* :670 */
+/* SetPreviewMcuInsert :682 / GetPreviewMcuInsert :693 ("UNUSED" in the reference: stored, triggers a re-render, no pixel effect) */
+void     jsnoop_set_preview_mcu_insert(JsnoopDecoder*, unsigned mcu_x, unsigned mcu_y, int len);
+void     jsnoop_get_preview_mcu_insert(JsnoopDecoder*, unsigned* mcu_x, unsigned* mcu_y, unsigned* len);
 
 /* ---- Progressive (SOF2) files -- beyond the reference, which refuses them (source/JfifDecode.cpp:4827-4833; the two
  *      entry points above refuse them the same way).  Walks ALL scans of the file (spectral selection and successive

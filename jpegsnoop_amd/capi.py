@@ -52,6 +52,9 @@ SIGNATURES = {
     "jsnoop_set_preview_mode": (None, [_p, _u]),
     "jsnoop_get_preview_mode": (_u, [_p]),
     "jsnoop_set_preview_ycc_offset": (None, [_p, _u, _u, _i, _i, _i]),
+    "jsnoop_get_preview_ycc_offset": (None, [_p, _PU, _PU, _PI, _PI, _PI]),
+    "jsnoop_set_preview_mcu_insert": (None, [_p, _u, _u, _i]),
+    "jsnoop_get_preview_mcu_insert": (None, [_p, _PU, _PU, _PU]),
     "jsnoop_get_geometry": (None, [_p, _PU]),
     "jsnoop_mcu_file_map": (_p, [_p]),
     "jsnoop_blk_dc_ptrs": (None, [_p, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p)]),

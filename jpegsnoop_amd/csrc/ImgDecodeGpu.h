@@ -101,6 +101,10 @@ public:
     unsigned GetPreviewMode() { return jsnoop_get_preview_mode(m_h); }
     void SetPreviewYccOffset(unsigned nMcuX, unsigned nMcuY, int nY, int nCb, int nCr) { jsnoop_set_preview_ycc_offset(m_h, nMcuX, nMcuY, nY, nCb, nCr); } // :650
 
+    void GetPreviewYccOffset(unsigned& nMcuX, unsigned& nMcuY, int& nY, int& nCb, int& nCr) { jsnoop_get_preview_ycc_offset(m_h, &nMcuX, &nMcuY, &nY, &nCb, &nCr); }   // :670
+    void SetPreviewMcuInsert(unsigned nMcuX, unsigned nMcuY, int nLen) { jsnoop_set_preview_mcu_insert(m_h, nMcuX, nMcuY, nLen); }                                        // :682
+    void GetPreviewMcuInsert(unsigned& nMcuX, unsigned& nMcuY, unsigned& nLen) { jsnoop_get_preview_mcu_insert(m_h, &nMcuX, &nMcuY, &nLen); }                             // :693
+
     JsnoopDecoder* Handle() { return m_h; }
 
 private:

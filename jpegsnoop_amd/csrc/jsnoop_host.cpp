@@ -573,6 +573,11 @@ void jsnoop_set_preview_mode(JsnoopDecoder* d, unsigned mode) { d->preview_mode 
 unsigned jsnoop_get_preview_mode(JsnoopDecoder* d) { return d->preview_mode; }
 void jsnoop_set_preview_ycc_offset(JsnoopDecoder* d, unsigned mx, unsigned my, int y, int cb, int cr)       // :650-659
 { d->shift_mcu_x = mx; d->shift_mcu_y = my; d->shift_y = y; d->shift_cb = cb; d->shift_cr = cr; d->rerender(); }
+void jsnoop_get_preview_ycc_offset(JsnoopDecoder* d, unsigned* mx, unsigned* my, int* y, int* cb, int* cr)                        // :670-677
+{ *mx = d->shift_mcu_x; *my = d->shift_mcu_y; *y = d->shift_y; *cb = d->shift_cb; *cr = d->shift_cr; }
+void jsnoop_set_preview_mcu_insert(JsnoopDecoder* d, unsigned mx, unsigned my, int len)                                          // :682-690
+{ d->ins_mcu_x = mx; d->ins_mcu_y = my; d->ins_mcu_len = (unsigned)len; d->rerender(); }
+void jsnoop_get_preview_mcu_insert(JsnoopDecoder* d, unsigned* mx, unsigned* my, unsigned* len) { *mx = d->ins_mcu_x; *my = d->ins_mcu_y; *len = d->ins_mcu_len; }
 
 // ---- batch ---------------------------------------------------------------------------
 JsnoopBatch* jsnoop_batch_create(void* stream)

@@ -30,6 +30,7 @@ struct JsnoopDecoder {
     jsnoop_log_fn log_fn; void* log_user;
     JsnoopBatch* batch;                         // private batch of one image (single-image API)
     unsigned preview_mode; int shift_y, shift_cb, shift_cr; unsigned shift_mcu_x, shift_mcu_y;
+    unsigned ins_mcu_x = 0, ins_mcu_y = 0, ins_mcu_len = 0;      // m_nPreviewInsMcu* (:682-699), stored only
     bool preview_is_jpeg, have_image; int host_valid; int last_path; uint32_t last_flags;
     unsigned geom[8];
     std::vector<uint8_t> h_dib; std::vector<int16_t> h_planes; std::vector<uint32_t> h_side;
