@@ -1041,6 +1041,8 @@ struct SubTabs {
     const uint16_t* lut1;              // n_rows x 2048 entries
     const uint16_t* lut2;              // second level (codes longer than JS_L1_BITS bits)
     const uint32_t* lutp;              // state-only pair entries (k_sync only; nullptr elsewhere)
+    const uint32_t* lut2p;             // ... and the single-symbol entries behind their escapes
+    uint32_t rb0, rb1, rb2;            // per component: byte offset of its DC row in lutp | of its AC row << 16
     const uint16_t* qzz;               // 3 x 64 quantiser entries, zig-zag order
     const uint8_t*  zz;                // 64: zig-zag index -> natural index
     uint32_t rows01, rows2;            // per component 16 bits: first-level row of its DC table | AC table << 8
@@ -1063,33 +1065,39 @@ __device__ __forceinline__ void load_subtabs(SubTabs& T, uint8_t* lds, const JsI
     for (uint32_t i = tid; i < ts.lut2_used; i += nthreads) l2[i] = ts.lut2[i];
     for (uint32_t i = tid; i < 3 * 64; i += nthreads) q[i] = (&ts.qzz[0][0])[i];
     if (tid < 64) z[tid] = c_zigzag[tid];
-    T.lut1 = l1; T.lut2 = l2; T.qzz = q; T.zz = z; T.lutp = nullptr;
+    T.lut1 = l1; T.lut2 = l2; T.qzz = q; T.zz = z; T.lutp = nullptr; T.lut2p = nullptr; T.rb0 = T.rb1 = T.rb2 = 0;
     if (PAIRS) {
         uint32_t* lp = reinterpret_cast<uint32_t*>(z + 64);
+        uint32_t* lp2 = lp + (size_t)tab_rows * (1u << JS_L1_BITS);
         const uint32_t* srcp = &ts.lutp[0][0];
         for (uint32_t i = tid; i < ts.n_rows * (1u << JS_L1_BITS); i += nthreads) lp[i] = srcp[i];
-        T.lutp = lp;
+        for (uint32_t i = tid; i < ts.lut2_used; i += nthreads) lp2[i] = ts.lut2p[i];
+        T.lutp = lp; T.lut2p = lp2;
+        const uint32_t rsh = JS_L1_BITS + 2;                     // a row of lutp is 4 << JS_L1_BITS bytes
+        T.rb0 = (ts.slot_row[0] << rsh) | (ts.slot_row[1] << (rsh + 16)); T.rb1 = (ts.slot_row[2] << rsh) | (ts.slot_row[3] << (rsh + 16));
+        T.rb2 = (ts.slot_row[4] << rsh) | (ts.slot_row[5] << (rsh + 16));
     }
     T.rows01 = ts.slot_row[0] | (ts.slot_row[1] << 8) | (ts.slot_row[2] << 16) | (ts.slot_row[3] << 24); T.rows2 = ts.slot_row[4] | (ts.slot_row[5] << 8);
     T.nb = im.blk_per_mcu; T.n1 = im.samp_h[1] * im.samp_v[1]; T.n2 = im.ncomp == 3 ? T.n1 + im.samp_h[2] * im.samp_v[2] : T.nb;
 }
 
-struct Cursor {                        // MSB-first bit cursor: two byte-swapped words + bit offset, one raw word prefetched
-    const uint32_t* words; uint32_t widx, w0, w1, nxt, off, p;
-};
+struct Cursor {                        // MSB-first bit cursor: two byte-swapped words, one raw word prefetched.  `sh` = 32 - (bits of w0 already
+    const uint32_t* words; uint32_t widx, w0, w1, nxt; int32_t sh; uint32_t p;   // consumed), kept in [0, 31]: at least one bit of w0 is always consumed,
+};                                     // so the window is ONE v_alignbit_b32 with no special case (sh == 0: the window is w1 itself)
 __device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
 template <int WL> __device__ __forceinline__ void cur_init(Cursor& c, const uint32_t* words, uint32_t p)
 {
-    c.words = words; c.p = p; c.widx = p >> 5; c.off = p & 31u;
-    c.w0 = bswap32(words[phys_word<WL>(c.widx)]); c.w1 = bswap32(words[phys_word<WL>(c.widx + 1)]);
-    c.nxt = words[phys_word<WL>(c.widx + 2)]; c.widx += 3;
+    const uint32_t wi = p ? ((p - 1u) >> 5) + 1u : 0u;           // index of w1; w0 is the word before it (nothing before bit 0)
+    c.words = words; c.p = p; c.sh = (int32_t)(31u - ((p - 1u) & 31u));
+    c.w0 = p ? bswap32(words[phys_word<WL>(wi - 1u)]) : 0u; c.w1 = bswap32(words[phys_word<WL>(wi)]);
+    c.nxt = words[phys_word<WL>(wi + 1u)]; c.widx = wi + 2u;
 }
-// the next 32 bits of the stream (one v_alignbit_b32)
-__device__ __forceinline__ uint32_t cur_peek(const Cursor& c) { return __funnelshift_l(c.w1, c.w0, c.off); }
+// the next 32 bits of the stream
+__device__ __forceinline__ uint32_t cur_peek(const Cursor& c) { return __builtin_amdgcn_alignbit(c.w0, c.w1, (uint32_t)c.sh); }
 template <int WL> __device__ __forceinline__ void cur_skip(Cursor& c, uint32_t n)      // n <= 32
 {
-    c.off += n; c.p += n;
-    if (c.off >= 32u) { c.off -= 32u; c.w0 = c.w1; c.w1 = bswap32(c.nxt); c.nxt = c.words[phys_word<WL>(c.widx++)]; }
+    c.sh -= (int32_t)n; c.p += n;
+    if (c.sh < 0) { c.sh += 32; c.w0 = c.w1; c.w1 = bswap32(c.nxt); c.nxt = c.words[phys_word<WL>(c.widx++)]; }
 }
 
 // state word: [31:12] interval index (up to 2^20 - 1 restart intervals), [11:6] block-in-MCU (< 48), [5:0] next coefficient index (0 = DC)
@@ -1148,6 +1156,9 @@ __device__ __forceinline__ bool walk_slow(const JsImage& im, const uint32_t* __r
 }
 
 // SYNC flavour: state only.  Walks the symbols that start inside [entry position, own_end).
+// The lanes of a wave step together (one table entry per lane and step); everything a lane rarely needs -- a code longer than
+// the first-level window, the end of a restart interval, a code that matches nothing -- sits behind a wave-level vote, so the
+// common step is one straight run of select code.
 template <int WL>
 __device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, const uint32_t* __restrict__ words, const uint32_t* __restrict__ st,
                                           uint32_t nseg, uint32_t total_bits, uint32_t own_end, uint32_t& p_io, uint32_t& s_io, uint32_t& nblk_out)
@@ -1156,38 +1167,50 @@ __device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, co
     if (p_io == P_END || (p_io >= total_bits && seg + 1 >= nseg)) { p_io = P_END; s_io = 0; nblk_out = 0; return; }
     uint32_t seg_end = st[seg + 1] * 8;
     Cursor cur; cur_init<WL>(cur, words, p_io);
-    uint32_t rp = rows_of(T, comp_of(T, c));
-    while (cur.p < own_end) {
+    const char* lp = reinterpret_cast<const char*>(T.lutp);
+    uint32_t rb = c < T.n1 ? T.rb0 : (c < T.n2 ? T.rb1 : T.rb2);
+    for (;;) {
+        const bool act = cur.p < own_end;
+        if (!__ballot(act)) break;
         const uint32_t win = cur_peek(cur);
         // One table entry describes the symbol at the cursor and, where its code was visible in the same window, the AC symbol
-        // behind it.  Both are taken together when the first one does not end the block, the second one starts inside this
-        // lane's own range, and everything lies inside the restart interval; anything else goes the one-symbol way below.
-        const uint32_t pe = T.lutp[((((k ? rp >> 8 : rp) & 255u)) << JS_L1_BITS) + (win >> (32 - JS_L1_BITS))];
-        const uint32_t bits1 = pe & 31u, k1 = k + ((pe >> 5) & 31u), bits12 = (pe >> 12) & 63u;
-        const bool done1 = k != 0 && (((pe >> 10) & 1u) || k1 >= 64u);
-        const bool two = ((pe >> 11) & 1u) && !done1 && cur.p + bits1 < own_end;
-        const uint32_t adv = two ? bits12 : bits1;
-        if (__builtin_expect(!(pe >> 31) && cur.p + adv <= seg_end, 1)) {
-            cur_skip<WL>(cur, adv);
-            const uint32_t k2 = k + ((pe >> 18) & 63u);
-            const bool done = two ? (((pe >> 24) & 1u) || k2 >= 64u) : done1;
-            k = done ? 0u : (two ? k2 : k1);
-            if (done) { c = c + 1 == T.nb ? 0u : c + 1; nblk++; rp = rows_of(T, comp_of(T, c)); }
-            continue;
+        // behind it: byte 0 = bits of symbol 1 (code + value), byte 1 = its advance of the coefficient index (64 for EOB: ends the
+        // block from any index), byte 2 = bits of both (0: no second symbol), byte 3 = index advance of both.
+        uint32_t pe = *reinterpret_cast<const uint32_t*>(lp + ((k ? rb >> 16 : rb & 0xFFFFu) + ((win >> (32 - JS_L1_BITS)) << 2)));
+        // A code longer than the window: a few % of symbols, but SOME lane of the wave holds one nearly every step.  One read of
+        // the second level replaces the entry by a single-symbol one and the lane stays on the common path.
+        const bool esc = act && (pe >> 30) == 2u;
+        if (__ballot(esc)) {
+            if (esc) { const uint32_t nbx = (pe >> 12) & 7u; pe = T.lut2p[(pe & 0xFFFu) + ((win >> (32 - JS_L1_BITS - nbx)) & ((1u << nbx) - 1u))]; }
         }
-        const uint32_t e = sym_lookup(T, win, rp, k);
-        const uint32_t len = (e >> 8) & 31u, run = (e >> 4) & 15u, size = e & 15u;
-        if (__builtin_expect(len == 0 || cur.p + len > seg_end, 0)) {
-            if (!walk_slow<false, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, 0, false, nullptr, fl)) break;
-            rp = rows_of(T, comp_of(T, c));
-            continue;
+        const uint32_t b1 = pe & 255u, k1 = k + ((pe >> 8) & 255u), b12 = (pe >> 16) & 255u;
+        // both symbols together when the first one does not end the block and the second one starts inside this lane's own range
+        const bool two = b12 != 0u && k1 < 64u && cur.p + b1 < own_end;
+        const uint32_t adv = two ? b12 : b1;
+        const bool slow = act && ((int32_t)pe < 0 || cur.p + adv > seg_end);
+        if (__ballot(slow)) {
+            if (slow) {                                          // no code here, or the end of the restart interval / of the data is near:
+                const uint32_t row = (k ? rb >> 16 : rb & 0xFFFFu) >> (JS_L1_BITS + 2);     // one symbol the careful way
+                const uint32_t e = sym_lookup(T, win, row, 0u);
+                const uint32_t len = (e >> 8) & 31u, run = (e >> 4) & 15u, size = e & 15u;
+                if (len == 0 || cur.p + len > seg_end) {
+                    walk_slow<false, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, 0, false, nullptr, fl);   // end of the data: p = P_END
+                } else {
+                    cur_skip<WL>(cur, len + size);
+                    const uint32_t kn = k == 0 ? 1u : k + run + 1u;
+                    const bool dn = k != 0 && ((e & 255u) == 0 || kn >= 64u);
+                    k = dn ? 0u : kn;
+                    if (dn) { c = c + 1 == T.nb ? 0u : c + 1; nblk++; }
+                }
+                rb = c < T.n1 ? T.rb0 : (c < T.n2 ? T.rb1 : T.rb2);
+            }
         }
-        cur_skip<WL>(cur, len + size);
-        const bool isdc = k == 0;
-        const uint32_t k2 = isdc ? 1u : k + run + 1u;
-        const bool done = !isdc && ((e & 255u) == 0 || k2 >= 64u);
-        k = done ? 0u : k2;
-        if (done) { c = c + 1 == T.nb ? 0u : c + 1; nblk++; rp = rows_of(T, comp_of(T, c)); }
+        const bool go = act && !slow;
+        cur_skip<WL>(cur, go ? adv : 0u);
+        const uint32_t kn = two ? k + (pe >> 24) : k1;
+        const bool dn = go && kn >= 64u;
+        k = dn ? 0u : (go ? kn : k);
+        if (dn) { c = c + 1 == T.nb ? 0u : c + 1; nblk++; rb = c < T.n1 ? T.rb0 : (c < T.n2 ? T.rb1 : T.rb2); }
     }
     p_io = cur.p; s_io = cur.p == P_END ? 0u : ST_MAKE(seg, c, k); nblk_out = nblk;
 }
@@ -1351,7 +1374,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
     uint32_t res_p = 0, res_s = 0, res_n = 0;                // what this lane reports for verification
     bool verify = false, check_n = false, active = false, captured = false, skip = false;
     const uint32_t own_end = min((i + 1) * SUB_BITS, total_bits);
-    Cursor cur; cur.words = words; cur.widx = 0; cur.w0 = cur.w1 = cur.nxt = 0; cur.off = 0; cur.p = 0;
+    Cursor cur; cur.words = words; cur.widx = 0; cur.w0 = cur.w1 = cur.nxt = 0; cur.sh = 0; cur.p = 0;
     if (in_data) {
         const uint32_t p0 = i ? A.out_p[g - 1] : 0u, s0 = i ? A.out_s[g - 1] : 0u;
         blk = A.base[g]; seg = ST_SEG(s0); c = ST_C(s0); k = ST_K(s0);
@@ -1398,8 +1421,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         if (SIDE && norm && !captured && blk < nblocks) atomicAdd(&s_histo[((isdc ? 0u : 4u) + tset.dest_id[comp * 2 + (isdc ? 0u : 1u)]) * 17u + len], 1u);
         dq0 = (norm && isdc) ? dq : dq0;
         const uint32_t tot = norm ? len + size : 0u;
-        cur.off += tot; cur.p += tot;
-        if (cur.off >= 32u) { cur.off -= 32u; cur.w0 = cur.w1; cur.w1 = bswap32(cur.nxt); cur.nxt = words[phys_word<WL>(cur.widx++)]; }
+        cur_skip<WL>(cur, tot);
         const uint32_t k2 = isdc ? 1u : k + run + 1u;
         const bool done = norm && !isdc && ((e & 255u) == 0 || k2 >= 64u);
         if (__ballot(norm && k2 > 64u)) { if (norm && k2 > 64u && blk < nblocks) fl |= F_COEF_OVERFLOW; }
@@ -1501,7 +1523,7 @@ void js_launch_unstuff(hipStream_t st, int wl, const JsImage* imgs, const uint32
 }
 static SubArrays sub_arrays(uint32_t* sub, uint64_t n) { SubArrays a; a.out_p = sub; a.out_s = sub + n; a.in_p = sub + 2 * n; a.in_s = sub + 3 * n; a.nblk = sub + 4 * n; a.base = sub + 5 * n; return a; }
 static size_t subtabs_bytes_host(uint32_t tab_rows, uint32_t tab_lut2, bool pairs = false)
-{ return (size_t)tab_rows * (2u << JS_L1_BITS) + (((size_t)tab_lut2 * 2 + 15) & ~15ull) + 3 * 64 * 2 + 64 + (pairs ? (size_t)tab_rows * (4u << JS_L1_BITS) : 0); }
+{ return (size_t)tab_rows * (2u << JS_L1_BITS) + (((size_t)tab_lut2 * 2 + 15) & ~15ull) + 3 * 64 * 2 + 64 + (pairs ? (size_t)tab_rows * (4u << JS_L1_BITS) + (size_t)tab_lut2 * 4 : 0); }
 void js_launch_sync(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
                     const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub, int first_pass)
 {

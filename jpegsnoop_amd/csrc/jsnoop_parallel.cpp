@@ -17,7 +17,7 @@
 void js_build_parallel_luts(JsTableSet* ts, uint32_t ncomp)
 {
     ts->lut_ok = 0; ts->n_rows = 0; ts->lut2_used = 0;
-    memset(ts->lut1, 0, sizeof ts->lut1); memset(ts->lut2, 0, sizeof ts->lut2); memset(ts->slot_row, 0, sizeof ts->slot_row); memset(ts->lutp, 0, sizeof ts->lutp);
+    memset(ts->lut1, 0, sizeof ts->lut1); memset(ts->lut2, 0, sizeof ts->lut2); memset(ts->slot_row, 0, sizeof ts->slot_row); memset(ts->lutp, 0, sizeof ts->lutp); memset(ts->lut2p, 0, sizeof ts->lut2p);
     uint32_t l2_used = 0;
     for (uint32_t slot = 0; slot < ncomp * 2; slot++) {
         const uint32_t n = ts->size[slot]; const bool is_dc = (slot & 1) == 0;
@@ -65,21 +65,32 @@ void js_build_parallel_luts(JsTableSet* ts, uint32_t ncomp)
     }
     ts->lut2_used = l2_used;
     // state-only pair entries, one row per distinct table (rows of DC tables describe single symbols)
+    auto single = [](uint32_t e, bool is_dc) -> uint32_t {       // one symbol: bits | index advance << 8
+        const uint32_t len = (e >> 8) & 31u, run = (e >> 4) & 15u, size = e & 15u;
+        if (len == 0) return 0xC0000000u;                         // no code starts with these bits
+        const uint32_t adv = is_dc ? 1u : ((e & 255u) == 0 ? 64u : run + 1u);
+        return (len + size) | (adv << 8);
+    };
+    memset(ts->lut2p, 0, sizeof ts->lut2p);
     for (uint32_t slot = 0; slot < ncomp * 2; slot++) {
         const uint32_t row = ts->slot_row[slot]; const bool is_dc = (slot & 1) == 0;
         const uint16_t* l1 = ts->lut1[row]; uint32_t* lp = ts->lutp[row];
         for (uint32_t w = 0; w < (1u << JS_L1_BITS); w++) {
-            const uint32_t e1 = l1[w], len1 = (e1 >> 8) & 31u;
-            if ((e1 & 0x8000u) || len1 == 0) { lp[w] = 0x80000000u; continue; }
-            const uint32_t run1 = (e1 >> 4) & 15u, size1 = e1 & 15u, bits1 = len1 + size1;
-            const uint32_t adv1 = is_dc ? 1u : run1 + 1u, eob1 = (!is_dc && (e1 & 255u) == 0) ? 1u : 0u;
-            uint32_t v = bits1 | (adv1 << 5) | (eob1 << 10);
-            if (!is_dc && !eob1 && bits1 < JS_L1_BITS) {
+            const uint32_t e1 = l1[w];
+            if (e1 & 0x8000u) {                                   // second level: [14:12] extra index bits, [11:0] base
+                lp[w] = 0x80000000u | (e1 & 0x7FFFu);
+                const uint32_t nb = (e1 >> 12) & 7u, base = e1 & 0xFFFu;
+                for (uint32_t q = 0; q < (1u << nb); q++) ts->lut2p[base + q] = single(ts->lut2[base + q], is_dc);
+                continue;
+            }
+            uint32_t v = single(e1, is_dc);
+            const uint32_t bits1 = v & 255u, adv1 = (v >> 8) & 255u;
+            if (!(v >> 31) && !is_dc && adv1 < 64u && bits1 < JS_L1_BITS) {
                 const uint32_t known = JS_L1_BITS - bits1;                       // bits of the window behind symbol 1
                 const uint32_t e2 = l1[(w << bits1) & ((1u << JS_L1_BITS) - 1u)], len2 = (e2 >> 8) & 31u;
                 if (!(e2 & 0x8000u) && len2 != 0 && len2 <= known) {            // its whole code was visible
-                    const uint32_t run2 = (e2 >> 4) & 15u, size2 = e2 & 15u;
-                    v |= (1u << 11) | ((bits1 + len2 + size2) << 12) | ((adv1 + run2 + 1u) << 18) | (((e2 & 255u) == 0 ? 1u : 0u) << 24);
+                    const uint32_t v2 = single(e2, false);
+                    v |= ((bits1 + (v2 & 255u)) << 16) | ((adv1 + ((v2 >> 8) & 255u)) << 24);
                 }
             }
             lp[w] = v;

@@ -40,10 +40,13 @@ struct JsTableSet {
     uint16_t lut2[JS_LUT2_MAX];
     // --- state-only form for the synchronisation walks (k_sync needs positions and coefficient indices, not values): one entry
     //     covers the symbol at the window AND, for AC rows, the next one when its code also lies inside the JS_L1_BITS window.
-    //     [4:0] bits of symbol 1 (code + value), [9:5] its advance of the coefficient index (DC rows: 1), [10] symbol 1 is EOB,
-    //     [11] a second symbol is described, [17:12] bits of both, [23:18] index advance of both, [24] symbol 2 is EOB,
-    //     [31] escape: code longer than the window or no code -- take the two-level path.
+    //     byte 0 = bits of symbol 1 (code + value), byte 1 = its advance of the coefficient index (DC rows: 1; EOB: 64, which ends
+    //     the block from any index), byte 2 = bits of both symbols (0 = no second symbol described), byte 3 = index advance of both
+    //     (a second symbol that is EOB adds 64).  Bit 31 = escape: the code is longer than the window, [14:12] extra index bits and
+    //     [11:0] base of its second level (as in lut1), whose entries (lut2p, parallel to lut2) are single-symbol entries of the
+    //     same form; bits 31 and 30: no code starts with these bits.
     uint32_t lutp[6][1 << JS_L1_BITS];
+    uint32_t lut2p[JS_LUT2_MAX];
     uint32_t slot_row[6];                   // row of lut1 holding the table of slot (comp-1)*2 + class
     uint32_t n_rows, lut2_used;
     uint32_t lut_ok;                        // 1 when every table fits the LUT form and is a canonical prefix code
