@@ -309,28 +309,31 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
 // q0 = x * RN(1/0.587f) followed by ONE fused correction step; for every numerator this function can produce
 // (y, cb, cr in [-128, 127] after the clamp: 2^24 cases) that is bit-identical to the IEEE quotient -- checked
 // exhaustively on the device against the oracle's true division (tests/test_gpu_parity.py::test_color_sweep).
-__device__ __forceinline__ void ycc_core(int y, int cb, int cr /*already clamped to [-128,127]*/, uint32_t& R, uint32_t& G, uint32_t& B)
+// Two pixels at a time: the fp32 multiplies, adds and the two FMAs are packed (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, IEEE
+// per element, so the results are those of the scalar sequence).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ycc_core2(s16x2 y, s16x2 cb, s16x2 cr /*already clamped to [-128,127]*/, uint32_t (&R)[2], uint32_t (&G)[2], uint32_t (&B)[2])
 {
     const float kr = 0.299f, kg = 0.587f, kb = 0.114f;
     const float cr_mul = 2 - 2 * kr, cb_mul = 2 - 2 * kb;       // folded in fp32 exactly as the reference's expression
     const float rkg = 1.0f / kg;
-    const float fy = (float)y;
-    float r = __fadd_rn(__fmul_rn((float)cr, cr_mul), fy);
-    float b = __fadd_rn(__fmul_rn((float)cb, cb_mul), fy);
-    const float x = __fsub_rn(__fsub_rn(fy, __fmul_rn(kb, b)), __fmul_rn(kr, r));
-    const float q0 = __fmul_rn(x, rkg);
-    float g = __fmaf_rn(__fmaf_rn(-kg, q0, x), rkg, q0);        // == x / kg, see above
-    r = __fadd_rn(r, 128.0f); b = __fadd_rn(b, 128.0f); g = __fadd_rn(g, 128.0f);
-    R = (uint32_t)(int)__builtin_amdgcn_fmed3f(r, 0.0f, 255.0f);   // <0 -> 0, >255 -> 255, else truncate (:4128-4136)
-    G = (uint32_t)(int)__builtin_amdgcn_fmed3f(g, 0.0f, 255.0f);
-    B = (uint32_t)(int)__builtin_amdgcn_fmed3f(b, 0.0f, 255.0f);
+    const f32x2 fy = { (float)y.x, (float)y.y }, fcb = { (float)cb.x, (float)cb.y }, fcr = { (float)cr.x, (float)cr.y };
+    f32x2 r = fcr * (f32x2){ cr_mul, cr_mul } + fy;              // -ffp-contract=off: separate multiply and add
+    f32x2 b = fcb * (f32x2){ cb_mul, cb_mul } + fy;
+    const f32x2 x = (fy - (f32x2){ kb, kb } * b) - (f32x2){ kr, kr } * r;
+    const f32x2 q0 = x * (f32x2){ rkg, rkg };
+    f32x2 g = __builtin_elementwise_fma(__builtin_elementwise_fma((f32x2){ -kg, -kg }, q0, x), (f32x2){ rkg, rkg }, q0);   // == x / kg, see above
+    const f32x2 h = { 128.0f, 128.0f };
+    r = r + h; b = b + h; g = g + h;
+    R[0] = (uint32_t)(int)__builtin_amdgcn_fmed3f(r.x, 0.0f, 255.0f); R[1] = (uint32_t)(int)__builtin_amdgcn_fmed3f(r.y, 0.0f, 255.0f);   // <0 -> 0, >255 -> 255,
+    G[0] = (uint32_t)(int)__builtin_amdgcn_fmed3f(g.x, 0.0f, 255.0f); G[1] = (uint32_t)(int)__builtin_amdgcn_fmed3f(g.y, 0.0f, 255.0f);   // else truncate (:4128-4136)
+    B[0] = (uint32_t)(int)__builtin_amdgcn_fmed3f(b.x, 0.0f, 255.0f); B[1] = (uint32_t)(int)__builtin_amdgcn_fmed3f(b.y, 0.0f, 255.0f);
 }
 // ... then ChannelExtract :4832-4872 on clamped values.  RGB_ONLY: the default preview mode (PREVIEW_RGB), no mode dispatch.
 template <bool RGB_ONLY>
-__device__ __forceinline__ uint32_t ycc_pixel(int y, int cb, int cr, uint32_t mode)
+__device__ __forceinline__ uint32_t channel_extract(uint32_t R, uint32_t G, uint32_t B, int y, int cb, int cr, uint32_t mode)
 {
-    uint32_t R, G, B;
-    ycc_core(y, cb, cr, R, G, B);
     if (!RGB_ONLY) {
         const uint32_t FY = (uint32_t)(y + 128), FCB = (uint32_t)(cb + 128), FCR = (uint32_t)(cr + 128);
         switch (mode) {
@@ -346,15 +349,25 @@ __device__ __forceinline__ uint32_t ycc_pixel(int y, int cb, int cr, uint32_t mo
     }
     return B | (G << 8) | (R << 16);              // bytes B,G,R,0 (:4786-4789)
 }
+template <bool RGB_ONLY>
+__device__ __forceinline__ void ycc_pixel2(s16x2 y, s16x2 cb, s16x2 cr, uint32_t mode, uint32_t& o0, uint32_t& o1)
+{
+    uint32_t R[2], G[2], B[2];
+    ycc_core2(y, cb, cr, R, G, B);
+    o0 = channel_extract<RGB_ONLY>(R[0], G[0], B[0], y.x, cb.x, cr.x, mode);
+    o1 = channel_extract<RGB_ONLY>(R[1], G[1], B[1], y.y, cb.y, cr.y, mode);
+}
 __device__ __forceinline__ int clamp_s8(int v) { return min(max(v, -128), 127); }
+// one pixel (probes, the exhaustive sweep): the same packed routine with the triple in both halves
 template <bool RGB_ONLY>
 __device__ __forceinline__ void ycc_to_rgb(int py, int pcb, int pcr, uint32_t mode, uint32_t& out_bgra, uint32_t& final_y)
 {
     const int y = clamp_s8(py >> 3), cb = clamp_s8(pcb >> 3), cr = clamp_s8(pcr >> 3);   // :4096-4104
-    out_bgra = ycc_pixel<RGB_ONLY>(y, cb, cr, mode); final_y = (uint32_t)(y + 128);
+    uint32_t o1;
+    ycc_pixel2<RGB_ONLY>((s16x2){ (short)y, (short)y }, (s16x2){ (short)cb, (short)cb }, (s16x2){ (short)cr, (short)cr }, mode, out_bgra, o1);
+    final_y = (uint32_t)(y + 128);
 }
 // two int16 samples at a time: >> 3, clamp to [-128, 127] (packed 16-bit VALU ops)
-typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { union { uint32_t u; s16x2 s; } c; c.u = v; return c.s; }
 __device__ __forceinline__ s16x2 clamp_s8x2(uint32_t packed)
 {
@@ -466,23 +479,24 @@ __device__ __forceinline__ void mcu_to_dib(const JsImage& im, const int16_t* til
             }
             best_y = (int)(uint32_t)(bright >> 32) - 32768;
         }
-        int cy[4], ccb[4], ccr[4];                             // clamped Y, Cb, Cr of the four pixels (:4096-4104)
+        s16x2 a0, a1, b0, b1, c0, c1;                          // clamped Y, Cb, Cr of the four pixels (:4096-4104), two per register
         if (!shifted) {
-            const s16x2 a0 = clamp_s8x2(qy.x), a1 = clamp_s8x2(qy.y), b0 = clamp_s8x2(qcb.x), b1 = clamp_s8x2(qcb.y), c0 = clamp_s8x2(qcr.x), c1 = clamp_s8x2(qcr.y);
-            cy[0] = a0.x; cy[1] = a0.y; cy[2] = a1.x; cy[3] = a1.y;
-            ccb[0] = b0.x; ccb[1] = b0.y; ccb[2] = b1.x; ccb[3] = b1.y;
-            ccr[0] = c0.x; ccr[1] = c0.y; ccr[2] = c1.x; ccr[3] = c1.y;
+            a0 = clamp_s8x2(qy.x); a1 = clamp_s8x2(qy.y); b0 = clamp_s8x2(qcb.x); b1 = clamp_s8x2(qcb.y); c0 = clamp_s8x2(qcr.x); c1 = clamp_s8x2(qcr.y);
         } else {                                               // nMcuInd >= nMcuShiftInd (:4735-4739): offsets added in int before the >> 3
             const int vy[4] = { (int)(int16_t)qy.x, (int)qy.x >> 16, (int)(int16_t)qy.y, (int)qy.y >> 16 };
             const int vcb[4] = { (int)(int16_t)qcb.x, (int)qcb.x >> 16, (int)(int16_t)qcb.y, (int)qcb.y >> 16 };
             const int vcr[4] = { (int)(int16_t)qcr.x, (int)qcr.x >> 16, (int)(int16_t)qcr.y, (int)qcr.y >> 16 };
+            short cy[4], ccb[4], ccr[4];
             #pragma unroll
-            for (int k = 0; k < 4; k++) { cy[k] = clamp_s8((vy[k] + sh_y) >> 3); ccb[k] = clamp_s8((vcb[k] + sh_cb) >> 3); ccr[k] = clamp_s8((vcr[k] + sh_cr) >> 3); }
+            for (int k = 0; k < 4; k++) { cy[k] = (short)clamp_s8((vy[k] + sh_y) >> 3); ccb[k] = (short)clamp_s8((vcb[k] + sh_cb) >> 3); ccr[k] = (short)clamp_s8((vcr[k] + sh_cr) >> 3); }
+            a0 = (s16x2){ cy[0], cy[1] }; a1 = (s16x2){ cy[2], cy[3] }; b0 = (s16x2){ ccb[0], ccb[1] }; b1 = (s16x2){ ccb[2], ccb[3] };
+            c0 = (s16x2){ ccr[0], ccr[1] }; c1 = (s16x2){ ccr[2], ccr[3] };
         }
         uint32_t o[4];
-        #pragma unroll
-        for (int k = 0; k < 4; k++) o[k] = ycc_pixel<RGB_ONLY>(cy[k], ccb[k], ccr[k], mode);
-        sum_y += (uint32_t)(cy[0] + cy[1] + cy[2] + cy[3] + 512);   // nSumY += nFinalY (:4751), wraps mod 2^32 like the reference
+        ycc_pixel2<RGB_ONLY>(a0, b0, c0, mode, o[0], o[1]);
+        ycc_pixel2<RGB_ONLY>(a1, b1, c1, mode, o[2], o[3]);
+        const s16x2 ys = a0 + a1;                              // |sum| <= 256: no int16 overflow
+        sum_y += (uint32_t)((int)ys.x + (int)ys.y + 512);      // nSumY += nFinalY (:4751), wraps mod 2^32 like the reference
         uint4 v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
         *reinterpret_cast<uint4*>(dibp + ((size_t)(img_y - 1 - py) * img_x + px) * 4) = v;
         if (want_planes) {
