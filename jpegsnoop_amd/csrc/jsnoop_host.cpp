@@ -272,8 +272,8 @@ int JsnoopBatch::upload()
     const size_t n = imgs.size();
     if (!n) { js_set_error("upload: empty batch"); return -1; }
     uint64_t blocks = 0, dibb = 0, plane = 0, side = 0, ustr = 0, subs = 0;
-    std::vector<uint32_t> wg(n + 1), usb(n + 1), syb(n + 1);
-    uint64_t segw = 0, mcub = 0; uint32_t usc = 0, syw = 0;
+    std::vector<uint32_t> wg(n + 1), usb(n + 1), syb(2 * (n + 1));       // syb: write-pass bases, then sync-pass bases
+    uint64_t segw = 0, mcub = 0; uint32_t usc = 0, syw = 0, snw = 0;
     strips_per_wg = 0; uint64_t total_mcus = 0; for (const JsImage& im : imgs) total_mcus += (uint64_t)im.mcu_xmax * im.mcu_ymax;
     const uint32_t mcus_per_wave = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, total_mcus / (8 * 4096)));
     // sub-sequence length: long (512 B) when the batch still yields plenty of lanes, short (128 B) for small jobs
@@ -298,10 +298,11 @@ int JsnoopBatch::upload()
         im.ev_cap = opt_events ? JS_EV_MAX : 0; im.ev_off = (uint64_t)i * (1 + JS_EV_WORDS * JS_EV_MAX);
         usb[i] = usc; usc += (uint32_t)(((im.scan_start & 15) + (uint64_t)im.scan_len + JS_US_CHUNK - 1) / JS_US_CHUNK);
         syb[i] = syw; syw += (im.n_subseq + JS_SY_THREADS - 1) / JS_SY_THREADS;
+        syb[n + 1 + i] = snw; snw += (im.n_subseq + JS_SY_THREADS - 2) / (JS_SY_THREADS - 1);   // sync pass: one thread per workgroup walks a halo
         max_mcu_h = std::max(max_mcu_h, im.mcu_h); max_mcu_w = std::max(max_mcu_w, im.mcu_w);
         wg[i] = wgs; wgs += std::max(1u, (nmcu + 8 * mcus_per_wave - 1) / (8 * mcus_per_wave));     // 8 waves per workgroup, one MCU per wave at a time
     }
-    usb[n] = usc; syb[n] = syw; us_chunks = usc; sy_wgs = syw; seg_words = segw; mcu_bytes = mcub;
+    usb[n] = usc; syb[n] = syw; syb[2 * n + 1] = snw; us_chunks = usc; sy_wgs = syw; sn_wgs = snw; seg_words = segw; mcu_bytes = mcub;
     wg[n] = wgs; total_wgs = wgs; total_blocks = blocks; dib_bytes = dibb; side_words = side; total_subseq = subs; ustr_bytes = ustr;
     if (grow(&dev.raw, &cap.raw, raw_bytes + 64) || grow(&dev.coef, &cap.coef, blocks * 128) || grow(&dev.dccum, &cap.dccum, blocks * 2 + 64) ||
         grow(&dev.dib, &cap.dib, dibb) || grow(&dev.side, &cap.side, side * 4) || grow(&dev.imgs, &cap.imgs, n * sizeof(JsImage)) ||
@@ -309,7 +310,7 @@ int JsnoopBatch::upload()
         grow(&dev.sel, &cap.sel, n * 4) || grow(&dev.sums, &cap.sums, n * 8) || grow(&dev.ustr, &cap.ustr, ustr + 64) ||
         grow(&dev.sub, &cap.sub, subs * 24 + 64) || grow(&dev.probe, &cap.probe, 1024) || grow(&dev.seg, &cap.seg, segw * 4 + 64) ||
         grow(&dev.chunk_keep, &cap.chunk_keep, (size_t)usc * 4 + 64) || grow(&dev.chunk_rst, &cap.chunk_rst, (size_t)usc * 4 + 64) ||
-        grow(&dev.us_base, &cap.us_base, (n + 1) * 4) || grow(&dev.sy_base, &cap.sy_base, (n + 1) * 4) ||
+        grow(&dev.us_base, &cap.us_base, (n + 1) * 4) || grow(&dev.sy_base, &cap.sy_base, 2 * (n + 1) * 4) ||
         grow(&dev.mcu_rst, &cap.mcu_rst, mcub + 64) || grow(&dev.ustr_lin, &cap.ustr_lin, ustr + 64) || grow(&dev.flags, &cap.flags, n * 4 + 64)) return -1;
     if (opt_want_planes && grow(&dev.planes, &cap.planes, plane * 2)) return -1;
     event_words = opt_events ? (uint64_t)n * (1 + JS_EV_WORDS * JS_EV_MAX) : 0;
@@ -320,9 +321,9 @@ int JsnoopBatch::upload()
     HIP_TRY(hipMemcpyAsync(dev.tables, tables.data(), tables.size() * sizeof(JsTableSet), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(dev.wg_base, wg.data(), (n + 1) * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(dev.us_base, usb.data(), (n + 1) * 4, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(dev.sy_base, syb.data(), (n + 1) * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(dev.sy_base, syb.data(), 2 * (n + 1) * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));          // host vectors above may go out of scope
-    h_us_base = usb; h_sy_base = syb;
+    h_us_base = usb; h_sy_base.assign(syb.begin(), syb.begin() + n + 1);
     uploaded = true;
     return 0;
 }

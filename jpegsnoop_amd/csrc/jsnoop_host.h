@@ -72,7 +72,7 @@ struct JsnoopBatch {
     uint8_t* pinned; size_t pinned_cap; uint64_t raw_bytes;
     JsDeviceArenas dev; JsArenaCaps cap;
     bool uploaded;
-    uint64_t total_blocks, dib_bytes, side_words, total_subseq, ustr_bytes, seg_words, mcu_bytes; uint32_t total_wgs, strips_per_wg, us_chunks, sy_wgs, max_mcu_h, max_mcu_w;
+    uint64_t total_blocks, dib_bytes, side_words, total_subseq, ustr_bytes, seg_words, mcu_bytes; uint32_t total_wgs, strips_per_wg, us_chunks, sy_wgs, sn_wgs, max_mcu_h, max_mcu_w;
     int sync_launches; int sub_wl;   // log2(words per sub-sequence): 5 = 128-byte, 7 = 512-byte sub-sequences (chosen per batch)
     uint32_t tab_rows, tab_lut2;     // largest decode-table footprint in the batch (sizes the kernels' LDS)
     hipEvent_t ev[JSNOOP_NUM_STAGES + 1];

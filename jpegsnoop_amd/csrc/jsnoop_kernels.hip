@@ -1257,35 +1257,42 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
     const uint32_t* sd = side + im.side_off;
     const uint32_t total_bits = sd[10] * 8, nseg = min(sd[11], im.seg_cap - 1);
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const uint32_t sub0 = (blockIdx.x - sy_base[img]) * SY_THREADS;
-    if (sub0 * SUB_BITS >= total_bits && sub0) return;          // whole workgroup lies past the end of the data
-    const size_t g0 = im.subseq_off + sub0;
+    // Threads 1..255 own one sub-sequence each; thread 0 walks the one BEFORE the workgroup's first, speculatively and only in
+    // the first iteration of the first launch: its exit state is where the first owned sub-sequence really starts in all but a
+    // few % of the cases, so the later launches (which carry the true states across workgroup boundaries) find next to nothing to do.
+    const uint32_t own0 = (blockIdx.x - sy_base[img]) * (SY_THREADS - 1);
+    if (own0 * SUB_BITS >= total_bits && own0) return;          // whole workgroup lies past the end of the data
+    const size_t g0 = im.subseq_off + own0;                      // slot of the first owned sub-sequence
+    const bool halo = t == 0;
+    const uint32_t i = own0 + t - 1u;                            // this thread's sub-sequence (thread 0 of the first workgroup: none)
+    const bool valid = halo ? own0 != 0 : i < im.n_subseq;
     // Later launches only carry exit states across workgroup boundaries: if the state entering this workgroup is the
     // one its first sub-sequence was last walked from, the whole workgroup is already at its fixed point.
     if (!first_pass) {
-        const uint32_t lp = sub0 ? A.out_p[g0 - 1] : 0u, ls = sub0 ? A.out_s[g0 - 1] : 0u;
+        const uint32_t lp = own0 ? A.out_p[g0 - 1] : 0u, ls = own0 ? A.out_s[g0 - 1] : 0u;
         if (lp == A.in_p[g0] && ls == A.in_s[g0]) return;
     }
     SubTabs T; load_subtabs<true>(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, t, SY_THREADS);
     const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);
     const uint32_t* st = seg_tab + im.seg_off;
-    if (first_pass) { s_inp[t] = 0xFFFFFFFEu; s_ins[t] = 0; s_outp[t] = 0; s_outs[t] = 0; s_nblk[t] = 0; }
-    else { s_inp[t] = A.in_p[g0 + t]; s_ins[t] = A.in_s[g0 + t]; s_outp[t] = A.out_p[g0 + t]; s_outs[t] = A.out_s[g0 + t]; s_nblk[t] = A.nblk[g0 + t]; }
-    // the exit state of the sub-sequence left of this workgroup, as of the previous launch (speculative start in the first pass)
-    uint32_t left_p = 0, left_s = 0;
-    if (t == 0 && sub0 && !first_pass) { left_p = A.out_p[g0 - 1]; left_s = A.out_s[g0 - 1]; }
+    const size_t gs = g0 + t - 1;                                // this thread's slot (not for the halo thread of the first workgroup)
+    if (first_pass || !valid) { s_inp[t] = 0xFFFFFFFEu; s_ins[t] = 0; s_outp[t] = valid ? 0u : P_END; s_outs[t] = 0; s_nblk[t] = 0; }
+    else if (halo) { s_inp[t] = 0xFFFFFFFEu; s_ins[t] = 0; s_outp[t] = A.out_p[gs]; s_outs[t] = A.out_s[gs]; s_nblk[t] = 0; }   // the true state left of the workgroup
+    else { s_inp[t] = A.in_p[gs]; s_ins[t] = A.in_s[gs]; s_outp[t] = A.out_p[gs]; s_outs[t] = A.out_s[gs]; s_nblk[t] = A.nblk[gs]; }
     __syncthreads();
     for (int it = 0; it < SY_THREADS + 2; it++) {
         // ---- phase A: which sub-sequences see a new entry state?  (reads last iteration's exit states only)
-        const uint32_t i = sub0 + t;
-        uint32_t ip, is;
-        if ((first_pass && (it == 0 || t == 0)) && i != 0) {     // speculative start at the first bit of the sub-sequence
-            ip = i * SUB_BITS < total_bits ? i * SUB_BITS : P_END;
-            is = i * SUB_BITS < total_bits ? ST_MAKE(find_interval(st, nseg, i * (SUB_BITS / 8)), 0u, 0u) : 0u;
-        } else if (i == 0) { ip = 0; is = 0; }                   // true start of the scan: interval 0, block 0, DC
-        else if (t == 0) { ip = left_p; is = left_s; }
-        else { ip = s_outp[t - 1]; is = s_outs[t - 1]; }
-        const bool active = ip != s_inp[t] || is != s_ins[t];
+        uint32_t ip = 0, is = 0;
+        bool active;
+        if (!valid || (halo && !(first_pass && it == 0))) active = false;
+        else {
+            if (first_pass && it == 0 && i != 0) {               // speculative start at the first bit of the sub-sequence
+                ip = i * SUB_BITS < total_bits ? i * SUB_BITS : P_END;
+                is = i * SUB_BITS < total_bits ? ST_MAKE(find_interval(st, nseg, i * (SUB_BITS / 8)), 0u, 0u) : 0u;
+            } else if (i == 0) { ip = 0; is = 0; }               // true start of the scan: interval 0, block 0, DC
+            else { ip = s_outp[t - 1]; is = s_outs[t - 1]; }
+            active = ip != s_inp[t] || is != s_ins[t];
+        }
         if (t == 0) s_changed = 0;
         const uint64_t bal = __ballot(active);
         if (lane == 0) s_wcount[wave] = (uint32_t)__builtin_popcountll(bal);
@@ -1301,7 +1308,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
         __syncthreads();
         // ---- phase B: the first `nact` threads each walk one of them (whole waves drop out as the chain converges)
         if (t < nact) {
-            const uint32_t u = s_act[t], iu = sub0 + u;
+            const uint32_t u = s_act[t], iu = own0 + u - 1u;
             uint32_t p = s_inp[u], s = s_ins[u], nblk = 0;
             const uint32_t own_end = min((iu + 1) * SUB_BITS, total_bits);
             if (!(p != P_END && p >= own_end))                   // else: owns no symbol, the state passes through
@@ -1313,7 +1320,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
         if (!s_changed) break;
         __syncthreads();
     }
-    A.out_p[g0 + t] = s_outp[t]; A.out_s[g0 + t] = s_outs[t]; A.in_p[g0 + t] = s_inp[t]; A.in_s[g0 + t] = s_ins[t]; A.nblk[g0 + t] = s_nblk[t];
+    if (valid && !halo) { A.out_p[gs] = s_outp[t]; A.out_s[gs] = s_outs[t]; A.in_p[gs] = s_inp[t]; A.in_s[gs] = s_ins[t]; A.nblk[gs] = s_nblk[t]; }
 }
 
 // One workgroup per image: exclusive scan of blocks-per-sub-sequence.
@@ -1399,55 +1406,67 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         else { active = true; check_n = true; seg_end = st[seg + 1] * 8; skip = k != 0; cur_init<WL>(cur, words, p0); }
     }
     int16_t dq0 = 0;
-    uint32_t comp = comp_of(T, c), rp = rows_of(T, comp);
+    // per component: byte offset of its DC row in lut1 | of its AC row << 16, and of its quantiser row in qzz
+    const uint32_t rsh = JS_L1_BITS + 1;
+    const uint32_t wb0 = (tset.slot_row[0] << rsh) | (tset.slot_row[1] << (rsh + 16)), wb1 = (tset.slot_row[2] << rsh) | (tset.slot_row[3] << (rsh + 16)),
+                   wb2 = (tset.slot_row[4] << rsh) | (tset.slot_row[5] << (rsh + 16));
+    const char* l1b = reinterpret_cast<const char*>(T.lut1);
+    uint32_t comp = comp_of(T, c), wb = comp == 0 ? wb0 : (comp == 1 ? wb1 : wb2);
     for (;;) {
         // ---- end of the owned range: report the state there; keep going only to finish a block this lane started
         const bool at_end = active && cur.p >= own_end;
-        const bool cap = at_end && !captured;
-        res_p = cap ? cur.p : res_p; res_s = cap ? ST_MAKE(seg, c, k) : res_s; res_n = cap ? nblk : res_n; captured = captured || cap;
-        active = active && !(at_end && (k == 0 || skip));
+        if (__ballot(at_end)) {
+            if (at_end) {
+                if (!captured) { res_p = cur.p; res_s = ST_MAKE(seg, c, k); res_n = nblk; captured = true; }
+                if (k == 0 || skip) active = false;
+            }
+        }
         if (!__ballot(active)) break;
         // ---- one symbol per lane: straight-line select code on the common path
         const uint32_t win = cur_peek(cur);
-        uint32_t e = T.lut1[((((k ? rp >> 8 : rp) & 255u)) << JS_L1_BITS) + (win >> (32 - JS_L1_BITS))];
+        const bool isdc = k == 0;
+        uint32_t e = *reinterpret_cast<const uint16_t*>(l1b + ((isdc ? wb & 0xFFFFu : wb >> 16) + ((win >> (32 - JS_L1_BITS)) << 1)));
         if (__ballot(active && (e & 0x8000u))) {                 // some lane holds a code longer than JS_L1_BITS bits (a few % of symbols)
             if (e & 0x8000u) { const uint32_t nbx = (e >> 12) & 7u; e = T.lut2[(e & 0xFFFu) + ((win >> (32 - JS_L1_BITS - nbx)) & ((1u << nbx) - 1u))]; }
         }
-        const uint32_t len = (e >> 8) & 31u, run = (e >> 4) & 15u, size = e & 15u;
-        const bool bad = active && (len == 0 || cur.p + len > seg_end);
-        if (__ballot(bad)) {                                     // interval / stream end, or a code that matches nothing: rare
-            if (bad) {
+        const uint32_t len = (e >> 8) & 31u, run = (e >> 4) & 15u, size = e & 15u, tot = len + size;
+        const uint32_t k2 = isdc ? 1u : k + run + 1u;            // coefficient index behind this symbol
+        // ---- anything out of the ordinary sits behind one vote: no code, the end of the interval inside the code or its value
+        //      bits, a run past the 64th coefficient
+        bool norm = active;
+        if (__ballot(active && (len == 0 || cur.p + tot > seg_end || k2 > 64u))) {
+            if (active && (len == 0 || cur.p + len > seg_end)) {  // interval / stream end, or a code that matches nothing
                 const bool more = walk_slow<true, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, blk, !captured, rstf, fl);
                 if (!more) { if (!captured) { captured = true; res_p = P_END; res_s = 0; res_n = nblk; } active = false; }
-                comp = comp_of(T, c); rp = rows_of(T, comp);
+                comp = comp_of(T, c); wb = comp == 0 ? wb0 : (comp == 1 ? wb1 : wb2);
+                norm = false;
+            } else if (active && blk < nblocks) {
+                if (cur.p + tot > seg_end) fl |= F_OVERRUN;
+                if (k2 > 64u) fl |= F_COEF_OVERFLOW;
             }
         }
-        const bool norm = active && !bad;
-        if (__ballot(norm && cur.p + len + size > seg_end)) { if (norm && cur.p + len + size > seg_end && blk < nblocks) fl |= F_OVERRUN; }
-        const bool isdc = k == 0;
         // value bits: EXTEND (HuffmanDc2Signed :859), precision divide (:1234-1238), dequantise (:2278)
-        const uint32_t vraw = size ? (win << len) >> (32 - size) : 0u;
-        int32_t val = (size && vraw < (1u << ((size - 1) & 31))) ? (int32_t)(vraw - ((1u << size) - 1u)) : (int32_t)vraw;
+        const uint32_t vraw = __builtin_amdgcn_ubfe(win, 32u - tot, size);           // size == 0: 0
+        const uint32_t lim = (1u << size) - 1u;
+        int32_t val = (int32_t)(win << len) < 0 ? (int32_t)vraw : (int32_t)(vraw - lim);   // first value bit clear: negative (size == 0: 0 - 0)
         if (prec_shift) val /= (int32_t)(1u << prec_shift);
-        const uint32_t ind = isdc ? 0u : k + run;
+        const uint32_t ind = k2 - 1u;                            // DC: 0, AC: k + run
         const int16_t dq = (int16_t)((int32_t)(int16_t)val * (int32_t)T.qzz[comp * 64 + (ind & 63u)]);
         if (!SIDE && norm && !skip && (isdc || (decode_ac && size)) && ind < 64) lbuf[T.zz[ind]] = dq;
         if (SIDE && norm && !captured && blk < nblocks) atomicAdd(&s_histo[((isdc ? 0u : 4u) + tset.dest_id[comp * 2 + (isdc ? 0u : 1u)]) * 17u + len], 1u);
         dq0 = (norm && isdc) ? dq : dq0;
-        const uint32_t tot = norm ? len + size : 0u;
-        cur_skip<WL>(cur, tot);
-        const uint32_t k2 = isdc ? 1u : k + run + 1u;
+        cur_skip<WL>(cur, norm ? tot : 0u);
         const bool done = norm && !isdc && ((e & 255u) == 0 || k2 >= 64u);
-        if (__ballot(norm && k2 > 64u)) { if (norm && k2 > 64u && blk < nblocks) fl |= F_COEF_OVERFLOW; }
         k = norm ? (done ? 0u : k2) : k;
-        const uint32_t c1 = c + 1 == T.nb ? 0u : c + 1;
-        c = done ? c1 : c; comp = comp_of(T, c); rp = rows_of(T, comp);
-        nblk += (done && !captured) ? 1u : 0u;
         const bool flush = done && !skip && blk < nblocks;
         const uint32_t fblk = blk;
-        if (!SIDE && flush) dbase[blk] = dq0;
-        if (SIDE && flush && c == 0) mcu_pos[(blk + 1) / T.nb] = cur.p;      // the next MCU starts here (before any restart handling)
-        skip = done ? false : skip; blk += done ? 1u : 0u;
+        if (done) {
+            c = c + 1 == T.nb ? 0u : c + 1; comp = comp_of(T, c); wb = comp == 0 ? wb0 : (comp == 1 ? wb1 : wb2);
+            nblk += captured ? 0u : 1u;
+            if (!SIDE && flush) dbase[blk] = dq0;
+            if (SIDE && flush && c == 0) mcu_pos[(blk + 1) / T.nb] = cur.p;      // the next MCU starts here (before any restart handling)
+            skip = false; blk++;
+        }
         // ---- the whole wave moves every block that completed in this iteration: one 128-byte line each ----
         uint64_t fm = SIDE ? 0ull : __ballot(flush);
         while (fm) {

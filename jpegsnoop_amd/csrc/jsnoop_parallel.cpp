@@ -111,7 +111,7 @@ int js_parallel_entropy(JsnoopBatch* b, bool timed)
                       b->dev.ustr_lin, b->dev.ustr, b->dev.seg, b->dev.side, b->dev.flags, b->dev.sy_base, b->sy_wgs);
     if (timed) HIP_TRY(hipEventRecord(b->ev[2], b->stream));
     for (int l = 0; l < b->sync_launches; l++)
-        js_launch_sync(b->stream, b->sub_wl, b->tab_rows, b->tab_lut2, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, l == 0);
+        js_launch_sync(b->stream, b->sub_wl, b->tab_rows, b->tab_lut2, b->dev.imgs, b->dev.sy_base + (n + 1), n, b->sn_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, l == 0);
     if (timed) HIP_TRY(hipEventRecord(b->ev[3], b->stream));
     js_launch_block_scan(b->stream, b->sub_wl, b->dev.imgs, n, b->dev.tables, sub, b->total_subseq, b->dev.side, b->dev.flags);
     if (timed) HIP_TRY(hipEventRecord(b->ev[4], b->stream));
@@ -155,7 +155,7 @@ static int js_parallel_resume(JsnoopBatch* b, int extra_launches)
     HIP_TRY(hipMemsetAsync(b->dev.flags, 0, (size_t)n * 4, b->stream));
     for (uint32_t i = 0; i < n; i++) HIP_TRY(hipMemsetAsync(b->dev.side + b->imgs[i].side_off + 12, 0, 16, b->stream));
     for (int l = 0; l < extra_launches; l++)
-        js_launch_sync(b->stream, b->sub_wl, b->tab_rows, b->tab_lut2, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, 0);
+        js_launch_sync(b->stream, b->sub_wl, b->tab_rows, b->tab_lut2, b->dev.imgs, b->dev.sy_base + (n + 1), n, b->sn_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, 0);
     js_launch_block_scan(b->stream, b->sub_wl, b->dev.imgs, n, b->dev.tables, sub, b->total_subseq, b->dev.side, b->dev.flags);
     js_launch_write(b->stream, b->sub_wl, b->tab_rows, b->tab_lut2, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
                     b->dev.coef, b->dev.dccum, b->dev.mcu_rst, b->dev.flags);
