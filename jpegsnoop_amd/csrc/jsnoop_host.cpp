@@ -275,7 +275,8 @@ int JsnoopBatch::upload()
     std::vector<uint32_t> wg(n + 1), usb(n + 1), syb(2 * (n + 1));       // syb: write-pass bases, then sync-pass bases
     uint64_t segw = 0, mcub = 0; uint32_t usc = 0, syw = 0, snw = 0;
     strips_per_wg = 0; uint64_t total_mcus = 0; for (const JsImage& im : imgs) total_mcus += (uint64_t)im.mcu_xmax * im.mcu_ymax;
-    const uint32_t mcus_per_wave = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, total_mcus / (8 * 4096)));
+    // back end: 8 waves per workgroup; enough MCUs per wave to amortise a workgroup's table load, enough workgroups (>= ~1500) to fill 256 CUs
+    const uint32_t mcus_per_wave = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (total_mcus + 8 * 1536 - 1) / (8 * 1536)));
     // sub-sequence length: long (512 B) when the batch still yields plenty of lanes, short (128 B) for small jobs
     uint64_t scan_total = 0; for (const JsImage& im : imgs) scan_total += im.scan_len;
     sub_wl = scan_total >= (96ull << 20) ? 7 : 5;

@@ -603,9 +603,16 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_idct_color(const JsImage* __r
         const uint64_t ob = __shfl_down(bright, off); bright = ob > bright ? ob : bright;
         sum_y += __shfl_down(sum_y, off);
     }
-    if (lane == 0) {
+    // one pair of atomics per workgroup (they all hit the same line of the image's status words), and the maximum only when it
+    // can still raise what is there
+    __shared__ unsigned long long s_bright[BK_WAVES]; __shared__ uint32_t s_sum[BK_WAVES];
+    if (lane == 0) { s_bright[wave] = bright; s_sum[wave] = sum_y; }
+    __syncthreads();
+    if (tid == 0) {
+        for (uint32_t w = 1; w < BK_WAVES; w++) { bright = s_bright[w] > bright ? s_bright[w] : bright; sum_y += s_sum[w]; }
         uint32_t* sd = side + im.side_off;
-        atomicMax(reinterpret_cast<unsigned long long*>(sd + 12), (unsigned long long)bright);
+        unsigned long long* bp = reinterpret_cast<unsigned long long*>(sd + 12);
+        if ((unsigned long long)bright > __atomic_load_n(bp, __ATOMIC_RELAXED)) atomicMax(bp, (unsigned long long)bright);
         atomicAdd(sd + 15, sum_y);
     }
 }
