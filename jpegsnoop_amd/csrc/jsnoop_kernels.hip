@@ -1504,23 +1504,19 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
 #define DC_THREADS 1024
 struct DcSeg { int s0, s1, s2; int r; };                            // sums since the last reset inside the span, reset seen
 __device__ __forceinline__ DcSeg dc_combine(const DcSeg& a, const DcSeg& b) { DcSeg o; if (b.r) o = b; else { o.s0 = a.s0 + b.s0; o.s1 = a.s1 + b.s1; o.s2 = a.s2 + b.s2; o.r = a.r; } return o; }
-__global__ void __launch_bounds__(DC_THREADS) k_dc_scan(const JsImage* __restrict__ imgs, const JsTableSet* __restrict__ tables,
-                                                        int16_t* __restrict__ dccum, const uint8_t* __restrict__ mcu_rst)
+template <int NBMAX>                                                 // blocks per MCU this instance is unrolled for
+__device__ __forceinline__ void dc_scan_image(const JsImage& im, int16_t* __restrict__ d, const uint8_t* __restrict__ rf, DcSeg* s_w)
 {
-    const uint32_t img = blockIdx.x; const JsImage& im = imgs[img];
-    if (!tables[im.tableset].lut_ok) return;
     const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax, nb = im.blk_per_mcu;
     const uint32_t n1 = im.samp_h[1] * im.samp_v[1], n2 = im.ncomp == 3 ? n1 + im.samp_h[2] * im.samp_v[2] : nb;
-    int16_t* d = dccum + im.coef_off; const uint8_t* rf = mcu_rst + im.mcu_off;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    __shared__ DcSeg s_w[DC_THREADS / 64];
     DcSeg carry = { 0, 0, 0, 0 };
     for (uint32_t base = 0; base < nmcu; base += DC_THREADS) {
         const uint32_t m = base + t; const bool valid = m < nmcu;
-        int v[JS_MAX_BLK_PER_MCU];
+        int v[NBMAX];
         DcSeg own = { 0, 0, 0, valid && rf[m] ? 1 : 0 };
         #pragma unroll
-        for (uint32_t c = 0; c < JS_MAX_BLK_PER_MCU; c++) {
+        for (uint32_t c = 0; c < NBMAX; c++) {
             v[c] = (valid && c < nb) ? (int)d[(size_t)m * nb + c] : 0;
             if (c < n1) own.s0 += v[c]; else if (c < n2) own.s1 += v[c]; else own.s2 += v[c];
         }
@@ -1539,7 +1535,7 @@ __global__ void __launch_bounds__(DC_THREADS) k_dc_scan(const JsImage* __restric
         int c0 = own.r ? 0 : inc.s0 - own.s0, c1 = own.r ? 0 : inc.s1 - own.s1, c2 = own.r ? 0 : inc.s2 - own.s2;
         if (valid) {
             #pragma unroll
-            for (uint32_t c = 0; c < JS_MAX_BLK_PER_MCU; c++) if (c < nb) {
+            for (uint32_t c = 0; c < NBMAX; c++) if (c < nb) {
                 int16_t o;
                 if (c < n1) { c0 += v[c]; o = (int16_t)c0; } else if (c < n2) { c1 += v[c]; o = (int16_t)c1; } else { c2 += v[c]; o = (int16_t)c2; }
                 d[(size_t)m * nb + c] = o;
@@ -1548,6 +1544,16 @@ __global__ void __launch_bounds__(DC_THREADS) k_dc_scan(const JsImage* __restric
         carry = tot; carry.r = 0;
         __syncthreads();
     }
+}
+__global__ void __launch_bounds__(DC_THREADS) k_dc_scan(const JsImage* __restrict__ imgs, const JsTableSet* __restrict__ tables,
+                                                        int16_t* __restrict__ dccum, const uint8_t* __restrict__ mcu_rst)
+{
+    const uint32_t img = blockIdx.x; const JsImage& im = imgs[img];
+    if (!tables[im.tableset].lut_ok) return;
+    __shared__ DcSeg s_w[DC_THREADS / 64];
+    int16_t* d = dccum + im.coef_off; const uint8_t* rf = mcu_rst + im.mcu_off;
+    if (im.blk_per_mcu <= 6) dc_scan_image<6>(im, d, rf, s_w);   // 4:4:4, 4:2:2, 4:2:0, grayscale: a short unrolled body
+    else dc_scan_image<JS_MAX_BLK_PER_MCU>(im, d, rf, s_w);
 }
 
 void js_launch_unstuff(hipStream_t st, int wl, const JsImage* imgs, const uint32_t* us_base, uint32_t nimg, uint32_t total_chunks, const uint8_t* raw,
