@@ -562,12 +562,15 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_idct_color(const JsImage* __r
     // nibble stores its value there (DecodeIdctSet with ind = zrl, :1713)
     const bool with_ac = im.decode_ac != 0;
     uint32_t meta[BK_CHUNK], toff[BK_CHUNK];                     // placement word (wave-uniform) and this lane's tile offset per block slot
+    // m is wave-uniform (kept in SGPRs): the row addresses are a scalar base plus the lane, the DC words a scalar address
     auto load_chunk = [&](uint32_t m, uint32_t base) {
+        const int16_t* p = cbase + ((size_t)m * nb + base) * 64 + lane;
+        const int16_t* q = dbase + ((size_t)m * nb + base);
         #pragma unroll
         for (int j = 0; j < BK_CHUNK; j++) {
             const uint32_t c = base + j;
-            cv[j] = (c < nb && with_ac) ? (int)cbase[((size_t)m * nb + c) * 64 + lane] : 0;
-            dcv[j] = c < nb ? dbase[(size_t)m * nb + c] : (int16_t)0;
+            cv[j] = (c < nb && with_ac) ? (int)p[j * 64] : 0;
+            dcv[j] = c < nb ? q[j] : (int16_t)0;
         }
     };
     auto place_chunk = [&](uint32_t base) {
@@ -579,9 +582,12 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_idct_color(const JsImage* __r
     };
     place_chunk(0);
     const uint32_t wstride = wgs_in_img * BK_WAVES;
-    uint32_t m = wg_in_img * BK_WAVES + wave;
+    uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg_in_img * BK_WAVES + wave));
+    const uint32_t xmax = im.mcu_xmax, step_x = wstride % xmax, step_y = wstride / xmax;
+    uint32_t mx = m % xmax, my = m / xmax;                       // MCU coordinates, stepped along with m (no division in the loop)
     if (m < nmcu) load_chunk(m, 0);
-    for (; m < nmcu; m += wstride) {
+    for (; m < nmcu; m += wstride, mx += step_x, my += step_y) {
+        if (mx >= xmax) { mx -= xmax; my++; }
         if (partial) { for (uint32_t i = lane; i < ncomp * plane_elems; i += 64) tile[i] = 0; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); }
         // ---- IDCT of the MCU's blocks, decode order ---------------------------------------------------
         for (uint32_t base = 0; base < nb; base += BK_CHUNK) {
@@ -593,7 +599,6 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_idct_color(const JsImage* __r
         }
         if (m + wstride < nmcu) load_chunk(m + wstride, 0);           // next MCU's rows fly during the colour phase
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        const uint32_t mx = m % im.mcu_xmax, my = m / im.mcu_xmax;
         const bool shifted = any_shift && my * mcus_across + mx >= shift_ind;
         if (rgb_only) mcu_to_dib<true>(im, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, shifted, dibp, planes, pw, want_planes, bright, best_y, sum_y);
         else          mcu_to_dib<false>(im, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, shifted, dibp, planes, pw, want_planes, bright, best_y, sum_y);
