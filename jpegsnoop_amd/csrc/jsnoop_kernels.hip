@@ -462,6 +462,8 @@ __device__ __forceinline__ void mcu_to_dib(const JsImage& im, const int16_t* til
     const int sh_y = im.shift_y, sh_cb = im.shift_cb, sh_cr = im.shift_cr;
     const uint32_t dq = 64u % quads, dy = 64u / quads;
     uint32_t y = ly0, q = lq0;
+    // the DIB is bottom-up: the MCU's last row has the lowest address (wave-uniform), rows above it follow at +img_x pixels
+    uint8_t* mcu_low = dibp + ((size_t)(img_y - (my + 1u) * mh) * img_x + (size_t)mx * mw) * 4;
     for (uint32_t p = lane; p < total; p += 64) {
         const uint32_t x = q * 4, py = my * mh + y, px = mx * mw + x;
         const uint2 qy = *reinterpret_cast<const uint2*>(tile + y * rs + x);
@@ -498,7 +500,7 @@ __device__ __forceinline__ void mcu_to_dib(const JsImage& im, const int16_t* til
         const s16x2 ys = a0 + a1;                              // |sum| <= 256: no int16 overflow
         sum_y += (uint32_t)((int)ys.x + (int)ys.y + 512);      // nSumY += nFinalY (:4751), wraps mod 2^32 like the reference
         uint4 v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
-        *reinterpret_cast<uint4*>(dibp + ((size_t)(img_y - 1 - py) * img_x + px) * 4) = v;
+        *reinterpret_cast<uint4*>(mcu_low + ((mh - 1u - y) * img_x + x) * 4u) = v;          // scalar base + a lane offset below 2^32
         if (want_planes) {
             int16_t* pb = planes + im.plane_off;
             const size_t pi = (size_t)py * pw + px, psz = (size_t)pw * im.blk_ymax * 8;
