@@ -1071,13 +1071,12 @@ struct SubTabs {
     const uint32_t* lutp;              // state-only pair entries (k_sync only; nullptr elsewhere)
     const uint32_t* lut2p;             // ... and the single-symbol entries behind their escapes
     uint32_t rb0, rb1, rb2;            // per component: byte offset of its DC row in lutp | of its AC row << 16
-    const uint16_t* qzz;               // 3 x 64 quantiser entries, zig-zag order
-    const uint8_t*  zz;                // 64: zig-zag index -> natural index
+    const uint32_t* qz;                // 3 x 64: quantiser entry (zig-zag order) | natural index of that position << 16 -- one read per coefficient
     uint32_t rows01, rows2;            // per component 16 bits: first-level row of its DC table | AC table << 8
     uint32_t n1, n2, nb;               // block-in-MCU index where Cb / Cr blocks start; blocks per MCU
 };
 __device__ __forceinline__ size_t subtabs_bytes(uint32_t tab_rows, uint32_t tab_lut2)
-{ return (size_t)tab_rows * (2u << JS_L1_BITS) + (((size_t)tab_lut2 * 2 + 15) & ~15ull) + 3 * 64 * 2 + 64; }
+{ return (size_t)tab_rows * (2u << JS_L1_BITS) + (((size_t)tab_lut2 * 2 + 15) & ~15ull) + 3 * 64 * 4; }
 
 template <bool PAIRS>
 __device__ __forceinline__ void load_subtabs(SubTabs& T, uint8_t* lds, const JsImage& im, const JsTableSet& ts, uint32_t tab_rows, uint32_t tab_lut2,
@@ -1085,17 +1084,15 @@ __device__ __forceinline__ void load_subtabs(SubTabs& T, uint8_t* lds, const JsI
 {
     uint16_t* l1 = reinterpret_cast<uint16_t*>(lds);
     uint16_t* l2 = l1 + (size_t)tab_rows * (1u << JS_L1_BITS);
-    uint16_t* q = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(l2) + (((size_t)tab_lut2 * 2 + 15) & ~15ull));
-    uint8_t* z = reinterpret_cast<uint8_t*>(q + 3 * 64);
+    uint32_t* q = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(l2) + (((size_t)tab_lut2 * 2 + 15) & ~15ull));
     const uint32_t* src1 = reinterpret_cast<const uint32_t*>(&ts.lut1[0][0]);
     uint32_t* dst1 = reinterpret_cast<uint32_t*>(l1);
     for (uint32_t i = tid; i < ts.n_rows * (1u << JS_L1_BITS) / 2; i += nthreads) dst1[i] = src1[i];
     for (uint32_t i = tid; i < ts.lut2_used; i += nthreads) l2[i] = ts.lut2[i];
-    for (uint32_t i = tid; i < 3 * 64; i += nthreads) q[i] = (&ts.qzz[0][0])[i];
-    if (tid < 64) z[tid] = c_zigzag[tid];
-    T.lut1 = l1; T.lut2 = l2; T.qzz = q; T.zz = z; T.lutp = nullptr; T.lut2p = nullptr; T.rb0 = T.rb1 = T.rb2 = 0;
+    for (uint32_t i = tid; i < 3 * 64; i += nthreads) q[i] = (uint32_t)(&ts.qzz[0][0])[i] | ((uint32_t)c_zigzag[i & 63u] << 16);
+    T.lut1 = l1; T.lut2 = l2; T.qz = q; T.lutp = nullptr; T.lut2p = nullptr; T.rb0 = T.rb1 = T.rb2 = 0;
     if (PAIRS) {
-        uint32_t* lp = reinterpret_cast<uint32_t*>(z + 64);
+        uint32_t* lp = q + 3 * 64;
         uint32_t* lp2 = lp + (size_t)tab_rows * (1u << JS_L1_BITS);
         const uint32_t* srcp = &ts.lutp[0][0];
         for (uint32_t i = tid; i < ts.n_rows * (1u << JS_L1_BITS); i += nthreads) lp[i] = srcp[i];
@@ -1465,8 +1462,9 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         int32_t val = (int32_t)(win << len) < 0 ? (int32_t)vraw : (int32_t)(vraw - lim);   // first value bit clear: negative (size == 0: 0 - 0)
         if (prec_shift) val /= (int32_t)(1u << prec_shift);
         const uint32_t ind = k2 - 1u;                            // DC: 0, AC: k + run
-        const int16_t dq = (int16_t)((int32_t)(int16_t)val * (int32_t)T.qzz[comp * 64 + (ind & 63u)]);
-        if (!SIDE && norm && !skip && (isdc || (decode_ac && size)) && ind < 64) lbuf[T.zz[ind]] = dq;
+        const uint32_t qz = T.qz[comp * 64 + (ind & 63u)];
+        const int16_t dq = (int16_t)((int32_t)(int16_t)val * (int32_t)(qz & 0xFFFFu));
+        if (!SIDE && norm && !skip && (isdc || (decode_ac && size)) && ind < 64) lbuf[qz >> 16] = dq;
         if (SIDE && norm && !captured && blk < nblocks) atomicAdd(&s_histo[((isdc ? 0u : 4u) + tset.dest_id[comp * 2 + (isdc ? 0u : 1u)]) * 17u + len], 1u);
         dq0 = (norm && isdc) ? dq : dq0;
         cur_skip<WL>(cur, norm ? tot : 0u);
@@ -1482,13 +1480,25 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
             skip = false; blk++;
         }
         // ---- the whole wave moves every block that completed in this iteration: one 128-byte line each ----
+        // Up to FOUR finished blocks per trip: 16 lanes move one block (8 bytes each), so a trip is one LDS read and one
+        // 512-byte store instruction -- few, wide stores keep the count of outstanding memory operations (which the next
+        // bit-window refill has to wait for) low.
         uint64_t fm = SIDE ? 0ull : __ballot(flush);
         while (fm) {
-            const uint32_t src = (uint32_t)__builtin_ctzll(fm); fm &= fm - 1;
-            const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)fblk, src);
-            int16_t* sb = s_blk[wave0 + src];
-            cbase[(size_t)b * 64 + lane] = sb[lane];
-            sb[lane] = 0;
+            const uint32_t s0 = (uint32_t)__builtin_ctzll(fm); fm &= fm - 1;
+            const uint32_t s1 = fm ? (uint32_t)__builtin_ctzll(fm) : 64u; fm &= fm - 1;
+            const uint32_t s2 = fm ? (uint32_t)__builtin_ctzll(fm) : 64u; fm &= fm - 1;
+            const uint32_t s3 = fm ? (uint32_t)__builtin_ctzll(fm) : 64u; fm &= fm - 1;
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)fblk, s0), b1 = (uint32_t)__builtin_amdgcn_readlane((int)fblk, s1 & 63u),
+                           b2 = (uint32_t)__builtin_amdgcn_readlane((int)fblk, s2 & 63u), b3 = (uint32_t)__builtin_amdgcn_readlane((int)fblk, s3 & 63u);
+            const uint32_t g = lane >> 4;
+            const uint32_t src = g == 0 ? s0 : (g == 1 ? s1 : (g == 2 ? s2 : s3)), b = g == 0 ? b0 : (g == 1 ? b1 : (g == 2 ? b2 : b3));
+            if (src < 64u) {
+                uint32_t* sb = reinterpret_cast<uint32_t*>(s_blk[wave0 + src]) + (lane & 15u) * 2u;
+                const uint32_t lo = sb[0], hi = sb[1];
+                sb[0] = 0u; sb[1] = 0u;
+                *reinterpret_cast<uint2*>(cbase + (size_t)b * 64 + (lane & 15u) * 4u) = make_uint2(lo, hi);
+            }
         }
     }
     if (verify) {
@@ -1576,7 +1586,7 @@ void js_launch_unstuff(hipStream_t st, int wl, const JsImage* imgs, const uint32
 }
 static SubArrays sub_arrays(uint32_t* sub, uint64_t n) { SubArrays a; a.out_p = sub; a.out_s = sub + n; a.in_p = sub + 2 * n; a.in_s = sub + 3 * n; a.nblk = sub + 4 * n; a.base = sub + 5 * n; return a; }
 static size_t subtabs_bytes_host(uint32_t tab_rows, uint32_t tab_lut2, bool pairs = false)
-{ return (size_t)tab_rows * (2u << JS_L1_BITS) + (((size_t)tab_lut2 * 2 + 15) & ~15ull) + 3 * 64 * 2 + 64 + (pairs ? (size_t)tab_rows * (4u << JS_L1_BITS) + (size_t)tab_lut2 * 4 : 0); }
+{ return (size_t)tab_rows * (2u << JS_L1_BITS) + (((size_t)tab_lut2 * 2 + 15) & ~15ull) + 3 * 64 * 4 + (pairs ? (size_t)tab_rows * (4u << JS_L1_BITS) + (size_t)tab_lut2 * 4 : 0); }
 void js_launch_sync(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
                     const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub, int first_pass)
 {
