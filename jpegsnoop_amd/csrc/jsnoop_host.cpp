@@ -191,7 +191,17 @@ JsnoopBatch::~JsnoopBatch()
     if (d_side_tmp) hipFree(d_side_tmp);
     if (pinned) hipHostFree(pinned);
     for (auto& e : ev) if (e) hipEventDestroy(e);
+    for (auto& e : aux_ev) if (e) hipEventDestroy(e);
+    for (auto& a : aux) if (a) hipStreamDestroy(a);
     if (own_stream && stream) hipStreamDestroy(stream);
+}
+int JsnoopBatch::ensure_aux()
+{
+    if (aux[0]) return 0;
+    HIP_TRY(hipSetDevice(device));
+    for (auto& a : aux) HIP_TRY(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+    for (auto& e : aux_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return 0;
 }
 void JsnoopBatch::clear()
 {

@@ -76,6 +76,10 @@ struct JsnoopBatch {
     int sync_launches; int sub_wl;   // log2(words per sub-sequence): 5 = 128-byte, 7 = 512-byte sub-sequences (chosen per batch)
     uint32_t tab_rows, tab_lut2;     // largest decode-table footprint in the batch (sizes the kernels' LDS)
     hipEvent_t ev[JSNOOP_NUM_STAGES + 1];
+    // helper streams for work that forks inside one decode (independent scans of a progressive file), created on first use
+    enum { kAux = 4 };
+    hipStream_t aux[kAux] = { nullptr, nullptr, nullptr, nullptr }; hipEvent_t aux_ev[kAux + 1] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    int ensure_aux();
     float lut[64][64]; float* d_lut;
     explicit JsnoopBatch(void* user_stream);
     ~JsnoopBatch();

@@ -191,7 +191,39 @@ extern "C" int jsnoop_decode_progressive(JsnoopDecoder* d, const uint8_t* f, siz
     hipMemsetAsync(b->dev.coef + dim.coef_off * 64, 0, (size_t)dim.total_blocks * 128, b->stream);
     hipMemsetAsync(b->dev.dccum + dim.coef_off, 0, (size_t)dim.total_blocks * 2, b->stream);
     hipMemsetAsync(b->dev.side, 0, b->side_words * 4, b->stream);
-    for (const JsProgScan& sc : scans) js_launch_prog_scan(b->stream, b->dev.imgs, fr, sc, d_tabs, d_segs, b->dev.raw, b->dev.coef, d_status);
+    // Scans that touch different coefficients are independent (a DC scan: slot 0 of its components; an AC first scan: its band of
+    // one component; an AC refinement: slots 1..63 of one component -- it reads the history of the whole band and writes the block
+    // back without slot 0).  Levels of the dependency order run one after the other, the scans of a level side by side on
+    // helper streams: a kernel of a few dozen single-lane decoders leaves the chip empty.
+    const size_t ns = scans.size();
+    std::vector<int> level(ns, 0); int nlev = 1;
+    auto band = [](const JsProgScan& q, unsigned& lo, unsigned& hi) { if (q.ss == 0) { lo = hi = 0; } else if (q.ah) { lo = 1; hi = 63; } else { lo = q.ss; hi = q.se; } };
+    for (size_t i = 0; i < ns; i++) {
+        unsigned li, hi; band(scans[i], li, hi);
+        for (size_t j = 0; j < i; j++) {
+            unsigned lj, hj; band(scans[j], lj, hj);
+            bool share = false;
+            for (unsigned a = 0; a < scans[i].ncomp; a++) for (unsigned c = 0; c < scans[j].ncomp; c++) share = share || scans[i].comp[a] == scans[j].comp[c];
+            if (share && li <= hj && lj <= hi) level[i] = std::max(level[i], level[j] + 1);
+        }
+        nlev = std::max(nlev, level[i] + 1);
+    }
+    const bool fork = ns > 1 && nlev < (int)ns && b->ensure_aux() == 0;
+    for (int lv = 0; lv < nlev; lv++) {
+        unsigned used = 0, k = 0;
+        if (fork) hipEventRecord(b->aux_ev[JsnoopBatch::kAux], b->stream);
+        for (size_t i = 0; i < ns; i++) {
+            if (level[i] != lv) continue;
+            hipStream_t st = b->stream;
+            if (fork && k % (JsnoopBatch::kAux + 1)) {
+                const unsigned a = k % (JsnoopBatch::kAux + 1) - 1; st = b->aux[a];
+                if (!(used >> a & 1u)) { hipStreamWaitEvent(st, b->aux_ev[JsnoopBatch::kAux], 0); used |= 1u << a; }
+            }
+            js_launch_prog_scan(st, b->dev.imgs, fr, scans[i], d_tabs, d_segs, b->dev.raw, b->dev.coef, d_status);
+            k++;
+        }
+        for (unsigned a = 0; a < JsnoopBatch::kAux; a++) if (used >> a & 1u) { hipEventRecord(b->aux_ev[a], b->aux[a]); hipStreamWaitEvent(b->stream, b->aux_ev[a], 0); }
+    }
     js_launch_prog_finalize(b->stream, b->dev.imgs, fr, dim.total_blocks, b->dev.coef, b->dev.dccum);
     js_launch_idct_color(b->stream, b->dev.imgs, b->dev.wg_base, 1, b->total_wgs, b->max_mcu_w, b->max_mcu_h, b->d_lut, b->dev.coef, b->dev.dccum, b->dev.dib, b->dev.planes, b->dev.side);
     uint32_t status[4] = { 0, 0, 0, 0 };

@@ -180,7 +180,9 @@ __global__ void __launch_bounds__(64) k_prog_scan(const JsImage* __restrict__ im
                 }
                 eobrun--;
             }
-            for (int q = 0; q < 8; q++) reinterpret_cast<uint4*>(gblk)[q] = reinterpret_cast<const uint4*>(blk)[q];
+            // write the block back WITHOUT slot 0: a DC scan of the same component may run at the same time (jsnoop_progressive.cpp)
+            for (int q = 1; q < 8; q++) gblk[q] = blk[q];
+            for (int q = 1; q < 8; q++) reinterpret_cast<uint4*>(gblk)[q] = reinterpret_cast<const uint4*>(blk)[q];
         }
     }
     if (bad) atomicOr(&status[0], 1u);                              // a code that matches nothing / illegal symbol
