@@ -191,13 +191,12 @@ extern "C" int jsnoop_decode_progressive(JsnoopDecoder* d, const uint8_t* f, siz
     hipMemsetAsync(b->dev.coef + dim.coef_off * 64, 0, (size_t)dim.total_blocks * 128, b->stream);
     hipMemsetAsync(b->dev.dccum + dim.coef_off, 0, (size_t)dim.total_blocks * 2, b->stream);
     hipMemsetAsync(b->dev.side, 0, b->side_words * 4, b->stream);
-    // Scans that touch different coefficients are independent (a DC scan: slot 0 of its components; an AC first scan: its band of
-    // one component; an AC refinement: slots 1..63 of one component -- it reads the history of the whole band and writes the block
-    // back without slot 0).  Levels of the dependency order run one after the other, the scans of a level side by side on
+    // Scans that touch different coefficients are independent (a DC scan: slot 0 of its components; an AC scan, first or
+    // refinement: its band of one component, read and written by position).  Levels of the dependency order run one after the other, the scans of a level side by side on
     // helper streams: a kernel of a few dozen single-lane decoders leaves the chip empty.
     const size_t ns = scans.size();
     std::vector<int> level(ns, 0); int nlev = 1;
-    auto band = [](const JsProgScan& q, unsigned& lo, unsigned& hi) { if (q.ss == 0) { lo = hi = 0; } else if (q.ah) { lo = 1; hi = 63; } else { lo = q.ss; hi = q.se; } };
+    auto band = [](const JsProgScan& q, unsigned& lo, unsigned& hi) { if (q.ss == 0) { lo = hi = 0; } else { lo = q.ss; hi = q.se; } };
     for (size_t i = 0; i < ns; i++) {
         unsigned li, hi; band(scans[i], li, hi);
         for (size_t j = 0; j < i; j++) {

@@ -81,7 +81,6 @@ __global__ void __launch_bounds__(64) k_prog_scan(const JsImage* __restrict__ im
                                                   uint32_t* __restrict__ status)
 {
     __shared__ JsProgTable s_tab[4];
-    __shared__ __attribute__((aligned(16))) int16_t s_blk[PG_LANES][72];      // AC refinement: the lane's current block (row stride 144 B: 16-byte aligned, banks staggered)
     __shared__ uint8_t s_zz[64];
     if (threadIdx.x < 64) s_zz[threadIdx.x] = c_zz_nat[threadIdx.x];
     for (uint32_t t = 0; t < sc.ntabs; t++) {
@@ -92,7 +91,8 @@ __global__ void __launch_bounds__(64) k_prog_scan(const JsImage* __restrict__ im
     // The intervals are independent sequential decoders with data-dependent control flow: lanes that share a wave would
     // serialise each other's branches, so only PG_LANES lanes of a wave carry one (a 1080p scan with one interval per MCU
     // row has ~135 of them -- far fewer than the chip has SIMDs).
-    if (threadIdx.x % (64 / PG_LANES)) return;
+    const bool wave_coop = sc.ss != 0 && sc.ah != 0;             // AC refinement: the whole wave works on one interval's blocks
+    if (!wave_coop && threadIdx.x % (64 / PG_LANES)) return;
     const uint32_t slot = threadIdx.x / (64 / PG_LANES);
     const uint32_t iv = blockIdx.x * PG_LANES + slot;
     if (iv >= sc.nseg) return;
@@ -147,42 +147,60 @@ __global__ void __launch_bounds__(64) k_prog_scan(const JsImage* __restrict__ im
             }
         }
     } else {
-        // ---- AC refinement scan (G.1.2.3): new coefficients of magnitude 1 << Al, correction bits for the known non-zero ones
+        // ---- AC refinement scan (G.1.2.3): new coefficients of magnitude 1 << Al, correction bits for the known non-zero ones.
+        // The WAVE works on the block: lane l holds the coefficient at zig-zag position l; bit reader and Huffman decode run
+        // identically in every lane.  A symbol (run, s) means "pass `run` coefficients with zero history; every non-zero one on
+        // the way takes a correction bit; put the new value on the next zero one": the history is one 64-bit ballot, the target
+        // position the (run+1)-th set bit of the zero mask (mbcnt + ballot), the correction bits of the whole stretch come out of
+        // the reader at once and each lane picks its own by the rank of its position.
+        const uint32_t lane = threadIdx.x & 63u;
         const uint32_t comp = sc.comp[0]; const JsProgTable& T = s_tab[sc.ac_slot[0]];
         const int p1 = 1 << al, m1 = -(1 << al);
+        const uint64_t below_ss = (1ull << sc.ss) - 1ull, upto_se = sc.se >= 63u ? ~0ull : ((1ull << (sc.se + 1u)) - 1ull);
+        const uint64_t bandmask = upto_se & ~below_ss;
+        const bool inband = lane >= sc.ss && lane <= sc.se;
+        const uint32_t nat = s_zz[lane];
         uint32_t eobrun = 0;
         for (uint32_t u = u0; u < u1 && !bad; u++) {
             int16_t* gblk = cbase + block_row(im, fr, comp, u % sc.nbx, u / sc.nbx) * 64;
-            int16_t* blk = s_blk[slot];                   // the history decides how the bits parse: keep the block next to the lane
-            for (int q = 0; q < 8; q++) reinterpret_cast<uint4*>(blk)[q] = reinterpret_cast<const uint4*>(gblk)[q];
+            int v = inband ? (int)gblk[nat] : 0;
+            const uint64_t H = __ballot(v != 0) & bandmask;       // non-zero history (positions only grow inside a block: new values never re-enter)
+            // correction bits for the non-zero-history positions in [from, to): the first bit read belongs to the lowest position
+            auto correct = [&](uint32_t from, uint32_t to) {
+                const uint64_t range = (to >= 64u ? ~0ull : ((1ull << to) - 1ull)) & ~((1ull << from) - 1ull);
+                const uint64_t C = H & range;
+                const uint32_t nc = (uint32_t)__builtin_popcountll(C);
+                uint64_t cb = 0;                                   // bit j = the j-th correction bit of the stretch
+                for (uint32_t got = 0; got < nc; ) {
+                    const uint32_t n = min(nc - got, 32u);
+                    const uint32_t w = r.bits((int)n);             // MSB first
+                    cb |= (uint64_t)(__brev(w) >> (32u - n)) << got; got += n;
+                }
+                if ((C >> lane) & 1ull) {
+                    const uint32_t j = (uint32_t)__builtin_popcountll(C & ((1ull << lane) - 1ull));
+                    if (((cb >> j) & 1ull) && !(v & p1)) v += (v >= 0 ? p1 : m1);
+                }
+            };
             uint32_t k = sc.ss;
             if (!eobrun) {
-                for (; k <= sc.se; k++) {
+                while (k <= sc.se) {
                     const int rs = huff(r, T);
                     if (rs < 0) { bad = 1; break; }
-                    int run = rs >> 4; const uint32_t s = (uint32_t)rs & 15u;
+                    const int run = rs >> 4; const uint32_t s = (uint32_t)rs & 15u;
                     int newv = 0;
                     if (s) { if (s != 1) { bad = 1; break; } newv = r.bit() ? p1 : m1; }
                     else if (run != 15) { eobrun = (1u << run) + r.bits(run); break; }     // EOBn (this block included)
-                    // skip `run` zero-history coefficients; every non-zero one passed on the way takes a correction bit
-                    for (; k <= sc.se; k++) {
-                        int16_t* c = blk + s_zz[k];
-                        if (*c) { if (r.bit() && !(*c & p1)) *c = (int16_t)(*c + (*c >= 0 ? p1 : m1)); }
-                        else if (--run < 0) break;
-                    }
-                    if (newv && k <= sc.se) blk[s_zz[k]] = (int16_t)newv;
+                    const uint64_t Z = ~H & bandmask & ~((1ull << k) - 1ull);            // zero history from k on
+                    const uint32_t zr = __builtin_amdgcn_mbcnt_hi((uint32_t)(Z >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Z, 0u));
+                    const uint64_t tb = __ballot(((Z >> lane) & 1ull) && zr == (uint32_t)run);
+                    const uint32_t t = tb ? (uint32_t)__builtin_ctzll(tb) : sc.se + 1u;  // the (run+1)-th of them, or the band ends first
+                    correct(k, t);
+                    if (newv && t <= sc.se && lane == t) v = newv;
+                    k = t + 1u;
                 }
             }
-            if (eobrun) {                                          // rest of the band: correction bits only
-                for (; k <= sc.se; k++) {
-                    int16_t* c = blk + s_zz[k];
-                    if (*c && r.bit() && !(*c & p1)) *c = (int16_t)(*c + (*c >= 0 ? p1 : m1));
-                }
-                eobrun--;
-            }
-            // write the block back WITHOUT slot 0: a DC scan of the same component may run at the same time (jsnoop_progressive.cpp)
-            for (int q = 1; q < 8; q++) gblk[q] = blk[q];
-            for (int q = 1; q < 8; q++) reinterpret_cast<uint4*>(gblk)[q] = reinterpret_cast<const uint4*>(blk)[q];
+            if (eobrun) { correct(k, sc.se + 1u); eobrun--; }      // rest of the band: correction bits only
+            if (inband) gblk[nat] = (int16_t)v;                    // the band only: other scans own the rest of the block
         }
     }
     if (bad) atomicOr(&status[0], 1u);                              // a code that matches nothing / illegal symbol
