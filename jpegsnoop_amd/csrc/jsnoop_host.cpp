@@ -189,6 +189,7 @@ JsnoopBatch::~JsnoopBatch()
                       (void**)&dev.sy_base, (void**)&dev.mcu_rst, (void**)&dev.flags, (void**)&dev.ustr_lin, (void**)&dev.events }) if (*p) hipFree(*p);
     if (d_lut) hipFree(d_lut);
     if (d_side_tmp) hipFree(d_side_tmp);
+    if (prog_buf) hipFree(prog_buf);
     if (pinned) hipHostFree(pinned);
     for (auto& e : ev) if (e) hipEventDestroy(e);
     for (auto& e : aux_ev) if (e) hipEventDestroy(e);

@@ -80,6 +80,7 @@ struct JsnoopBatch {
     enum { kAux = 4 };
     hipStream_t aux[kAux] = { nullptr, nullptr, nullptr, nullptr }; hipEvent_t aux_ev[kAux + 1] = { nullptr, nullptr, nullptr, nullptr, nullptr };
     int ensure_aux();
+    void* prog_buf = nullptr; size_t prog_cap = 0;               // scan tables / interval list / status word of the progressive path
     float lut[64][64]; float* d_lut;
     explicit JsnoopBatch(void* user_stream);
     ~JsnoopBatch();

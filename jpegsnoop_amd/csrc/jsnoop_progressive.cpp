@@ -181,10 +181,16 @@ extern "C" int jsnoop_decode_progressive(JsnoopDecoder* d, const uint8_t* f, siz
     if (b->upload()) return -1;
     HIP_TRY(hipSetDevice(b->device));
     const JsImage& dim = b->imgs[0];
-    JsProgTable* d_tabs = nullptr; JsProgSeg* d_segs = nullptr; uint32_t* d_status = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_tabs, tabs.size() * sizeof(JsProgTable) + 16));
-    if (hipMalloc((void**)&d_segs, segs.size() * sizeof(JsProgSeg) + 16) != hipSuccess || hipMalloc((void**)&d_status, 16) != hipSuccess) {
-        hipFree(d_tabs); if (d_segs) hipFree(d_segs); js_set_error("hipMalloc failed"); return -1; }
+    // scan tables, interval list and status word live in one grow-only device buffer of the batch (no allocation per call)
+    const size_t tab_bytes = (tabs.size() * sizeof(JsProgTable) + 255) & ~(size_t)255, seg_bytes = (segs.size() * sizeof(JsProgSeg) + 255) & ~(size_t)255;
+    if (b->prog_cap < tab_bytes + seg_bytes + 256) {
+        if (b->prog_buf) { hipStreamSynchronize(b->stream); hipFree(b->prog_buf); b->prog_buf = nullptr; b->prog_cap = 0; }
+        const size_t want = (tab_bytes + seg_bytes + 256) * 2;
+        if (hipMalloc(&b->prog_buf, want) != hipSuccess) { b->prog_buf = nullptr; js_set_error("hipMalloc failed"); return -1; }
+        b->prog_cap = want;
+    }
+    JsProgTable* d_tabs = (JsProgTable*)b->prog_buf; JsProgSeg* d_segs = (JsProgSeg*)((uint8_t*)b->prog_buf + tab_bytes);
+    uint32_t* d_status = (uint32_t*)((uint8_t*)b->prog_buf + tab_bytes + seg_bytes);
     hipMemcpyAsync(d_tabs, tabs.data(), tabs.size() * sizeof(JsProgTable), hipMemcpyHostToDevice, b->stream);
     hipMemcpyAsync(d_segs, segs.data(), segs.size() * sizeof(JsProgSeg), hipMemcpyHostToDevice, b->stream);
     hipMemsetAsync(d_status, 0, 16, b->stream);
@@ -228,7 +234,6 @@ extern "C" int jsnoop_decode_progressive(JsnoopDecoder* d, const uint8_t* f, siz
     uint32_t status[4] = { 0, 0, 0, 0 };
     hipError_t e = hipMemcpyAsync(status, d_status, 16, hipMemcpyDeviceToHost, b->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
-    hipFree(d_tabs); hipFree(d_segs); hipFree(d_status);
     if (e != hipSuccess) { js_set_error("progressive decode: device error: %s", hipGetErrorString(e)); return -1; }
     b->host_flags.assign(1, status[0] ? JSNOOP_FLAG_BAD_CODE : 0u); b->host_path.assign(1, 3u);
     d->have_image = true; d->host_valid = 0; d->preview_is_jpeg = true;
