@@ -209,7 +209,7 @@ def main():
         ms5 = (time.perf_counter() - t5) * 100.0
         extra["config5_progressive_1920x1080_422_rst"] = {"scans": nsc, "ms_end_to_end": round(ms5, 3), "mpix_per_s": round(1920 * 1080 / ms5 / 1e3, 1),
                                                           "bit_exact_vs_baseline_encoding": ok5,
-                                                          "note": "host parse + H2D + 10 scan launches (one lane per restart interval) + back end, per call"}
+                                                          "note": "host parse + H2D + 10 scan launches in 3 dependency levels (one wave per restart interval) + back end, per call"}
         dec.close()
 
     if rank == 0:
