@@ -10,7 +10,8 @@
 // Entropy decoding follows ITU-T T.81 Annex G: DC first / refinement scans (G.1.2.1), AC first scans with EOBRUN
 // (G.1.2.2) and AC refinement scans with correction bits (G.1.2.3), spectral selection and successive approximation.
 // Parallelism is what the stream offers without speculation: restart intervals are independent, so every
-// (scan, interval) pair is one lane with its own bit reader; the scans of one image are launched in file order.
+// (scan, interval) pair is one wave with its own bit reader (one lane of it for the DC and AC-first scans, all 64 for AC
+// refinement); scans that touch different coefficients run side by side (jsnoop_progressive.cpp orders them into levels).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "jsnoop_types.h"
@@ -75,7 +76,7 @@ __device__ size_t block_row(const JsImage& im, const JsProgFrame& fr, uint32_t c
 
 }  // namespace
 
-// One lane per restart interval of one scan.
+// One wave per restart interval of one scan.
 __global__ void __launch_bounds__(64) k_prog_scan(const JsImage* __restrict__ imgs, JsProgFrame fr, JsProgScan sc, const JsProgTable* __restrict__ tabs,
                                                   const JsProgSeg* __restrict__ segs, const uint8_t* __restrict__ raw, int16_t* __restrict__ coef,
                                                   uint32_t* __restrict__ status)
