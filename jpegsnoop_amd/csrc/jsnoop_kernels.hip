@@ -891,6 +891,7 @@ void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, 
 #define SY_THREADS 256
 // sub-sequence length is a per-batch choice: WL = log2(32-bit words per sub-sequence) = 5 (128 B) or 7 (512 B)
 #define SUB_BITS   (32u << WL)
+#define SYNC_SPEC_TAIL (WL == 7 ? 2048u : 1024u)   // bits at the end of a sub-sequence the first (speculative) walk covers
 
 #define F_BAD_CODE      0x0001u
 #define F_OVERRUN       0x0002u
@@ -1297,9 +1298,14 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
         bool active;
         if (!valid || (halo && !(first_pass && it == 0))) active = false;
         else {
-            if (first_pass && it == 0 && i != 0) {               // speculative start at the first bit of the sub-sequence
-                ip = i * SUB_BITS < total_bits ? i * SUB_BITS : P_END;
-                is = i * SUB_BITS < total_bits ? ST_MAKE(find_interval(st, nseg, i * (SUB_BITS / 8)), 0u, 0u) : 0u;
+            if (first_pass && it == 0 && i != 0) {
+                // Speculative start.  This first walk only has to hand an exit state to the right neighbour (every lane walks
+                // again from its true entry state in the next round), so it covers the TAIL of the sub-sequence only: JPEG codes
+                // resynchronise within a few hundred bits, and the few lanes whose tail was too short are redone one round later.
+                const uint32_t sp = i * SUB_BITS + (SUB_BITS - SYNC_SPEC_TAIL);
+                const bool in_data = i * SUB_BITS < total_bits;
+                ip = !in_data ? P_END : (sp < total_bits ? sp : i * SUB_BITS);
+                is = in_data ? ST_MAKE(find_interval(st, nseg, ip / 8), 0u, 0u) : 0u;
             } else if (i == 0) { ip = 0; is = 0; }               // true start of the scan: interval 0, block 0, DC
             else { ip = s_outp[t - 1]; is = s_outs[t - 1]; }
             active = ip != s_inp[t] || is != s_ins[t];
