@@ -179,6 +179,8 @@ PROGRESSIVE = [
     dict(width=96, height=80, hs=1, vs=2, restart_interval=1, quality=30),
     dict(width=333, height=217, restart_interval=5),                    # not a multiple of the MCU: compare the visible region
     dict(width=141, height=93, hs=2, vs=1, optimize_huffman=1),
+    dict(width=256, height=128, quality=98, restart_interval=4),       # dense blocks: refinement stretches with more than 32 correction bits
+    dict(width=192, height=128, hs=1, vs=1, quality=100),               # all-ones quantisers, no restart markers
 ]
 
 
