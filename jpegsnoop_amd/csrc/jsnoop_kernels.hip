@@ -1349,17 +1349,21 @@ __global__ void __launch_bounds__(256) k_block_scan(const JsImage* __restrict__ 
     if (!tables[im.tableset].lut_ok) { if (threadIdx.x == 0) atomicOr(&flags[img], 0x0020u); return; }
     const uint32_t total_bits = side[im.side_off + 10] * 8;
     const uint32_t n = min(im.n_subseq, (total_bits + SUB_BITS - 1) / SUB_BITS);
-    __shared__ uint32_t s_v[256]; __shared__ uint32_t run;
-    if (threadIdx.x == 0) run = 0;
-    __syncthreads();
-    for (uint32_t b = 0; b < n; b += 256) {
+    // 256 sub-sequences per step: inclusive scan inside each wave (shuffles), the four wave totals through LDS, a running carry
+    __shared__ uint32_t s_w[2][4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t run = 0, par = 0;
+    for (uint32_t b = 0; b < n; b += 256, par ^= 1u) {
         const uint32_t i = b + threadIdx.x; const uint32_t v = i < n ? A.nblk[im.subseq_off + i] : 0;
-        s_v[threadIdx.x] = v; __syncthreads();
-        for (uint32_t d = 1; d < 256; d <<= 1) { uint32_t a = threadIdx.x >= d ? s_v[threadIdx.x - d] : 0; __syncthreads(); s_v[threadIdx.x] += a; __syncthreads(); }
-        if (i < n) A.base[im.subseq_off + i] = run + s_v[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 255) run += s_v[255];
-        __syncthreads();
+        uint32_t inc = v;
+        #pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t a = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += a; }
+        if (lane == 63) s_w[par][wave] = inc;
+        __syncthreads();                                          // (the other parity's slots are rewritten one step later: one barrier per step)
+        uint32_t pre = 0, tot = 0;
+        for (uint32_t w = 0; w < 4; w++) { const uint32_t x = s_w[par][w]; if (w < wave) pre += x; tot += x; }
+        if (i < n) A.base[im.subseq_off + i] = run + pre + inc - v;
+        run += tot;
     }
     if (threadIdx.x == 0) { side[im.side_off + 14] = run; if (run < im.total_blocks) atomicOr(&flags[img], F_SHORT); }
 }

@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import harness as H
 import jpegsnoop_amd as J
 H.build(["oracle", "synth"])
