@@ -219,6 +219,28 @@ def test_progressive_transitive_parity(harness, oracle, gpu, kw, mode):
     assert gpu.lib.jsnoop_jfif_walk(gpu.h, C.cast(buf, C.c_void_p), len(prog), C.byref(start)) == -1
 
 
+def test_progressive_random_scripts(harness, oracle, gpu):
+    """Randomised transitive parity of the progressive path (tools/fuzz_progressive.py runs the long version): random size,
+    sampling, quality, restart interval and scan script; visible DIB and planes must equal the baseline decode."""
+    rng = np.random.default_rng(2024)
+    for k in range(80):
+        gray = int(rng.integers(6) == 0)
+        hs, vs = (1, 1) if gray else [(1, 1), (2, 1), (1, 2), (2, 2)][int(rng.integers(4))]
+        kw = dict(width=int(rng.integers(8, 500)), height=int(rng.integers(8, 360)), hs=hs, vs=vs, gray=gray,
+                  quality=int(rng.choice([10, 30, 50, 75, 85, 95, 100])), restart_interval=int(rng.choice([0, 0, 1, 2, 7, 33, 200])),
+                  seed=int(rng.integers(1 << 30)), optimize_huffman=int(rng.integers(2)))
+        mode = int(rng.integers(1, 3))
+        harness.drive(oracle, harness.synth_jpeg(progressive=0, **kw))
+        assert gpu.decode_progressive(harness.synth_jpeg(progressive=mode, **kw)) > 0, (k, kw, gpu.lib.jsnoop_last_error())
+        assert gpu.lib.jsnoop_last_flags(gpu.h) == 0, (k, kw)
+        a, b = oracle.dib(), gpu.dib()
+        H, W = kw["height"], kw["width"]
+        assert a.shape == b.shape and np.array_equal(a[a.shape[0] - H:, :W], b[b.shape[0] - H:, :W]), f"case {k} {kw} mode {mode}: visible DIB differs"
+        for pa, pb in zip(oracle.planes(), gpu.planes()):
+            if pa is not None:
+                assert np.array_equal(pa[:H, :W], pb[:H, :W]), f"case {k} {kw} mode {mode}: visible planes differ"
+
+
 def test_tiff_export(harness, oracle, gpu):
     """Export to TIFF (RGB 8 / 16 bit, YCC 8 bit): file bytes against the compiled reference's FileTiff output (golden
     hashes) and against the oracle's writer on a larger image."""
