@@ -1076,8 +1076,6 @@ struct SubTabs {
     uint32_t rows01, rows2;            // per component 16 bits: first-level row of its DC table | AC table << 8
     uint32_t n1, n2, nb;               // block-in-MCU index where Cb / Cr blocks start; blocks per MCU
 };
-__device__ __forceinline__ size_t subtabs_bytes(uint32_t tab_rows, uint32_t tab_lut2)
-{ return (size_t)tab_rows * (2u << JS_L1_BITS) + (((size_t)tab_lut2 * 2 + 15) & ~15ull) + 3 * 64 * 4; }
 
 template <bool PAIRS>
 __device__ __forceinline__ void load_subtabs(SubTabs& T, uint8_t* lds, const JsImage& im, const JsTableSet& ts, uint32_t tab_rows, uint32_t tab_lut2,
@@ -1133,7 +1131,7 @@ template <int WL> __device__ __forceinline__ void cur_skip(Cursor& c, uint32_t n
 #define ST_MAKE(seg, c, k) (((seg) << 12) | ((c) << 6) | (k))
 #define P_END 0xFFFFFFFFu
 #define WR_STRIDE 66                   // int16 per thread-private LDS block buffer (64 + pad: 33-dword rows stagger the banks; 33 KiB per
-                                       // workgroup leaves room for the decode tables with FOUR workgroups per CU -- the walk is latency-bound)
+                                       // workgroup leaves room for the decode tables with FOUR workgroups per CU)
 
 // component (0..2) of block-in-MCU index c, without a table lookup
 __device__ __forceinline__ uint32_t comp_of(const SubTabs& T, uint32_t c) { return (c >= T.n1 ? 1u : 0u) + (c >= T.n2 ? 1u : 0u); }

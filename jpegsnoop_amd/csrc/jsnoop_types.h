@@ -19,7 +19,7 @@
 #define JS_DHT_CODES       260     // MAX_DHT_CODES, ImgDecode.h:68
 #define JS_FAST_BITS       9       // DHT_FAST_SIZE, ImgDecode.h:96
 #define JS_CODE_UNUSED     0xFFFFFFFFu
-#define JS_L1_BITS         9       // first-level index width of the parallel path's decode tables (1 KiB rows: LDS occupancy of the write pass)
+#define JS_L1_BITS         9       // first-level index width of the parallel path's decode tables (1 KiB rows: four workgroups of the write pass fit a CU)
 #define JS_LUT2_MAX        2048    // second-level entries (all tables together) in the parallel path's LUT form
 #define JS_SUBSEQ_BYTES    128     // bytes of un-stuffed stream per sub-sequence (parallel entropy path)
 
