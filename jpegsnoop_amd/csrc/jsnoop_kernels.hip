@@ -567,12 +567,17 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_idct_color(const JsImage* __r
     // m is wave-uniform (kept in SGPRs): the row addresses are a scalar base plus the lane, the DC words a scalar address
     auto load_chunk = [&](uint32_t m, uint32_t base) {
         const int16_t* p = cbase + ((size_t)m * nb + base) * 64 + lane;
-        const int16_t* q = dbase + ((size_t)m * nb + base);
+        // the DC words of the chunk: wave-uniform, so they come as aligned dwords through the scalar cache into SGPRs
+        const size_t d0 = im.coef_off + (size_t)m * nb + base;
+        const uint32_t* q32 = reinterpret_cast<const uint32_t*>(dccum) + (d0 >> 1);
+        const uint32_t odd = (uint32_t)d0 & 1u;
+        const uint32_t w0 = q32[0], w1 = q32[1], w2 = q32[2], w3 = q32[3];       // 8 int16 from an even index cover BK_CHUNK = 6 from d0 (the arena has slack)
         #pragma unroll
         for (int j = 0; j < BK_CHUNK; j++) {
             const uint32_t c = base + j;
             cv[j] = (c < nb && with_ac) ? (int)p[j * 64] : 0;
-            dcv[j] = c < nb ? q[j] : (int16_t)0;
+            const uint32_t h = (uint32_t)j + odd, w = (h >> 1) == 0 ? w0 : ((h >> 1) == 1 ? w1 : ((h >> 1) == 2 ? w2 : w3));
+            dcv[j] = c < nb ? (int16_t)(w >> ((h & 1u) * 16u)) : (int16_t)0;
         }
     };
     auto place_chunk = [&](uint32_t base) {
