@@ -327,7 +327,9 @@ int JsnoopBatch::upload()
     if (opt_want_planes && grow(&dev.planes, &cap.planes, plane * 2)) return -1;
     event_words = opt_events ? (uint64_t)n * (1 + JS_EV_WORDS * JS_EV_MAX) : 0;
     if (event_words && grow(&dev.events, &cap.events, event_words * 4)) return -1;
-    tab_rows = 1; tab_lut2 = 0; for (const JsTableSet& t : tables) { tab_rows = std::max(tab_rows, t.n_rows); tab_lut2 = std::max(tab_lut2, t.lut2_used); }
+    tab_rows = 1; tab_lut2 = 0; uint32_t tdc = 1, tac = 1;
+    for (const JsTableSet& t : tables) { tab_rows = std::max(tab_rows, t.n_rows); tab_lut2 = std::max(tab_lut2, t.lut2_used); tdc = std::max(tdc, t.n_dc_rows); tac = std::max(tac, t.n_ac_rows); }
+    tab_rows_w = tdc | (tac << 8);                                 // write pass: DC rows (16-bit entries) and AC rows (32-bit pair entries) separately
     HIP_TRY(hipMemcpyAsync(dev.raw, pinned, raw_bytes, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(dev.imgs, imgs.data(), n * sizeof(JsImage), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(dev.tables, tables.data(), tables.size() * sizeof(JsTableSet), hipMemcpyHostToDevice, stream));

@@ -74,7 +74,7 @@ struct JsnoopBatch {
     bool uploaded;
     uint64_t total_blocks, dib_bytes, side_words, total_subseq, ustr_bytes, seg_words, mcu_bytes; uint32_t total_wgs, strips_per_wg, us_chunks, sy_wgs, sn_wgs, max_mcu_h, max_mcu_w;
     int sync_launches; int sub_wl;   // log2(words per sub-sequence): 5 = 128-byte, 7 = 512-byte sub-sequences (chosen per batch)
-    uint32_t tab_rows, tab_lut2;     // largest decode-table footprint in the batch (sizes the kernels' LDS)
+    uint32_t tab_rows, tab_lut2, tab_rows_w;     // largest decode-table footprint in the batch (sizes the kernels' LDS); _w: DC rows | AC rows << 8
     hipEvent_t ev[JSNOOP_NUM_STAGES + 1];
     // helper streams for work that forks inside one decode (independent scans of a progressive file), created on first use
     enum { kAux = 4 };

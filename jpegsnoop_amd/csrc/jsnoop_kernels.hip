@@ -1082,6 +1082,41 @@ struct SubTabs {
     uint32_t n1, n2, nb;               // block-in-MCU index where Cb / Cr blocks start; blocks per MCU
 };
 
+// Write-pass view: DC tables as 16-bit first-level rows, AC tables as 32-bit value-pair rows (JsTableSet::lutw), the shared
+// second level, the q|zz table.  tabw = DC rows | AC rows << 8 of the largest table set of the batch.
+struct WriteTabs {
+    const char* rows;                  // DC rows, then AC rows
+    const uint16_t* lut2;
+    const uint32_t* qz;
+    uint32_t wb0, wb1, wb2;            // per component: byte offset of its DC row | of its AC row << 16 (from `rows`)
+};
+__host__ __device__ __forceinline__ size_t wtabs_bytes(uint32_t tabw, uint32_t tab_lut2)
+{ return (size_t)(tabw & 255u) * (2u << JS_L1_BITS) + (size_t)(tabw >> 8) * (4u << JS_L1_BITS) + (((size_t)tab_lut2 * 2 + 15) & ~15ull) + 3 * 64 * 4; }
+__device__ __forceinline__ void load_wtabs(WriteTabs& W, uint8_t* lds, const JsTableSet& ts, uint32_t tabw, uint32_t tab_lut2, uint32_t ncomp, uint32_t tid, uint32_t nthreads)
+{
+    const uint32_t dc_bytes = (tabw & 255u) * (2u << JS_L1_BITS), ac_bytes = (tabw >> 8) * (4u << JS_L1_BITS);
+    uint16_t* l2 = reinterpret_cast<uint16_t*>(lds + dc_bytes + ac_bytes);
+    uint32_t* q = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(l2) + (((size_t)tab_lut2 * 2 + 15) & ~15ull));
+    uint32_t off[6];                                             // byte offset of the table of slot (comp-1)*2 + class
+    for (uint32_t slot = 0; slot < 6; slot++) {
+        const uint32_t row = ts.slot_row[slot], sub = ts.row_sub[row];
+        if (slot >= ncomp * 2) { off[slot] = 0; continue; }
+        if (slot & 1) {
+            off[slot] = dc_bytes + sub * (4u << JS_L1_BITS);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(lds + off[slot]);
+            for (uint32_t i = tid; i < (1u << JS_L1_BITS); i += nthreads) dst[i] = ts.lutw[row][i];        // (shared rows are copied once per slot: same bytes)
+        } else {
+            off[slot] = sub * (2u << JS_L1_BITS);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(lds + off[slot]); const uint32_t* src = reinterpret_cast<const uint32_t*>(ts.lut1[row]);
+            for (uint32_t i = tid; i < (1u << JS_L1_BITS) / 2; i += nthreads) dst[i] = src[i];
+        }
+    }
+    for (uint32_t i = tid; i < ts.lut2_used; i += nthreads) l2[i] = ts.lut2[i];
+    for (uint32_t i = tid; i < 3 * 64; i += nthreads) q[i] = (uint32_t)(&ts.qzz[0][0])[i] | ((uint32_t)c_zigzag[i & 63u] << 16);
+    W.rows = reinterpret_cast<const char*>(lds); W.lut2 = l2; W.qz = q;
+    W.wb0 = off[0] | (off[1] << 16); W.wb1 = off[2] | (off[3] << 16); W.wb2 = off[4] | (off[5] << 16);
+}
+
 template <bool PAIRS>
 __device__ __forceinline__ void load_subtabs(SubTabs& T, uint8_t* lds, const JsImage& im, const JsTableSet& ts, uint32_t tab_rows, uint32_t tab_lut2,
                                              uint32_t tid, uint32_t nthreads)
@@ -1135,8 +1170,8 @@ template <int WL> __device__ __forceinline__ void cur_skip(Cursor& c, uint32_t n
 #define ST_K(s)   ((s) & 63u)
 #define ST_MAKE(seg, c, k) (((seg) << 12) | ((c) << 6) | (k))
 #define P_END 0xFFFFFFFFu
-#define WR_STRIDE 66                   // int16 per thread-private LDS block buffer (64 + pad: 33-dword rows stagger the banks; 33 KiB per
-                                       // workgroup leaves room for the decode tables with FOUR workgroups per CU)
+#define WR_STRIDE 64                   // int16 per thread-private LDS block buffer: 32 KiB per workgroup + the decode tables (DC rows 1 KiB,
+                                       // AC pair rows 2 KiB each) fit a CU four times
 
 // component (0..2) of block-in-MCU index c, without a table lookup
 __device__ __forceinline__ uint32_t comp_of(const SubTabs& T, uint32_t c) { return (c >= T.n1 ? 1u : 0u) + (c >= T.n2 ? 1u : 0u); }
@@ -1404,7 +1439,8 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
     if (sub0 * SUB_BITS >= total_bits) return;
     if (SIDE) for (uint32_t q = threadIdx.x; q < 2 * 4 * 17; q += SY_THREADS) s_histo[q] = 0;
     const JsTableSet& tset = tables[im.tableset];
-    SubTabs T; load_subtabs<false>(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, threadIdx.x, SY_THREADS);
+    SubTabs T; T.nb = im.blk_per_mcu; T.n1 = im.samp_h[1] * im.samp_v[1]; T.n2 = im.ncomp == 3 ? T.n1 + im.samp_h[2] * im.samp_v[2] : T.nb;
+    WriteTabs W; load_wtabs(W, s_dyn, tset, tab_rows, tab_lut2, im.ncomp, threadIdx.x, SY_THREADS);
     { uint32_t* z = reinterpret_cast<uint32_t*>(s_blk[threadIdx.x]); for (int j = 0; j < WR_STRIDE / 2; j++) z[j] = 0u; }
     __syncthreads();
 
@@ -1430,11 +1466,8 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         else { active = true; check_n = true; seg_end = st[seg + 1] * 8; skip = k != 0; cur_init<WL>(cur, words, p0); }
     }
     int16_t dq0 = 0;
-    // per component: byte offset of its DC row in lut1 | of its AC row << 16, and of its quantiser row in qzz
-    const uint32_t rsh = JS_L1_BITS + 1;
-    const uint32_t wb0 = (tset.slot_row[0] << rsh) | (tset.slot_row[1] << (rsh + 16)), wb1 = (tset.slot_row[2] << rsh) | (tset.slot_row[3] << (rsh + 16)),
-                   wb2 = (tset.slot_row[4] << rsh) | (tset.slot_row[5] << (rsh + 16));
-    const char* l1b = reinterpret_cast<const char*>(T.lut1);
+    const uint32_t wb0 = W.wb0, wb1 = W.wb1, wb2 = W.wb2;       // per component: byte offset of its DC row | of its AC row << 16
+    const char* l1b = W.rows;
     uint32_t comp = comp_of(T, c), wb = comp == 0 ? wb0 : (comp == 1 ? wb1 : wb2);
     for (;;) {
         // ---- end of the owned range: report the state there; keep going only to finish a block this lane started
@@ -1446,15 +1479,28 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
             }
         }
         if (!__ballot(active)) break;
-        // ---- one symbol per lane: straight-line select code on the common path
+        // ---- one or two symbols per lane: straight-line select code on the common path
         const uint32_t win = cur_peek(cur);
         const bool isdc = k == 0;
-        uint32_t e = *reinterpret_cast<const uint16_t*>(l1b + ((isdc ? wb & 0xFFFFu : wb >> 16) + ((win >> (32 - JS_L1_BITS)) << 1)));
-        if (__ballot(active && (e & 0x8000u))) {                 // some lane holds a code longer than JS_L1_BITS bits (a few % of symbols)
-            if (e & 0x8000u) { const uint32_t nbx = (e >> 12) & 7u; e = T.lut2[(e & 0xFFFu) + ((win >> (32 - JS_L1_BITS - nbx)) & ((1u << nbx) - 1u))]; }
+        const uint32_t widx = win >> (32 - JS_L1_BITS);
+        const uint32_t e_dc = *reinterpret_cast<const uint16_t*>(l1b + ((wb & 0xFFFFu) + (widx << 1)));
+        uint32_t e = *reinterpret_cast<const uint32_t*>(l1b + ((wb >> 16) + (widx << 2)));   // AC: this symbol and, where visible, the one behind it
+        if (isdc) { const uint32_t l = (e_dc >> 8) & 31u; e = (e_dc & 0x8000u) ? (0x80000000u | (e_dc & 0x7FFFu)) : (l ? (l | ((e_dc & 15u) << 4)) : 0xC0000000u); }
+        uint32_t len = e & 15u, size = (e >> 4) & 15u, run = (e >> 8) & 15u;
+        if (__ballot(active && (int32_t)e < 0)) {                // some lane holds a code longer than JS_L1_BITS bits (a few % of symbols), or no code
+            if ((int32_t)e < 0) {
+                if (e & 0x40000000u) { len = 0; size = 0; run = 0; }
+                else { const uint32_t nbx = (e >> 12) & 7u; const uint32_t e2 = W.lut2[(e & 0xFFFu) + ((win >> (32 - JS_L1_BITS - nbx)) & ((1u << nbx) - 1u))];
+                       len = (e2 >> 8) & 31u; run = (e2 >> 4) & 15u; size = e2 & 15u; }
+                e = 0;                                           // a single symbol
+            }
         }
-        const uint32_t len = (e >> 8) & 31u, run = (e >> 4) & 15u, size = e & 15u, tot = len + size;
+        const uint32_t tot = len + size;
         const uint32_t k2 = isdc ? 1u : k + run + 1u;            // coefficient index behind this symbol
+        // the AC symbol behind it goes along when the first one neither ends the block nor the lane's own range, and nothing
+        // out of the ordinary can happen on the way (interval end, coefficient overflow)
+        const uint32_t len2 = (e >> 12) & 15u, size2 = (e >> 16) & 15u, run2 = (e >> 20) & 15u, tot2 = len2 + size2, k3 = k2 + run2 + 1u;
+        bool two = !SIDE && active && ((e >> 24) & 1u) && (run | size) != 0u && k2 < 64u && k3 <= 64u && cur.p + tot < own_end && cur.p + tot + tot2 <= seg_end;
         // ---- anything out of the ordinary sits behind one vote: no code, the end of the interval inside the code or its value
         //      bits, a run past the 64th coefficient
         bool norm = active;
@@ -1475,14 +1521,24 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         int32_t val = (int32_t)(win << len) < 0 ? (int32_t)vraw : (int32_t)(vraw - lim);   // first value bit clear: negative (size == 0: 0 - 0)
         if (prec_shift) val /= (int32_t)(1u << prec_shift);
         const uint32_t ind = k2 - 1u;                            // DC: 0, AC: k + run
-        const uint32_t qz = T.qz[comp * 64 + (ind & 63u)];
+        const uint32_t qz = W.qz[comp * 64 + (ind & 63u)];
         const int16_t dq = (int16_t)((int32_t)(int16_t)val * (int32_t)(qz & 0xFFFFu));
         if (!SIDE && norm && !skip && (isdc || (decode_ac && size)) && ind < 64) lbuf[qz >> 16] = dq;
         if (SIDE && norm && !captured && blk < nblocks) atomicAdd(&s_histo[((isdc ? 0u : 4u) + tset.dest_id[comp * 2 + (isdc ? 0u : 1u)]) * 17u + len], 1u);
         dq0 = (norm && isdc) ? dq : dq0;
-        cur_skip<WL>(cur, norm ? tot : 0u);
-        const bool done = norm && !isdc && ((e & 255u) == 0 || k2 >= 64u);
-        k = norm ? (done ? 0u : k2) : k;
+        two = two && norm;
+        if (!SIDE) {                                             // second symbol: bits [tot, tot + tot2) of the same window (tot + tot2 <= 24)
+            const uint32_t vraw2 = __builtin_amdgcn_ubfe(win, 32u - tot - tot2, size2);
+            int32_t val2 = (int32_t)(win << (tot + len2)) < 0 ? (int32_t)vraw2 : (int32_t)(vraw2 - ((1u << size2) - 1u));
+            if (prec_shift) val2 /= (int32_t)(1u << prec_shift);
+            const uint32_t qz2 = W.qz[comp * 64 + ((k3 - 1u) & 63u)];
+            const int16_t dq2 = (int16_t)((int32_t)(int16_t)val2 * (int32_t)(qz2 & 0xFFFFu));
+            if (two && !skip && decode_ac && size2) lbuf[qz2 >> 16] = dq2;             // k3 - 1 < 64 by construction
+        }
+        cur_skip<WL>(cur, norm ? (two ? tot + tot2 : tot) : 0u);
+        const uint32_t kn = two ? k3 : k2;
+        const bool done = norm && !isdc && (two ? ((run2 | size2) == 0u || k3 >= 64u) : ((run | size) == 0u || k2 >= 64u));
+        k = norm ? (done ? 0u : kn) : k;
         const bool flush = done && !skip && blk < nblocks;
         const uint32_t fblk = blk;
         if (done) {
@@ -1620,9 +1676,9 @@ void js_launch_write(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut
                      int16_t* coef, int16_t* dccum, uint8_t* mcu_rst, uint32_t* flags)
 {
     if (!total_wgs) return;
-    if (wl == 7) hipLaunchKernelGGL((k_write<7, false>), dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+    if (wl == 7) hipLaunchKernelGGL((k_write<7, false>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2, 0u, (uint32_t*)nullptr);
-    else hipLaunchKernelGGL((k_write<5, false>), dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+    else hipLaunchKernelGGL((k_write<5, false>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2, 0u, (uint32_t*)nullptr);
 }
 // =====================================================================================
@@ -1754,9 +1810,9 @@ void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab
 {
     if (!us_wgs || !sy_wgs) return;
     hipLaunchKernelGGL(k_unstuff_write, dim3(us_wgs), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, (uint8_t*)nullptr, seg_tab, us_wg0, us_out);
-    if (wl == 7) hipLaunchKernelGGL((k_write<7, true>), dim3(sy_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+    if (wl == 7) hipLaunchKernelGGL((k_write<7, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos);
-    else hipLaunchKernelGGL((k_write<5, true>), dim3(sy_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+    else hipLaunchKernelGGL((k_write<5, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos);
     hipLaunchKernelGGL(k_side_maps, dim3(64), dim3(256), 0, st, imgs, img, tables, raw, seg_tab, dccum, mcu_rst, mcu_pos, us_out, us_wgs * US_THREADS, side, events);
 }

@@ -96,6 +96,30 @@ void js_build_parallel_luts(JsTableSet* ts, uint32_t ncomp)
             lp[w] = v;
         }
     }
+    // value form of the AC tables for the write pass, rows numbered per class
+    memset(ts->lutw, 0, sizeof ts->lutw); memset(ts->row_sub, 0, sizeof ts->row_sub); ts->n_dc_rows = ts->n_ac_rows = 0;
+    bool seen[6] = { false, false, false, false, false, false };
+    for (uint32_t slot = 0; slot < ncomp * 2; slot++) {
+        const uint32_t row = ts->slot_row[slot]; const bool is_dc = (slot & 1) == 0;
+        if (seen[row]) continue;
+        seen[row] = true;
+        ts->row_sub[row] = is_dc ? ts->n_dc_rows++ : ts->n_ac_rows++;
+        if (is_dc) continue;
+        const uint16_t* l1 = ts->lut1[row]; uint32_t* lw = ts->lutw[row];
+        for (uint32_t w = 0; w < (1u << JS_L1_BITS); w++) {
+            const uint32_t e1 = l1[w], len1 = (e1 >> 8) & 31u;
+            if (e1 & 0x8000u) { lw[w] = 0x80000000u | (e1 & 0x7FFFu); continue; }
+            if (len1 == 0) { lw[w] = 0xC0000000u; continue; }
+            const uint32_t run1 = (e1 >> 4) & 15u, size1 = e1 & 15u, bits1 = len1 + size1;
+            uint32_t v = len1 | (size1 << 4) | (run1 << 8);
+            if ((e1 & 255u) != 0 && bits1 < JS_L1_BITS) {                          // not EOB, and bits of the window remain behind it
+                const uint32_t e2 = l1[(w << bits1) & ((1u << JS_L1_BITS) - 1u)], len2 = (e2 >> 8) & 31u;
+                if (!(e2 & 0x8000u) && len2 != 0 && len2 <= JS_L1_BITS - bits1)
+                    v |= (len2 << 12) | ((e2 & 15u) << 16) | (((e2 >> 4) & 15u) << 20) | (1u << 24);
+            }
+            lw[w] = v;
+        }
+    }
     ts->lut_ok = 1;
 }
 
@@ -115,7 +139,7 @@ int js_parallel_entropy(JsnoopBatch* b, bool timed)
     if (timed) HIP_TRY(hipEventRecord(b->ev[3], b->stream));
     js_launch_block_scan(b->stream, b->sub_wl, b->dev.imgs, n, b->dev.tables, sub, b->total_subseq, b->dev.side, b->dev.flags);
     if (timed) HIP_TRY(hipEventRecord(b->ev[4], b->stream));
-    js_launch_write(b->stream, b->sub_wl, b->tab_rows, b->tab_lut2, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
+    js_launch_write(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
                     b->dev.coef, b->dev.dccum, b->dev.mcu_rst, b->dev.flags);
     if (timed) HIP_TRY(hipEventRecord(b->ev[5], b->stream));
     js_launch_dc_scan(b->stream, b->dev.imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst);
@@ -157,7 +181,7 @@ static int js_parallel_resume(JsnoopBatch* b, int extra_launches)
     for (int l = 0; l < extra_launches; l++)
         js_launch_sync(b->stream, b->sub_wl, b->tab_rows, b->tab_lut2, b->dev.imgs, b->dev.sy_base + (n + 1), n, b->sn_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, 0);
     js_launch_block_scan(b->stream, b->sub_wl, b->dev.imgs, n, b->dev.tables, sub, b->total_subseq, b->dev.side, b->dev.flags);
-    js_launch_write(b->stream, b->sub_wl, b->tab_rows, b->tab_lut2, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
+    js_launch_write(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
                     b->dev.coef, b->dev.dccum, b->dev.mcu_rst, b->dev.flags);
     js_launch_dc_scan(b->stream, b->dev.imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst);
     js_launch_idct_color(b->stream, b->dev.imgs, b->dev.wg_base, n, b->total_wgs, b->max_mcu_w, b->max_mcu_h, b->d_lut, b->dev.coef, b->dev.dccum, b->dev.dib, b->dev.planes, b->dev.side);
@@ -219,7 +243,7 @@ int js_side_only(JsnoopBatch* b, uint32_t i)
         }
         uint32_t* mcu_pos = b->d_side_tmp; uint32_t* us_out = mcu_pos + (((size_t)nmcu + 1 + 15) & ~(size_t)15);
         HIP_TRY(hipMemsetAsync(mcu_pos, 0, ((size_t)nmcu + 1) * 4, b->stream));
-        js_launch_side_pass(b->stream, b->sub_wl, b->tab_rows, b->tab_lut2, b->dev.imgs, b->dev.us_base, b->dev.sy_base, (uint32_t)b->imgs.size(), i, us0, usn, sy0, syn,
+        js_launch_side_pass(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.us_base, b->dev.sy_base, (uint32_t)b->imgs.size(), i, us0, usn, sy0, syn,
                             b->dev.tables, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst, b->dev.ustr, b->dev.seg, b->dev.side, (uint32_t*)b->dev.sub, b->total_subseq,
                             b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out, b->event_words ? b->dev.events : nullptr);
     } else {

@@ -47,6 +47,12 @@ struct JsTableSet {
     //     same form; bits 31 and 30: no code starts with these bits.
     uint32_t lutp[6][1 << JS_L1_BITS];
     uint32_t lut2p[JS_LUT2_MAX];
+    // --- value form for the write pass (AC tables only; DC tables use their lut1 row): the symbol at the window and, when its
+    //     code is visible in the same window, the AC symbol behind it -- [3:0] code length, [7:4] size, [11:8] run of symbol 1,
+    //     [15:12] / [19:16] / [23:20] the same of symbol 2, [24] a second symbol is described.  Bit 31 = escape as in lutp.
+    uint32_t lutw[6][1 << JS_L1_BITS];
+    uint32_t row_sub[6];                    // index of a lut1 row among the rows of its class (DC tables / AC tables)
+    uint32_t n_dc_rows, n_ac_rows;
     uint32_t slot_row[6];                   // row of lut1 holding the table of slot (comp-1)*2 + class
     uint32_t n_rows, lut2_used;
     uint32_t lut_ok;                        // 1 when every table fits the LUT form and is a canonical prefix code
