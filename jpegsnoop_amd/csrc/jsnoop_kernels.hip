@@ -542,7 +542,6 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_idct_color(const JsImage* __r
     const uint32_t nb = im.blk_per_mcu, nmcu = im.mcu_xmax * im.mcu_ymax, pw = im.blk_xmax * 8;
     const uint32_t mw = im.mcu_w, mh = im.mcu_h, rs = mw + 8, plane_elems = mh * rs, ncomp = im.ncomp;
     const int16_t* cbase = coef + im.coef_off * 64;
-    const int16_t* dbase = dccum + im.coef_off;
     uint8_t* dibp = dib + im.dib_off;
     const uint32_t mcus_across = im.img_x / mw, shift_ind = im.shift_mcu_y * mcus_across + im.shift_mcu_x;
     const bool want_planes = im.want_planes != 0, rgb_only = im.preview_mode == 1, any_shift = (im.shift_y | im.shift_cb | im.shift_cr) != 0;
