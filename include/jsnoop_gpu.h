@@ -35,6 +35,10 @@ typedef struct JsnoopBatch   JsnoopBatch;
 
 /* ---- library / device ------------------------------------------------------ */
 int         jsnoop_abi_version(void);
+/* Host-only self test (no device needed): `rounds` random canonical Huffman table sets through the builders of the parallel
+ * path's decode tables (two-level tables, state-only pair entries of the sync pass, value-pair entries of the write pass), every
+ * first-level window checked against a plain search through the code list.  Returns the number of disagreements (0 = pass). */
+int         jsnoop_selftest_tables(unsigned seed, unsigned rounds);
 const char* jsnoop_last_error(void);                /* thread-local text of the last failure      */
 int         jsnoop_device_count(void);              /* number of visible HIP devices (0 = none)   */
 int         jsnoop_set_device(int device);          /* device used by objects created afterwards  */

@@ -382,6 +382,7 @@ int JsnoopBatch::sync()
 extern "C" {
 
 int jsnoop_abi_version(void) { return JSNOOP_ABI_VERSION; }
+int jsnoop_selftest_tables(unsigned seed, unsigned rounds) { return js_selftest_tables(seed, rounds); }
 const char* jsnoop_last_error(void) { return g_err.c_str(); }
 int jsnoop_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 int jsnoop_set_device(int device)

@@ -104,6 +104,7 @@ bool js_describe_image(JsnoopDecoder* d, JsImage* im, JsTableSet* ts, uint32_t f
 void js_emit_decode_events(JsnoopDecoder* d);                      // jsnoop_report.cpp
 void js_emit_report(JsnoopDecoder* d, bool display, bool quiet);
 void js_build_parallel_luts(JsTableSet* ts, uint32_t ncomp);          // jsnoop_parallel.cpp
+int js_selftest_tables(unsigned seed, unsigned rounds);                // jsnoop_parallel.cpp (host only)
 int  js_parallel_entropy(JsnoopBatch* b, bool timed);                 // 1 = launched, 0 = not applicable, <0 error
 int  js_parallel_fixup(JsnoopBatch* b);
 int  js_side_only(JsnoopBatch* b, uint32_t i);

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 #include "jsnoop_host.h"
 #include "jsnoop_launch.h"
 
@@ -121,6 +122,113 @@ void js_build_parallel_luts(JsTableSet* ts, uint32_t ncomp)
         }
     }
     ts->lut_ok = 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Host-only self test of the table builders above (no device needed): random canonical Huffman tables, every first-level
+// window of every table checked against a plain search through the code list -- the two-level decode tables, the state-only
+// pair entries of the sync pass (+ their second level) and the value-pair entries of the write pass.  Returns the number
+// of disagreements (0 = pass), -1 when no usable table set could be generated.
+namespace {
+struct SelfRng { uint64_t s; uint32_t next() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(s >> 33); } uint32_t below(uint32_t n) { return next() % n; } };
+void random_code(SelfRng& r, bool dc, JsTableSet* ts, uint32_t slot)
+{
+    std::vector<uint32_t> syms;
+    if (dc) { for (uint32_t v = 0; v < 12; v++) if (v < 2 || r.below(4)) syms.push_back(v); }
+    else {
+        syms.push_back(0x00); syms.push_back(0xF0);
+        for (uint32_t run = 0; run < 16; run++) for (uint32_t size = 1; size <= 10; size++) if (r.below(3)) syms.push_back((run << 4) | size);
+    }
+    for (size_t i = syms.size(); i > 1; i--) std::swap(syms[i - 1], syms[r.below((uint32_t)i)]);      // which symbol gets which length
+    std::vector<uint32_t> depth = { 1, 1 };                                                          // grow a random prefix tree
+    while (depth.size() < syms.size()) {
+        const uint32_t k = r.below((uint32_t)depth.size());
+        if (depth[k] >= 16) { bool room = false; for (uint32_t d : depth) room = room || d < 16; if (!room) break; continue; }
+        depth[k]++; depth.push_back(depth[k]);
+    }
+    if (depth.size() > 2 && r.below(2)) depth.pop_back();                                            // sometimes an incomplete code (JPEG leaves all-ones unused)
+    std::sort(depth.begin(), depth.end());
+    const uint32_t n = (uint32_t)std::min(depth.size(), syms.size());
+    uint32_t code = 0, prev = depth[0];
+    ts->size[slot] = n;
+    for (uint32_t i = 0; i < n; i++) {
+        code <<= (depth[i] - prev); prev = depth[i];
+        ts->bitlen[slot][i] = depth[i]; ts->bits[slot][i] = code << (32 - depth[i]); ts->mask[slot][i] = 0xFFFFFFFFu << (32 - depth[i]); ts->code[slot][i] = syms[i];
+        code++;
+    }
+}
+// plain search (what ReadScanVal's slow path does, :1110-1160): length and symbol of the code at the top of `win`, 0 = none
+uint32_t search_code(const JsTableSet* ts, uint32_t slot, uint32_t win, uint32_t* sym)
+{
+    for (uint32_t i = 0; i < ts->size[slot]; i++) if ((win & ts->mask[slot][i]) == ts->bits[slot][i]) { *sym = ts->code[slot][i]; return ts->bitlen[slot][i]; }
+    return 0;
+}
+}  // namespace
+int js_selftest_tables(unsigned seed, unsigned rounds)
+{
+    SelfRng r = { 0x9E3779B97F4A7C15ull ^ seed };
+    int bad = 0; unsigned usable = 0;
+    std::vector<JsTableSet> store(1); JsTableSet* ts = &store[0];
+    for (unsigned round = 0; round < rounds; round++) {
+        memset(ts, 0, sizeof *ts);
+        const bool share = r.below(2);                                                               // Cb and Cr usually share their tables
+        for (uint32_t slot = 0; slot < 6; slot++) {
+            if (share && slot >= 4) { ts->size[slot] = ts->size[slot - 2]; memcpy(ts->bitlen[slot], ts->bitlen[slot - 2], sizeof ts->bitlen[slot]); memcpy(ts->bits[slot], ts->bits[slot - 2], sizeof ts->bits[slot]);
+                                      memcpy(ts->mask[slot], ts->mask[slot - 2], sizeof ts->mask[slot]); memcpy(ts->code[slot], ts->code[slot - 2], sizeof ts->code[slot]); }
+            else random_code(r, (slot & 1) == 0, ts, slot);
+        }
+        js_build_parallel_luts(ts, 3);
+        if (!ts->lut_ok) continue;                                                                   // second level too large for the LUT form: the exact kernel's case
+        usable++;
+        for (uint32_t slot = 0; slot < 6; slot++) {
+            const bool is_dc = (slot & 1) == 0; const uint32_t row = ts->slot_row[slot];
+            for (uint32_t w = 0; w < (1u << JS_L1_BITS); w++) for (int fill = 0; fill < 6; fill++) {
+                const uint32_t win = (w << (32 - JS_L1_BITS)) | (r.next() >> JS_L1_BITS);
+                uint32_t sym1 = 0; const uint32_t len1 = search_code(ts, slot, win, &sym1);
+                const uint32_t size1 = sym1 & 15u, run1 = sym1 >> 4, adv1 = is_dc ? 1u : (sym1 == 0 ? 64u : run1 + 1u);
+                // two-level tables
+                uint32_t e = ts->lut1[row][w];
+                if (e & 0x8000u) { const uint32_t nb = (e >> 12) & 7u; e = ts->lut2[(e & 0xFFFu) + ((win >> (32 - JS_L1_BITS - nb)) & ((1u << nb) - 1u))]; if (len1 && len1 <= JS_L1_BITS) bad++; }
+                if (((e >> 8) & 31u) != len1 || (len1 && (e & 255u) != sym1)) bad++;
+                // the AC symbol behind symbol 1, as far as the window shows it
+                bool vis2 = false; uint32_t len2 = 0, sym2 = 0;
+                const uint32_t bits1 = len1 + size1;
+                if (!is_dc && len1 && len1 <= JS_L1_BITS && sym1 != 0 && bits1 < JS_L1_BITS) {
+                    len2 = search_code(ts, slot, win << bits1, &sym2);
+                    // visible: its whole code lies in what is left of the window (a prefix code: no filling of the unknown bits changes that)
+                    vis2 = len2 != 0 && len2 <= JS_L1_BITS - bits1;
+                }
+                const uint32_t size2 = sym2 & 15u, run2 = sym2 >> 4, adv2 = sym2 == 0 ? 64u : run2 + 1u;
+                // state-only pair entries of the sync pass
+                uint32_t pe = ts->lutp[row][w];
+                if ((int32_t)pe < 0) {
+                    if (pe & 0x40000000u) { if (len1) bad++; }
+                    else {
+                        if (len1 && len1 <= JS_L1_BITS) bad++;
+                        const uint32_t nb = (pe >> 12) & 7u; const uint32_t e2 = ts->lut2p[(pe & 0xFFFu) + ((win >> (32 - JS_L1_BITS - nb)) & ((1u << nb) - 1u))];
+                        if (!len1) { if (e2 != 0xC0000000u) bad++; }
+                        else if ((e2 & 255u) != bits1 || ((e2 >> 8) & 255u) != adv1 || (e2 >> 16)) bad++;
+                    }
+                } else {
+                    if (!len1 || len1 > JS_L1_BITS || (pe & 255u) != bits1 || ((pe >> 8) & 255u) != adv1) bad++;
+                    const uint32_t b12 = (pe >> 16) & 255u;
+                    if (vis2 != (b12 != 0)) bad++;
+                    if (vis2 && (b12 != bits1 + len2 + size2 || (pe >> 24) != adv1 + adv2)) bad++;
+                }
+                // value-pair entries of the write pass (AC tables)
+                if (!is_dc) {
+                    const uint32_t we = ts->lutw[row][w];
+                    if ((int32_t)we < 0) { if ((we & 0x40000000u) ? len1 != 0 : (len1 && len1 <= JS_L1_BITS)) bad++; if (!(we & 0x40000000u) && (we & 0x7FFFu) != (ts->lut1[row][w] & 0x7FFFu)) bad++; }
+                    else {
+                        if (!len1 || (we & 15u) != len1 || ((we >> 4) & 15u) != size1 || ((we >> 8) & 15u) != run1) bad++;
+                        if (vis2 != (((we >> 24) & 1u) != 0)) bad++;
+                        if (vis2 && (((we >> 12) & 15u) != len2 || ((we >> 16) & 15u) != size2 || ((we >> 20) & 15u) != run2)) bad++;
+                    }
+                }
+            }
+        }
+    }
+    return usable ? bad : -1;
 }
 
 // Launches stages 1..5 (unstuff, sync, block scan, write, DC scan) for the whole batch.

@@ -37,6 +37,13 @@ def test_every_declared_symbol_is_exported(lib):
     assert exported == names, "exports and header disagree"
 
 
+def test_decode_table_builders_selftest(lib):
+    """Host logic, no device: random canonical Huffman tables through the builders of the parallel path's decode tables (two-level
+    tables, pair entries of the sync pass, value-pair entries of the write pass) against a plain search through the code list."""
+    assert lib.jsnoop_selftest_tables(1, 40) == 0
+    assert lib.jsnoop_selftest_tables(20260924, 40) == 0
+
+
 def test_no_cpu_fallback(lib):
     import jpegsnoop_amd
     import torch
