@@ -26,7 +26,7 @@ void js_set_error(const char* fmt, ...)
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
     js_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return -1; } } while (0)
 
-static int g_device = 0;
+static thread_local int g_device = 0;        // jsnoop_set_device is per host thread (one thread per GPU is the natural use of the C ABI)
 
 static const uint8_t kZigZag[64] = {
      0, 1, 8,16, 9, 2, 3,10, 17,24,32,25,18,11, 4, 5, 12,19,26,33,40,48,41,34, 27,20,13, 6, 7,14,21,28,
@@ -152,7 +152,7 @@ static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a
 
 JsnoopBatch::JsnoopBatch(void* user_stream)
 {
-    stream = (hipStream_t)user_stream; own_stream = false;
+    stream = (hipStream_t)user_stream; own_stream = false; device = g_device;
     opt_decode_ac = 1; opt_want_planes = 0; opt_force_exact = 0;
     memset(&dev, 0, sizeof dev); memset(&cap, 0, sizeof cap);
     pinned = nullptr; pinned_cap = 0; raw_bytes = 0; uploaded = false; sync_launches = 2;
@@ -162,8 +162,7 @@ JsnoopBatch::JsnoopBatch(void* user_stream)
 }
 int JsnoopBatch::init()
 {
-    HIP_TRY(hipSetDevice(g_device));
-    device = g_device;
+    HIP_TRY(hipSetDevice(device));
     if (!stream) { HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
     for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
     // PrecalcIdct :2313-2351: built once on the host in fp32, then transposed to [vu][yx] for lane-contiguous reads
@@ -262,9 +261,19 @@ int JsnoopBatch::add_described(const JsImage& desc, const uint8_t* file, size_t 
 }
 int JsnoopBatch::tile(int total)
 {
+    // Replicates the batch PHYSICALLY up to `total` images: every copy gets its own file bytes in the pinned staging area
+    // (and so in the raw arena), so that a "1024-image" batch really uploads and reads 1024 files' worth of bytes.
     const size_t n = imgs.size();
     if (!n) { js_set_error("tile: empty batch"); return -1; }
-    for (size_t i = n; i < (size_t)total; i++) imgs.push_back(imgs[i % n]);
+    for (size_t i = n; i < (size_t)total; i++) {
+        JsImage im = imgs[i % n];
+        const uint64_t off = align_up(raw_bytes, 16);
+        if (reserve_pinned(off + im.file_len + 16)) return -1;
+        memset(pinned + raw_bytes, 0, off - raw_bytes);
+        memcpy(pinned + off, pinned + im.file_off, im.file_len); memset(pinned + off + im.file_len, 0, 16);
+        raw_bytes = off + im.file_len + 16; im.file_off = off;
+        imgs.push_back(im);
+    }
     uploaded = false;
     return (int)imgs.size();
 }
@@ -608,7 +617,16 @@ void jsnoop_batch_clear(JsnoopBatch* b) { b->clear(); }
 void jsnoop_batch_set_options(JsnoopBatch* b, int decode_ac, int want_planes, int force_exact)
 { b->opt_decode_ac = decode_ac; b->opt_want_planes = want_planes; b->opt_force_exact = force_exact; b->uploaded = false; }
 int jsnoop_batch_add(JsnoopBatch* b, const JsnoopDecoder* tables, const uint8_t* file, size_t len, unsigned scan_start)
-{ return b->add(const_cast<JsnoopDecoder*>(tables), file, len, scan_start, 1); }
+{
+    // the geometry step rewrites the sampling factors of single-component scans and records the geometry (as DecodeScanImg does
+    // on its own object): done on a private copy here, `tables` really is const and may be shared between batches and threads
+    JsnoopDecoder tmp;
+    tmp.t = tables->t; tmp.opt_decode_ac = tables->opt_decode_ac; tmp.opt_err_max = tables->opt_err_max;
+    tmp.log_fn = tables->log_fn; tmp.log_user = tables->log_user;
+    tmp.preview_mode = tables->preview_mode; tmp.shift_y = tables->shift_y; tmp.shift_cb = tables->shift_cb; tmp.shift_cr = tables->shift_cr;
+    tmp.shift_mcu_x = tables->shift_mcu_x; tmp.shift_mcu_y = tables->shift_mcu_y;
+    return b->add(&tmp, file, len, scan_start, 1);
+}
 int jsnoop_batch_add_jpeg(JsnoopBatch* b, const uint8_t* file, size_t len)
 {
     JsnoopDecoder tmp; unsigned scan_start = 0;

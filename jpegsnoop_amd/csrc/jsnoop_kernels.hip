@@ -1317,9 +1317,14 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
     const bool valid = halo ? own0 != 0 : i < im.n_subseq;
     // Later launches only carry exit states across workgroup boundaries: if the state entering this workgroup is the
     // one its first sub-sequence was last walked from, the whole workgroup is already at its fixed point.
+    // The left neighbour writes those slots at the end of this same launch, unordered: ONE thread reads them and the whole
+    // workgroup follows its verdict (waves that disagreed would leave the others with a half-loaded table).
     if (!first_pass) {
-        const uint32_t lp = own0 ? A.out_p[g0 - 1] : 0u, ls = own0 ? A.out_s[g0 - 1] : 0u;
-        if (lp == A.in_p[g0] && ls == A.in_s[g0]) return;
+        if (t == 0) { const uint32_t lp = own0 ? A.out_p[g0 - 1] : 0u, ls = own0 ? A.out_s[g0 - 1] : 0u; s_changed = (lp == A.in_p[g0] && ls == A.in_s[g0]) ? 0 : 1; }
+        __syncthreads();
+        const int go = s_changed;
+        __syncthreads();
+        if (!go) return;
     }
     SubTabs T; load_subtabs<true>(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, t, SY_THREADS);
     const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);
