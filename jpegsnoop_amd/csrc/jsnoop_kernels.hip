@@ -300,136 +300,152 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
 // =====================================================================================
 #define BK_THREADS 512
 #define BK_WAVES (BK_THREADS / 64)
-#define BK_CHUNK 6                      // blocks per wave held in registers at a time (8 waves x 6 = one 4:2:0 strip of 8 MCUs)
-#define BK_MAX_STRIP_W 128
-#define BK_ROW 144                      // int16 per LDS plane row: 128 + padding so the 8 rows of a block fall in distinct banks
-#define BK_MAX_MCU_H 32
+#define BK_CHUNK 6                      // blocks per wave held in registers at a time (one 4:2:0 MCU)
 
-// ConvertYCCtoRGBFastFloat :4086-4139.  The reference divides by 0.587f (IEEE).  The quotient is formed here as
-// q0 = x * RN(1/0.587f) followed by ONE fused correction step; for every numerator this function can produce
-// (y, cb, cr in [-128, 127] after the clamp: 2^24 cases) that is bit-identical to the IEEE quotient -- checked
-// exhaustively on the device against the oracle's true division (tests/test_gpu_parity.py::test_color_sweep).
-// Two pixels at a time: the fp32 multiplies, adds and the two FMAs are packed (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, IEEE
-// per element, so the results are those of the scalar sequence).
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void ycc_core2(s16x2 y, s16x2 cb, s16x2 cr /*already clamped to [-128,127]*/, uint32_t (&R)[2], uint32_t (&G)[2], uint32_t (&B)[2])
+// ConvertYCCtoRGBFastFloat :4086-4139 on clamped Y, Cb, Cr (already int -> float).  The reference divides by 0.587f (IEEE).
+// The quotient is formed here as q0 = x * RN(1/0.587f) followed by ONE fused correction step; for every numerator this
+// function can produce (y, cb, cr in [-128, 127] after the clamp: 2^24 cases) that is bit-identical to the IEEE quotient --
+// checked exhaustively on the device against the oracle's true division (tests/test_gpu_parity.py::test_color_sweep).
+// Plain fp32 multiplies and adds issue at full rate on gfx950; their packed forms do not (profiles/r02_instr_rates.txt), so
+// the pixels are converted one at a time.  crm = RN(Cr * (2 - 2*0.299f)) and cbm = RN(Cb * (2 - 2*0.114f)) depend on the
+// chroma sample only: subsampled images form them once per chroma sample, not per pixel.
+struct Rgbf { float r, g, b; };                                  // the three channels after "+= 128", before the range cap
+__device__ __forceinline__ float chroma_r(float fcr) { const float kr = 0.299f; return __fmul_rn(fcr, 2 - 2 * kr); }   // folded in fp32 exactly as the reference's expression
+__device__ __forceinline__ float chroma_b(float fcb) { const float kb = 0.114f; return __fmul_rn(fcb, 2 - 2 * kb); }
+__device__ __forceinline__ Rgbf ycc_core(float fy, float crm, float cbm)
 {
-    const float kr = 0.299f, kg = 0.587f, kb = 0.114f;
-    const float cr_mul = 2 - 2 * kr, cb_mul = 2 - 2 * kb;       // folded in fp32 exactly as the reference's expression
-    const float rkg = 1.0f / kg;
-    const f32x2 fy = { (float)y.x, (float)y.y }, fcb = { (float)cb.x, (float)cb.y }, fcr = { (float)cr.x, (float)cr.y };
-    f32x2 r = fcr * (f32x2){ cr_mul, cr_mul } + fy;              // -ffp-contract=off: separate multiply and add
-    f32x2 b = fcb * (f32x2){ cb_mul, cb_mul } + fy;
-    const f32x2 x = (fy - (f32x2){ kb, kb } * b) - (f32x2){ kr, kr } * r;
-    const f32x2 q0 = x * (f32x2){ rkg, rkg };
-    f32x2 g = __builtin_elementwise_fma(__builtin_elementwise_fma((f32x2){ -kg, -kg }, q0, x), (f32x2){ rkg, rkg }, q0);   // == x / kg, see above
-    const f32x2 h = { 128.0f, 128.0f };
-    r = r + h; b = b + h; g = g + h;
-    R[0] = (uint32_t)(int)__builtin_amdgcn_fmed3f(r.x, 0.0f, 255.0f); R[1] = (uint32_t)(int)__builtin_amdgcn_fmed3f(r.y, 0.0f, 255.0f);   // <0 -> 0, >255 -> 255,
-    G[0] = (uint32_t)(int)__builtin_amdgcn_fmed3f(g.x, 0.0f, 255.0f); G[1] = (uint32_t)(int)__builtin_amdgcn_fmed3f(g.y, 0.0f, 255.0f);   // else truncate (:4128-4136)
-    B[0] = (uint32_t)(int)__builtin_amdgcn_fmed3f(b.x, 0.0f, 255.0f); B[1] = (uint32_t)(int)__builtin_amdgcn_fmed3f(b.y, 0.0f, 255.0f);
+    const float kr = 0.299f, kg = 0.587f, kb = 0.114f, rkg = 1.0f / kg;
+    Rgbf o;
+    const float r = __fadd_rn(crm, fy), b = __fadd_rn(cbm, fy);
+    const float x = __fsub_rn(__fsub_rn(fy, __fmul_rn(kb, b)), __fmul_rn(kr, r));
+    const float q0 = __fmul_rn(x, rkg);
+    const float g = __builtin_fmaf(__builtin_fmaf(-kg, q0, x), rkg, q0);          // == x / kg, see above
+    o.r = __fadd_rn(r, 128.0f); o.g = __fadd_rn(g, 128.0f); o.b = __fadd_rn(b, 128.0f);
+    return o;
 }
-// ... then ChannelExtract :4832-4872 on clamped values.  RGB_ONLY: the default preview mode (PREVIEW_RGB), no mode dispatch.
-template <bool RGB_ONLY>
-__device__ __forceinline__ uint32_t channel_extract(uint32_t R, uint32_t G, uint32_t B, int y, int cb, int cr, uint32_t mode)
+// <0 -> 0, >255 -> 255, else truncate (:4128-4136); bytes B,G,R,0 (:4786-4789).  floor() equals the truncation wherever the value
+// is not capped to 0 anyway, and v_cvt_pk_u8_f32 saturates an integral float to [0, 255] into the byte it is told to fill.
+__device__ __forceinline__ uint32_t pack_bgr(const Rgbf& c)
 {
-    if (!RGB_ONLY) {
-        const uint32_t FY = (uint32_t)(y + 128), FCB = (uint32_t)(cb + 128), FCR = (uint32_t)(cr + 128);
-        switch (mode) {
-        case 2: R = FCR; G = FY; B = FCB; break;      // PREVIEW_YCC
-        case 3: G = B = R; break;                     // PREVIEW_R
-        case 4: R = B = G; break;                     // PREVIEW_G
-        case 5: R = G = B; break;                     // PREVIEW_B
-        case 6: R = G = B = FY; break;                // PREVIEW_Y
-        case 7: R = G = B = FCB; break;               // PREVIEW_CB
-        case 8: R = G = B = FCR; break;               // PREVIEW_CR
-        default: break;
-        }
+    uint32_t o = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(c.b), 0, 0u);
+    o = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(c.g), 1, o);
+    return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(c.r), 2, o);
+}
+// ... then ChannelExtract :4832-4872 on the capped values (the preview modes other than RGB)
+__device__ __forceinline__ uint32_t channel_extract(const Rgbf& c, int y, int cb, int cr, uint32_t mode)
+{
+    uint32_t R = (uint32_t)(int)__builtin_amdgcn_fmed3f(c.r, 0.0f, 255.0f), G = (uint32_t)(int)__builtin_amdgcn_fmed3f(c.g, 0.0f, 255.0f),
+             B = (uint32_t)(int)__builtin_amdgcn_fmed3f(c.b, 0.0f, 255.0f);
+    const uint32_t FY = (uint32_t)(y + 128), FCB = (uint32_t)(cb + 128), FCR = (uint32_t)(cr + 128);
+    switch (mode) {
+    case 2: R = FCR; G = FY; B = FCB; break;      // PREVIEW_YCC
+    case 3: G = B = R; break;                     // PREVIEW_R
+    case 4: R = B = G; break;                     // PREVIEW_G
+    case 5: R = G = B; break;                     // PREVIEW_B
+    case 6: R = G = B = FY; break;                // PREVIEW_Y
+    case 7: R = G = B = FCB; break;               // PREVIEW_CB
+    case 8: R = G = B = FCR; break;               // PREVIEW_CR
+    default: break;
     }
-    return B | (G << 8) | (R << 16);              // bytes B,G,R,0 (:4786-4789)
-}
-template <bool RGB_ONLY>
-__device__ __forceinline__ void ycc_pixel2(s16x2 y, s16x2 cb, s16x2 cr, uint32_t mode, uint32_t& o0, uint32_t& o1)
-{
-    uint32_t R[2], G[2], B[2];
-    ycc_core2(y, cb, cr, R, G, B);
-    o0 = channel_extract<RGB_ONLY>(R[0], G[0], B[0], y.x, cb.x, cr.x, mode);
-    o1 = channel_extract<RGB_ONLY>(R[1], G[1], B[1], y.y, cb.y, cr.y, mode);
+    return B | (G << 8) | (R << 16);
 }
 __device__ __forceinline__ int clamp_s8(int v) { return min(max(v, -128), 127); }
-// one pixel (probes, the exhaustive sweep): the same packed routine with the triple in both halves
+// one pixel from raw int16-range samples (:4096-4104: >> 3, clamp to [-128, 127])
 template <bool RGB_ONLY>
-__device__ __forceinline__ void ycc_to_rgb(int py, int pcb, int pcr, uint32_t mode, uint32_t& out_bgra, uint32_t& final_y)
+__device__ __forceinline__ uint32_t ycc_to_bgra(int py, int pcb, int pcr, uint32_t mode)
 {
-    const int y = clamp_s8(py >> 3), cb = clamp_s8(pcb >> 3), cr = clamp_s8(pcr >> 3);   // :4096-4104
-    uint32_t o1;
-    ycc_pixel2<RGB_ONLY>((s16x2){ (short)y, (short)y }, (s16x2){ (short)cb, (short)cb }, (s16x2){ (short)cr, (short)cr }, mode, out_bgra, o1);
-    final_y = (uint32_t)(y + 128);
+    const int y = clamp_s8(py >> 3), cb = clamp_s8(pcb >> 3), cr = clamp_s8(pcr >> 3);
+    const Rgbf c = ycc_core((float)y, chroma_r((float)cr), chroma_b((float)cb));
+    return RGB_ONLY ? pack_bgr(c) : channel_extract(c, y, cb, cr, mode);
 }
-// two int16 samples at a time: >> 3, clamp to [-128, 127] (packed 16-bit VALU ops)
-__device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { union { uint32_t u; s16x2 s; } c; c.u = v; return c.s; }
-__device__ __forceinline__ s16x2 clamp_s8x2(uint32_t packed)
-{
-    s16x2 v = as_s16x2(packed) >> (s16x2){3, 3};
-    v = __builtin_elementwise_max(v, (s16x2){-128, -128});
-    return __builtin_elementwise_min(v, (s16x2){127, 127});
-}
+__device__ __forceinline__ int s16_lo(uint32_t w) { return (int)(int16_t)w; }
+__device__ __forceinline__ int s16_hi(uint32_t w) { return (int)w >> 16; }
 
-// Lane I of every 16-lane row, broadcast to the whole row: folds into the consuming VALU instruction as a DPP
-// operand (row_newbcast), so a value every lane needs costs neither an LDS broadcast read nor a scalar round trip.
-template <int I> __device__ __forceinline__ uint32_t row_bc(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + I, 0xF, 0xF, true); }
+// ---- IDCT term loop ------------------------------------------------------------------------------------------------------
+// What an instruction costs on gfx950 (tools/probes/pk_f32_rate.hip, profiles/r02_instr_rates.txt): plain fp32 / integer VOP2
+// with VGPR operands issue in 2.2 cycles per wave, anything with a DPP or SGPR operand, every conversion, min/max/med3, left
+// shifts and the three-operand integer ops in 4.1, one LDS read in 8.5 cycles of the CU's LDS pipe per SIMD.  A term of the
+// sum therefore costs: the table row (one LDS read), the multiply with the coefficient as a DPP row-broadcast operand (4.1)
+// and the add (2.2) -- and nothing else: the row's LDS address comes from M0 (ds_read_addtid_b32: M0 + lane * 4), written by
+// the scalar unit from row numbers that sit four to a dword (one v_readlane per four terms).  The cosine table therefore has
+// to start at LDS offset 0 (the kernels use dynamic shared memory only and check it).
+//
+// List of a block (this wave's LDS): coefficients as fp32 at slot = rank among the non-zero AC coefficients (ascending natural
+// order, the reference's summation order), padded with up to three 0.0f (their products are exact +-0 and leave the sum
+// unchanged) -- all written by ONE store instruction: zero lanes fill the padding; row numbers (= natural index) as bytes.
+struct WaveList { float* coef; uint8_t* rowb; };             // 68 floats, 68 bytes (4-byte aligned)
+#define LIST_BYTES (68 * 4 + 80)
 
-// Four terms of the sum: entries I..I+3 of the list registers E (x = byte offset of the table row, y = coefficient).
-#define IDCT_G4(E, I)                                                                                                   \
-    {                                                                                                                   \
-        const float l0 = *reinterpret_cast<const float*>(lut_b + (row_bc<I>(E.x) + lane4));                           \
-        const float l1 = *reinterpret_cast<const float*>(lut_b + (row_bc<I + 1>(E.x) + lane4));                       \
-        const float l2 = *reinterpret_cast<const float*>(lut_b + (row_bc<I + 2>(E.x) + lane4));                       \
-        const float l3 = *reinterpret_cast<const float*>(lut_b + (row_bc<I + 3>(E.x) + lane4));                       \
-        acc = __fadd_rn(acc, __fmul_rn(__uint_as_float(row_bc<I>(E.y)), l0));                                          \
-        acc = __fadd_rn(acc, __fmul_rn(__uint_as_float(row_bc<I + 1>(E.y)), l1));                                      \
-        acc = __fadd_rn(acc, __fmul_rn(__uint_as_float(row_bc<I + 2>(E.y)), l2));                                      \
-        acc = __fadd_rn(acc, __fmul_rn(__uint_as_float(row_bc<I + 3>(E.y)), l3));                                      \
+#define IDCT_M0_G4(Q, I0, I1, I2, I3)                                                                                    \
+    asm volatile(                                                                                                        \
+        "v_readlane_b32 %[sp], %[rows], " #Q "\n\t"                                                                      \
+        "s_bfe_u32 %[s2], %[sp], 0x80000\n\t"                                                                            \
+        "s_lshl_b32 m0, %[s2], 8\n\t"                                                                                    \
+        "s_bfe_u32 %[s2], %[sp], 0x80010\n\t"                                                                            \
+        "ds_read_addtid_b32 %[l0]\n\t"                                                                                   \
+        "s_and_b32 m0, %[sp], 0xff00\n\t"                                                                                \
+        "s_lshr_b32 %[s3], %[sp], 24\n\t"                                                                                \
+        "ds_read_addtid_b32 %[l1]\n\t"                                                                                   \
+        "s_lshl_b32 m0, %[s2], 8\n\t"                                                                                    \
+        "s_nop 0\n\t"                                                                                                    \
+        "ds_read_addtid_b32 %[l2]\n\t"                                                                                   \
+        "s_lshl_b32 m0, %[s3], 8\n\t"                                                                                    \
+        "s_nop 0\n\t"                                                                                                    \
+        "ds_read_addtid_b32 %[l3]\n\t"                                                                                   \
+        "s_waitcnt lgkmcnt(3)\n\t"                                                                                       \
+        "v_mul_f32_dpp %[l0], %[ey], %[l0] row_newbcast:" #I0 " row_mask:0xf bank_mask:0xf\n\t"                          \
+        "v_add_f32 %[acc], %[acc], %[l0]\n\t"                                                                            \
+        "s_waitcnt lgkmcnt(2)\n\t"                                                                                       \
+        "v_mul_f32_dpp %[l1], %[ey], %[l1] row_newbcast:" #I1 " row_mask:0xf bank_mask:0xf\n\t"                          \
+        "v_add_f32 %[acc], %[acc], %[l1]\n\t"                                                                            \
+        "s_waitcnt lgkmcnt(1)\n\t"                                                                                       \
+        "v_mul_f32_dpp %[l2], %[ey], %[l2] row_newbcast:" #I2 " row_mask:0xf bank_mask:0xf\n\t"                          \
+        "v_add_f32 %[acc], %[acc], %[l2]\n\t"                                                                            \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                       \
+        "v_mul_f32_dpp %[l3], %[ey], %[l3] row_newbcast:" #I3 " row_mask:0xf bank_mask:0xf\n\t"                          \
+        "v_add_f32 %[acc], %[acc], %[l3]"                                                                                \
+        : [acc] "+v"(acc), [l0] "=&v"(l0), [l1] "=&v"(l1), [l2] "=&v"(l2), [l3] "=&v"(l3), [sp] "=&s"(sp), [s2] "=&s"(s2), [s3] "=&s"(s3) \
+        : [rows] "v"(rows4), [ey] "v"(ey) : "scc")
+#define IDCT_M0_G16(R, Q0, Q1, Q2, Q3)                                                                                   \
+    {                                                                                                                    \
+        const float ey = L.coef[(R) * 16 + li];                                                                          \
+        IDCT_M0_G4(Q0, 0, 1, 2, 3);     if (n <= (R) * 16 + 4) break;                                                    \
+        IDCT_M0_G4(Q1, 4, 5, 6, 7);     if (n <= (R) * 16 + 8) break;                                                    \
+        IDCT_M0_G4(Q2, 8, 9, 10, 11);   if (n <= (R) * 16 + 12) break;                                                   \
+        IDCT_M0_G4(Q3, 12, 13, 14, 15);                                                                                  \
     }
-#define IDCT_G16(R)                                                                                                     \
-    {                                                                                                                   \
-        const uint2 e = s_list[(R) * 16 + li];                                                                          \
-        IDCT_G4(e, 0)  if (n <= (R) * 16 + 4) break;                                                                    \
-        IDCT_G4(e, 4)  if (n <= (R) * 16 + 8) break;                                                                    \
-        IDCT_G4(e, 8)  if (n <= (R) * 16 + 12) break;                                                                   \
-        IDCT_G4(e, 12)                                                                                                  \
-    }
 
-// DecodeIdctCalcFloat(64) :2372-2392 on one block held one coefficient per lane.  Only non-zero coefficients are
-// visited, in ascending natural order (separate multiply and add, the reference's summation order).  The wave
-// compacts them with one ballot + mbcnt through a small LDS list (row offset of the cosine table, coefficient as
-// fp32), padded to a multiple of four with (DC row, 0.0f) entries whose products are exact +-0 and leave the fp32
-// sum unchanged.  Every 16-lane row then holds 16 list entries in registers (entry i in lane i of the row); the
-// accumulation reads them as DPP row-broadcast operands: per term one address add, one table read, one multiply,
-// one add -- no list traffic in the loop.
-__device__ __forceinline__ float idct_sparse(int cv16, const float* s_lut, uint2* s_list /*this wave's 68 slots*/, uint32_t lane)
+// DecodeIdctCalcFloat(64) :2372-2392 on one block held one coefficient per lane (lane = natural index; the caller has zeroed
+// lane 0: DC is excluded from the sum, :2381).  Only non-zero coefficients are visited, in ascending natural order, separate
+// multiply and add.  Returns the sum BEFORE the reference's final * 0.25.
+__device__ __forceinline__ float idct_terms(int cv16, const WaveList L, uint32_t lane)
 {
-    const bool nz = cv16 != 0 && lane != 0;                      // DC is excluded from the sum (:2381)
+    const bool nz = cv16 != 0;
     const uint64_t mask = __ballot(nz);
-    const uint32_t n = (uint32_t)__builtin_popcountll(mask);
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_popcountll(mask));   // wave-uniform: the exit tests below are scalar compares
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    if (nz) s_list[rank] = make_uint2(lane * 256u, __float_as_uint((float)cv16));
-    if (lane < 4) s_list[n + lane] = make_uint2(0u, 0u);
+    const uint32_t zrank = lane - rank;                          // zero lanes: how many zero lanes lie below
+    if (nz || zrank < 3u) L.coef[nz ? rank : n + zrank] = (float)cv16;          // zero lanes write the 0.0f padding
+    if (nz) L.rowb[rank] = (uint8_t)lane;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     float acc = 0.0f;
-    const uint32_t lane4 = lane * 4u, li = lane & 15u;
-    const char* lut_b = reinterpret_cast<const char*>(s_lut);
+    const uint32_t li = lane & 15u;
     do {
         if (n == 0) break;
-        IDCT_G16(0) if (n <= 16) break;
-        IDCT_G16(1) if (n <= 32) break;
-        IDCT_G16(2) if (n <= 48) break;
-        IDCT_G16(3)
+        const uint32_t rows4 = reinterpret_cast<const uint32_t*>(L.rowb)[li];      // lane q (< 16): rows of terms 4q .. 4q+3
+        float l0, l1, l2, l3; uint32_t sp, s2, s3;
+        IDCT_M0_G16(0, 0, 1, 2, 3)     if (n <= 16) break;
+        IDCT_M0_G16(1, 4, 5, 6, 7)     if (n <= 32) break;
+        IDCT_M0_G16(2, 8, 9, 10, 11)   if (n <= 48) break;
+        IDCT_M0_G16(3, 12, 13, 14, 15)
     } while (0);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    return __fmul_rn(acc, 0.25f);
+    return acc;
 }
+__device__ __forceinline__ void list_init(const WaveList L, uint32_t lane)    // row bytes must always name a table row: stale entries are read as padding
+{ if (lane < 20) reinterpret_cast<uint32_t*>(L.rowb)[lane] = 0u; }
+
+
 // SetFullRes :2468-2561 into the wave's LDS MCU tile (replicated eH x eV times).
 // meta = comp-1 | eh<<4 | ev<<8 | (blk_ch*8)<<12 | (blk_cv*8)<<20 of the block's slot in the MCU.
 __device__ __forceinline__ uint32_t tile_offset(uint32_t meta, uint32_t plane_elems, uint32_t rs, uint32_t lane)
@@ -438,9 +454,11 @@ __device__ __forceinline__ uint32_t tile_offset(uint32_t meta, uint32_t plane_el
     const uint32_t x0 = ((meta >> 12) & 255u) + (lane & 7) * eh, y0 = ((meta >> 20) & 255u) + (lane >> 3) * ev;
     return comp0 * plane_elems + y0 * rs + x0;
 }
-__device__ __forceinline__ void sample_to_lds(uint32_t meta /*wave-uniform*/, float idct, int16_t dc, int16_t* pl, uint32_t rs)
+// fp32 sum of the terms -> sample: the reference forms f = sum * 0.25 (:2389) and (short)((short)(f * 8) + dc) (:2517-2519); both
+// scalings are exact powers of two (no term sum is small enough to go denormal), so f * 8 is sum * 2 bit for bit.
+__device__ __forceinline__ int16_t to_sample(float sum, int16_t dc) { return (int16_t)((int16_t)(int)__fmul_rn(sum, 2.0f) + dc); }
+__device__ __forceinline__ void sample_to_lds(uint32_t meta /*wave-uniform*/, int16_t smp, int16_t* pl, uint32_t rs)
 {
-    const int16_t smp = (int16_t)((int16_t)(int)__fmul_rn(idct, 8.0f) + dc);   // :2517-2519
     const uint32_t eh = (meta >> 4) & 15u, ev = (meta >> 8) & 15u;
     if (eh == 1 && ev == 1) pl[0] = smp;
     else if (eh == 2 && ev <= 2) {                               // 4:2:2 / 4:2:0 chroma: one or two 32-bit stores
@@ -451,7 +469,23 @@ __device__ __forceinline__ void sample_to_lds(uint32_t meta /*wave-uniform*/, fl
         for (uint32_t jy = 0; jy < ev; jy++) for (uint32_t ix = 0; ix < eh; ix++) pl[jy * rs + ix] = smp;
 }
 
-// Colour conversion + DIB rows of one MCU: 4 pixels (16 bytes) per lane and trip.
+// brightest-pixel search (:4722-4730) over the four Y samples of a lane's trip: larger Y wins, earlier raster position breaks
+// ties.  The 64-bit key is only formed when one of the four can beat (or tie with) what this lane has seen so far.
+__device__ __forceinline__ void bright4(const uint2 qy, uint32_t raster0, uint64_t& bright, int& best_y)
+{
+    const int vy[4] = { s16_lo(qy.x), s16_hi(qy.x), s16_lo(qy.y), s16_hi(qy.y) };
+    if (max(max(vy[0], vy[1]), max(vy[2], vy[3])) >= best_y) {
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint64_t key = ((uint64_t)(uint32_t)(vy[k] + 32768) << 32) | (0xFFFFFFFFu - (raster0 + k));
+            bright = key > bright ? key : bright;
+        }
+        best_y = (int)(uint32_t)(bright >> 32) - 32768;
+    }
+}
+
+// Colour conversion + DIB rows of one MCU, general form: any sampling, any preview mode, optional YCC shift; the tile holds
+// three full-resolution (replicated) planes.  4 pixels (16 bytes) per lane and trip.
 template <bool RGB_ONLY>
 __device__ __forceinline__ void mcu_to_dib(const JsImage& im, const int16_t* tile, uint32_t plane_elems, uint32_t rs, uint32_t quads, uint32_t total,
                                            uint32_t lane, uint32_t ly0, uint32_t lq0, uint32_t my, uint32_t mx, uint32_t mw, uint32_t mh, bool shifted,
@@ -459,7 +493,7 @@ __device__ __forceinline__ void mcu_to_dib(const JsImage& im, const int16_t* til
                                            uint64_t& bright, int& best_y, uint32_t& sum_y)
 {
     const uint32_t img_x = im.img_x, img_y = im.img_y, mode = im.preview_mode, ncomp = im.ncomp;
-    const int sh_y = im.shift_y, sh_cb = im.shift_cb, sh_cr = im.shift_cr;
+    const int sh_y = shifted ? im.shift_y : 0, sh_cb = shifted ? im.shift_cb : 0, sh_cr = shifted ? im.shift_cr : 0;   // nMcuInd >= nMcuShiftInd (:4735-4739): added in int before the >> 3
     const uint32_t dq = 64u % quads, dy = 64u / quads;
     uint32_t y = ly0, q = lq0;
     // the DIB is bottom-up: the MCU's last row has the lowest address (wave-uniform), rows above it follow at +img_x pixels
@@ -469,36 +503,16 @@ __device__ __forceinline__ void mcu_to_dib(const JsImage& im, const int16_t* til
         const uint2 qy = *reinterpret_cast<const uint2*>(tile + y * rs + x);
         const uint2 qcb = *reinterpret_cast<const uint2*>(tile + plane_elems + y * rs + x);
         const uint2 qcr = *reinterpret_cast<const uint2*>(tile + 2 * plane_elems + y * rs + x);
-        // brightest-pixel search (:4722-4730): larger Y wins, earlier raster position breaks ties.  The 64-bit key
-        // is only formed when one of the four pixels can beat (or tie with) what this lane has seen so far.
-        const s16x2 m2 = __builtin_elementwise_max(as_s16x2(qy.x), as_s16x2(qy.y));
-        if (max((int)m2.x, (int)m2.y) >= best_y) {
-            const int vy[4] = { (int)(int16_t)qy.x, (int)qy.x >> 16, (int)(int16_t)qy.y, (int)qy.y >> 16 };
-            #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint64_t key = ((uint64_t)(uint32_t)(vy[k] + 32768) << 32) | (0xFFFFFFFFu - (py * img_x + px + k));
-                bright = key > bright ? key : bright;
-            }
-            best_y = (int)(uint32_t)(bright >> 32) - 32768;
-        }
-        s16x2 a0, a1, b0, b1, c0, c1;                          // clamped Y, Cb, Cr of the four pixels (:4096-4104), two per register
-        if (!shifted) {
-            a0 = clamp_s8x2(qy.x); a1 = clamp_s8x2(qy.y); b0 = clamp_s8x2(qcb.x); b1 = clamp_s8x2(qcb.y); c0 = clamp_s8x2(qcr.x); c1 = clamp_s8x2(qcr.y);
-        } else {                                               // nMcuInd >= nMcuShiftInd (:4735-4739): offsets added in int before the >> 3
-            const int vy[4] = { (int)(int16_t)qy.x, (int)qy.x >> 16, (int)(int16_t)qy.y, (int)qy.y >> 16 };
-            const int vcb[4] = { (int)(int16_t)qcb.x, (int)qcb.x >> 16, (int)(int16_t)qcb.y, (int)qcb.y >> 16 };
-            const int vcr[4] = { (int)(int16_t)qcr.x, (int)qcr.x >> 16, (int)(int16_t)qcr.y, (int)qcr.y >> 16 };
-            short cy[4], ccb[4], ccr[4];
-            #pragma unroll
-            for (int k = 0; k < 4; k++) { cy[k] = (short)clamp_s8((vy[k] + sh_y) >> 3); ccb[k] = (short)clamp_s8((vcb[k] + sh_cb) >> 3); ccr[k] = (short)clamp_s8((vcr[k] + sh_cr) >> 3); }
-            a0 = (s16x2){ cy[0], cy[1] }; a1 = (s16x2){ cy[2], cy[3] }; b0 = (s16x2){ ccb[0], ccb[1] }; b1 = (s16x2){ ccb[2], ccb[3] };
-            c0 = (s16x2){ ccr[0], ccr[1] }; c1 = (s16x2){ ccr[2], ccr[3] };
-        }
+        bright4(qy, py * img_x + px, bright, best_y);
+        const int vy[4] = { s16_lo(qy.x), s16_hi(qy.x), s16_lo(qy.y), s16_hi(qy.y) };
+        const int vcb[4] = { s16_lo(qcb.x), s16_hi(qcb.x), s16_lo(qcb.y), s16_hi(qcb.y) };
+        const int vcr[4] = { s16_lo(qcr.x), s16_hi(qcr.x), s16_lo(qcr.y), s16_hi(qcr.y) };
         uint32_t o[4];
-        ycc_pixel2<RGB_ONLY>(a0, b0, c0, mode, o[0], o[1]);
-        ycc_pixel2<RGB_ONLY>(a1, b1, c1, mode, o[2], o[3]);
-        const s16x2 ys = a0 + a1;                              // |sum| <= 256: no int16 overflow
-        sum_y += (uint32_t)((int)ys.x + (int)ys.y + 512);      // nSumY += nFinalY (:4751), wraps mod 2^32 like the reference
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            o[k] = ycc_to_bgra<RGB_ONLY>(vy[k] + sh_y, vcb[k] + sh_cb, vcr[k] + sh_cr, mode);
+            sum_y += (uint32_t)(clamp_s8((vy[k] + sh_y) >> 3) + 128);      // nSumY += nFinalY (:4751), wraps mod 2^32 like the reference
+        }
         uint4 v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
         *reinterpret_cast<uint4*>(mcu_low + ((mh - 1u - y) * img_x + x) * 4u) = v;          // scalar base + a lane offset below 2^32
         if (want_planes) {
@@ -511,70 +525,105 @@ __device__ __forceinline__ void mcu_to_dib(const JsImage& im, const int16_t* til
     }
 }
 
+// The same for the common layouts -- three components, Y un-expanded, Cb and Cr one block each replicated EH x EV times with
+// EH, EV in {1, 2} (4:4:4, 4:2:2, 4:4:0, 4:2:0), default preview mode, no YCC shift.  The tile holds the Y plane and the two chroma
+// blocks UN-replicated (one LDS store per block instead of up to four); a lane's four pixels share EH-fold chroma samples, whose
+// clamp, int -> float conversion and multiplication by (2 - 2*0.299f) / (2 - 2*0.114f) are done once per sample.
+template <uint32_t EH, uint32_t EV>
+__device__ __forceinline__ void mcu_to_dib_fast(const JsImage& im, const int16_t* tile, uint32_t plane_elems, uint32_t rs, uint32_t quads, uint32_t total,
+                                                uint32_t lane, uint32_t ly0, uint32_t lq0, uint32_t my, uint32_t mx, uint32_t mw, uint32_t mh,
+                                                uint8_t* __restrict__ dibp, int16_t* __restrict__ planes, uint32_t pw, bool want_planes,
+                                                uint64_t& bright, int& best_y, uint32_t& sum_y)
+{
+    const uint32_t img_x = im.img_x, img_y = im.img_y;
+    const uint32_t dq = 64u % quads, dy = 64u / quads;
+    uint32_t y = ly0, q = lq0;
+    uint8_t* mcu_low = dibp + ((size_t)(img_y - (my + 1u) * mh) * img_x + (size_t)mx * mw) * 4;
+    const int16_t* cbp = tile + plane_elems; const int16_t* crp = cbp + 64;
+    for (uint32_t p = lane; p < total; p += 64) {
+        const uint32_t x = q * 4, py = my * mh + y, px = mx * mw + x;
+        const uint2 qy = *reinterpret_cast<const uint2*>(tile + y * rs + x);
+        const uint32_t ci = (y / EV) * 8 + x / EH;                                         // first chroma sample of the lane's four pixels
+        uint2 qcb, qcr;                                                                    // the four pixels' chroma samples (replicated form)
+        float crm[4], cbm[4];
+        if (EH == 2) {
+            const uint32_t wb = *reinterpret_cast<const uint32_t*>(cbp + ci), wr = *reinterpret_cast<const uint32_t*>(crp + ci);
+            const float r0 = chroma_r((float)clamp_s8(s16_lo(wr) >> 3)), r1 = chroma_r((float)clamp_s8(s16_hi(wr) >> 3));
+            const float b0 = chroma_b((float)clamp_s8(s16_lo(wb) >> 3)), b1 = chroma_b((float)clamp_s8(s16_hi(wb) >> 3));
+            crm[0] = crm[1] = r0; crm[2] = crm[3] = r1; cbm[0] = cbm[1] = b0; cbm[2] = cbm[3] = b1;
+            qcb.x = (wb & 0xFFFFu) * 0x10001u; qcb.y = (wb >> 16) * 0x10001u; qcr.x = (wr & 0xFFFFu) * 0x10001u; qcr.y = (wr >> 16) * 0x10001u;
+        } else {
+            qcb = *reinterpret_cast<const uint2*>(cbp + ci); qcr = *reinterpret_cast<const uint2*>(crp + ci);
+            const int vcb[4] = { s16_lo(qcb.x), s16_hi(qcb.x), s16_lo(qcb.y), s16_hi(qcb.y) }, vcr[4] = { s16_lo(qcr.x), s16_hi(qcr.x), s16_lo(qcr.y), s16_hi(qcr.y) };
+            #pragma unroll
+            for (int k = 0; k < 4; k++) { crm[k] = chroma_r((float)clamp_s8(vcr[k] >> 3)); cbm[k] = chroma_b((float)clamp_s8(vcb[k] >> 3)); }
+        }
+        bright4(qy, py * img_x + px, bright, best_y);
+        const int cy[4] = { clamp_s8(s16_lo(qy.x) >> 3), clamp_s8(s16_hi(qy.x) >> 3), clamp_s8(s16_lo(qy.y) >> 3), clamp_s8(s16_hi(qy.y) >> 3) };
+        uint4 v;
+        v.x = pack_bgr(ycc_core((float)cy[0], crm[0], cbm[0])); v.y = pack_bgr(ycc_core((float)cy[1], crm[1], cbm[1]));
+        v.z = pack_bgr(ycc_core((float)cy[2], crm[2], cbm[2])); v.w = pack_bgr(ycc_core((float)cy[3], crm[3], cbm[3]));
+        sum_y += (uint32_t)(cy[0] + cy[1] + cy[2] + cy[3] + 512);                          // nSumY += nFinalY (:4751)
+        *reinterpret_cast<uint4*>(mcu_low + ((mh - 1u - y) * img_x + x) * 4u) = v;
+        if (want_planes) {
+            int16_t* pb = planes + im.plane_off;
+            const size_t pi = (size_t)py * pw + px, psz = (size_t)pw * im.blk_ymax * 8;
+            *reinterpret_cast<uint2*>(pb + pi) = qy; *reinterpret_cast<uint2*>(pb + psz + pi) = qcb; *reinterpret_cast<uint2*>(pb + 2 * psz + pi) = qcr;
+        }
+        q += dq; y += dy; if (q >= quads) { q -= quads; y++; }
+    }
+}
+
 // One WAVE owns one MCU at a time: IDCT of its blocks in decode order (so self-overlapping replication,
 // SetFullRes :2498-2557, resolves exactly as in the reference: later blocks overwrite earlier ones),
 // samples staged in a wave-private LDS tile, then colour conversion and the MCU's DIB rows.  No
 // workgroup barrier in the loop; the next MCU's coefficient rows are prefetched into registers while
 // the current MCU is converted.
-__global__ void __launch_bounds__(BK_THREADS, 6) k_idct_color(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ wg_base, uint32_t nimg,
-                                                           uint32_t tile_bytes, const float* __restrict__ lut_t /*[vu][yx]*/,
-                                                           const int16_t* __restrict__ coef, const int16_t* __restrict__ dccum,
-                                                           uint8_t* __restrict__ dib, int16_t* __restrict__ planes, uint32_t* __restrict__ side)
+struct BackEndCtx {
+    const JsImage* im; const int16_t* cbase; const int16_t* dccum; uint8_t* dibp; int16_t* planes;
+    WaveList L; int16_t* tile; const uint32_t* s_meta; uint32_t lane, wg_in_img, wgs_in_img, wave;
+};
+// FAST: the layouts of mcu_to_dib_fast (EH, EV = chroma expansion); otherwise the general path.
+template <bool FAST, uint32_t EH, uint32_t EV>
+__device__ __forceinline__ void back_end_mcus(const BackEndCtx& C, uint64_t& bright, uint32_t& sum_y)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
-    float* s_lut = reinterpret_cast<float*>(s_dyn);                               // 16 KiB transposed cosine table
-    uint32_t* s_meta = reinterpret_cast<uint32_t*>(s_dyn + 64 * 64 * sizeof(float)); // per block-in-MCU placement word
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint8_t* wave_mem = s_dyn + 64 * 64 * sizeof(float) + JS_MAX_BLK_PER_MCU * 4 + wave * (68 * 8 + tile_bytes);
-    uint2* s_list = reinterpret_cast<uint2*>(wave_mem);                           // this wave's non-zero list
-    int16_t* tile = reinterpret_cast<int16_t*>(wave_mem + 68 * 8);                // this wave's MCU tile: 3 planes x mcu_h x rs
-
-    uint32_t lo = 0, hi = nimg;                                  // wg_base is an exclusive prefix, nimg+1 entries
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (wg_base[mid] <= blockIdx.x) lo = mid; else hi = mid; }
-    const JsImage& im = imgs[lo];
-    const uint32_t wg_in_img = blockIdx.x - wg_base[lo], wgs_in_img = wg_base[lo + 1] - wg_base[lo];
-
-    for (uint32_t i = tid; i < 64 * 64; i += BK_THREADS) s_lut[i] = lut_t[i];
-    if (tid < im.blk_per_mcu) { const uint32_t comp = im.blk_comp[tid];
-        s_meta[tid] = (comp - 1) | (im.expand_h[comp] << 4) | (im.expand_v[comp] << 8) | ((uint32_t)im.blk_ch[tid] * 8u << 12) | ((uint32_t)im.blk_cv[tid] * 8u << 20); }
-    __syncthreads();
-
-    const uint32_t nb = im.blk_per_mcu, nmcu = im.mcu_xmax * im.mcu_ymax, pw = im.blk_xmax * 8;
-    const uint32_t mw = im.mcu_w, mh = im.mcu_h, rs = mw + 8, plane_elems = mh * rs, ncomp = im.ncomp;
-    const int16_t* cbase = coef + im.coef_off * 64;
-    uint8_t* dibp = dib + im.dib_off;
+    const JsImage& im = *C.im;
+    const uint32_t lane = C.lane;
+    const WaveList L = C.L; int16_t* tile = C.tile;
+    const uint32_t nb = FAST ? EH * EV + 2u : im.blk_per_mcu, nmcu = im.mcu_xmax * im.mcu_ymax, pw = im.blk_xmax * 8;   // FAST: known at compile time
+    const uint32_t mw = FAST ? 8u * EH : im.mcu_w, mh = FAST ? 8u * EV : im.mcu_h, rs = mw + 8, plane_elems = mh * rs, ncomp = im.ncomp;
     const uint32_t mcus_across = im.img_x / mw, shift_ind = im.shift_mcu_y * mcus_across + im.shift_mcu_x;
     const bool want_planes = im.want_planes != 0, rgb_only = im.preview_mode == 1, any_shift = (im.shift_y | im.shift_cb | im.shift_cr) != 0;
     const uint32_t quads = mw / 4, total = quads * mh, ly0 = lane / quads, lq0 = lane % quads;
-    uint64_t bright = 0; uint32_t sum_y = 0; int best_y = -0x7FFFFFFF;
-    if (ncomp == 1) for (uint32_t i = lane; i < 2 * plane_elems; i += 64) tile[plane_elems + i] = 0;   // Cb = Cr = 0 for grayscale (:4709-4715)
+    int best_y = -0x7FFFFFFF;
+    if (!FAST && ncomp == 1) for (uint32_t i = lane; i < 2 * plane_elems; i += 64) tile[plane_elems + i] = 0;   // Cb = Cr = 0 for grayscale (:4709-4715)
     // A component with 1 < H < Hmax (or V) does not cover its share of the MCU: SetFullRes places its blocks 8 samples
     // apart but replicates each Hmax/H times (:2498-2557), so part of the MCU keeps the zeros of ClrFullRes (:2443).
     // The same happens when H does not divide Hmax (expansion = Hmax / H truncates: H = 2 under Hmax = 3 fills 16 of 24 columns).
     bool partial = false;
-    for (uint32_t cc = 1; cc <= ncomp; cc++) {
+    if (!FAST) for (uint32_t cc = 1; cc <= ncomp; cc++) {
         const bool full_h = (im.samp_h[cc] * 8 == mw && im.expand_h[cc] == 1) || (im.samp_h[cc] == 1 && im.expand_h[cc] * 8 == mw);
         const bool full_v = (im.samp_v[cc] * 8 == mh && im.expand_v[cc] == 1) || (im.samp_v[cc] == 1 && im.expand_v[cc] * 8 == mh);
         partial = partial || !full_h || !full_v;
     }
-
     int cv[BK_CHUNK]; int16_t dcv[BK_CHUNK];
     // DC-only mode: the reference does not run the IDCT at all (:1827), whatever sits at the AC positions -- a DC symbol with a run
     // nibble stores its value there (DecodeIdctSet with ind = zrl, :1713)
     const bool with_ac = im.decode_ac != 0;
+    const int ac_mask = (lane != 0 && with_ac) ? -1 : 0;         // lane 0 holds the DC difference: not part of the sum (:2381)
     uint32_t meta[BK_CHUNK], toff[BK_CHUNK];                     // placement word (wave-uniform) and this lane's tile offset per block slot
     // m is wave-uniform (kept in SGPRs): the row addresses are a scalar base plus the lane, the DC words a scalar address
     auto load_chunk = [&](uint32_t m, uint32_t base) {
-        const int16_t* p = cbase + ((size_t)m * nb + base) * 64 + lane;
+        const int16_t* p = C.cbase + ((size_t)m * nb + base) * 64 + lane;
         // the DC words of the chunk: wave-uniform, so they come as aligned dwords through the scalar cache into SGPRs
         const size_t d0 = im.coef_off + (size_t)m * nb + base;
-        const uint32_t* q32 = reinterpret_cast<const uint32_t*>(dccum) + (d0 >> 1);
+        const uint32_t* q32 = reinterpret_cast<const uint32_t*>(C.dccum) + (d0 >> 1);
         const uint32_t odd = (uint32_t)d0 & 1u;
         const uint32_t w0 = q32[0], w1 = q32[1], w2 = q32[2], w3 = q32[3];       // 8 int16 from an even index cover BK_CHUNK = 6 from d0 (the arena has slack)
         #pragma unroll
         for (int j = 0; j < BK_CHUNK; j++) {
             const uint32_t c = base + j;
-            cv[j] = (c < nb && with_ac) ? (int)p[j * 64] : 0;
+            cv[j] = c < nb ? ((int)p[j * 64] & ac_mask) : 0;
             const uint32_t h = (uint32_t)j + odd, w = (h >> 1) == 0 ? w0 : ((h >> 1) == 1 ? w1 : ((h >> 1) == 2 ? w2 : w3));
             dcv[j] = c < nb ? (int16_t)(w >> ((h & 1u) * 16u)) : (int16_t)0;
         }
@@ -582,13 +631,16 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_idct_color(const JsImage* __r
     auto place_chunk = [&](uint32_t base) {
         #pragma unroll
         for (int j = 0; j < BK_CHUNK; j++) {
-            meta[j] = base + j < nb ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_meta[base + j]) : 0u;
-            toff[j] = tile_offset(meta[j], plane_elems, rs, lane);
+            meta[j] = base + j < nb ? (uint32_t)__builtin_amdgcn_readfirstlane((int)C.s_meta[base + j]) : 0u;
+            if (FAST) {                                          // Y blocks into the Y plane, the two chroma blocks as they are (64 samples each)
+                const uint32_t comp0 = meta[j] & 15u;
+                toff[j] = comp0 == 0 ? (((meta[j] >> 20) & 255u) + (lane >> 3)) * rs + ((meta[j] >> 12) & 255u) + (lane & 7) : plane_elems + (comp0 - 1u) * 64u + lane;
+            } else toff[j] = tile_offset(meta[j], plane_elems, rs, lane);
         }
     };
     place_chunk(0);
-    const uint32_t wstride = wgs_in_img * BK_WAVES;
-    uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg_in_img * BK_WAVES + wave));
+    const uint32_t wstride = C.wgs_in_img * BK_WAVES;
+    uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(C.wg_in_img * BK_WAVES + C.wave));
     const uint32_t xmax = im.mcu_xmax, step_x = wstride % xmax, step_y = wstride / xmax;
     uint32_t mx = m % xmax, my = m / xmax;                       // MCU coordinates, stepped along with m (no division in the loop)
     if (m < nmcu) load_chunk(m, 0);
@@ -601,22 +653,71 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_idct_color(const JsImage* __r
             if (nb > BK_CHUNK) place_chunk(base);
             #pragma unroll
             for (int j = 0; j < BK_CHUNK; j++)
-                if (base + j < nb) sample_to_lds(meta[j], idct_sparse(cv[j], s_lut, s_list, lane), dcv[j], tile + toff[j], rs);
+                if (base + j < nb) {
+                    const int16_t smp = to_sample(idct_terms(cv[j], L, lane), dcv[j]);
+                    if (FAST) tile[toff[j]] = smp; else sample_to_lds(meta[j], smp, tile + toff[j], rs);
+                }
         }
         if (m + wstride < nmcu) load_chunk(m + wstride, 0);           // next MCU's rows fly during the colour phase
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        const bool shifted = any_shift && my * mcus_across + mx >= shift_ind;
-        if (rgb_only) mcu_to_dib<true>(im, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, shifted, dibp, planes, pw, want_planes, bright, best_y, sum_y);
-        else          mcu_to_dib<false>(im, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, shifted, dibp, planes, pw, want_planes, bright, best_y, sum_y);
+        if (FAST) mcu_to_dib_fast<EH, EV>(im, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, C.dibp, C.planes, pw, want_planes, bright, best_y, sum_y);
+        else {
+            const bool shifted = any_shift && my * mcus_across + mx >= shift_ind;
+            if (rgb_only) mcu_to_dib<true>(im, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, shifted, C.dibp, C.planes, pw, want_planes, bright, best_y, sum_y);
+            else          mcu_to_dib<false>(im, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, shifted, C.dibp, C.planes, pw, want_planes, bright, best_y, sum_y);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+}
+
+__global__ void __launch_bounds__(BK_THREADS, 6) k_idct_color(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ wg_base, uint32_t nimg,
+                                                           uint32_t tile_bytes, const float* __restrict__ lut_t /*[vu][yx]*/,
+                                                           const int16_t* __restrict__ coef, const int16_t* __restrict__ dccum,
+                                                           uint8_t* __restrict__ dib, int16_t* __restrict__ planes, uint32_t* __restrict__ side)
+{
+    // dynamic shared memory only: the cosine table must sit at LDS offset 0 (idct_terms addresses its rows through M0)
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    float* s_lut = reinterpret_cast<float*>(s_dyn);                               // 16 KiB transposed cosine table
+    uint32_t* s_meta = reinterpret_cast<uint32_t*>(s_dyn + 64 * 64 * sizeof(float)); // per block-in-MCU placement word
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint8_t* wave_mem = s_dyn + 64 * 64 * sizeof(float) + JS_MAX_BLK_PER_MCU * 4 + wave * (LIST_BYTES + tile_bytes);
+    uint8_t* tail = s_dyn + 64 * 64 * sizeof(float) + JS_MAX_BLK_PER_MCU * 4 + BK_WAVES * (LIST_BYTES + tile_bytes);
+    unsigned long long* s_bright = reinterpret_cast<unsigned long long*>(tail); uint32_t* s_sum = reinterpret_cast<uint32_t*>(tail + BK_WAVES * 8);
+    if ((uint32_t)(size_t)s_dyn != 0u) __builtin_trap();
+
+    uint32_t lo = 0, hi = nimg;                                  // wg_base is an exclusive prefix, nimg+1 entries
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (wg_base[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+    const JsImage& im = imgs[lo];
+
+    for (uint32_t i = tid; i < 64 * 64; i += BK_THREADS) s_lut[i] = lut_t[i];
+    if (tid < im.blk_per_mcu) { const uint32_t comp = im.blk_comp[tid];
+        s_meta[tid] = (comp - 1) | (im.expand_h[comp] << 4) | (im.expand_v[comp] << 8) | ((uint32_t)im.blk_ch[tid] * 8u << 12) | ((uint32_t)im.blk_cv[tid] * 8u << 20); }
+    BackEndCtx C;
+    C.im = &im; C.cbase = coef + im.coef_off * 64; C.dccum = dccum; C.dibp = dib + im.dib_off; C.planes = planes;
+    C.L.coef = reinterpret_cast<float*>(wave_mem); C.L.rowb = wave_mem + 68 * 4; C.tile = reinterpret_cast<int16_t*>(wave_mem + LIST_BYTES);
+    C.s_meta = s_meta; C.lane = lane; C.wave = wave; C.wg_in_img = blockIdx.x - wg_base[lo]; C.wgs_in_img = wg_base[lo + 1] - wg_base[lo];
+    list_init(C.L, lane);
+    __syncthreads();
+
+    uint64_t bright = 0; uint32_t sum_y = 0;
+    // the common layouts take the short colour path: Y un-expanded, Cb and Cr one block each, both expanded EH x EV with EH, EV in {1, 2}
+    const uint32_t eh = im.expand_h[2], ev = im.expand_v[2];
+    const bool fast = im.ncomp == 3 && im.preview_mode == 1 && (im.shift_y | im.shift_cb | im.shift_cr) == 0 &&
+                      im.expand_h[1] == 1 && im.expand_v[1] == 1 && im.samp_h[1] == eh && im.samp_v[1] == ev &&
+                      im.samp_h[2] == 1 && im.samp_v[2] == 1 && im.samp_h[3] == 1 && im.samp_v[3] == 1 && im.expand_h[3] == eh && im.expand_v[3] == ev &&
+                      eh >= 1 && eh <= 2 && ev >= 1 && ev <= 2;
+    if (fast && eh == 2 && ev == 2) back_end_mcus<true, 2, 2>(C, bright, sum_y);
+    else if (fast && eh == 2) back_end_mcus<true, 2, 1>(C, bright, sum_y);
+    else if (fast && ev == 2) back_end_mcus<true, 1, 2>(C, bright, sum_y);
+    else if (fast) back_end_mcus<true, 1, 1>(C, bright, sum_y);
+    else back_end_mcus<false, 1, 1>(C, bright, sum_y);
+
     for (int off = 32; off > 0; off >>= 1) {
         const uint64_t ob = __shfl_down(bright, off); bright = ob > bright ? ob : bright;
         sum_y += __shfl_down(sum_y, off);
     }
     // one pair of atomics per workgroup (they all hit the same line of the image's status words), and the maximum only when it
     // can still raise what is there
-    __shared__ unsigned long long s_bright[BK_WAVES]; __shared__ uint32_t s_sum[BK_WAVES];
     if (lane == 0) { s_bright[wave] = bright; s_sum[wave] = sum_y; }
     __syncthreads();
     if (tid == 0) {
@@ -628,25 +729,31 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_idct_color(const JsImage* __r
     }
 }
 
-// One block through the device IDCT (known-answer probe for jsnoop_idct_block).
+// One block through the device IDCT (known-answer probe for jsnoop_idct_block): the production term loop, then the reference's * 0.25.
 __global__ void __launch_bounds__(64) k_idct_probe(const float* __restrict__ lut_t, const int16_t* __restrict__ coef64, float* __restrict__ out64)
 {
-    __shared__ float s_lut[64 * 64]; __shared__ uint2 s_list[68];
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    float* s_lut = reinterpret_cast<float*>(s_dyn);
+    WaveList L; L.coef = reinterpret_cast<float*>(s_dyn + 64 * 64 * sizeof(float)); L.rowb = s_dyn + 64 * 64 * sizeof(float) + 68 * 4;
+    if ((uint32_t)(size_t)s_dyn != 0u) __builtin_trap();
     const uint32_t lane = threadIdx.x;
     for (uint32_t i = lane; i < 64 * 64; i += 64) s_lut[i] = lut_t[i];
+    list_init(L, lane);
     __syncthreads();
-    out64[lane] = idct_sparse((int)coef64[lane], s_lut, s_list, lane);      // the production routine of k_idct_color
+    out64[lane] = __fmul_rn(idct_terms(lane ? (int)coef64[lane] : 0, L, lane), 0.25f);
 }
 
 // ConvertYCCtoRGBFastFloat on one triple (the RGB of the brightest pixel, :4805-4811).
-__global__ void k_color_probe(int y, int cb, int cr, uint32_t* out)
-{ uint32_t bgra, fy; ycc_to_rgb<true>(y, cb, cr, 1, bgra, fy); out[0] = bgra; }
+__global__ void k_color_probe(int y, int cb, int cr, uint32_t* out) { out[0] = ycc_to_bgra<true>(y, cb, cr, 1); }
 // Every (y, cb, cr) in [-128, 127]^3 through the device colour conversion: out[(y+128)<<16 | (cb+128)<<8 | (cr+128)] = BGRA.
+// Both ways of finishing a pixel (packed bytes straight from the floats; capped integers for the preview modes) must agree:
+// a triple on which they do not comes back with a non-zero alpha byte.
 __global__ void __launch_bounds__(256) k_color_sweep(uint32_t* __restrict__ out)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    uint32_t bgra, fy; ycc_to_rgb<true>(((int)(i >> 16) - 128) * 8, ((int)((i >> 8) & 255u) - 128) * 8, ((int)(i & 255u) - 128) * 8, 1, bgra, fy);
-    out[i] = bgra;
+    const int y = ((int)(i >> 16) - 128) * 8, cb = ((int)((i >> 8) & 255u) - 128) * 8, cr = ((int)(i & 255u) - 128) * 8;
+    const uint32_t a = ycc_to_bgra<true>(y, cb, cr, 1), b = ycc_to_bgra<false>(y, cb, cr, 1);
+    out[i] = a == b ? a : 0xFF000000u | a;
 }
 
 // Position-keyed 64-bit checksum of every DIB: sum over 32-bit pixels of mix64(index<<32 | pixel).
@@ -848,11 +955,11 @@ void js_launch_idct_color(hipStream_t st, const JsImage* imgs, const uint32_t* w
 {
     if (!total_wgs) return;
     const uint32_t tile_bytes = ((3u * max_mcu_h * (max_mcu_w + 8u) * 2u) + 15u) & ~15u;
-    const size_t lds = 64 * 64 * sizeof(float) + JS_MAX_BLK_PER_MCU * 4 + (size_t)BK_WAVES * (68 * 8 + tile_bytes);
+    const size_t lds = 64 * 64 * sizeof(float) + JS_MAX_BLK_PER_MCU * 4 + (size_t)BK_WAVES * (LIST_BYTES + tile_bytes) + BK_WAVES * 12;
     hipLaunchKernelGGL(k_idct_color, dim3(total_wgs), dim3(BK_THREADS), lds, st, imgs, wg_base, nimg, tile_bytes, lut_t, coef, dccum, dib, planes, side);
 }
 void js_launch_idct_probe(hipStream_t st, const float* lut_t, const int16_t* coef64, float* out64)
-{ hipLaunchKernelGGL(k_idct_probe, dim3(1), dim3(64), 0, st, lut_t, coef64, out64); }
+{ hipLaunchKernelGGL(k_idct_probe, dim3(1), dim3(64), 64 * 64 * sizeof(float) + LIST_BYTES, st, lut_t, coef64, out64); }
 void js_launch_color_probe(hipStream_t st, int y, int cb, int cr, uint32_t* out)
 { hipLaunchKernelGGL(k_color_probe, dim3(1), dim3(1), 0, st, y, cb, cr, out); }
 void js_launch_color_sweep(hipStream_t st, uint32_t* out)
