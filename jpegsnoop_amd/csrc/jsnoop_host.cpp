@@ -375,9 +375,18 @@ int JsnoopBatch::decode(bool timed)
     if (timed && !used_parallel) for (int s = 2; s <= 6; s++) HIP_TRY(hipEventRecord(ev[s], stream));
     if (!used_parallel) js_launch_entropy_exact(stream, dev.imgs, nullptr, n, dev.tables, dev.raw, dev.coef, dev.dccum, dev.side, 0, event_words ? dev.events : nullptr);
     if (timed) HIP_TRY(hipEventRecord(ev[7], stream));
-    js_launch_idct_color(stream, dev.imgs, dev.wg_base, n, total_wgs, max_mcu_w, max_mcu_h, d_lut, dev.coef, dev.dccum, dev.dib, dev.planes, dev.side);
+    if (launch_back_end(n)) return -1;
     if (timed) HIP_TRY(hipEventRecord(ev[8], stream));
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+int JsnoopBatch::launch_back_end(uint32_t nimg)
+{
+    uint32_t tile = 16;
+    for (uint32_t i = 0; i < nimg && i < imgs.size(); i++) tile = std::max(tile, js_tile_bytes(imgs[i]));
+    const int rc = js_launch_idct_color(stream, dev.imgs, dev.wg_base, nimg, total_wgs, tile, d_lut, dev.coef, dev.dccum, dev.dib, dev.planes, dev.side);
+    if (rc == -2) { js_set_error("back end: an MCU tile of %u bytes per wave does not fit the 160 KiB LDS", tile); return -1; }
+    if (rc) { js_set_error("back end launch failed (%d): %s", rc, hipGetErrorString(hipGetLastError())); return -1; }
     return 0;
 }
 int JsnoopBatch::sync()
@@ -731,7 +740,7 @@ void JsnoopDecoder::rerender()                                  // CalcChannelPr
     hipSetDevice(b->device);
     hipMemcpyAsync(b->dev.imgs, &im, sizeof im, hipMemcpyHostToDevice, b->stream);
     hipMemsetAsync(b->dev.side + im.side_off + 12, 0, 16, b->stream);      // brightest-pixel key and sum of Y are recomputed
-    js_launch_idct_color(b->stream, b->dev.imgs, b->dev.wg_base, 1, b->total_wgs, b->max_mcu_w, b->max_mcu_h, b->d_lut, b->dev.coef, b->dev.dccum, b->dev.dib, b->dev.planes, b->dev.side);
+    if (b->launch_back_end(1)) log(2, "*** ERROR: device re-render failed: %s", g_err.c_str());
     hipStreamSynchronize(b->stream);
     host_valid = 0; fetch_side();
     stats_pass(); flush_pending_log();

@@ -96,6 +96,7 @@ struct JsnoopBatch {
     int  read_dib(int i, uint8_t* dst);
     int  read_planes(int i, int16_t* y, int16_t* cb, int16_t* cr);
     int  run_exact(const std::vector<uint32_t>& which);
+    int  launch_back_end(uint32_t nimg);        // k_idct_color over the first nimg images (tile size from their CURRENT preview state)
 };
 
 void js_set_error(const char* fmt, ...);

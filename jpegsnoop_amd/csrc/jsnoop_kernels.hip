@@ -367,53 +367,52 @@ __device__ __forceinline__ int s16_hi(uint32_t w) { return (int)w >> 16; }
 // shifts and the three-operand integer ops in 4.1, one LDS read in 8.5 cycles of the CU's LDS pipe per SIMD.  A term of the
 // sum therefore costs: the table row (one LDS read), the multiply with the coefficient as a DPP row-broadcast operand (4.1)
 // and the add (2.2) -- and nothing else: the row's LDS address comes from M0 (ds_read_addtid_b32: M0 + lane * 4), written by
-// the scalar unit from row numbers that sit four to a dword (one v_readlane per four terms).  The cosine table therefore has
+// the scalar unit from row offsets that sit two to a dword (one v_readlane per two terms, one scalar instruction per term).  The cosine table therefore has
 // to start at LDS offset 0 (the kernels use dynamic shared memory only and check it).
 //
 // List of a block (this wave's LDS): coefficients as fp32 at slot = rank among the non-zero AC coefficients (ascending natural
 // order, the reference's summation order), padded with up to three 0.0f (their products are exact +-0 and leave the sum
-// unchanged) -- all written by ONE store instruction: zero lanes fill the padding; row numbers (= natural index) as bytes.
-struct WaveList { float* coef; uint8_t* rowb; };             // 68 floats, 68 bytes (4-byte aligned)
-#define LIST_BYTES (68 * 4 + 80)
+// unchanged) -- all written by ONE store instruction: zero lanes fill the padding; row offsets (natural index * 256) as 16-bit words.
+struct WaveList { float* coef; uint16_t* rowh; };           // 68 floats; 68 x 16 bit: row * 256 = the row's LDS offset, two to a dword
+#define LIST_BYTES (68 * 4 + 144)
 
-#define IDCT_M0_G4(Q, I0, I1, I2, I3)                                                                                    \
-    asm volatile(                                                                                                        \
-        "v_readlane_b32 %[sp], %[rows], " #Q "\n\t"                                                                      \
-        "s_bfe_u32 %[s2], %[sp], 0x80000\n\t"                                                                            \
-        "s_lshl_b32 m0, %[s2], 8\n\t"                                                                                    \
-        "s_bfe_u32 %[s2], %[sp], 0x80010\n\t"                                                                            \
-        "ds_read_addtid_b32 %[l0]\n\t"                                                                                   \
-        "s_and_b32 m0, %[sp], 0xff00\n\t"                                                                                \
-        "s_lshr_b32 %[s3], %[sp], 24\n\t"                                                                                \
-        "ds_read_addtid_b32 %[l1]\n\t"                                                                                   \
-        "s_lshl_b32 m0, %[s2], 8\n\t"                                                                                    \
-        "s_nop 0\n\t"                                                                                                    \
-        "ds_read_addtid_b32 %[l2]\n\t"                                                                                   \
-        "s_lshl_b32 m0, %[s3], 8\n\t"                                                                                    \
-        "s_nop 0\n\t"                                                                                                    \
-        "ds_read_addtid_b32 %[l3]\n\t"                                                                                   \
-        "s_waitcnt lgkmcnt(3)\n\t"                                                                                       \
-        "v_mul_f32_dpp %[l0], %[ey], %[l0] row_newbcast:" #I0 " row_mask:0xf bank_mask:0xf\n\t"                          \
-        "v_add_f32 %[acc], %[acc], %[l0]\n\t"                                                                            \
-        "s_waitcnt lgkmcnt(2)\n\t"                                                                                       \
-        "v_mul_f32_dpp %[l1], %[ey], %[l1] row_newbcast:" #I1 " row_mask:0xf bank_mask:0xf\n\t"                          \
-        "v_add_f32 %[acc], %[acc], %[l1]\n\t"                                                                            \
-        "s_waitcnt lgkmcnt(1)\n\t"                                                                                       \
-        "v_mul_f32_dpp %[l2], %[ey], %[l2] row_newbcast:" #I2 " row_mask:0xf bank_mask:0xf\n\t"                          \
-        "v_add_f32 %[acc], %[acc], %[l2]\n\t"                                                                            \
-        "s_waitcnt lgkmcnt(0)\n\t"                                                                                       \
-        "v_mul_f32_dpp %[l3], %[ey], %[l3] row_newbcast:" #I3 " row_mask:0xf bank_mask:0xf\n\t"                          \
-        "v_add_f32 %[acc], %[acc], %[l3]"                                                                                \
-        : [acc] "+v"(acc), [l0] "=&v"(l0), [l1] "=&v"(l1), [l2] "=&v"(l2), [l3] "=&v"(l3), [sp] "=&s"(sp), [s2] "=&s"(s2), [s3] "=&s"(s3) \
-        : [rows] "v"(rows4), [ey] "v"(ey) : "scc")
-#define IDCT_M0_G16(R, Q0, Q1, Q2, Q3)                                                                                   \
-    {                                                                                                                    \
-        const float ey = L.coef[(R) * 16 + li];                                                                          \
-        IDCT_M0_G4(Q0, 0, 1, 2, 3);     if (n <= (R) * 16 + 4) break;                                                    \
-        IDCT_M0_G4(Q1, 4, 5, 6, 7);     if (n <= (R) * 16 + 8) break;                                                    \
-        IDCT_M0_G4(Q2, 8, 9, 10, 11);   if (n <= (R) * 16 + 12) break;                                                   \
-        IDCT_M0_G4(Q3, 12, 13, 14, 15);                                                                                  \
-    }
+#define DPP_BC(I) " row_newbcast:" #I " row_mask:0xf bank_mask:0xf\n\t"
+// first group of a round: four table reads in flight (M0 needs one wait state before the read that uses it)
+#define T_ISSUE(L0, L1, L2, L3, QA, QB)                                                                                          \
+    "v_readlane_b32 %[sp0], %[rows], " #QA "\n\t" "s_and_b32 m0, %[sp0], 0xffff\n\t" "v_readlane_b32 %[sp1], %[rows], " #QB "\n\t"  \
+    "ds_read_addtid_b32 %[" #L0 "]\n\t" "s_lshr_b32 m0, %[sp0], 16\n\t" "s_nop 0\n\t" "ds_read_addtid_b32 %[" #L1 "]\n\t"            \
+    "s_and_b32 m0, %[sp1], 0xffff\n\t" "s_nop 0\n\t" "ds_read_addtid_b32 %[" #L2 "]\n\t"                                             \
+    "s_lshr_b32 m0, %[sp1], 16\n\t" "s_nop 0\n\t" "ds_read_addtid_b32 %[" #L3 "]\n\t"
+// one term of the group in flight retires (multiply with the coefficient as DPP operand, add) while the read of a term of the next
+// group is issued: per term one scalar instruction (M0), one LDS read, two vector instructions
+#define T_STEP1(X, Y, I, M0OP)                                                                                                   \
+    M0OP "s_waitcnt lgkmcnt(3)\n\t" "v_mul_f32_dpp %[" #X "], %[ey], %[" #X "]" DPP_BC(I) "ds_read_addtid_b32 %[" #Y "]\n\t" "v_add_f32 %[acc], %[acc], %[" #X "]\n\t"
+#define T_STEP(X0, X1, X2, X3, Y0, Y1, Y2, Y3, I0, I1, I2, I3, QA, QB)                                                           \
+    "v_readlane_b32 %[sp0], %[rows], " #QA "\n\t" "v_readlane_b32 %[sp1], %[rows], " #QB "\n\t"                                      \
+    T_STEP1(X0, Y0, I0, "s_and_b32 m0, %[sp0], 0xffff\n\t") T_STEP1(X1, Y1, I1, "s_lshr_b32 m0, %[sp0], 16\n\t")                     \
+    T_STEP1(X2, Y2, I2, "s_and_b32 m0, %[sp1], 0xffff\n\t") T_STEP1(X3, Y3, I3, "s_lshr_b32 m0, %[sp1], 16\n\t")
+#define T_DRAIN1(X, I, CNT) "s_waitcnt lgkmcnt(" #CNT ")\n\t" "v_mul_f32_dpp %[" #X "], %[ey], %[" #X "]" DPP_BC(I) "v_add_f32 %[acc], %[acc], %[" #X "]\n\t"
+#define T_DRAIN(X0, X1, X2, X3, I0, I1, I2, I3) T_DRAIN1(X0, I0, 3) T_DRAIN1(X1, I1, 2) T_DRAIN1(X2, I2, 1) T_DRAIN1(X3, I3, 0)
+#define T_EXIT_IF_LE(K, LABEL) "s_cmp_le_u32 %[nl], " #K "\n\t" "s_cbranch_scc1 " LABEL "%=\n\t"
+// sixteen terms (one round): rows of the round in dwords Q0 .. Q0+7 of `rows`, coefficients in lanes 0 .. 15 of every row of `ey`,
+// nl = terms left including this round's (> 0; the list is padded to a multiple of four)
+#define IDCT_ROUND(Q0, Q1, Q2, Q3, Q4, Q5, Q6, Q7)                                                                               \
+    asm volatile(                                                                                                                \
+        T_ISSUE(a0, a1, a2, a3, Q0, Q1)                                                                                          \
+        T_EXIT_IF_LE(4, ".Lda")                                                                                                  \
+        T_STEP(a0, a1, a2, a3, b0, b1, b2, b3, 0, 1, 2, 3, Q2, Q3)                                                               \
+        T_EXIT_IF_LE(8, ".Ldb")                                                                                                  \
+        T_STEP(b0, b1, b2, b3, a0, a1, a2, a3, 4, 5, 6, 7, Q4, Q5)                                                               \
+        T_EXIT_IF_LE(12, ".Ldc")                                                                                                 \
+        T_STEP(a0, a1, a2, a3, b0, b1, b2, b3, 8, 9, 10, 11, Q6, Q7)                                                             \
+        T_DRAIN(b0, b1, b2, b3, 12, 13, 14, 15) "s_branch .Lend%=\n\t"                                                           \
+        ".Lda%=:\n\t" T_DRAIN(a0, a1, a2, a3, 0, 1, 2, 3) "s_branch .Lend%=\n\t"                                                 \
+        ".Ldb%=:\n\t" T_DRAIN(b0, b1, b2, b3, 4, 5, 6, 7) "s_branch .Lend%=\n\t"                                                 \
+        ".Ldc%=:\n\t" T_DRAIN(a0, a1, a2, a3, 8, 9, 10, 11)                                                                      \
+        ".Lend%=:"                                                                                                               \
+        : [acc] "+v"(acc), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), \
+          [sp0] "=&s"(sp0), [sp1] "=&s"(sp1)                                                                                     \
+        : [rows] "v"(rows2), [ey] "v"(ey), [nl] "s"(nl) : "scc")
 
 // DecodeIdctCalcFloat(64) :2372-2392 on one block held one coefficient per lane (lane = natural index; the caller has zeroed
 // lane 0: DC is excluded from the sum, :2381).  Only non-zero coefficients are visited, in ascending natural order, separate
@@ -422,29 +421,31 @@ __device__ __forceinline__ float idct_terms(int cv16, const WaveList L, uint32_t
 {
     const bool nz = cv16 != 0;
     const uint64_t mask = __ballot(nz);
-    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_popcountll(mask));   // wave-uniform: the exit tests below are scalar compares
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_popcountll(mask));   // wave-uniform: the exit tests are scalar compares
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     const uint32_t zrank = lane - rank;                          // zero lanes: how many zero lanes lie below
     if (nz || zrank < 3u) L.coef[nz ? rank : n + zrank] = (float)cv16;          // zero lanes write the 0.0f padding
-    if (nz) L.rowb[rank] = (uint8_t)lane;
+    if (nz) L.rowh[rank] = (uint16_t)(lane << 8);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     float acc = 0.0f;
     const uint32_t li = lane & 15u;
-    do {
-        if (n == 0) break;
-        const uint32_t rows4 = reinterpret_cast<const uint32_t*>(L.rowb)[li];      // lane q (< 16): rows of terms 4q .. 4q+3
-        float l0, l1, l2, l3; uint32_t sp, s2, s3;
-        IDCT_M0_G16(0, 0, 1, 2, 3)     if (n <= 16) break;
-        IDCT_M0_G16(1, 4, 5, 6, 7)     if (n <= 32) break;
-        IDCT_M0_G16(2, 8, 9, 10, 11)   if (n <= 48) break;
-        IDCT_M0_G16(3, 12, 13, 14, 15)
-    } while (0);
+#ifndef JS_EXP_NOTERMS
+    if (n) {
+        const uint32_t rows2 = reinterpret_cast<const uint32_t*>(L.rowh)[lane & 31u];  // lane q (< 32): rows of terms 2q, 2q+1
+        float a0, a1, a2, a3, b0, b1, b2, b3; uint32_t sp0, sp1;
+        { const float ey = L.coef[li]; const uint32_t nl = n; IDCT_ROUND(0, 1, 2, 3, 4, 5, 6, 7); }
+        if (n > 16) { const float ey = L.coef[16 + li]; const uint32_t nl = n - 16; IDCT_ROUND(8, 9, 10, 11, 12, 13, 14, 15); }
+        if (n > 32) { const float ey = L.coef[32 + li]; const uint32_t nl = n - 32; IDCT_ROUND(16, 17, 18, 19, 20, 21, 22, 23); }
+        if (n > 48) { const float ey = L.coef[48 + li]; const uint32_t nl = n - 48; IDCT_ROUND(24, 25, 26, 27, 28, 29, 30, 31); }
+    }
+#else
+    acc = (float)(n + li);
+#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     return acc;
 }
-__device__ __forceinline__ void list_init(const WaveList L, uint32_t lane)    // row bytes must always name a table row: stale entries are read as padding
-{ if (lane < 20) reinterpret_cast<uint32_t*>(L.rowb)[lane] = 0u; }
-
+__device__ __forceinline__ void list_init(const WaveList L, uint32_t lane)    // row entries must always name a table row: stale entries are read as padding
+{ if (lane < 36) reinterpret_cast<uint32_t*>(L.rowh)[lane] = 0u; }
 
 // SetFullRes :2468-2561 into the wave's LDS MCU tile (replicated eH x eV times).
 // meta = comp-1 | eh<<4 | ev<<8 | (blk_ch*8)<<12 | (blk_cv*8)<<20 of the block's slot in the MCU.
@@ -660,17 +661,22 @@ __device__ __forceinline__ void back_end_mcus(const BackEndCtx& C, uint64_t& bri
         }
         if (m + wstride < nmcu) load_chunk(m + wstride, 0);           // next MCU's rows fly during the colour phase
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#ifndef JS_EXP_NOCOLOR
         if (FAST) mcu_to_dib_fast<EH, EV>(im, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, C.dibp, C.planes, pw, want_planes, bright, best_y, sum_y);
         else {
             const bool shifted = any_shift && my * mcus_across + mx >= shift_ind;
             if (rgb_only) mcu_to_dib<true>(im, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, shifted, C.dibp, C.planes, pw, want_planes, bright, best_y, sum_y);
             else          mcu_to_dib<false>(im, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, shifted, C.dibp, C.planes, pw, want_planes, bright, best_y, sum_y);
         }
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
-__global__ void __launch_bounds__(BK_THREADS, 6) k_idct_color(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ wg_base, uint32_t nimg,
+#ifndef JS_BK_OCC
+#define JS_BK_OCC 8     // 64 VGPRs: with the small tiles of the common layouts four workgroups (32 waves) fit a CU
+#endif
+__global__ void __launch_bounds__(BK_THREADS, JS_BK_OCC) k_idct_color(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ wg_base, uint32_t nimg,
                                                            uint32_t tile_bytes, const float* __restrict__ lut_t /*[vu][yx]*/,
                                                            const int16_t* __restrict__ coef, const int16_t* __restrict__ dccum,
                                                            uint8_t* __restrict__ dib, int16_t* __restrict__ planes, uint32_t* __restrict__ side)
@@ -694,7 +700,7 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_idct_color(const JsImage* __r
         s_meta[tid] = (comp - 1) | (im.expand_h[comp] << 4) | (im.expand_v[comp] << 8) | ((uint32_t)im.blk_ch[tid] * 8u << 12) | ((uint32_t)im.blk_cv[tid] * 8u << 20); }
     BackEndCtx C;
     C.im = &im; C.cbase = coef + im.coef_off * 64; C.dccum = dccum; C.dibp = dib + im.dib_off; C.planes = planes;
-    C.L.coef = reinterpret_cast<float*>(wave_mem); C.L.rowb = wave_mem + 68 * 4; C.tile = reinterpret_cast<int16_t*>(wave_mem + LIST_BYTES);
+    C.L.coef = reinterpret_cast<float*>(wave_mem); C.L.rowh = reinterpret_cast<uint16_t*>(wave_mem + 68 * 4); C.tile = reinterpret_cast<int16_t*>(wave_mem + LIST_BYTES);
     C.s_meta = s_meta; C.lane = lane; C.wave = wave; C.wg_in_img = blockIdx.x - wg_base[lo]; C.wgs_in_img = wg_base[lo + 1] - wg_base[lo];
     list_init(C.L, lane);
     __syncthreads();
@@ -702,10 +708,7 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_idct_color(const JsImage* __r
     uint64_t bright = 0; uint32_t sum_y = 0;
     // the common layouts take the short colour path: Y un-expanded, Cb and Cr one block each, both expanded EH x EV with EH, EV in {1, 2}
     const uint32_t eh = im.expand_h[2], ev = im.expand_v[2];
-    const bool fast = im.ncomp == 3 && im.preview_mode == 1 && (im.shift_y | im.shift_cb | im.shift_cr) == 0 &&
-                      im.expand_h[1] == 1 && im.expand_v[1] == 1 && im.samp_h[1] == eh && im.samp_v[1] == ev &&
-                      im.samp_h[2] == 1 && im.samp_v[2] == 1 && im.samp_h[3] == 1 && im.samp_v[3] == 1 && im.expand_h[3] == eh && im.expand_v[3] == ev &&
-                      eh >= 1 && eh <= 2 && ev >= 1 && ev <= 2;
+    const bool fast = js_fast_layout(im);
     if (fast && eh == 2 && ev == 2) back_end_mcus<true, 2, 2>(C, bright, sum_y);
     else if (fast && eh == 2) back_end_mcus<true, 2, 1>(C, bright, sum_y);
     else if (fast && ev == 2) back_end_mcus<true, 1, 2>(C, bright, sum_y);
@@ -734,7 +737,7 @@ __global__ void __launch_bounds__(64) k_idct_probe(const float* __restrict__ lut
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     float* s_lut = reinterpret_cast<float*>(s_dyn);
-    WaveList L; L.coef = reinterpret_cast<float*>(s_dyn + 64 * 64 * sizeof(float)); L.rowb = s_dyn + 64 * 64 * sizeof(float) + 68 * 4;
+    WaveList L; L.coef = reinterpret_cast<float*>(s_dyn + 64 * 64 * sizeof(float)); L.rowh = reinterpret_cast<uint16_t*>(s_dyn + 64 * 64 * sizeof(float) + 68 * 4);
     if ((uint32_t)(size_t)s_dyn != 0u) __builtin_trap();
     const uint32_t lane = threadIdx.x;
     for (uint32_t i = lane; i < 64 * 64; i += 64) s_lut[i] = lut_t[i];
@@ -950,13 +953,20 @@ void js_launch_entropy_exact(hipStream_t st, const JsImage* imgs, const uint32_t
     if (!nsel) return;
     hipLaunchKernelGGL(k_entropy_exact, dim3(nsel), dim3(64), 0, st, imgs, sel, nsel, tables, raw, coef, dccum, side, side_only, events);
 }
-void js_launch_idct_color(hipStream_t st, const JsImage* imgs, const uint32_t* wg_base, uint32_t nimg, uint32_t total_wgs, uint32_t max_mcu_w, uint32_t max_mcu_h,
-                          const float* lut_t, const int16_t* coef, const int16_t* dccum, uint8_t* dib, int16_t* planes, uint32_t* side)
+int js_launch_idct_color(hipStream_t st, const JsImage* imgs, const uint32_t* wg_base, uint32_t nimg, uint32_t total_wgs, uint32_t tile_bytes,
+                         const float* lut_t, const int16_t* coef, const int16_t* dccum, uint8_t* dib, int16_t* planes, uint32_t* side)
 {
-    if (!total_wgs) return;
-    const uint32_t tile_bytes = ((3u * max_mcu_h * (max_mcu_w + 8u) * 2u) + 15u) & ~15u;
+    if (!total_wgs) return 0;
+    // tile_bytes: the largest per-wave tile any image of the launch needs (js_tile_bytes).  Ordinary images leave room for four
+    // workgroups per CU; a 4 x 4 sampled image (32 x 32 MCU) needs more than the default 64 KiB limit and is opted in explicitly.
     const size_t lds = 64 * 64 * sizeof(float) + JS_MAX_BLK_PER_MCU * 4 + (size_t)BK_WAVES * (LIST_BYTES + tile_bytes) + BK_WAVES * 12;
+    if (lds > 160u * 1024u) return -2;
+    if (lds > 64u * 1024u) {
+        static size_t opted = 0;                              // raised monotonically; the attribute is per function, not per launch
+        if (lds > opted) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_idct_color), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3; opted = lds; }
+    }
     hipLaunchKernelGGL(k_idct_color, dim3(total_wgs), dim3(BK_THREADS), lds, st, imgs, wg_base, nimg, tile_bytes, lut_t, coef, dccum, dib, planes, side);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 void js_launch_idct_probe(hipStream_t st, const float* lut_t, const int16_t* coef64, float* out64)
 { hipLaunchKernelGGL(k_idct_probe, dim3(1), dim3(64), 64 * 64 * sizeof(float) + LIST_BYTES, st, lut_t, coef64, out64); }

@@ -269,7 +269,7 @@ int JsnoopBatch::run_exact(const std::vector<uint32_t>& which)
     }
     HIP_TRY(hipMemcpyAsync(dev.sel, which.data(), which.size() * 4, hipMemcpyHostToDevice, stream));
     js_launch_entropy_exact(stream, dev.imgs, dev.sel, (uint32_t)which.size(), dev.tables, dev.raw, dev.coef, dev.dccum, dev.side, 0, event_words ? dev.events : nullptr);
-    js_launch_idct_color(stream, dev.imgs, dev.wg_base, (uint32_t)imgs.size(), total_wgs, max_mcu_w, max_mcu_h, d_lut, dev.coef, dev.dccum, dev.dib, dev.planes, dev.side);
+    if (launch_back_end((uint32_t)imgs.size())) return -1;
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -292,7 +292,7 @@ static int js_parallel_resume(JsnoopBatch* b, int extra_launches)
     js_launch_write(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
                     b->dev.coef, b->dev.dccum, b->dev.mcu_rst, b->dev.flags);
     js_launch_dc_scan(b->stream, b->dev.imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst);
-    js_launch_idct_color(b->stream, b->dev.imgs, b->dev.wg_base, n, b->total_wgs, b->max_mcu_w, b->max_mcu_h, b->d_lut, b->dev.coef, b->dev.dccum, b->dev.dib, b->dev.planes, b->dev.side);
+    if (b->launch_back_end(n)) return -1;
     HIP_TRY(hipMemcpyAsync(b->host_flags.data(), b->dev.flags, (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return 0;

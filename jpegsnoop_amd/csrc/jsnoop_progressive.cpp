@@ -230,7 +230,7 @@ extern "C" int jsnoop_decode_progressive(JsnoopDecoder* d, const uint8_t* f, siz
         for (unsigned a = 0; a < JsnoopBatch::kAux; a++) if (used >> a & 1u) { hipEventRecord(b->aux_ev[a], b->aux[a]); hipStreamWaitEvent(b->stream, b->aux_ev[a], 0); }
     }
     js_launch_prog_finalize(b->stream, b->dev.imgs, fr, dim.total_blocks, b->dev.coef, b->dev.dccum);
-    js_launch_idct_color(b->stream, b->dev.imgs, b->dev.wg_base, 1, b->total_wgs, b->max_mcu_w, b->max_mcu_h, b->d_lut, b->dev.coef, b->dev.dccum, b->dev.dib, b->dev.planes, b->dev.side);
+    if (b->launch_back_end(1)) return -1;
     uint32_t status[4] = { 0, 0, 0, 0 };
     hipError_t e = hipMemcpyAsync(status, d_status, 16, hipMemcpyDeviceToHost, b->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);

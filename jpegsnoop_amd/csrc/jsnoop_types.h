@@ -104,4 +104,24 @@ enum { JS_EV_OVERREAD_BEFORE = 1, JS_EV_OVERREAD_CODE, JS_EV_OVERREAD_BITS, JS_E
 #define JS_SIDE_HISTO  16
 #define JS_SIDE_MCUMAP 152
 
+// Layouts the back end converts without a replicated LDS tile (k_idct_color, mcu_to_dib_fast): three components, Y un-expanded,
+// Cb and Cr one block each and both expanded eh x ev with eh, ev in {1, 2} (4:4:4, 4:2:2, 4:4:0, 4:2:0), default preview, no YCC shift.
+#if defined(__HIPCC__) || defined(__CUDACC__)
+__host__ __device__
+#endif
+static inline bool js_fast_layout(const JsImage& im)
+{
+    const uint32_t eh = im.expand_h[2], ev = im.expand_v[2];
+    return im.ncomp == 3 && im.preview_mode == 1 && (im.shift_y | im.shift_cb | im.shift_cr) == 0 &&
+           im.expand_h[1] == 1 && im.expand_v[1] == 1 && im.samp_h[1] == eh && im.samp_v[1] == ev &&
+           im.samp_h[2] == 1 && im.samp_v[2] == 1 && im.samp_h[3] == 1 && im.samp_v[3] == 1 && im.expand_h[3] == eh && im.expand_v[3] == ev &&
+           eh >= 1 && eh <= 2 && ev >= 1 && ev <= 2;
+}
+// bytes of the back end's per-wave LDS tile for this image: Y plane + two bare chroma blocks (fast layouts), else three replicated planes
+static inline uint32_t js_tile_bytes(const JsImage& im)
+{
+    const uint32_t b = js_fast_layout(im) ? im.mcu_h * (im.mcu_w + 8u) * 2u + 256u : 3u * im.mcu_h * (im.mcu_w + 8u) * 2u;
+    return (b + 15u) & ~15u;
+}
+
 static inline uint32_t js_side_words(uint32_t nmcu, uint32_t nblk) { return JS_SIDE_MCUMAP + nmcu + 3 * ((nblk + 1) / 2); }
