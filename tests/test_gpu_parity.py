@@ -193,7 +193,9 @@ def test_progressive_transitive_parity(harness, oracle, gpu, kw, mode):
     picture are not coded by non-interleaved scans (T.81 A.2.3), so for sizes that are not MCU multiples the comparison
     covers the visible region.  mode 1: spectral selection only (DC scan + two AC bands per component); mode 2: spectral
     selection and successive approximation (DC and AC first scans with point transform, two refinement levels for
-    luminance AC, DC refinement) -- a script in the style of the IJG default, cross-checked with libjpeg via PIL here."""
+    luminance AC, DC refinement) -- a script in the style of the IJG default.  Both ends of the chain are pinned to libjpeg in
+    tests/test_progressive_pillow.py: the generator's progressive output (libjpeg must decode it to the baseline form's pixels) and
+    the decoder (progressive files written by libjpeg-turbo must give the oracle's DIB of libjpeg-turbo's baseline encoding)."""
     base = harness.synth_jpeg(seed=61, progressive=0, **kw)
     prog = harness.synth_jpeg(seed=61, progressive=mode, **kw)
     harness.drive(oracle, base)
