@@ -85,8 +85,8 @@ int  jsnoop_jfif_walk(JsnoopDecoder*, const uint8_t* file, size_t len, unsigned*
 /* ---- decode: DecodeScanImg(nStart,bDisplay,bQuiet) :2723 ------------------------
  * `file`/`len` is the whole file image that the reference reads through
  * CwindowBuf::Buf (source/WindowBuf.cpp:639; bytes past `len` read as 0).  The bytes are
- * staged through pinned host memory with hipMemcpyAsync; overlays must be applied by
- * the caller beforehand.  Blocks until the DIB is resident in HBM.                  */
+ * staged through pinned host memory with hipMemcpyAsync, with the overlays installed through
+ * jsnoop_overlay_install applied to the staged copy.  Blocks until the DIB is resident in HBM. */
 void jsnoop_decode_scan_img(JsnoopDecoder*, const uint8_t* file, size_t len, unsigned start, int display, int quiet);
 
 /* ---- results: IsPreviewReady :3753, GetImageSize :4929, GetBitmapPtr :4940,
@@ -102,6 +102,26 @@ void           jsnoop_get_pixmap_ptrs(JsnoopDecoder*, const int16_t** y, const i
 void           jsnoop_lookup_file_pos_mcu(JsnoopDecoder*, unsigned mcu_x, unsigned mcu_y, unsigned* byte, unsigned* bit);
 void           jsnoop_lookup_file_pos_pix(JsnoopDecoder*, unsigned pix_x, unsigned pix_y, unsigned* byte, unsigned* bit);
 void           jsnoop_lookup_blk_ycc(JsnoopDecoder*, unsigned blk_x, unsigned blk_y, int* y, int* cb, int* cr);
+
+/* PixelToMcu :5056, PixelToBlk :5071, McuXyToLinear :5088 (the hover / status-bar helpers of source/JPEGsnoopViewImg.cpp:294-334) */
+void     jsnoop_pixel_to_mcu(JsnoopDecoder*, unsigned pix_x, unsigned pix_y, unsigned* mcu_x, unsigned* mcu_y);
+void     jsnoop_pixel_to_blk(JsnoopDecoder*, unsigned pix_x, unsigned pix_y, unsigned* blk_x, unsigned* blk_y);
+unsigned jsnoop_mcu_xy_to_linear(JsnoopDecoder*, unsigned mcu_x, unsigned mcu_y);
+
+/* bDumpHistoY (CSnoopConfig, read at ImgDecode.cpp:2730): with bHistoEn and bDisplay the decode log ends with
+ * ReportHistogramY's 256 lines of the 2048-bin Y histogram (:3740-3741, :3845-3868).                          */
+void jsnoop_set_dump_histo_y(JsnoopDecoder*, int on);
+
+/* ---- byte overlays: CwindowBuf::OverlayInstall / OverlayRemoveAll / OverlayGet / OverlayGetNum
+ *      (source/WindowBuf.cpp:516-620).  The reference's fault-injection tool: Buf() (:639-660) returns an overlay's
+ *      byte instead of the file's wherever an enabled overlay covers the offset, the LAST installed one winning.
+ *      jsnoop_decode_scan_img applies the installed overlays to its staged copy of the file image (offsets inside the
+ *      file), so a re-decode after an install shows the patched stream exactly as the reference's would.
+ *      At most 500 overlays of fewer than 500 bytes (NUM_OVERLAYS / MAX_OVERLAY, WindowBuf.h:42-43).           */
+int      jsnoop_overlay_install(JsnoopDecoder*, const uint8_t* data, unsigned len, unsigned begin);   /* 1 = installed, 0 = refused */
+void     jsnoop_overlay_remove_all(JsnoopDecoder*);
+unsigned jsnoop_overlay_get_num(JsnoopDecoder*);
+int      jsnoop_overlay_get(JsnoopDecoder*, unsigned ind, const uint8_t** data, unsigned* len, unsigned* begin);
 
 /* ---- preview re-render on the retained planes: SetPreviewMode :633,
  *      SetPreviewYccOffset :650 (each re-runs the colour kernel only)            */
@@ -210,6 +230,18 @@ int          jsnoop_batch_color_stats(JsnoopBatch*, int i, int histo_en, uint32_
 int          jsnoop_batch_dib_hashes(JsnoopBatch*, uint64_t* host_dst);
 uint64_t     jsnoop_batch_algorithmic_bytes(const JsnoopBatch*);                   /* sum(scan bytes + DIB bytes), SURVEY.md 8(d) */
 uint64_t     jsnoop_batch_pixels(const JsnoopBatch*);                              /* sum(SOF X*Y) */
+
+/* ---- staging pipeline: the CwindowBuf replacement at batch scale (source/WindowBuf.cpp:351-416 BufLoadWindow, :639-714 Buf) ----
+ * `slots` batch slots, each with its own pinned staging area, HBM arenas and stream (fill them through jsnoop_pipeline_slot and
+ * the jsnoop_batch_add* calls).  jsnoop_pipeline_run cycles `batches` batches through the slots: while one slot decodes, the next
+ * slot's compressed bytes cross PCIe, and with d2h != 0 the previous slot's DIBs are copied back to pinned host memory meanwhile.
+ * out_ms6: [0] wall ms per batch in steady state (timing scope T2 with d2h = 0, T3 with d2h = 1), then the pieces on their own:
+ * [1] H2D ms, [2] decode ms (T1), [3] D2H ms (0 without d2h), [4] compressed bytes per batch, [5] DIB bytes per batch.       */
+typedef struct JsnoopPipeline JsnoopPipeline;
+JsnoopPipeline* jsnoop_pipeline_create(int slots);
+void            jsnoop_pipeline_destroy(JsnoopPipeline*);
+JsnoopBatch*    jsnoop_pipeline_slot(JsnoopPipeline*, int i);
+int             jsnoop_pipeline_run(JsnoopPipeline*, int batches, int d2h, double* out_ms6);
 
 #ifdef __cplusplus
 }

@@ -5,5 +5,5 @@ include/jsnoop_gpu.h).  This package is its binding layer: `CimgDecode` mirrors 
 reference's decoder object, `JpegBatch` is the batched submit.
 """
 from .capi import load, last_error, LIB_PATH  # noqa: F401
-from .imgdecode import CimgDecode, JpegBatch, dib_checksum_numpy  # noqa: F401
+from .imgdecode import CimgDecode, JpegBatch, JpegPipeline, dib_checksum_numpy  # noqa: F401
 from .shard import partition_lpt, partition_contiguous, reduce_job_stats  # noqa: F401

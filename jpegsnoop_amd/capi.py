@@ -50,6 +50,14 @@ SIGNATURES = {
     "jsnoop_lookup_file_pos_mcu": (None, [_p, _u, _u, _PU, _PU]),
     "jsnoop_lookup_file_pos_pix": (None, [_p, _u, _u, _PU, _PU]),
     "jsnoop_lookup_blk_ycc": (None, [_p, _u, _u, _PI, _PI, _PI]),
+    "jsnoop_pixel_to_mcu": (None, [_p, _u, _u, _PU, _PU]),
+    "jsnoop_pixel_to_blk": (None, [_p, _u, _u, _PU, _PU]),
+    "jsnoop_mcu_xy_to_linear": (_u, [_p, _u, _u]),
+    "jsnoop_set_dump_histo_y": (None, [_p, _i]),
+    "jsnoop_overlay_install": (_i, [_p, _p, _u, _u]),
+    "jsnoop_overlay_remove_all": (None, [_p]),
+    "jsnoop_overlay_get_num": (_u, [_p]),
+    "jsnoop_overlay_get": (_i, [_p, _u, C.POINTER(_p), _PU, _PU]),
     "jsnoop_set_preview_mode": (None, [_p, _u]),
     "jsnoop_get_preview_mode": (_u, [_p]),
     "jsnoop_set_preview_ycc_offset": (None, [_p, _u, _u, _i, _i, _i]),
@@ -91,6 +99,10 @@ SIGNATURES = {
     "jsnoop_batch_color_stats": (_i, [_p, _i, _i, _p]),
     "jsnoop_batch_dib_hashes": (_i, [_p, _p]),
     "jsnoop_batch_algorithmic_bytes": (C.c_uint64, [_p]),
+    "jsnoop_pipeline_create": (_p, [_i]),
+    "jsnoop_pipeline_destroy": (None, [_p]),
+    "jsnoop_pipeline_slot": (_p, [_p, _i]),
+    "jsnoop_pipeline_run": (_i, [_p, _i, _i, C.POINTER(C.c_double)]),
     "jsnoop_batch_pixels": (C.c_uint64, [_p]),
 }
 

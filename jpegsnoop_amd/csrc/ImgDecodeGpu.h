@@ -14,6 +14,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
 #include <functional>
 #include <stdexcept>
 #include <string>
@@ -47,8 +48,8 @@ public:
     void ResetState() { jsnoop_reset_state(m_h); }              // :286
 
     // ---- options: the CSnoopConfig fields DecodeScanImg reads (:2730-2741) -------------------------
-    void SetConfig(bool bDecodeScanImgAc, bool bHistoEn = false, bool bStatClipEn = false, unsigned nErrMaxDecodeScan = 20)
-    { jsnoop_set_options(m_h, bDecodeScanImgAc, bHistoEn, bStatClipEn, nErrMaxDecodeScan); }
+    void SetConfig(bool bDecodeScanImgAc, bool bHistoEn = false, bool bStatClipEn = false, unsigned nErrMaxDecodeScan = 20, bool bDumpHistoY = false)
+    { jsnoop_set_options(m_h, bDecodeScanImgAc, bHistoEn, bStatClipEn, nErrMaxDecodeScan); jsnoop_set_dump_histo_y(m_h, bDumpHistoY); }
 
     // ---- tables / geometry (same names, same bool returns) -------------------------------------------
     bool SetDqtEntry(unsigned nTblDestId, unsigned nCoeffInd, unsigned nCoeffIndZz, unsigned short nCoeffVal)
@@ -93,6 +94,15 @@ public:
     void GetColorStats(uint32_t* pStats) { jsnoop_get_color_stats(m_h, pStats); }
     // Export to TIFF (CJPEGsnoopDoc::OnToolsExporttiff + FileTiff::WriteFile): nMode 0 RGB8, 1 RGB16, 2 YCC8
     bool ExportTiff(const std::string& strFnameOut, int nMode) { return jsnoop_export_tiff(m_h, strFnameOut.c_str(), nMode) == 0; }
+    // hover helpers next to LookupFilePosMcu (source/JPEGsnoopViewImg.cpp:294-334); CPoint is a pair of unsigned here
+    void PixelToMcu(unsigned nPixX, unsigned nPixY, unsigned& nMcuX, unsigned& nMcuY) { jsnoop_pixel_to_mcu(m_h, nPixX, nPixY, &nMcuX, &nMcuY); }               // :5056
+    void PixelToBlk(unsigned nPixX, unsigned nPixY, unsigned& nBlkX, unsigned& nBlkY) { jsnoop_pixel_to_blk(m_h, nPixX, nPixY, &nBlkX, &nBlkY); }               // :5071
+    unsigned McuXyToLinear(unsigned nMcuX, unsigned nMcuY) { return jsnoop_mcu_xy_to_linear(m_h, nMcuX, nMcuY); }                                              // :5088
+    // CwindowBuf overlays (source/WindowBuf.cpp:516-620): the next DecodeScanImg reads the patched bytes, as CwindowBuf::Buf would hand them out
+    bool OverlayInstall(unsigned /*nOvrInd*/, const uint8_t* pOverlay, unsigned nLen, unsigned nBegin) { return jsnoop_overlay_install(m_h, pOverlay, nLen, nBegin) != 0; }
+    void OverlayRemoveAll() { jsnoop_overlay_remove_all(m_h); }
+    unsigned OverlayGetNum() { return jsnoop_overlay_get_num(m_h); }
+    bool OverlayGet(unsigned nOvrInd, const uint8_t*& pOverlay, unsigned& nLen, unsigned& nBegin) { return jsnoop_overlay_get(m_h, nOvrInd, &pOverlay, &nLen, &nBegin) != 0; }
     unsigned PackFileOffset(unsigned nByte, unsigned nBit) const { return (nByte << 4) + nBit; }                 // :5104
     void UnpackFileOffset(unsigned nPacked, unsigned& nByte, unsigned& nBit) const { nBit = nPacked & 0x7; nByte = nPacked >> 4; } // :5123
 
@@ -114,27 +124,100 @@ private:
     LogFn m_log;
 };
 
-// The slice of CJPEGsnoopCore that belongs to the scan-decode path: I_* pass-throughs and a batched
-// replacement for the per-file loop.  AnalyzeBuffer() walks the JFIF header with the built-in front
-// end (the subset of CjfifDecode::DecodeMarker that feeds CimgDecode) and decodes the first scan.
+// The slice of CJPEGsnoopCore that belongs to the scan-decode path (source/JPEGsnoopCore.h:79-117, JPEGsnoopCore.cpp:1211-1399):
+// the data-bearing I_* accessors over the core's one CimgDecode (source/JPEGsnoopCore.cpp:46), an AnalyzeFile-shaped entry
+// (source/JPEGsnoopCore.cpp:325: open, analyse, close) fed from a file or from bytes, the B_Overlay* pass-throughs of its
+// CwindowBuf, and a batched replacement for the strictly sequential per-file loop (DoBatchFileProcess :765-845).  Not carried:
+// the status-bar / zoom / marker / GDI accessors (I_SetStatusBar, I_*Zoom*, I_*Marker*, I_ViewOnDraw, I_*StatusText) -- Windows
+// GUI state that never reaches the decoder -- and the J_* metadata-report accessors (out of scope).
 class CJPEGsnoopCoreGpu {
 public:
-    CJPEGsnoopCoreGpu() { m_b = jsnoop_batch_create(nullptr); if (!m_b) throw std::runtime_error(std::string("jsnoop_batch_create: ") + jsnoop_last_error()); }
-    ~CJPEGsnoopCoreGpu() { jsnoop_batch_destroy(m_b); }
+    explicit CJPEGsnoopCoreGpu(CimgDecodeGpu::LogFn pLog = nullptr) : m_pImgDec(new CimgDecodeGpu(std::move(pLog), &m_view))
+    { m_b = jsnoop_batch_create(nullptr); if (!m_b) { delete m_pImgDec; throw std::runtime_error(std::string("jsnoop_batch_create: ") + jsnoop_last_error()); } }
+    ~CJPEGsnoopCoreGpu() { jsnoop_batch_destroy(m_b); delete m_pImgDec; }
+    CJPEGsnoopCoreGpu(const CJPEGsnoopCoreGpu&) = delete;
+    CJPEGsnoopCoreGpu& operator=(const CJPEGsnoopCoreGpu&) = delete;
 
-    // batch: N files -> N DIBs resident in HBM (per-file semantics of DoBatchFileProcess preserved)
+    // ---- AnalyzeFile :325 (AnalyzeOpen, AnalyzeFileDo, AnalyzeClose): header walk with the built-in front end, then DecodeScanImg(nStart, true, false) as
+    //      CjfifDecode::DecodeMarker issues it (source/JfifDecode.cpp:5299).  The file image stays owned by the core until the next Analyze*.
+    bool AnalyzeBuffer(const uint8_t* pFile, size_t nLen)
+    {
+        m_file.assign(pFile, pFile + nLen); m_view.pData = m_file.data(); m_view.nLen = m_file.size(); m_bFileAnalyzed = false;
+        if (nLen == 0) return false;                             // "ERROR: File length is zero, no decoding done." (:301)
+        m_pImgDec->ResetState(); m_pImgDec->Reset();             // CjfifDecode::Reset (source/JfifDecode.cpp:7306-7308)
+        unsigned nStart = 0;
+        if (!m_pImgDec->WalkJfifHeader(nStart)) return false;
+        m_pImgDec->DecodeScanImg(nStart, true, false);
+        m_bFileAnalyzed = true;
+        return true;
+    }
+    bool AnalyzeFile(const std::string& strFname)
+    {
+        FILE* f = fopen(strFname.c_str(), "rb");                 // AnalyzeOpen :157: FALSE when the file cannot be opened
+        if (!f) return false;
+        std::vector<uint8_t> buf; uint8_t tmp[65536]; size_t n;
+        while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+        fclose(f);
+        m_strPathName = strFname;
+        AnalyzeBuffer(buf.data(), buf.size());
+        return true;                                             // the status of opening the file, like the reference
+    }
+    bool IsAnalyzed() const { return m_bFileAnalyzed; }          // :138
+
+    // ---- I_* accessor wrappers for CimgDecode (:1211-1399) ---------------------------------------------------------------------
+    unsigned I_GetDqtEntry(unsigned nTblDestId, unsigned nCoeffInd) { return m_pImgDec->GetDqtEntry(nTblDestId, nCoeffInd); }                       // :1216
+    void     I_SetPreviewMode(unsigned nMode) { m_pImgDec->SetPreviewMode(nMode); }                                                                 // :1221
+    unsigned I_GetPreviewMode() { return m_pImgDec->GetPreviewMode(); }                                                                             // :1226
+    void     I_SetPreviewYccOffset(unsigned nMcuX, unsigned nMcuY, int nY, int nCb, int nCr) { m_pImgDec->SetPreviewYccOffset(nMcuX, nMcuY, nY, nCb, nCr); }   // :1231
+    void     I_GetPreviewYccOffset(unsigned& nMcuX, unsigned& nMcuY, int& nY, int& nCb, int& nCr) { m_pImgDec->GetPreviewYccOffset(nMcuX, nMcuY, nY, nCb, nCr); } // :1236
+    void     I_SetPreviewMcuInsert(unsigned nMcuX, unsigned nMcuY, int nLen) { m_pImgDec->SetPreviewMcuInsert(nMcuX, nMcuY, nLen); }               // :1241
+    void     I_GetPreviewMcuInsert(unsigned& nMcuX, unsigned& nMcuY, unsigned& nLen) { m_pImgDec->GetPreviewMcuInsert(nMcuX, nMcuY, nLen); }       // :1246
+    void     I_PixelToMcu(unsigned nPixX, unsigned nPixY, unsigned& nMcuX, unsigned& nMcuY) { m_pImgDec->PixelToMcu(nPixX, nPixY, nMcuX, nMcuY); } // :1276
+    void     I_PixelToBlk(unsigned nPixX, unsigned nPixY, unsigned& nBlkX, unsigned& nBlkY) { m_pImgDec->PixelToBlk(nPixX, nPixY, nBlkX, nBlkY); } // :1281
+    unsigned I_McuXyToLinear(unsigned nMcuX, unsigned nMcuY) { return m_pImgDec->McuXyToLinear(nMcuX, nMcuY); }                                    // :1286
+    void     I_GetImageSize(unsigned& nX, unsigned& nY) { m_pImgDec->GetImageSize(nX, nY); }                                                       // :1291
+    void     I_GetPixMapPtrs(short*& pMapY, short*& pMapCb, short*& pMapCr) { m_pImgDec->GetPixMapPtrs(pMapY, pMapCb, pMapCr); }                   // :1296
+    void     I_GetBitmapPtr(unsigned char*& pBitmap) { m_pImgDec->GetBitmapPtr(pBitmap); }                                                         // :1361: the decoder-owned pointer, nothing copied
+    void     I_LookupFilePosMcu(unsigned nMcuX, unsigned nMcuY, unsigned& nByte, unsigned& nBit) { m_pImgDec->LookupFilePosMcu(nMcuX, nMcuY, nByte, nBit); } // :1366
+    void     I_LookupFilePosPix(unsigned nPixX, unsigned nPixY, unsigned& nByte, unsigned& nBit) { m_pImgDec->LookupFilePosPix(nPixX, nPixY, nByte, nBit); } // :1371
+    void     I_LookupBlkYCC(unsigned nBlkX, unsigned nBlkY, int& nY, int& nCb, int& nCr) { m_pImgDec->LookupBlkYCC(nBlkX, nBlkY, nY, nCb, nCr); } // :1376
+    bool     I_IsPreviewReady() { return m_pImgDec->IsPreviewReady(); }                                                                           // :1396
+    const void* I_GetBitmapDevicePtr() { return m_pImgDec->GetBitmapDevicePtr(); }                                                                 // (HBM copy, no reference counterpart)
+
+    // ---- B_* accessor wrappers for CwindowBuf that reach the decoder: byte fetch and overlays (:1180-1207) ------------------------
+    uint8_t  B_Buf(unsigned long nOffset, bool bClean = false)                                                                                     // :1180 -> CwindowBuf::Buf (source/WindowBuf.cpp:639)
+    {
+        if (!bClean) {
+            const uint8_t* p; unsigned n, b; uint8_t v = 0; bool hit = false;
+            for (unsigned i = 0; i < m_pImgDec->OverlayGetNum(); i++)
+                if (m_pImgDec->OverlayGet(i, p, n, b) && nOffset >= b && nOffset < (unsigned long)b + n) { v = p[nOffset - b]; hit = true; }
+            if (hit) return v;
+        }
+        return m_view.Buf(nOffset);
+    }
+    bool     B_OverlayInstall(unsigned nOvrInd, const uint8_t* pOverlay, unsigned nLen, unsigned nBegin, unsigned /*nMcuX*/ = 0, unsigned /*nMcuY*/ = 0,
+                              unsigned /*nMcuLen*/ = 0, unsigned /*nMcuLenIns*/ = 0, int /*nAdjY*/ = 0, int /*nAdjCb*/ = 0, int /*nAdjCr*/ = 0)
+    { return m_pImgDec->OverlayInstall(nOvrInd, pOverlay, nLen, nBegin); }                                                                         // :1191
+    void     B_OverlayRemoveAll() { m_pImgDec->OverlayRemoveAll(); }                                                                              // :1198
+    bool     B_OverlayGet(unsigned nOvrInd, const uint8_t*& pOverlay, unsigned& nLen, unsigned& nBegin) { return m_pImgDec->OverlayGet(nOvrInd, pOverlay, nLen, nBegin); } // :1203
+    // re-run the scan decode of the analysed file on the (re-)patched bytes: what the reference's "Tools -> File overlay" does after an install
+    bool     ReprocessFile() { if (!m_bFileAnalyzed) return false; const std::vector<uint8_t> copy(m_file); return AnalyzeBuffer(copy.data(), copy.size()); }
+
+    // ---- batch: N files -> N DIBs resident in HBM (per-file semantics of DoBatchFileProcess :765-845 preserved) -------------------
     void     BatchClear() { jsnoop_batch_clear(m_b); }
     int      BatchAddFile(const uint8_t* pFile, size_t nLen) { return jsnoop_batch_add_jpeg(m_b, pFile, nLen); }
-    unsigned GetBatchFileCount() const { return (unsigned)jsnoop_batch_count(m_b); }
+    unsigned GetBatchFileCount() const { return (unsigned)jsnoop_batch_count(m_b); }                                                             // :680
     bool     DoBatchProcess() { return jsnoop_batch_upload(m_b) == 0 && jsnoop_batch_decode(m_b) == 0 && jsnoop_batch_sync(m_b) == 0; }
-    const void* I_GetBitmapDevicePtr(int nFileInd) const { return jsnoop_batch_dib_dev(m_b, nFileInd); }
-    bool     I_GetBitmap(int nFileInd, std::vector<uint8_t>& dib, unsigned& nX, unsigned& nY)
+    const void* BatchBitmapDevicePtr(int nFileInd) const { return jsnoop_batch_dib_dev(m_b, nFileInd); }
+    bool     BatchGetBitmap(int nFileInd, std::vector<uint8_t>& dib, unsigned& nX, unsigned& nY)
     {
         unsigned info[16]; if (jsnoop_batch_image_info(m_b, nFileInd, info)) return false;
         nX = info[2]; nY = info[3]; dib.resize((size_t)nX * nY * 4);
         return jsnoop_batch_read_dib(m_b, nFileInd, dib.data()) == 0;
     }
+    CimgDecodeGpu* ImgDec() { return m_pImgDec; }
     JsnoopBatch* Handle() { return m_b; }
 private:
-    JsnoopBatch* m_b = nullptr;
+    CwindowBufView m_view; std::vector<uint8_t> m_file; std::string m_strPathName; bool m_bFileAnalyzed = false;
+    CimgDecodeGpu* m_pImgDec; JsnoopBatch* m_b = nullptr;
 };

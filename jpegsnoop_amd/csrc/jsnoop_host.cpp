@@ -473,8 +473,38 @@ void jsnoop_set_image_details(JsnoopDecoder* d, unsigned x, unsigned y, unsigned
 
 int jsnoop_jfif_walk(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned* scan_start) { return js_jfif_walk(d, file, len, scan_start); }
 
+void jsnoop_pixel_to_mcu(JsnoopDecoder* d, unsigned px, unsigned py, unsigned* mx, unsigned* my)        // :5056-5062
+{ *mx = d->geom[0] ? px / d->geom[0] : 0; *my = d->geom[1] ? py / d->geom[1] : 0; }
+void jsnoop_pixel_to_blk(JsnoopDecoder*, unsigned px, unsigned py, unsigned* bx, unsigned* by) { *bx = px / 8; *by = py / 8; }   // :5071-5077 (BLK_SZ_X/Y = 8)
+unsigned jsnoop_mcu_xy_to_linear(JsnoopDecoder* d, unsigned mx, unsigned my) { return my * d->geom[2] + mx; }                   // :5088-5093
+void jsnoop_set_dump_histo_y(JsnoopDecoder* d, int on) { d->opt_dump_histo_y = on != 0; }
+
+int jsnoop_overlay_install(JsnoopDecoder* d, const uint8_t* data, unsigned len, unsigned begin)          // OverlayInstall :516-556
+{
+    if (d->overlays.size() >= 500) return 0;                     // NUM_OVERLAYS (OverlayAlloc fails)
+    if (len >= 500) { d->log(2, "ERROR: CwindowBuf:OverlayInstall() overlay too large"); return 0; }   // MAX_OVERLAY
+    JsnoopDecoder::Overlay o; o.data.assign(data, data + len); o.begin = begin;
+    d->overlays.push_back(std::move(o)); return 1;
+}
+void jsnoop_overlay_remove_all(JsnoopDecoder* d) { d->overlays.clear(); }                                 // :585-593
+unsigned jsnoop_overlay_get_num(JsnoopDecoder* d) { return (unsigned)d->overlays.size(); }               // :618-621
+int jsnoop_overlay_get(JsnoopDecoder* d, unsigned ind, const uint8_t** data, unsigned* len, unsigned* begin)   // :607-617
+{
+    if (ind >= d->overlays.size()) return 0;
+    *data = d->overlays[ind].data.data(); *len = (unsigned)d->overlays[ind].data.size(); *begin = d->overlays[ind].begin; return 1;
+}
+
 void jsnoop_decode_scan_img(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned start, int display, int quiet)
 {
+    // CwindowBuf::Buf :639-660: an enabled overlay that covers an offset replaces the file's byte there, the last installed one
+    // winning -- applied to a private copy of the file image, in installation order
+    std::vector<uint8_t> patched;
+    if (!d->overlays.empty()) {
+        patched.assign(file, file + len);
+        for (const JsnoopDecoder::Overlay& o : d->overlays)
+            for (size_t i = 0; i < o.data.size(); i++) if ((size_t)o.begin + i < len) patched[(size_t)o.begin + i] = o.data[i];
+        file = patched.data();
+    }
     d->hist_latched = d->opt_histo_en != 0; d->clip_latched = d->opt_stat_clip_en != 0;      // :2740-2741
     jsnoop_reset(d);
     JsnoopBatch* b = d->batch;

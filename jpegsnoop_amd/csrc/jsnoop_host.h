@@ -26,7 +26,9 @@ struct JsnoopBatch;
 
 struct JsnoopDecoder {
     JsTables t;
-    int opt_decode_ac, opt_histo_en, opt_stat_clip_en; unsigned opt_err_max;
+    int opt_decode_ac, opt_histo_en, opt_stat_clip_en; unsigned opt_err_max; int opt_dump_histo_y = 0;
+    struct Overlay { std::vector<uint8_t> data; unsigned begin; };      // CwindowBuf overlays (WindowBuf.cpp:516-620)
+    std::vector<Overlay> overlays;
     jsnoop_log_fn log_fn; void* log_user;
     JsnoopBatch* batch;                         // private batch of one image (single-image API)
     unsigned preview_mode; int shift_y, shift_cb, shift_cr; unsigned shift_mcu_x, shift_mcu_y;

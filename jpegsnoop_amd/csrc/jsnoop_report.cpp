@@ -179,4 +179,13 @@ void js_emit_report(JsnoopDecoder* d, bool display, bool quiet)
         d->log(0, "    Next position in scan buffer: Offset 0x%08X.%u", sd[4], sd[5]);
         d->log(0, "");
     }
+    if (display && d->hist_latched && d->opt_dump_histo_y) {      // ReportHistogramY :3740-3741, :3845-3868: m_anHistoYFull, eight bins a line
+        const uint32_t* bins = d->stats + 434;
+        d->log(0, "  Y Histogram in DC: (DCT sums) Full");
+        for (unsigned row = 0; row < 2048 / 8; row++) {
+            char line[160]; int n = snprintf(line, sizeof line, "    Y=%5d..%5d: ", -1024 + (int)(row * 8), -1024 + (int)(row * 8) + 7);
+            for (unsigned col = 0; col < 8; col++) n += snprintf(line + n, sizeof line - (size_t)n, "0x%06x, ", bins[col + row * 8]);
+            d->log(0, "%s", line);
+        }
+    }
 }

@@ -112,6 +112,27 @@ class CimgDecode:
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         self._lib.jsnoop_lookup_blk_ycc(self._h, nBlkX, nBlkY, C.byref(a), C.byref(b), C.byref(c))
         return a.value, b.value, c.value
+    def PixelToMcu(self, nPixX, nPixY):
+        a, b = C.c_uint(), C.c_uint()
+        self._lib.jsnoop_pixel_to_mcu(self._h, nPixX, nPixY, C.byref(a), C.byref(b))
+        return a.value, b.value
+    def PixelToBlk(self, nPixX, nPixY):
+        a, b = C.c_uint(), C.c_uint()
+        self._lib.jsnoop_pixel_to_blk(self._h, nPixX, nPixY, C.byref(a), C.byref(b))
+        return a.value, b.value
+    def McuXyToLinear(self, nMcuX, nMcuY): return self._lib.jsnoop_mcu_xy_to_linear(self._h, nMcuX, nMcuY)
+    def SetDumpHistoY(self, bDumpHistoY): self._lib.jsnoop_set_dump_histo_y(self._h, int(bDumpHistoY))
+    # CwindowBuf overlays (source/WindowBuf.cpp:516-620): patched bytes seen by the next DecodeScanImg
+    def OverlayInstall(self, data: bytes, nBegin: int) -> bool:
+        buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(data or b"\0")
+        return bool(self._lib.jsnoop_overlay_install(self._h, C.cast(buf, C.c_void_p), len(data), nBegin))
+    def OverlayRemoveAll(self): self._lib.jsnoop_overlay_remove_all(self._h)
+    def OverlayGetNum(self): return self._lib.jsnoop_overlay_get_num(self._h)
+    def OverlayGet(self, nOvrInd):
+        p, n, b = C.c_void_p(), C.c_uint(), C.c_uint()
+        if not self._lib.jsnoop_overlay_get(self._h, nOvrInd, C.byref(p), C.byref(n), C.byref(b)):
+            return None
+        return bytes((C.c_uint8 * n.value).from_address(p.value)), b.value
     def SetPreviewMode(self, nMode): self._lib.jsnoop_set_preview_mode(self._h, nMode)
     def GetPreviewMode(self): return self._lib.jsnoop_get_preview_mode(self._h)
     def SetPreviewYccOffset(self, nMcuX, nMcuY, nY, nCb, nCr): self._lib.jsnoop_set_preview_ycc_offset(self._h, nMcuX, nMcuY, nY, nCb, nCr)
@@ -202,6 +223,41 @@ class JpegBatch:
 
     def algorithmic_bytes(self): return int(self._lib.jsnoop_batch_algorithmic_bytes(self._h))
     def pixels(self): return int(self._lib.jsnoop_batch_pixels(self._h))
+
+
+class JpegPipeline:
+    """Overlapped staging (the CwindowBuf replacement at batch scale): `slots` JpegBatch slots cycled by jsnoop_pipeline_run --
+    H2D of the next batch and, on request, D2H of the previous one overlap the decode of the current one."""
+
+    def __init__(self, slots=2):
+        self._lib = capi.load()
+        self._h = self._lib.jsnoop_pipeline_create(slots)
+        if not self._h:
+            raise RuntimeError("jsnoop_pipeline_create failed: " + capi.last_error())
+        self.slots = []
+        for i in range(slots):
+            b = JpegBatch.__new__(JpegBatch)
+            b._lib, b._h, b.want_planes, b._borrowed = self._lib, self._lib.jsnoop_pipeline_slot(self._h, i), False, True
+            self.slots.append(b)
+
+    def run(self, batches, d2h=False):
+        out = (C.c_double * 6)()
+        if self._lib.jsnoop_pipeline_run(self._h, batches, int(d2h), out) < 0:
+            raise RuntimeError("jsnoop_pipeline_run failed: " + capi.last_error())
+        return {"ms_per_batch": out[0], "h2d_ms": out[1], "decode_ms": out[2], "d2h_ms": out[3], "compressed_bytes": int(out[4]), "dib_bytes": int(out[5])}
+
+    def close(self):
+        if self._h:
+            for b in self.slots:
+                b._h = None                      # owned by the pipeline
+            self._lib.jsnoop_pipeline_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def dib_checksum_numpy(dib: np.ndarray) -> int:

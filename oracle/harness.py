@@ -243,6 +243,13 @@ class Backend:
         else:
             fn(C.c_void_p(self.h), int(decode_ac), int(histo_en), int(stat_clip_en), C.c_uint(err_max))
 
+    def set_dump_histo_y(self, on):
+        """bDumpHistoY: ReportHistogramY's 256 lines at the end of the decode log (reference and HIP library; the oracle keeps no log)."""
+        if self.prefix == "jsref_":
+            self.lib.jsref_set_dump_histo_y(int(on))
+        elif self.prefix == "jsnoop_":
+            self.lib.jsnoop_set_dump_histo_y(C.c_void_p(self.h), int(on))
+
     def close(self):
         if self.h:
             self._f("destroy")(C.c_void_p(self.h))

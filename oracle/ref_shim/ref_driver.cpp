@@ -46,6 +46,8 @@ void jsref_set_options(int decode_ac, int histo_en, int stat_clip_en, unsigned e
     c->nErrMaxDecodeScan = err_max;
 }
 
+void jsref_set_dump_histo_y(int on) { ShimConfig()->bDumpHistoY = on != 0; }      // CSnoopConfig::bDumpHistoY, read at ImgDecode.cpp:2730
+
 int jsref_set_dqt_entry(void* h, unsigned tbl, unsigned nat, unsigned zz, unsigned val)
 { return ((JsRef*)h)->dec->SetDqtEntry(tbl, nat, zz, (unsigned short)val); }
 int jsref_set_dqt_tables(void* h, unsigned comp, unsigned tbl)

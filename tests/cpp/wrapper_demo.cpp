@@ -33,8 +33,30 @@ int main(int argc, char** argv)
         for (int i = 0; i < 3; i++) core.BatchAddFile(bytes.data(), bytes.size());
         if (!core.DoBatchProcess()) { printf("batch_failed %s\n", jsnoop_last_error()); return 1; }
         std::vector<uint8_t> d2; unsigned bx, by;
-        core.I_GetBitmap(2, d2, bx, by);
+        core.BatchGetBitmap(2, d2, bx, by);
         printf("batch count=%u size=%ux%u dib_fnv=%016llx\n", core.GetBatchFileCount(), bx, by, (unsigned long long)fnv(d2.data(), d2.size()));
+        // the core facade: AnalyzeFile-shaped entry, I_* accessors, a byte overlay (the reference's fault-injection tool) and the re-decode
+        if (!core.AnalyzeFile(argv[1]) || !core.IsAnalyzed()) { printf("analyze_failed %s\n", jsnoop_last_error()); return 1; }
+        unsigned cx = 0, cy = 0; core.I_GetImageSize(cx, cy);
+        unsigned char* cdib = nullptr; core.I_GetBitmapPtr(cdib);
+        unsigned mx, my, kx, ky; core.I_PixelToMcu(100, 50, mx, my); core.I_PixelToBlk(100, 50, kx, ky);
+        unsigned fb, fbit; core.I_LookupFilePosPix(100, 50, fb, fbit);
+        int ly, lcb, lcr; core.I_LookupBlkYCC(kx, ky, ly, lcb, lcr);
+        short *cyp, *ccb, *ccr; core.I_GetPixMapPtrs(cyp, ccb, ccr);
+        printf("core ready=%d size=%ux%u dib_fnv=%016llx mcu=%u,%u lin=%u blk=%u,%u pos=%u.%u ycc=%d,%d,%d dqt=%u mode=%u y0=%d\n", (int)core.I_IsPreviewReady(), cx, cy,
+               (unsigned long long)(cdib ? fnv(cdib, (size_t)cx * cy * 4) : 0), mx, my, core.I_McuXyToLinear(mx, my), kx, ky, fb, fbit, ly, lcb, lcr,
+               core.I_GetDqtEntry(0, 0), core.I_GetPreviewMode(), cyp ? cyp[0] : 0);
+        if (argc > 3) {                                          // overlay: argv[2] = file offset, argv[3] = hex bytes
+            std::vector<uint8_t> ov; for (const char* h = argv[3]; h[0] && h[1]; h += 2) { unsigned v; sscanf(h, "%2x", &v); ov.push_back((uint8_t)v); }
+            const unsigned at = (unsigned)strtoul(argv[2], nullptr, 0);
+            const bool ok = core.B_OverlayInstall(0, ov.data(), (unsigned)ov.size(), at);
+            const uint8_t seen = core.B_Buf(at), clean = core.B_Buf(at, true);
+            core.ReprocessFile();
+            core.I_GetBitmapPtr(cdib);
+            printf("overlay installed=%d seen=%02x clean=%02x dib_fnv=%016llx\n", (int)ok, seen, clean, (unsigned long long)(cdib ? fnv(cdib, (size_t)cx * cy * 4) : 0));
+            core.B_OverlayRemoveAll(); core.ReprocessFile(); core.I_GetBitmapPtr(cdib);
+            printf("restored dib_fnv=%016llx\n", (unsigned long long)(cdib ? fnv(cdib, (size_t)cx * cy * 4) : 0));
+        }
     } catch (const std::exception& e) { printf("exception %s\n", e.what()); return 3; }
     return 0;
 }

@@ -35,7 +35,13 @@ def test_wrapper_decodes_like_the_oracle(harness, oracle, tmp_path):
     data = harness.synth_jpeg(width=333, height=217, seed=77)
     p = tmp_path / "x.jpg"
     p.write_bytes(data)
-    out = subprocess.check_output([EXE, str(p)], text=True)
+    # a byte overlay in the middle of the entropy-coded segment (the reference's fault-injection tool, source/WindowBuf.cpp:516-590)
+    at = len(data) // 2
+    patch = bytes([data[at] ^ 0x5A, data[at + 1] ^ 0x33, 0x00]) if data[at + 1] != 0xFF else bytes([0x12, 0x34, 0x56])
+    out = subprocess.check_output([EXE, str(p), str(at), patch.hex()], text=True)
+    patched = bytearray(data); patched[at:at + len(patch)] = patch
+    harness.drive(oracle, bytes(patched))
+    want_patched = "%016x" % harness.fnv1a64(oracle.dib().tobytes())
     harness.drive(oracle, data)
     want = "%016x" % harness.fnv1a64(oracle.dib().tobytes())
     lines = dict(l.split(" ", 1) for l in out.strip().splitlines())
@@ -44,3 +50,13 @@ def test_wrapper_decodes_like_the_oracle(harness, oracle, tmp_path):
     mm = oracle.mcu_map()[0, 0]
     assert f"mcu0={mm >> 4}.{mm & 7}" in lines["single"]
     assert f"dib_fnv={want}" in lines["batch"] and "count=3" in lines["batch"]
+    # the CJPEGsnoopCore facade: AnalyzeFile, I_* accessors, overlay + re-decode
+    core = lines["core"]
+    assert f"dib_fnv={want}" in core and "ready=1" in core and "size=336x224" in core
+    assert "mcu=6,3 lin=%d blk=12,6" % (3 * 21 + 6) in core                   # 100 / 16, 50 / 16; 21 MCUs across; 100 / 8, 50 / 8
+    mm = oracle.mcu_map()[3, 6]
+    assert f"pos={mm >> 4}.{mm & 7}" in core
+    bd = oracle.blk_dc(); y, cb, cr = int(bd[0][6, 12]), int(bd[1][6, 12]), int(bd[2][6, 12])
+    assert f"ycc={y},{cb},{cr} " in core and "mode=1" in core
+    assert f"installed=1 seen={patch[0]:02x} clean={data[at]:02x} dib_fnv={want_patched}" in lines["overlay"]
+    assert want_patched != want and f"dib_fnv={want}" in lines["restored"]

@@ -95,3 +95,29 @@ def test_two_batches_two_streams_two_host_threads(harness, oracle):
     for t in ts:
         t.join()
     assert not errors, errors[:5]
+
+
+def test_staging_pipeline_overlaps_and_stays_exact(harness, oracle):
+    """Two slots cycled by jsnoop_pipeline_run (H2D of the next batch while the current one decodes, D2H of the previous one on
+    request): every slot's DIBs equal the oracle's afterwards, and the overlapped time per batch is below the sum of its pieces."""
+    import jpegsnoop_amd as J
+    files = [harness.synth_jpeg(width=1280, height=720, seed=300 + i) for i in range(4)]
+    want = []
+    for f in files:
+        harness.drive(oracle, f)
+        want.append(J.dib_checksum_numpy(oracle.dib()))
+    pipe = J.JpegPipeline(2)
+    for b in pipe.slots:
+        for f in files:
+            b.add_jpeg(f)
+        b.tile(128)
+    r2 = pipe.run(6, d2h=False)
+    r3 = pipe.run(3, d2h=True)
+    for b in pipe.slots:
+        sums = b.dib_checksums()
+        assert all(int(sums[i]) == want[i % 4] for i in range(128))
+        assert all(b.info(i)["flags"] == 0 for i in range(128))
+    assert r2["h2d_ms"] > 0 and r2["decode_ms"] > 0 and r3["d2h_ms"] > 0
+    assert r2["ms_per_batch"] < 0.95 * (r2["h2d_ms"] + r2["decode_ms"]), r2          # the transfer hides behind the decode (or the other way round)
+    assert r3["ms_per_batch"] < 0.95 * (r3["h2d_ms"] + r3["decode_ms"] + r3["d2h_ms"]), r3
+    pipe.close()

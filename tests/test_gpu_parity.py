@@ -285,6 +285,27 @@ def test_decode_log_text(harness, gpu):
     assert not bad, "\n".join(bad[:25]) + f"\n... {len(bad)} mismatching logs"
 
 
+def test_decode_log_text_with_y_histogram_dump(harness, gpu):
+    """bDumpHistoY (one of the five CSnoopConfig fields that reach DecodeScanImg, :2730): with bHistoEn the log ends with
+    ReportHistogramY's 256 lines of the 2048-bin Y histogram (:3740-3741, :3845-3868) -- whole log, line for line, against what the
+    compiled reference wrote (tests/golden/histo_dump.json, tests/golden/make_histo_dump.py)."""
+    import json, os
+    from golden_util import load_case
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "histo_dump.json")))
+    try:
+        for name, lines in want.items():
+            gpu.set_options(decode_ac=1, histo_en=1)
+            gpu.set_dump_histo_y(1)
+            harness.drive(gpu, load_case(name), quiet=0)
+            got = gpu.log_lines()
+            assert len(lines) > 300 and got == lines, (name, next((i, a, b) for i, (a, b) in enumerate(zip(got + [None], lines + [None])) if a != b))
+            gpu.set_dump_histo_y(0)
+            harness.drive(gpu, load_case(name), quiet=0)
+            assert not any("Y Histogram in DC" in l for l in gpu.log_lines())
+    finally:
+        gpu.set_dump_histo_y(0); gpu.set_options()
+
+
 def test_histogram_path(harness, oracle, gpu):
     """bHistoEn / bStatClipEn colour statistics: the committed records of the compiled reference,
     then the oracle on fresh streams (incl. corrupted ones whose DC drift trips the YCC range checks and their
