@@ -26,6 +26,9 @@ void js_set_error(const char* fmt, ...)
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
     js_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return -1; } } while (0)
 
+// for the void entry points (the reference's getters return nothing): a failed device call is recorded for jsnoop_last_error()
+#define HIP_NOTE(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) js_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
 static thread_local int g_device = 0;        // jsnoop_set_device is per host thread (one thread per GPU is the natural use of the C ABI)
 
 static const uint8_t kZigZag[64] = {
@@ -288,6 +291,7 @@ template <class T> static int grow(T** p, size_t* cap, size_t need_bytes)
 }
 int JsnoopBatch::upload()
 {
+    JsRange r_("jsnoop:upload (pinned H2D + descriptors)");
     HIP_TRY(hipSetDevice(device));
     const size_t n = imgs.size();
     if (!n) { js_set_error("upload: empty batch"); return -1; }
@@ -357,6 +361,7 @@ int JsnoopBatch::decode(bool timed)
     HIP_TRY(hipSetDevice(device));
     if (!uploaded && upload()) return -1;
     const uint32_t n = (uint32_t)imgs.size();
+    JsRange r_("jsnoop:decode (enqueue)");
     if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
     bool parallel_ok = !opt_force_exact; if (parallel_ok) { parallel_ok = false; for (const JsTableSet& t : tables) parallel_ok = parallel_ok || t.lut_ok; }
     if (!parallel_ok) {           // the exact-mirror kernel stores only what it decodes; the parallel path writes every block whole
@@ -375,7 +380,7 @@ int JsnoopBatch::decode(bool timed)
     if (timed && !used_parallel) for (int s = 2; s <= 6; s++) HIP_TRY(hipEventRecord(ev[s], stream));
     if (!used_parallel) js_launch_entropy_exact(stream, dev.imgs, nullptr, n, dev.tables, dev.raw, dev.coef, dev.dccum, dev.side, 0, event_words ? dev.events : nullptr);
     if (timed) HIP_TRY(hipEventRecord(ev[7], stream));
-    if (launch_back_end(n)) return -1;
+    { JsRange r2_("jsnoop:idct+colour"); if (launch_back_end(n)) return -1; }
     if (timed) HIP_TRY(hipEventRecord(ev[8], stream));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -391,6 +396,7 @@ int JsnoopBatch::launch_back_end(uint32_t nimg)
 }
 int JsnoopBatch::sync()
 {
+    JsRange r_("jsnoop:sync (wait + exact-path fix-up)");
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamSynchronize(stream));
     return js_parallel_fixup(this);     // re-decodes flagged images on the exact path (no-op when none)
@@ -601,7 +607,7 @@ void jsnoop_bright_avg(JsnoopDecoder* d, int* o)
     {   // RGB of the brightest pixel through the device colour routine (:4805-4811)
         JsnoopBatch* b = d->batch; uint32_t bgra = 0; hipSetDevice(b->device);
         js_launch_color_probe(b->stream, o[1], o[2], o[3], (uint32_t*)b->dev.probe);
-        hipMemcpyAsync(&bgra, b->dev.probe, 4, hipMemcpyDeviceToHost, b->stream); hipStreamSynchronize(b->stream);
+        HIP_NOTE(hipMemcpyAsync(&bgra, b->dev.probe, 4, hipMemcpyDeviceToHost, b->stream)); HIP_NOTE(hipStreamSynchronize(b->stream));
         o[4] = (bgra >> 16) & 255; o[5] = (bgra >> 8) & 255; o[6] = bgra & 255;
     }
     unsigned long npix = (unsigned)((im.img_y + 1) * (im.img_x + 1)); if (!npix) npix = 1;
@@ -613,10 +619,10 @@ void jsnoop_idct_block(JsnoopDecoder* d, const int16_t* coef64, float* out64)
 {
     JsnoopBatch* b = d->batch; hipSetDevice(b->device);
     size_t c = b->cap.probe; if (grow(&b->dev.probe, &c, 1024)) return; b->cap.probe = c;
-    hipMemcpyAsync(b->dev.probe, coef64, 128, hipMemcpyHostToDevice, b->stream);
+    HIP_NOTE(hipMemcpyAsync(b->dev.probe, coef64, 128, hipMemcpyHostToDevice, b->stream));
     js_launch_idct_probe(b->stream, b->d_lut, (const int16_t*)b->dev.probe, (float*)(b->dev.probe + 256));
-    hipMemcpyAsync(out64, b->dev.probe + 256, 256, hipMemcpyDeviceToHost, b->stream);
-    hipStreamSynchronize(b->stream);
+    HIP_NOTE(hipMemcpyAsync(out64, b->dev.probe + 256, 256, hipMemcpyDeviceToHost, b->stream));
+    HIP_NOTE(hipStreamSynchronize(b->stream));
 }
 int jsnoop_color_sweep(JsnoopDecoder* d, uint32_t* out_bgra)
 {
@@ -734,6 +740,7 @@ int JsnoopBatch::read_dib(int i, uint8_t* dst)
 {
     if (i < 0 || (size_t)i >= imgs.size()) { js_set_error("image index out of range"); return -1; }
     const JsImage& im = imgs[i];
+    JsRange r_("jsnoop:read_dib (D2H)");
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipMemcpyAsync(dst, dev.dib + im.dib_off, (size_t)im.img_x * im.img_y * 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -759,8 +766,8 @@ void JsnoopDecoder::fetch_side()
     const JsImage& im = batch->imgs[0];
     h_side.assign(js_side_words(im.mcu_xmax * im.mcu_ymax, im.blk_xmax * im.blk_ymax), 0);
     hipSetDevice(batch->device);
-    hipMemcpyAsync(h_side.data(), batch->dev.side + im.side_off, h_side.size() * 4, hipMemcpyDeviceToHost, batch->stream);
-    hipStreamSynchronize(batch->stream);
+    HIP_NOTE(hipMemcpyAsync(h_side.data(), batch->dev.side + im.side_off, h_side.size() * 4, hipMemcpyDeviceToHost, batch->stream));
+    HIP_NOTE(hipStreamSynchronize(batch->stream));
 }
 void JsnoopDecoder::rerender()                                  // CalcChannelPreview :4965 on the retained data: colour kernel only
 {
@@ -768,8 +775,8 @@ void JsnoopDecoder::rerender()                                  // CalcChannelPr
     JsnoopBatch* b = batch; JsImage& im = b->imgs[0];
     im.preview_mode = preview_mode; im.shift_y = shift_y; im.shift_cb = shift_cb; im.shift_cr = shift_cr; im.shift_mcu_x = shift_mcu_x; im.shift_mcu_y = shift_mcu_y;
     hipSetDevice(b->device);
-    hipMemcpyAsync(b->dev.imgs, &im, sizeof im, hipMemcpyHostToDevice, b->stream);
-    hipMemsetAsync(b->dev.side + im.side_off + 12, 0, 16, b->stream);      // brightest-pixel key and sum of Y are recomputed
+    HIP_NOTE(hipMemcpyAsync(b->dev.imgs, &im, sizeof im, hipMemcpyHostToDevice, b->stream));
+    HIP_NOTE(hipMemsetAsync(b->dev.side + im.side_off + 12, 0, 16, b->stream));      // brightest-pixel key and sum of Y are recomputed
     if (b->launch_back_end(1)) log(2, "*** ERROR: device re-render failed: %s", g_err.c_str());
     hipStreamSynchronize(b->stream);
     host_valid = 0; fetch_side();

@@ -102,6 +102,10 @@ struct JsnoopBatch {
 };
 
 void js_set_error(const char* fmt, ...);
+// roctx ranges around the host-side stages (rocprofv3 --marker-trace makes a timeline self-describing: upload / clear / entropy
+// stages / back end / read-back).  One push and pop per stage and call: nothing per image.
+#include <rocprofiler-sdk-roctx/roctx.h>
+struct JsRange { explicit JsRange(const char* name) { roctxRangePushA(name); } ~JsRange() { roctxRangePop(); } };
 bool js_geometry(JsnoopDecoder* d, JsImage* im);
 bool js_describe_image(JsnoopDecoder* d, JsImage* im, JsTableSet* ts, uint32_t file_len, uint32_t scan_start, int display, int quiet);
 void js_emit_decode_events(JsnoopDecoder* d);                      // jsnoop_report.cpp

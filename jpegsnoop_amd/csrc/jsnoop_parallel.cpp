@@ -239,18 +239,24 @@ int js_parallel_entropy(JsnoopBatch* b, bool timed)
     for (const JsTableSet& t : b->tables) any = any || t.lut_ok;
     if (!any) return 0;
     uint32_t* sub = (uint32_t*)b->dev.sub;
+    roctxRangePushA("jsnoop:unstuff");
     js_launch_unstuff(b->stream, b->sub_wl, b->dev.imgs, b->dev.us_base, n, b->us_chunks, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst,
                       b->dev.ustr_lin, b->dev.ustr, b->dev.seg, b->dev.side, b->dev.flags, b->dev.sy_base, b->sy_wgs);
+    roctxRangePop();
     if (timed) HIP_TRY(hipEventRecord(b->ev[2], b->stream));
+    roctxRangePushA("jsnoop:sub-sequence sync");
     for (int l = 0; l < b->sync_launches; l++)
         js_launch_sync(b->stream, b->sub_wl, b->tab_rows, b->tab_lut2, b->dev.imgs, b->dev.sy_base + (n + 1), n, b->sn_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, l == 0);
+    roctxRangePop();
     if (timed) HIP_TRY(hipEventRecord(b->ev[3], b->stream));
+    roctxRangePushA("jsnoop:block scan + coefficient write + DC scan");
     js_launch_block_scan(b->stream, b->sub_wl, b->dev.imgs, n, b->dev.tables, sub, b->total_subseq, b->dev.side, b->dev.flags);
     if (timed) HIP_TRY(hipEventRecord(b->ev[4], b->stream));
     js_launch_write(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
                     b->dev.coef, b->dev.dccum, b->dev.mcu_rst, b->dev.flags);
     if (timed) HIP_TRY(hipEventRecord(b->ev[5], b->stream));
     js_launch_dc_scan(b->stream, b->dev.imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst);
+    roctxRangePop();
     if (timed) { HIP_TRY(hipEventRecord(b->ev[6], b->stream)); }
     return 1;
 }

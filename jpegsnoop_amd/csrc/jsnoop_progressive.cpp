@@ -191,12 +191,12 @@ extern "C" int jsnoop_decode_progressive(JsnoopDecoder* d, const uint8_t* f, siz
     }
     JsProgTable* d_tabs = (JsProgTable*)b->prog_buf; JsProgSeg* d_segs = (JsProgSeg*)((uint8_t*)b->prog_buf + tab_bytes);
     uint32_t* d_status = (uint32_t*)((uint8_t*)b->prog_buf + tab_bytes + seg_bytes);
-    hipMemcpyAsync(d_tabs, tabs.data(), tabs.size() * sizeof(JsProgTable), hipMemcpyHostToDevice, b->stream);
-    hipMemcpyAsync(d_segs, segs.data(), segs.size() * sizeof(JsProgSeg), hipMemcpyHostToDevice, b->stream);
-    hipMemsetAsync(d_status, 0, 16, b->stream);
-    hipMemsetAsync(b->dev.coef + dim.coef_off * 64, 0, (size_t)dim.total_blocks * 128, b->stream);
-    hipMemsetAsync(b->dev.dccum + dim.coef_off, 0, (size_t)dim.total_blocks * 2, b->stream);
-    hipMemsetAsync(b->dev.side, 0, b->side_words * 4, b->stream);
+    HIP_TRY(hipMemcpyAsync(d_tabs, tabs.data(), tabs.size() * sizeof(JsProgTable), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(d_segs, segs.data(), segs.size() * sizeof(JsProgSeg), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemsetAsync(d_status, 0, 16, b->stream));
+    HIP_TRY(hipMemsetAsync(b->dev.coef + dim.coef_off * 64, 0, (size_t)dim.total_blocks * 128, b->stream));
+    HIP_TRY(hipMemsetAsync(b->dev.dccum + dim.coef_off, 0, (size_t)dim.total_blocks * 2, b->stream));
+    HIP_TRY(hipMemsetAsync(b->dev.side, 0, b->side_words * 4, b->stream));
     // Scans that touch different coefficients are independent (a DC scan: slot 0 of its components; an AC scan, first or
     // refinement: its band of one component, read and written by position).  Levels of the dependency order run one after the other, the scans of a level side by side on
     // helper streams: a kernel of a few dozen single-lane decoders leaves the chip empty.

@@ -23,8 +23,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF_SO = os.path.join(HERE, "_ref", "libjsnoop_ref.so")
-ORC_SO = os.path.join(HERE, "liboracle_imgdecode.so")
-SYNTH_SO = os.path.join(HERE, "libjsnoop_synth.so")
+_ALT = os.environ.get("JSNOOP_ORACLE_DIR")              # sanitizer builds of the checker libraries (tools/sanitize/run_sanitizers.sh)
+ORC_SO = os.path.join(_ALT or HERE, "liboracle_imgdecode.so")
+SYNTH_SO = os.path.join(_ALT or HERE, "libjsnoop_synth.so")
 
 ZIGZAG = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34,
           27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
