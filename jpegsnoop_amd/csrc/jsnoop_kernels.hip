@@ -1499,20 +1499,22 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
     if (valid && !halo) { A.out_p[gs] = s_outp[t]; A.out_s[gs] = s_outs[t]; A.in_p[gs] = s_inp[t]; A.in_s[gs] = s_ins[t]; A.nblk[gs] = s_nblk[t]; }
 }
 
-// One workgroup per image: exclusive scan of blocks-per-sub-sequence.
-template <int WL>
-__global__ void __launch_bounds__(256) k_block_scan(const JsImage* __restrict__ imgs, const JsTableSet* __restrict__ tables,
-                                                    SubArrays A, uint32_t* side, uint32_t* __restrict__ flags)
+// One workgroup per image: exclusive scan of blocks-per-sub-sequence.  THREADS = 256 for batches (one workgroup per image, many
+// images), 1024 for small jobs (a single large image: a quarter of the serial steps).
+template <int WL, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_block_scan(const JsImage* __restrict__ imgs, const JsTableSet* __restrict__ tables,
+                                                        SubArrays A, uint32_t* side, uint32_t* __restrict__ flags)
 {
     const uint32_t img = blockIdx.x; const JsImage& im = imgs[img];
     if (!tables[im.tableset].lut_ok) { if (threadIdx.x == 0) atomicOr(&flags[img], 0x0020u); return; }
     const uint32_t total_bits = side[im.side_off + 10] * 8;
     const uint32_t n = min(im.n_subseq, (total_bits + SUB_BITS - 1) / SUB_BITS);
-    // 256 sub-sequences per step: inclusive scan inside each wave (shuffles), the four wave totals through LDS, a running carry
-    __shared__ uint32_t s_w[2][4];
+    // THREADS sub-sequences per step: inclusive scan inside each wave (shuffles), the wave totals through LDS, a running carry
+    constexpr uint32_t NW = THREADS / 64;
+    __shared__ uint32_t s_w[2][NW];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t run = 0, par = 0;
-    for (uint32_t b = 0; b < n; b += 256, par ^= 1u) {
+    for (uint32_t b = 0; b < n; b += THREADS, par ^= 1u) {
         const uint32_t i = b + threadIdx.x; const uint32_t v = i < n ? A.nblk[im.subseq_off + i] : 0;
         uint32_t inc = v;
         #pragma unroll
@@ -1520,7 +1522,7 @@ __global__ void __launch_bounds__(256) k_block_scan(const JsImage* __restrict__ 
         if (lane == 63) s_w[par][wave] = inc;
         __syncthreads();                                          // (the other parity's slots are rewritten one step later: one barrier per step)
         uint32_t pre = 0, tot = 0;
-        for (uint32_t w = 0; w < 4; w++) { const uint32_t x = s_w[par][w]; if (w < wave) pre += x; tot += x; }
+        for (uint32_t w = 0; w < NW; w++) { const uint32_t x = s_w[par][w]; if (w < wave) pre += x; tot += x; }
         if (i < n) A.base[im.subseq_off + i] = run + pre + inc - v;
         run += tot;
     }
@@ -1711,15 +1713,18 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
 #define DC_THREADS 1024
 struct DcSeg { int s0, s1, s2; int r; };                            // sums since the last reset inside the span, reset seen
 __device__ __forceinline__ DcSeg dc_combine(const DcSeg& a, const DcSeg& b) { DcSeg o; if (b.r) o = b; else { o.s0 = a.s0 + b.s0; o.s1 = a.s1 + b.s1; o.s2 = a.s2 + b.s2; o.r = a.r; } return o; }
-template <int NBMAX>                                                 // blocks per MCU this instance is unrolled for
-__device__ __forceinline__ void dc_scan_image(const JsImage& im, int16_t* __restrict__ d, const uint8_t* __restrict__ rf, DcSeg* s_w)
+// MCUs [m_begin, m_end) of the image; `carry` = the sums that enter m_begin.  WRITE: store the cumulative values; else only
+// summarise the range (sums since its last reset, reset seen) into *summary -- the first level of the two-level scan of small jobs.
+template <int NBMAX, bool WRITE>                                     // blocks per MCU this instance is unrolled for
+__device__ __forceinline__ void dc_scan_range(const JsImage& im, int16_t* __restrict__ d, const uint8_t* __restrict__ rf, DcSeg* s_w,
+                                              uint32_t m_begin, uint32_t m_end, DcSeg carry, DcSeg* summary)
 {
-    const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax, nb = im.blk_per_mcu;
+    const uint32_t nb = im.blk_per_mcu;
     const uint32_t n1 = im.samp_h[1] * im.samp_v[1], n2 = im.ncomp == 3 ? n1 + im.samp_h[2] * im.samp_v[2] : nb;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    DcSeg carry = { 0, 0, 0, 0 };
-    for (uint32_t base = 0; base < nmcu; base += DC_THREADS) {
-        const uint32_t m = base + t; const bool valid = m < nmcu;
+    int any_reset = 0;
+    for (uint32_t base = m_begin; base < m_end; base += DC_THREADS) {
+        const uint32_t m = base + t; const bool valid = m < m_end;
         int v[NBMAX];
         DcSeg own = { 0, 0, 0, valid && rf[m] ? 1 : 0 };
         #pragma unroll
@@ -1740,7 +1745,7 @@ __device__ __forceinline__ void dc_scan_image(const JsImage& im, int16_t* __rest
         inc = dc_combine(pre, inc);
         // sums entering this MCU: nothing after a reset, else the inclusive result minus the MCU's own contribution
         int c0 = own.r ? 0 : inc.s0 - own.s0, c1 = own.r ? 0 : inc.s1 - own.s1, c2 = own.r ? 0 : inc.s2 - own.s2;
-        if (valid) {
+        if (WRITE && valid) {
             #pragma unroll
             for (uint32_t c = 0; c < NBMAX; c++) if (c < nb) {
                 int16_t o;
@@ -1748,9 +1753,11 @@ __device__ __forceinline__ void dc_scan_image(const JsImage& im, int16_t* __rest
                 d[(size_t)m * nb + c] = o;
             }
         }
+        any_reset |= tot.r;
         carry = tot; carry.r = 0;
         __syncthreads();
     }
+    if (!WRITE && t == 0) { carry.r = any_reset; *summary = carry; }
 }
 __global__ void __launch_bounds__(DC_THREADS) k_dc_scan(const JsImage* __restrict__ imgs, const JsTableSet* __restrict__ tables,
                                                         int16_t* __restrict__ dccum, const uint8_t* __restrict__ mcu_rst)
@@ -1759,8 +1766,31 @@ __global__ void __launch_bounds__(DC_THREADS) k_dc_scan(const JsImage* __restric
     if (!tables[im.tableset].lut_ok) return;
     __shared__ DcSeg s_w[DC_THREADS / 64];
     int16_t* d = dccum + im.coef_off; const uint8_t* rf = mcu_rst + im.mcu_off;
-    if (im.blk_per_mcu <= 6) dc_scan_image<6>(im, d, rf, s_w);   // 4:4:4, 4:2:2, 4:2:0, grayscale: a short unrolled body
-    else dc_scan_image<JS_MAX_BLK_PER_MCU>(im, d, rf, s_w);
+    const DcSeg zero = { 0, 0, 0, 0 };
+    if (im.blk_per_mcu <= 6) dc_scan_range<6, true>(im, d, rf, s_w, 0, im.mcu_xmax * im.mcu_ymax, zero, nullptr);   // 4:4:4, 4:2:2, 4:2:0, grayscale: a short unrolled body
+    else dc_scan_range<JS_MAX_BLK_PER_MCU, true>(im, d, rf, s_w, 0, im.mcu_xmax * im.mcu_ymax, zero, nullptr);
+}
+// Small jobs (a single large image): the MCUs of an image are cut into DC_PARTS_MAX ranges, one workgroup each.  Level 1
+// (apply = 0) summarises every range; level 2 (apply = 1) folds the summaries of the ranges before its own into the sums that
+// enter it and writes.  Two launches instead of one serial pass of nmcu / 1024 steps.
+#define DC_PARTS_MAX 64
+__global__ void __launch_bounds__(DC_THREADS) k_dc_scan_parts(const JsImage* __restrict__ imgs, const JsTableSet* __restrict__ tables,
+                                                              int16_t* __restrict__ dccum, const uint8_t* __restrict__ mcu_rst, DcSeg* __restrict__ summaries, int apply)
+{
+    const uint32_t img = blockIdx.y, part = blockIdx.x; const JsImage& im = imgs[img];
+    if (!tables[im.tableset].lut_ok) return;
+    const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax;
+    const uint32_t per = ((nmcu + DC_PARTS_MAX - 1) / DC_PARTS_MAX + DC_THREADS - 1) / DC_THREADS * DC_THREADS;   // whole steps per range
+    const uint32_t m0 = part * per, m1 = min(nmcu, m0 + per);
+    DcSeg* sm = summaries + (size_t)img * DC_PARTS_MAX;
+    if (m0 >= nmcu) { if (!apply && threadIdx.x == 0) { const DcSeg z = { 0, 0, 0, 0 }; sm[part] = z; } return; }
+    __shared__ DcSeg s_w[DC_THREADS / 64];
+    int16_t* d = dccum + im.coef_off; const uint8_t* rf = mcu_rst + im.mcu_off;
+    DcSeg carry = { 0, 0, 0, 0 };
+    if (apply) { for (uint32_t q = 0; q < part; q++) carry = dc_combine(carry, sm[q]); carry.r = 0; }
+    const bool small = im.blk_per_mcu <= 6;
+    if (!apply) { if (small) dc_scan_range<6, false>(im, d, rf, s_w, m0, m1, carry, sm + part); else dc_scan_range<JS_MAX_BLK_PER_MCU, false>(im, d, rf, s_w, m0, m1, carry, sm + part); }
+    else        { if (small) dc_scan_range<6, true>(im, d, rf, s_w, m0, m1, carry, nullptr);  else dc_scan_range<JS_MAX_BLK_PER_MCU, true>(im, d, rf, s_w, m0, m1, carry, nullptr); }
 }
 
 void js_launch_unstuff(hipStream_t st, int wl, const JsImage* imgs, const uint32_t* us_base, uint32_t nimg, uint32_t total_chunks, const uint8_t* raw,
@@ -1789,8 +1819,11 @@ void js_launch_sync(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2
 void js_launch_block_scan(hipStream_t st, int wl, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, uint32_t* sub, uint64_t nsub, uint32_t* side, uint32_t* flags)
 {
     if (!nimg) return;
-    if (wl == 7) hipLaunchKernelGGL(k_block_scan<7>, dim3(nimg), dim3(256), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
-    else hipLaunchKernelGGL(k_block_scan<5>, dim3(nimg), dim3(256), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
+    if (nimg <= 8) {                                             // a few (large) images: wide workgroups, fewer serial steps
+        if (wl == 7) hipLaunchKernelGGL((k_block_scan<7, 1024>), dim3(nimg), dim3(1024), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
+        else hipLaunchKernelGGL((k_block_scan<5, 1024>), dim3(nimg), dim3(1024), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
+    } else if (wl == 7) hipLaunchKernelGGL((k_block_scan<7, 256>), dim3(nimg), dim3(256), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
+    else hipLaunchKernelGGL((k_block_scan<5, 256>), dim3(nimg), dim3(256), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
 }
 void js_launch_write(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
                      const uint8_t* ustr, const uint32_t* seg_tab, uint32_t* side, uint32_t* sub, uint64_t nsub,
@@ -1937,5 +1970,11 @@ void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab
                        sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos);
     hipLaunchKernelGGL(k_side_maps, dim3(64), dim3(256), 0, st, imgs, img, tables, raw, seg_tab, dccum, mcu_rst, mcu_pos, us_out, us_wgs * US_THREADS, side, events);
 }
-void js_launch_dc_scan(hipStream_t st, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, int16_t* dccum, const uint8_t* mcu_rst)
-{ if (nimg) hipLaunchKernelGGL(k_dc_scan, dim3(nimg), dim3(DC_THREADS), 0, st, imgs, tables, dccum, mcu_rst); }
+void js_launch_dc_scan(hipStream_t st, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, int16_t* dccum, const uint8_t* mcu_rst, void* parts_scratch)
+{
+    if (!nimg) return;
+    if (parts_scratch && nimg <= JS_DC_PARTS_IMAGES) {           // small job: two-level scan, DC_PARTS_MAX workgroups per image
+        hipLaunchKernelGGL(k_dc_scan_parts, dim3(DC_PARTS_MAX, nimg), dim3(DC_THREADS), 0, st, imgs, tables, dccum, mcu_rst, (DcSeg*)parts_scratch, 0);
+        hipLaunchKernelGGL(k_dc_scan_parts, dim3(DC_PARTS_MAX, nimg), dim3(DC_THREADS), 0, st, imgs, tables, dccum, mcu_rst, (DcSeg*)parts_scratch, 1);
+    } else hipLaunchKernelGGL(k_dc_scan, dim3(nimg), dim3(DC_THREADS), 0, st, imgs, tables, dccum, mcu_rst);
+}

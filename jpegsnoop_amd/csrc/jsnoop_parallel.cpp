@@ -255,7 +255,7 @@ int js_parallel_entropy(JsnoopBatch* b, bool timed)
     js_launch_write(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
                     b->dev.coef, b->dev.dccum, b->dev.mcu_rst, b->dev.flags);
     if (timed) HIP_TRY(hipEventRecord(b->ev[5], b->stream));
-    js_launch_dc_scan(b->stream, b->dev.imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst);
+    js_launch_dc_scan(b->stream, b->dev.imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst, b->dev.dc_parts);
     roctxRangePop();
     if (timed) { HIP_TRY(hipEventRecord(b->ev[6], b->stream)); }
     return 1;
@@ -297,7 +297,7 @@ static int js_parallel_resume(JsnoopBatch* b, int extra_launches)
     js_launch_block_scan(b->stream, b->sub_wl, b->dev.imgs, n, b->dev.tables, sub, b->total_subseq, b->dev.side, b->dev.flags);
     js_launch_write(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
                     b->dev.coef, b->dev.dccum, b->dev.mcu_rst, b->dev.flags);
-    js_launch_dc_scan(b->stream, b->dev.imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst);
+    js_launch_dc_scan(b->stream, b->dev.imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst, b->dev.dc_parts);
     if (b->launch_back_end(n)) return -1;
     HIP_TRY(hipMemcpyAsync(b->host_flags.data(), b->dev.flags, (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
