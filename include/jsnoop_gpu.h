@@ -202,6 +202,10 @@ int          jsnoop_batch_add(JsnoopBatch*, const JsnoopDecoder* tables, const u
 /* Adds one JPEG file image, walking its header with the built-in minimal JFIF front
  * end (the subset of CjfifDecode::DecodeMarker that feeds CimgDecode).               */
 int          jsnoop_batch_add_jpeg(JsnoopBatch*, const uint8_t* file, size_t len);
+/* A progressive (SOF2) file into a batch -- jsnoop_batch_add_jpeg routes such files here by itself.  A batch holds either
+ * baseline or progressive files; all scans of all its images then decode together, one launch per dependency level
+ * (every restart interval of every scan of every image is one lane), then one finalize pass and the common back end.      */
+int          jsnoop_batch_add_progressive(JsnoopBatch*, const uint8_t* file, size_t len);
 /* Tiles already-added images so the batch holds `total` images (image i reuses the
  * bytes of image i % n): the bench's "N distinct seeds tiled to 1024".               */
 int          jsnoop_batch_tile(JsnoopBatch*, int total);

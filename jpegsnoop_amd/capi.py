@@ -99,6 +99,7 @@ SIGNATURES = {
     "jsnoop_batch_color_stats": (_i, [_p, _i, _i, _p]),
     "jsnoop_batch_dib_hashes": (_i, [_p, _p]),
     "jsnoop_batch_algorithmic_bytes": (C.c_uint64, [_p]),
+    "jsnoop_batch_add_progressive": (_i, [_p, _p, _sz]),
     "jsnoop_pipeline_create": (_p, [_i]),
     "jsnoop_pipeline_destroy": (None, [_p]),
     "jsnoop_pipeline_slot": (_p, [_p, _i]),

@@ -191,7 +191,7 @@ JsnoopBatch::~JsnoopBatch()
                       (void**)&dev.sy_base, (void**)&dev.mcu_rst, (void**)&dev.dc_parts, (void**)&dev.flags, (void**)&dev.ustr_lin, (void**)&dev.events }) if (*p) hipFree(*p);
     if (d_lut) hipFree(d_lut);
     if (d_side_tmp) hipFree(d_side_tmp);
-    if (prog_buf) hipFree(prog_buf);
+    js_prog_free(this);
     if (pinned) hipHostFree(pinned);
     for (auto& e : ev) if (e) hipEventDestroy(e);
     for (auto& e : aux_ev) if (e) hipEventDestroy(e);
@@ -209,6 +209,7 @@ int JsnoopBatch::ensure_aux()
 void JsnoopBatch::clear()
 {
     imgs.clear(); tables.clear(); raw_bytes = 0; uploaded = false; host_flags.clear();
+    js_prog_clear(this);
 }
 int JsnoopBatch::reserve_pinned(size_t need)
 {
@@ -223,6 +224,7 @@ int JsnoopBatch::reserve_pinned(size_t need)
 int JsnoopBatch::add(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned scan_start, int display, int quiet)
 {
     if (len >= (1ull << 32) - 64) { js_set_error("file too large for the 32-bit offsets of the reference format"); return -1; }
+    if (js_prog_count(this)) { js_set_error("a batch holds either baseline or progressive files, not both"); return -1; }
     JsImage im; JsTableSet* ts = new JsTableSet;
     if (!js_describe_image(d, &im, ts, (uint32_t)len, scan_start, display, quiet)) { delete ts; js_set_error("image not decodable (see log callback)"); return -1; }
     im.decode_ac = display ? (uint32_t)(d->batch == this ? d->opt_decode_ac : opt_decode_ac) : 0;
@@ -276,6 +278,7 @@ int JsnoopBatch::tile(int total)
         memcpy(pinned + off, pinned + im.file_off, im.file_len); memset(pinned + off + im.file_len, 0, 16);
         raw_bytes = off + im.file_len + 16; im.file_off = off;
         imgs.push_back(im);
+        if (js_prog_count(this)) js_prog_dup(this, (uint32_t)(i % n), (uint32_t)i);
     }
     uploaded = false;
     return (int)imgs.size();
@@ -362,6 +365,7 @@ int JsnoopBatch::decode(bool timed)
     if (!uploaded && upload()) return -1;
     const uint32_t n = (uint32_t)imgs.size();
     JsRange r_("jsnoop:decode (enqueue)");
+    if (js_prog_count(this)) return decode_progressive(timed);     // SOF2 files: every scan of every image, one launch per dependency level
     if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
     bool parallel_ok = !opt_force_exact; if (parallel_ok) { parallel_ok = false; for (const JsTableSet& t : tables) parallel_ok = parallel_ok || t.lut_ok; }
     if (!parallel_ok) {           // the exact-mirror kernel stores only what it decodes; the parallel path writes every block whole
@@ -398,6 +402,7 @@ int JsnoopBatch::sync()
 {
     JsRange r_("jsnoop:sync (wait + exact-path fix-up)");
     HIP_TRY(hipSetDevice(device));
+    if (js_prog_count(this)) return sync_progressive();
     HIP_TRY(hipStreamSynchronize(stream));
     return js_parallel_fixup(this);     // re-decodes flagged images on the exact path (no-op when none)
 }
@@ -674,6 +679,7 @@ int jsnoop_batch_add(JsnoopBatch* b, const JsnoopDecoder* tables, const uint8_t*
 }
 int jsnoop_batch_add_jpeg(JsnoopBatch* b, const uint8_t* file, size_t len)
 {
+    if (js_is_progressive(file, len)) { JsnoopDecoder tmpd; return b->add_progressive(&tmpd, file, len); }   // beyond the reference (it refuses SOF2)
     JsnoopDecoder tmp; unsigned scan_start = 0;
     if (js_jfif_walk(&tmp, file, len, &scan_start)) return -1;
     return b->add(&tmp, file, len, scan_start, 1);

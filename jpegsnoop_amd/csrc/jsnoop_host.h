@@ -23,6 +23,7 @@ struct JsTables {
 };
 
 struct JsnoopBatch;
+struct JsProgBatch;          // progressive-path state of a batch (jsnoop_progressive.cpp)
 
 struct JsnoopDecoder {
     JsTables t;
@@ -82,7 +83,10 @@ struct JsnoopBatch {
     enum { kAux = 4 };
     hipStream_t aux[kAux] = { nullptr, nullptr, nullptr, nullptr }; hipEvent_t aux_ev[kAux + 1] = { nullptr, nullptr, nullptr, nullptr, nullptr };
     int ensure_aux();
-    void* prog_buf = nullptr; size_t prog_cap = 0;               // scan tables / interval list / status word of the progressive path
+    JsProgBatch* prog = nullptr;                                 // set once a progressive (SOF2) file was added: the batch then holds only such files
+    int  add_progressive(JsnoopDecoder* d, const uint8_t* file, size_t len);
+    int  decode_progressive(bool timed);
+    int  sync_progressive();
     float lut[64][64]; float* d_lut;
     explicit JsnoopBatch(void* user_stream);
     ~JsnoopBatch();
@@ -116,3 +120,8 @@ int  js_parallel_entropy(JsnoopBatch* b, bool timed);                 // 1 = lau
 int  js_parallel_fixup(JsnoopBatch* b);
 int  js_side_only(JsnoopBatch* b, uint32_t i);
 int  js_jfif_walk(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned* scan_start);   // jfif_front.cpp
+size_t js_prog_count(const JsnoopBatch* b);                            // jsnoop_progressive.cpp: progressive images in the batch
+void js_prog_clear(JsnoopBatch* b);
+void js_prog_free(JsnoopBatch* b);
+void js_prog_dup(JsnoopBatch* b, uint32_t src, uint32_t dst);
+bool js_is_progressive(const uint8_t* file, size_t len);               // first SOF marker of the stream is SOF2

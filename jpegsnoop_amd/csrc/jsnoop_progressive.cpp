@@ -4,6 +4,7 @@
 //
 // "Beyond-reference" mode: the reference refuses these files (source/JfifDecode.cpp:4827-4833), the
 // drop-in entry points (jsnoop_jfif_walk / jsnoop_decode_scan_img) keep refusing them the same way; this is a separate call.
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <vector>
@@ -42,18 +43,22 @@ bool build_table(const RawDht& h, JsProgTable* t)                // T.81 Annex C
 
 }  // namespace
 
-extern "C" int jsnoop_decode_progressive(JsnoopDecoder* d, const uint8_t* f, size_t n)
+// One parsed progressive file: frame, every scan with the tables in force at its SOS and its restart intervals, dependency levels.
+struct ProgImage { JsImage im; JsProgFrame fr; std::vector<JsProgScan> scans; std::vector<JsProgTable> tabs; std::vector<JsProgSeg> segs; std::vector<int> level; int nlev = 1; };
+
+// Walks the file and fills P.  `d` supplies the preview state and the log sink and receives the geometry (js_geometry), like the
+// decoder object of the baseline path; its table state is reset first.
+static int prog_parse(JsnoopDecoder* d, const uint8_t* f, size_t n, ProgImage* P)
 {
-    if (!d || !f) { js_set_error("jsnoop_decode_progressive: bad argument"); return -1; }
+    if (!d || !f) { js_set_error("progressive decode: bad argument"); return -1; }
     auto B = [&](size_t i) -> unsigned { return i < n ? f[i] : 0u; };
     if (n < 4 || f[0] != 0xFF || f[1] != 0xD8) { js_set_error("not a JPEG stream (no SOI)"); return -1; }
-    jsnoop_reset(d); jsnoop_reset_state(d);
-    d->preview_is_jpeg = false; d->last_path = 0; d->last_flags = 0;
+    jsnoop_reset_state(d);
 
     RawDht dht[2][4]; uint16_t dqt[4][64]; bool dqt_set[4] = { false, false, false, false };
     unsigned nf = 0, X = 0, Y = 0, comp_id[3] = { 0, 0, 0 }, comp_h[3] = { 1, 1, 1 }, comp_v[3] = { 1, 1, 1 }, comp_tq[3] = { 0, 0, 0 };
     bool have_sof = false; unsigned rst_interval = 0;
-    std::vector<JsProgScan> scans; std::vector<JsProgTable> tabs; std::vector<JsProgSeg> segs;
+    std::vector<JsProgScan>& scans = P->scans; std::vector<JsProgTable>& tabs = P->tabs; std::vector<JsProgSeg>& segs = P->segs;
     size_t pos = 2;
     while (pos + 4 <= n) {
         if (f[pos] != 0xFF) { pos++; continue; }
@@ -149,7 +154,7 @@ extern "C" int jsnoop_decode_progressive(JsnoopDecoder* d, const uint8_t* f, siz
     }
     jsnoop_set_precision(d, 8);
     jsnoop_set_image_details(d, X, Y, nf, nf, rst_interval != 0, rst_interval);
-    JsImage im;
+    JsImage& im = P->im;
     if (!js_geometry(d, &im)) { js_set_error("image geometry not decodable (see log callback)"); return -1; }
     im.precision = 8; im.decode_ac = 1; im.err_max = d->opt_err_max; im.file_len = (uint32_t)n;
     im.rst_en = rst_interval != 0; im.rst_interval = rst_interval;
@@ -157,7 +162,7 @@ extern "C" int jsnoop_decode_progressive(JsnoopDecoder* d, const uint8_t* f, siz
     im.preview_mode = d->preview_mode; im.shift_y = d->shift_y; im.shift_cb = d->shift_cb; im.shift_cr = d->shift_cr;
     im.shift_mcu_x = d->shift_mcu_x; im.shift_mcu_y = d->shift_mcu_y;
 
-    JsProgFrame fr; memset(&fr, 0, sizeof fr);
+    JsProgFrame& fr = P->fr; memset(&fr, 0, sizeof fr);
     fr.ncomp = im.ncomp;
     for (unsigned c = 0, fb = 0; c < im.ncomp; c++) {
         fr.hs[c] = im.samp_h[c + 1]; fr.vs[c] = im.samp_v[c + 1]; fr.first_blk[c] = fb; fb += fr.hs[c] * fr.vs[c];
@@ -174,34 +179,10 @@ extern "C" int jsnoop_decode_progressive(JsnoopDecoder* d, const uint8_t* f, siz
         if (sc.nseg > want) sc.nseg = want;                        // surplus RSTn: ignore what follows the last expected interval
     }
 
-    // stage through the decoder's private batch: arenas, file bytes, descriptors
-    JsnoopBatch* b = d->batch;
-    b->clear();
-    if (b->add_described(im, f, n) < 0) return -1;
-    if (b->upload()) return -1;
-    HIP_TRY(hipSetDevice(b->device));
-    const JsImage& dim = b->imgs[0];
-    // scan tables, interval list and status word live in one grow-only device buffer of the batch (no allocation per call)
-    const size_t tab_bytes = (tabs.size() * sizeof(JsProgTable) + 255) & ~(size_t)255, seg_bytes = (segs.size() * sizeof(JsProgSeg) + 255) & ~(size_t)255;
-    if (b->prog_cap < tab_bytes + seg_bytes + 256) {
-        if (b->prog_buf) { hipStreamSynchronize(b->stream); hipFree(b->prog_buf); b->prog_buf = nullptr; b->prog_cap = 0; }
-        const size_t want = (tab_bytes + seg_bytes + 256) * 2;
-        if (hipMalloc(&b->prog_buf, want) != hipSuccess) { b->prog_buf = nullptr; js_set_error("hipMalloc failed"); return -1; }
-        b->prog_cap = want;
-    }
-    JsProgTable* d_tabs = (JsProgTable*)b->prog_buf; JsProgSeg* d_segs = (JsProgSeg*)((uint8_t*)b->prog_buf + tab_bytes);
-    uint32_t* d_status = (uint32_t*)((uint8_t*)b->prog_buf + tab_bytes + seg_bytes);
-    HIP_TRY(hipMemcpyAsync(d_tabs, tabs.data(), tabs.size() * sizeof(JsProgTable), hipMemcpyHostToDevice, b->stream));
-    HIP_TRY(hipMemcpyAsync(d_segs, segs.data(), segs.size() * sizeof(JsProgSeg), hipMemcpyHostToDevice, b->stream));
-    HIP_TRY(hipMemsetAsync(d_status, 0, 16, b->stream));
-    HIP_TRY(hipMemsetAsync(b->dev.coef + dim.coef_off * 64, 0, (size_t)dim.total_blocks * 128, b->stream));
-    HIP_TRY(hipMemsetAsync(b->dev.dccum + dim.coef_off, 0, (size_t)dim.total_blocks * 2, b->stream));
-    HIP_TRY(hipMemsetAsync(b->dev.side, 0, b->side_words * 4, b->stream));
     // Scans that touch different coefficients are independent (a DC scan: slot 0 of its components; an AC scan, first or
-    // refinement: its band of one component, read and written by position).  Levels of the dependency order run one after the other, the scans of a level side by side on
-    // helper streams: a kernel of a few dozen single-lane decoders leaves the chip empty.
+    // refinement: its band of one component, read and written by position): dependency levels, the scans of a level decode together.
     const size_t ns = scans.size();
-    std::vector<int> level(ns, 0); int nlev = 1;
+    P->level.assign(ns, 0); P->nlev = 1;
     auto band = [](const JsProgScan& q, unsigned& lo, unsigned& hi) { if (q.ss == 0) { lo = hi = 0; } else { lo = q.ss; hi = q.se; } };
     for (size_t i = 0; i < ns; i++) {
         unsigned li, hi; band(scans[i], li, hi);
@@ -209,39 +190,184 @@ extern "C" int jsnoop_decode_progressive(JsnoopDecoder* d, const uint8_t* f, siz
             unsigned lj, hj; band(scans[j], lj, hj);
             bool share = false;
             for (unsigned a = 0; a < scans[i].ncomp; a++) for (unsigned c = 0; c < scans[j].ncomp; c++) share = share || scans[i].comp[a] == scans[j].comp[c];
-            if (share && li <= hj && lj <= hi) level[i] = std::max(level[i], level[j] + 1);
+            if (share && li <= hj && lj <= hi) P->level[i] = std::max(P->level[i], P->level[j] + 1);
         }
-        nlev = std::max(nlev, level[i] + 1);
+        P->nlev = std::max(P->nlev, P->level[i] + 1);
     }
-    const bool fork = ns > 1 && nlev < (int)ns && b->ensure_aux() == 0;
-    for (int lv = 0; lv < nlev; lv++) {
-        unsigned used = 0, k = 0;
-        if (fork) hipEventRecord(b->aux_ev[JsnoopBatch::kAux], b->stream);
-        for (size_t i = 0; i < ns; i++) {
-            if (level[i] != lv) continue;
-            hipStream_t st = b->stream;
-            if (fork && k % (JsnoopBatch::kAux + 1)) {
-                const unsigned a = k % (JsnoopBatch::kAux + 1) - 1; st = b->aux[a];
-                if (!(used >> a & 1u)) { hipStreamWaitEvent(st, b->aux_ev[JsnoopBatch::kAux], 0); used |= 1u << a; }
-            }
-            js_launch_prog_scan(st, b->dev.imgs, fr, scans[i], d_tabs, d_segs, b->dev.raw, b->dev.coef, d_status);
-            k++;
-        }
-        for (unsigned a = 0; a < JsnoopBatch::kAux; a++) if (used >> a & 1u) { hipEventRecord(b->aux_ev[a], b->aux[a]); hipStreamWaitEvent(b->stream, b->aux_ev[a], 0); }
+    return 0;
+}
+
+bool js_is_progressive(const uint8_t* f, size_t n)                  // the first frame header of the stream: SOF2?
+{
+    size_t pos = 2;
+    while (pos + 4 <= n) {
+        if (f[pos] != 0xFF) { pos++; continue; }
+        while (pos < n && f[pos] == 0xFF) pos++;
+        if (pos >= n) break;
+        const unsigned m = f[pos++];
+        if (m == 0xD8 || m == 0x01 || m == 0x00 || (m >= 0xD0 && m <= 0xD7)) continue;
+        if (m == 0xC2) return true;
+        if ((m >= 0xC0 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) || m == 0xDA || m == 0xD9) return false;
+        if (pos + 2 > n) break;
+        pos += (size_t)f[pos] * 256 + f[pos + 1];
     }
-    js_launch_prog_finalize(b->stream, b->dev.imgs, fr, dim.total_blocks, b->dev.coef, b->dev.dccum);
-    if (b->launch_back_end(1)) return -1;
-    uint32_t status[4] = { 0, 0, 0, 0 };
-    hipError_t e = hipMemcpyAsync(status, d_status, 16, hipMemcpyDeviceToHost, b->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
-    if (e != hipSuccess) { js_set_error("progressive decode: device error: %s", hipGetErrorString(e)); return -1; }
-    b->host_flags.assign(1, status[0] ? JSNOOP_FLAG_BAD_CODE : 0u); b->host_path.assign(1, 3u);
+    return false;
+}
+
+// ---- batch state of the progressive path (behind JsnoopBatch::prog) --------------------------------------------------------------
+struct JsProgBatch {
+    std::vector<JsProgFrame> frames; std::vector<JsProgScan> scans; std::vector<JsProgTable> tabs; std::vector<JsProgSeg> segs;
+    std::vector<int> level; int nlev = 0;                         // per scan; levels are per image, level L of every image decodes in launch L
+    std::vector<uint32_t> first_scan;                              // per image: its first scan (+ end sentinel)
+    void* d_buf = nullptr; size_t d_cap = 0; bool dirty = true;
+    // device views into d_buf (valid after js_prog_upload)
+    JsProgFrame* d_frames = nullptr; JsProgScan* d_scans = nullptr; JsProgTable* d_tabs = nullptr; JsProgSeg* d_segs = nullptr;
+    uint32_t *d_status = nullptr, *d_lvl_scans = nullptr, *d_lvl_wg = nullptr, *d_blk_base = nullptr;
+    std::vector<uint32_t> lvl_first, lvl_count, lvl_wgs;          // per level: slice of d_lvl_scans / d_lvl_wg, total workgroups
+    uint32_t pg_lanes = 1;                                         // intervals per wave of the sequential scan kinds (batch-wide choice)
+};
+size_t js_prog_count(const JsnoopBatch* b) { return b->prog ? b->prog->frames.size() : 0; }
+void js_prog_clear(JsnoopBatch* b) { if (b->prog) { JsProgBatch* g = b->prog; g->frames.clear(); g->scans.clear(); g->tabs.clear(); g->segs.clear(); g->level.clear(); g->first_scan.clear(); g->nlev = 0; g->dirty = true; } }
+void js_prog_free(JsnoopBatch* b) { if (b->prog) { if (b->prog->d_buf) hipFree(b->prog->d_buf); delete b->prog; b->prog = nullptr; } }
+// image `src` once more as image `dst` (tile): same scans, tables and intervals (file-relative), its own frame entry
+void js_prog_dup(JsnoopBatch* b, uint32_t src, uint32_t dst)
+{
+    JsProgBatch* g = b->prog;
+    g->frames.push_back(g->frames[src]);
+    const uint32_t s0 = g->first_scan[src], s1 = g->first_scan[src + 1];
+    g->first_scan.back() = (uint32_t)g->scans.size();            // sentinel becomes the first scan of dst
+    for (uint32_t q = s0; q < s1; q++) { JsProgScan sc = g->scans[q]; sc.img = dst; g->scans.push_back(sc); g->level.push_back(g->level[q]); }
+    g->first_scan.push_back((uint32_t)g->scans.size());
+    g->dirty = true;
+}
+
+int JsnoopBatch::add_progressive(JsnoopDecoder* d, const uint8_t* f, size_t n)
+{
+    if (imgs.size() != js_prog_count(this)) { js_set_error("a batch holds either baseline or progressive files, not both"); return -1; }
+    ProgImage P;
+    if (prog_parse(d, f, n, &P)) return -1;
+    if (!prog) prog = new JsProgBatch;
+    JsProgBatch* g = prog;
+    const int idx = add_described(P.im, f, n);
+    if (idx < 0) return -1;
+    const uint32_t tab0 = (uint32_t)g->tabs.size(), seg0 = (uint32_t)g->segs.size();
+    if (g->first_scan.empty()) g->first_scan.push_back(0);
+    g->frames.push_back(P.fr);
+    g->tabs.insert(g->tabs.end(), P.tabs.begin(), P.tabs.end());
+    g->segs.insert(g->segs.end(), P.segs.begin(), P.segs.end());
+    for (size_t q = 0; q < P.scans.size(); q++) {
+        JsProgScan sc = P.scans[q]; sc.img = (uint32_t)idx; sc.seg_first += seg0;
+        for (uint32_t k = 0; k < sc.ntabs; k++) sc.tab[k] += tab0;
+        g->scans.push_back(sc); g->level.push_back(P.level[q]);
+    }
+    g->first_scan.push_back((uint32_t)g->scans.size());
+    g->nlev = std::max(g->nlev, P.nlev);
+    g->dirty = true;
+    return idx;
+}
+
+// scan tables, interval lists, per-level work lists and the per-image status words: one grow-only device buffer
+static int js_prog_upload(JsnoopBatch* b)
+{
+    JsProgBatch* g = b->prog;
+    const size_t nimg = g->frames.size(), nsc = g->scans.size();
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_fr = 0, o_sc = o_fr + up(nimg * sizeof(JsProgFrame)), o_tb = o_sc + up(nsc * sizeof(JsProgScan)), o_sg = o_tb + up(g->tabs.size() * sizeof(JsProgTable)),
+                 o_st = o_sg + up(g->segs.size() * sizeof(JsProgSeg)), o_ls = o_st + up(nimg * 16), o_lw = o_ls + up(nsc * 4), o_bb = o_lw + up((nsc + (size_t)g->nlev) * 4),
+                 total = o_bb + up((nimg + 1) * 4);
+    if (g->d_cap < total) {
+        if (g->d_buf) { hipStreamSynchronize(b->stream); hipFree(g->d_buf); g->d_buf = nullptr; g->d_cap = 0; }
+        if (hipMalloc(&g->d_buf, total * 2) != hipSuccess) { js_set_error("hipMalloc failed (progressive tables)"); return -1; }
+        g->d_cap = total * 2; g->dirty = true;
+    }
+    uint8_t* base = (uint8_t*)g->d_buf;
+    g->d_frames = (JsProgFrame*)(base + o_fr); g->d_scans = (JsProgScan*)(base + o_sc); g->d_tabs = (JsProgTable*)(base + o_tb); g->d_segs = (JsProgSeg*)(base + o_sg);
+    g->d_status = (uint32_t*)(base + o_st); g->d_lvl_scans = (uint32_t*)(base + o_ls); g->d_lvl_wg = (uint32_t*)(base + o_lw); g->d_blk_base = (uint32_t*)(base + o_bb);
+    if (!g->dirty) return 0;
+    // per level: the scans of that level over all images, and the exclusive prefix of their workgroup counts
+    // a single file leaves the chip mostly idle: one interval per wave; a batch that fills it packs several (JSNOOP_PG_LANES overrides)
+    size_t total_iv = 0; for (const JsProgScan& sc : g->scans) total_iv += sc.nseg;
+    g->pg_lanes = total_iv > 32768 ? 8u : 1u;
+    if (const char* e = getenv("JSNOOP_PG_LANES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) g->pg_lanes = (uint32_t)v; }
+    std::vector<uint32_t> ls, lw; g->lvl_first.clear(); g->lvl_count.clear(); g->lvl_wgs.clear();
+    for (int lv = 0; lv < g->nlev; lv++) {
+        g->lvl_first.push_back((uint32_t)ls.size()); uint32_t acc = 0; const size_t w0 = lw.size();
+        for (size_t q = 0; q < nsc; q++) if (g->level[q] == lv) { ls.push_back((uint32_t)q); lw.push_back(acc); acc += js_prog_wgs_of(g->scans[q], g->pg_lanes); }
+        lw.push_back(acc);
+        g->lvl_count.push_back((uint32_t)(ls.size() - g->lvl_first.back())); g->lvl_wgs.push_back(acc);
+        (void)w0;
+    }
+    std::vector<uint32_t> bb(nimg + 1, 0);
+    for (size_t i = 0; i < nimg; i++) bb[i + 1] = bb[i] + b->imgs[i].total_blocks;
+    HIP_TRY(hipMemcpyAsync(g->d_frames, g->frames.data(), nimg * sizeof(JsProgFrame), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(g->d_scans, g->scans.data(), nsc * sizeof(JsProgScan), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(g->d_tabs, g->tabs.data(), g->tabs.size() * sizeof(JsProgTable), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(g->d_segs, g->segs.data(), g->segs.size() * sizeof(JsProgSeg), hipMemcpyHostToDevice, b->stream));
+    if (!ls.empty()) HIP_TRY(hipMemcpyAsync(g->d_lvl_scans, ls.data(), ls.size() * 4, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(g->d_lvl_wg, lw.data(), lw.size() * 4, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(g->d_blk_base, bb.data(), bb.size() * 4, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));                      // the host vectors above go out of scope
+    g->dirty = false;
+    return 0;
+}
+
+// Every scan of every image: one launch per dependency level, then the dequantising finalize pass and the unchanged back end.
+int JsnoopBatch::decode_progressive(bool timed)
+{
+    JsProgBatch* g = prog;
+    const uint32_t n = (uint32_t)imgs.size();
+    if (js_prog_upload(this)) return -1;
+    if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
+    HIP_TRY(hipMemsetAsync(g->d_status, 0, (size_t)n * 16, stream));
+    HIP_TRY(hipMemsetAsync(dev.coef, 0, total_blocks * 128, stream));
+    HIP_TRY(hipMemsetAsync(dev.dccum, 0, total_blocks * 2, stream));
+    HIP_TRY(hipMemsetAsync(dev.side, 0, side_words * 4, stream));
+    if (timed) for (int s = 1; s <= 4; s++) HIP_TRY(hipEventRecord(ev[s], stream));
+    size_t wg_off = 0;
+    for (int lv = 0; lv < g->nlev; lv++) {
+        js_launch_prog_level(stream, dev.imgs, g->d_frames, g->d_scans, g->d_lvl_scans + g->lvl_first[lv], g->d_lvl_wg + wg_off, g->lvl_count[lv], g->lvl_wgs[lv], g->pg_lanes,
+                             g->d_tabs, g->d_segs, dev.raw, dev.coef, g->d_status);
+        wg_off += g->lvl_count[lv] + 1;
+    }
+    if (timed) HIP_TRY(hipEventRecord(ev[5], stream));            // reported under "write": the scans are this path's coefficient writers
+    js_launch_prog_finalize(stream, dev.imgs, g->d_frames, n, g->d_blk_base, (uint32_t)total_blocks, dev.coef, dev.dccum);
+    if (timed) { HIP_TRY(hipEventRecord(ev[6], stream)); HIP_TRY(hipEventRecord(ev[7], stream)); }
+    if (launch_back_end(n)) return -1;
+    if (timed) HIP_TRY(hipEventRecord(ev[8], stream));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int JsnoopBatch::sync_progressive()
+{
+    const uint32_t n = (uint32_t)imgs.size();
+    std::vector<uint32_t> st((size_t)n * 4, 0);
+    HIP_TRY(hipMemcpyAsync(st.data(), prog->d_status, st.size() * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    host_flags.assign(n, 0); host_path.assign(n, 3u);
+    for (uint32_t i = 0; i < n; i++) host_flags[i] = st[(size_t)i * 4] ? JSNOOP_FLAG_BAD_CODE : 0u;
+    return 0;
+}
+
+extern "C" int jsnoop_batch_add_progressive(JsnoopBatch* b, const uint8_t* file, size_t len)
+{ JsnoopDecoder tmp; return b->add_progressive(&tmp, file, len); }
+
+extern "C" int jsnoop_decode_progressive(JsnoopDecoder* d, const uint8_t* f, size_t n)
+{
+    if (!d || !f) { js_set_error("jsnoop_decode_progressive: bad argument"); return -1; }
+    jsnoop_reset(d);
+    d->preview_is_jpeg = false; d->last_path = 0; d->last_flags = 0;
+    JsnoopBatch* b = d->batch;
+    b->clear();
+    if (b->add_progressive(d, f, n) < 0) return -1;
+    if (b->upload() || b->decode(false) || b->sync()) return -1;
+    const uint32_t status0 = b->host_flags[0];
+    const int nscans = (int)(b->prog->first_scan[1] - b->prog->first_scan[0]);
     d->have_image = true; d->host_valid = 0; d->preview_is_jpeg = true;
     d->last_path = 3; d->last_flags = b->host_flags[0];
     d->side_ready = true; d->fetch_side();                         // no file map / DC maps for a multi-scan image: zeros, plus the back end's reductions
     d->hist_latched = d->opt_histo_en != 0; d->clip_latched = d->opt_stat_clip_en != 0;
     memset(d->stats, 0, sizeof d->stats); d->pending_log.clear();
     d->stats_pass(); d->flush_pending_log();
-    if (status[0]) d->log(2, "*** ERROR: progressive scan data is malformed (status 0x%X); the image is decoded as far as the data goes", status[0]);
-    return (int)scans.size();
+    if (status0) d->log(2, "*** ERROR: progressive scan data is malformed; the image is decoded as far as the data goes");
+    return nscans;
 }

@@ -21,7 +21,8 @@ __device__ __constant__ uint8_t c_zz_nat[64] = {       // zig-zag index -> natur
      0, 1, 8,16, 9, 2, 3,10, 17,24,32,25,18,11, 4, 5, 12,19,26,33,40,48,41,34, 27,20,13, 6, 7,14,21,28,
     35,42,49,56,57,50,43,36, 29,22,15,23,30,37,44,51, 58,59,52,45,38,31,39,46, 53,60,61,54,47,55,62,63 };
 
-#define PG_LANES 1                    // active lanes (restart intervals) per wave
+// Active lanes (restart intervals) per wave of the sequential scan kinds: 1 for small jobs (lanes that share a wave serialise each
+// other's branches, and a single file leaves most SIMDs idle anyway), more once a batch fills the chip with waves.
 
 namespace {
 
@@ -76,11 +77,18 @@ __device__ size_t block_row(const JsImage& im, const JsProgFrame& fr, uint32_t c
 
 }  // namespace
 
-// One wave per restart interval of one scan.
-__global__ void __launch_bounds__(64) k_prog_scan(const JsImage* __restrict__ imgs, JsProgFrame fr, JsProgScan sc, const JsProgTable* __restrict__ tabs,
-                                                  const JsProgSeg* __restrict__ segs, const uint8_t* __restrict__ raw, int16_t* __restrict__ coef,
-                                                  uint32_t* __restrict__ status)
+// One wave per restart interval of one scan; one launch covers every scan of a dependency level of the batch.
+__global__ void __launch_bounds__(64) k_prog_scan(const JsImage* __restrict__ imgs, const JsProgFrame* __restrict__ frames, const JsProgScan* __restrict__ scans,
+                                                  const uint32_t* __restrict__ lvl_scans, const uint32_t* __restrict__ lvl_wg, uint32_t nsc, uint32_t pg_lanes,
+                                                  const JsProgTable* __restrict__ tabs, const JsProgSeg* __restrict__ segs, const uint8_t* __restrict__ raw,
+                                                  int16_t* __restrict__ coef, uint32_t* __restrict__ status_all)
 {
+    uint32_t lo = 0, hi = nsc;                                   // lvl_wg is an exclusive prefix, nsc + 1 entries
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (lvl_wg[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+    const JsProgScan sc = scans[lvl_scans[lo]];                  // wave-uniform: lives in SGPRs
+    const uint32_t wg_in_scan = blockIdx.x - lvl_wg[lo];
+    const JsProgFrame& fr = frames[sc.img];
+    uint32_t* status = status_all + sc.img * 4u;
     __shared__ JsProgTable s_tab[4];
     __shared__ uint8_t s_zz[64];
     if (threadIdx.x < 64) s_zz[threadIdx.x] = c_zz_nat[threadIdx.x];
@@ -93,11 +101,12 @@ __global__ void __launch_bounds__(64) k_prog_scan(const JsImage* __restrict__ im
     // serialise each other's branches, so only PG_LANES lanes of a wave carry one (a 1080p scan with one interval per MCU
     // row has ~135 of them -- far fewer than the chip has SIMDs).
     const bool wave_coop = sc.ss != 0 && sc.ah != 0;             // AC refinement: the whole wave works on one interval's blocks
-    if (!wave_coop && threadIdx.x % (64 / PG_LANES)) return;
-    const uint32_t slot = threadIdx.x / (64 / PG_LANES);
-    const uint32_t iv = blockIdx.x * PG_LANES + slot;
+    const uint32_t per = wave_coop ? 1u : pg_lanes;                // intervals this wave carries
+    if (!wave_coop && threadIdx.x % (64u / per)) return;
+    const uint32_t slot = wave_coop ? 0u : threadIdx.x / (64u / per);
+    const uint32_t iv = wg_in_scan * per + slot;
     if (iv >= sc.nseg) return;
-    const JsImage& im = imgs[0];
+    const JsImage& im = imgs[sc.img];
     const JsProgSeg sg = segs[sc.seg_first + iv];
     PReader r; r.init(raw + im.file_off, sg.start, sg.end);      // file images are 16-byte aligned and zero padded in the raw arena
     int16_t* cbase = coef + im.coef_off * 64;
@@ -211,11 +220,13 @@ __global__ void __launch_bounds__(64) k_prog_scan(const JsImage* __restrict__ im
 // Quantised, point-transformed coefficients -> what the baseline path leaves behind: dequantised AC terms in place
 // ((short)(val * Q), DecodeIdctSet :2278) and the dequantised DC in `dccum` (the reference's running DC sum equals
 // Q * DC in wrapping int16 arithmetic, :3280); slot 0 of the block is cleared (the back end never reads it).
-__global__ void __launch_bounds__(256) k_prog_finalize(const JsImage* __restrict__ imgs, JsProgFrame fr, int16_t* __restrict__ coef, int16_t* __restrict__ dccum)
+__global__ void __launch_bounds__(256) k_prog_finalize(const JsImage* __restrict__ imgs, const JsProgFrame* __restrict__ frames, uint32_t nimg,
+                                                       const uint32_t* __restrict__ blk_base, uint32_t total_blocks, int16_t* __restrict__ coef, int16_t* __restrict__ dccum)
 {
-    const JsImage& im = imgs[0];
     const uint32_t lane = threadIdx.x & 63;
+    const JsImage& im = imgs[blockIdx.y]; const JsProgFrame& fr = frames[blockIdx.y];       // one grid row per image
     int16_t* cbase = coef + im.coef_off * 64; int16_t* dbase = dccum + im.coef_off;
+    (void)nimg; (void)blk_base; (void)total_blocks;
     for (uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6); b < im.total_blocks; b += gridDim.x * 4) {
         const uint32_t comp = im.blk_comp[b % im.blk_per_mcu] - 1u;
         const int16_t v = cbase[(size_t)b * 64 + lane];
@@ -225,14 +236,18 @@ __global__ void __launch_bounds__(256) k_prog_finalize(const JsImage* __restrict
     }
 }
 
-void js_launch_prog_scan(hipStream_t st, const JsImage* imgs, const JsProgFrame& fr, const JsProgScan& sc, const JsProgTable* tabs, const JsProgSeg* segs,
-                         const uint8_t* raw, int16_t* coef, uint32_t* status)
+uint32_t js_prog_wgs_of(const JsProgScan& sc, uint32_t pg_lanes) { const uint32_t per = (sc.ss != 0 && sc.ah != 0) ? 1u : pg_lanes; return (sc.nseg + per - 1) / per; }
+void js_launch_prog_level(hipStream_t st, const JsImage* imgs, const JsProgFrame* frames, const JsProgScan* scans, const uint32_t* lvl_scans, const uint32_t* lvl_wg,
+                          uint32_t nsc, uint32_t total_wgs, uint32_t pg_lanes, const JsProgTable* tabs, const JsProgSeg* segs, const uint8_t* raw, int16_t* coef, uint32_t* status)
 {
-    if (!sc.nseg) return;
-    hipLaunchKernelGGL(k_prog_scan, dim3((sc.nseg + PG_LANES - 1) / PG_LANES), dim3(64), 0, st, imgs, fr, sc, tabs, segs, raw, coef, status);
+    if (!nsc || !total_wgs) return;
+    hipLaunchKernelGGL(k_prog_scan, dim3(total_wgs), dim3(64), 0, st, imgs, frames, scans, lvl_scans, lvl_wg, nsc, pg_lanes, tabs, segs, raw, coef, status);
 }
-void js_launch_prog_finalize(hipStream_t st, const JsImage* imgs, const JsProgFrame& fr, uint32_t total_blocks, int16_t* coef, int16_t* dccum)
+void js_launch_prog_finalize(hipStream_t st, const JsImage* imgs, const JsProgFrame* frames, uint32_t nimg, const uint32_t* blk_base, uint32_t total_blocks,
+                             int16_t* coef, int16_t* dccum)
 {
-    const uint32_t g = (total_blocks + 3) / 4;
-    hipLaunchKernelGGL(k_prog_finalize, dim3(g < 4096 ? (g ? g : 1) : 4096), dim3(256), 0, st, imgs, fr, coef, dccum);
+    if (!nimg) return;
+    const uint32_t per_img = (total_blocks / nimg + 3) / 4;           // workgroups of four blocks; each strides over its image
+    const uint32_t gx = nimg >= 64 ? 64u : (per_img < 2048 ? (per_img ? per_img : 1u) : 2048u);
+    hipLaunchKernelGGL(k_prog_finalize, dim3(gx, nimg), dim3(256), 0, st, imgs, frames, nimg, blk_base, total_blocks, coef, dccum);
 }

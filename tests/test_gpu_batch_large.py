@@ -121,3 +121,54 @@ def test_staging_pipeline_overlaps_and_stays_exact(harness, oracle):
     assert r2["ms_per_batch"] < 0.95 * (r2["h2d_ms"] + r2["decode_ms"]), r2          # the transfer hides behind the decode (or the other way round)
     assert r3["ms_per_batch"] < 0.95 * (r3["h2d_ms"] + r3["decode_ms"] + r3["d2h_ms"]), r3
     pipe.close()
+
+
+def test_progressive_batch_matches_single_decodes_and_is_faster(harness, oracle):
+    """BASELINE config 5 as a batch citizen: progressive (SOF2) files through jsnoop_batch_add_jpeg, every scan of every image
+    decoded together (one launch per dependency level).  DIBs equal the oracle's decode of the baseline form of the same
+    coefficients (own encoder and libjpeg-turbo fixtures mixed in one batch), and a 64-image batch of the config-5 file is at
+    least 10x faster per image than 64 single-file calls."""
+    import json, os, time
+    import jpegsnoop_amd as J
+    here = os.path.dirname(os.path.abspath(__file__))
+    cases = []                                                   # (progressive bytes, baseline bytes, W, H)
+    for i, kw in enumerate([dict(width=160, height=96, hs=2, vs=1, restart_interval=10), dict(width=333, height=217, restart_interval=5),
+                            dict(width=120, height=80, gray=1, restart_interval=3), dict(width=192, height=128, hs=1, vs=1, quality=100)]):
+        cases.append((harness.synth_jpeg(seed=90 + i, progressive=1 + i % 2, **kw), harness.synth_jpeg(seed=90 + i, progressive=0, **kw), kw["width"], kw["height"]))
+    for c in json.load(open(os.path.join(here, "golden", "pillow", "manifest.json")))["cases"]:
+        rd = lambda kind: open(os.path.join(here, "golden", "pillow", f"{c['name']}_{kind}.jpg"), "rb").read()
+        cases.append((rd("prog"), rd("base"), c["w"], c["h"]))
+    b = J.JpegBatch()
+    for prog, _, _, _ in cases:
+        b.add_jpeg(prog)
+    b.tile(2 * len(cases))
+    b.upload(); b.decode(); b.sync()
+    for i in range(2 * len(cases)):
+        _, base, W, H = cases[i % len(cases)]
+        harness.drive(oracle, base)
+        a, g = oracle.dib(), b.dib(i)
+        assert b.info(i)["path"] == 3 and b.info(i)["flags"] == 0
+        assert a.shape == g.shape and np.array_equal(a[a.shape[0] - H:, :W], g[g.shape[0] - H:, :W]), f"image {i}: visible DIB differs"
+    # a batch refuses to mix the two kinds
+    with pytest.raises(RuntimeError):
+        b.add_jpeg(cases[0][1])
+    b.close()
+    # throughput: 64 x config 5 (1920x1080 4:2:2, RSTn per MCU row, 10 scans)
+    kw5 = dict(width=1920, height=1080, hs=2, vs=1, restart_interval=120, quality=85, seed=55)
+    prog5, base5 = harness.synth_jpeg(progressive=2, **kw5), harness.synth_jpeg(progressive=0, **kw5)
+    dec = J.CimgDecode()
+    dec.DecodeProgressive(prog5)
+    t0 = time.perf_counter()
+    for _ in range(8):
+        dec.DecodeProgressive(prog5)
+    single_ms = (time.perf_counter() - t0) / 8 * 1e3
+    harness.drive(oracle, base5)
+    assert np.array_equal(dec.GetBitmapPtr(), oracle.dib())
+    dec.close()
+    bb = J.JpegBatch(); bb.add_jpeg(prog5); bb.tile(64); bb.upload(); bb.decode(); bb.sync()
+    want = J.dib_checksum_numpy(oracle.dib())
+    assert all(int(s) == want for s in bb.dib_checksums())
+    ms, _ = bb.decode_timed(3)
+    bb.close()
+    print(f"config 5: single call {single_ms:.2f} ms per image, 64-image batch {ms / 64:.3f} ms per image")
+    assert ms / 64 * 10 <= single_ms, (ms / 64, single_ms)
