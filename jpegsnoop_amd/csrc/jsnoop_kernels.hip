@@ -19,6 +19,9 @@
 #include "jsnoop_launch.h"
 
 #define WAVE 64
+// wave vote on a bool: the HIP wrapper __ballot(int) makes the compiler materialise the predicate as 0 / 1 and compare it again (two
+// half-rate VALU instructions per vote in the entropy loops); the builtin takes the lane mask as it stands
+#define WBALLOT(x) __builtin_amdgcn_ballot_w64(static_cast<bool>(x))
 
 __device__ __constant__ uint8_t c_zigzag[64] = {       // ITU-T T.81 Figure A.6 (General.cpp:257-267)
      0, 1, 8,16, 9, 2, 3,10, 17,24,32,25,18,11, 4, 5,
@@ -420,7 +423,7 @@ struct WaveList { float* coef; uint16_t* rowh; };           // 68 floats; 68 x 1
 __device__ __forceinline__ float idct_terms(int cv16, const WaveList L, uint32_t lane)
 {
     const bool nz = cv16 != 0;
-    const uint64_t mask = __ballot(nz);
+    const uint64_t mask = WBALLOT(nz);
     const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_popcountll(mask));   // wave-uniform: the exit tests are scalar compares
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     const uint32_t zrank = lane - rank;                          // zero lanes: how many zero lanes lie below
@@ -1198,7 +1201,7 @@ struct SubTabs {
     uint32_t n1, n2, nb;               // block-in-MCU index where Cb / Cr blocks start; blocks per MCU
 };
 
-// Write-pass view: DC tables as 16-bit first-level rows, AC tables as 32-bit value-pair rows (JsTableSet::lutw), the shared
+// Write-pass view: DC tables as 16-bit single-symbol rows, AC tables as 32-bit value-pair rows (both from JsTableSet::lutw), the shared
 // second level, the q|zz table.  tabw = DC rows | AC rows << 8 of the largest table set of the batch.
 struct WriteTabs {
     const char* rows;                  // DC rows, then AC rows
@@ -1210,7 +1213,7 @@ __host__ __device__ __forceinline__ size_t wtabs_bytes(uint32_t tabw, uint32_t t
 { return (size_t)(tabw & 255u) * (2u << JS_L1_BITS) + (size_t)(tabw >> 8) * (4u << JS_L1_BITS) + (((size_t)tab_lut2 * 2 + 15) & ~15ull) + 3 * 64 * 4; }
 __device__ __forceinline__ void load_wtabs(WriteTabs& W, uint8_t* lds, const JsTableSet& ts, uint32_t tabw, uint32_t tab_lut2, uint32_t ncomp, uint32_t tid, uint32_t nthreads)
 {
-    const uint32_t dc_bytes = (tabw & 255u) * (2u << JS_L1_BITS), ac_bytes = (tabw >> 8) * (4u << JS_L1_BITS);
+    const uint32_t dc_bytes = (tabw & 255u) * (2u << JS_L1_BITS), ac_bytes = (tabw >> 8) * (4u << JS_L1_BITS);   // DC rows: 16-bit entries (low halves of JsTableSet::lutw), AC rows: 32-bit pair entries
     uint16_t* l2 = reinterpret_cast<uint16_t*>(lds + dc_bytes + ac_bytes);
     uint32_t* q = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(l2) + (((size_t)tab_lut2 * 2 + 15) & ~15ull));
     uint32_t off[6];                                             // byte offset of the table of slot (comp-1)*2 + class
@@ -1221,10 +1224,10 @@ __device__ __forceinline__ void load_wtabs(WriteTabs& W, uint8_t* lds, const JsT
             off[slot] = dc_bytes + sub * (4u << JS_L1_BITS);
             uint32_t* dst = reinterpret_cast<uint32_t*>(lds + off[slot]);
             for (uint32_t i = tid; i < (1u << JS_L1_BITS); i += nthreads) dst[i] = ts.lutw[row][i];        // (shared rows are copied once per slot: same bytes)
-        } else {
+        } else {                                                 // DC rows: the 16-bit form of the same entries (code length | size << 4; bit 15: escape)
             off[slot] = sub * (2u << JS_L1_BITS);
-            uint32_t* dst = reinterpret_cast<uint32_t*>(lds + off[slot]); const uint32_t* src = reinterpret_cast<const uint32_t*>(ts.lut1[row]);
-            for (uint32_t i = tid; i < (1u << JS_L1_BITS) / 2; i += nthreads) dst[i] = src[i];
+            uint16_t* dst = reinterpret_cast<uint16_t*>(lds + off[slot]);
+            for (uint32_t i = tid; i < (1u << JS_L1_BITS); i += nthreads) dst[i] = (uint16_t)ts.lutw[row][i];
         }
     }
     for (uint32_t i = tid; i < ts.lut2_used; i += nthreads) l2[i] = ts.lut2[i];
@@ -1351,7 +1354,7 @@ __device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, co
     uint32_t rb = c < T.n1 ? T.rb0 : (c < T.n2 ? T.rb1 : T.rb2);
     for (;;) {
         const bool act = cur.p < own_end;
-        if (!__ballot(act)) break;
+        if (!WBALLOT(act)) break;
         const uint32_t win = cur_peek(cur);
         // One table entry describes the symbol at the cursor and, where its code was visible in the same window, the AC symbol
         // behind it: byte 0 = bits of symbol 1 (code + value), byte 1 = its advance of the coefficient index (64 for EOB: ends the
@@ -1360,7 +1363,7 @@ __device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, co
         // A code longer than the window: a few % of symbols, but SOME lane of the wave holds one nearly every step.  One read of
         // the second level replaces the entry by a single-symbol one and the lane stays on the common path.
         const bool esc = act && (pe >> 30) == 2u;
-        if (__ballot(esc)) {
+        if (WBALLOT(esc)) {
             if (esc) { const uint32_t nbx = (pe >> 12) & 7u; pe = T.lut2p[(pe & 0xFFFu) + ((win >> (32 - JS_L1_BITS - nbx)) & ((1u << nbx) - 1u))]; }
         }
         const uint32_t b1 = pe & 255u, k1 = k + ((pe >> 8) & 255u), b12 = (pe >> 16) & 255u;
@@ -1368,7 +1371,7 @@ __device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, co
         const bool two = b12 != 0u && k1 < 64u && cur.p + b1 < own_end;
         const uint32_t adv = two ? b12 : b1;
         const bool slow = act && ((int32_t)pe < 0 || cur.p + adv > seg_end);
-        if (__ballot(slow)) {
+        if (WBALLOT(slow)) {
             if (slow) {                                          // no code here, or the end of the restart interval / of the data is near:
                 const uint32_t row = (k ? rb >> 16 : rb & 0xFFFFu) >> (JS_L1_BITS + 2);     // one symbol the careful way
                 const uint32_t e = sym_lookup(T, win, row, 0u);
@@ -1470,7 +1473,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
             active = ip != s_inp[t] || is != s_ins[t];
         }
         if (t == 0) s_changed = 0;
-        const uint64_t bal = __ballot(active);
+        const uint64_t bal = WBALLOT(active);
         if (lane == 0) s_wcount[wave] = (uint32_t)__builtin_popcountll(bal);
         __syncthreads();                                         // everybody has read the old exit states
         if (active) {
@@ -1595,22 +1598,26 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
     for (;;) {
         // ---- end of the owned range: report the state there; keep going only to finish a block this lane started
         const bool at_end = active && cur.p >= own_end;
-        if (__ballot(at_end)) {
+        if (WBALLOT(at_end)) {
             if (at_end) {
                 if (!captured) { res_p = cur.p; res_s = ST_MAKE(seg, c, k); res_n = nblk; captured = true; }
                 if (k == 0 || skip) active = false;
             }
         }
-        if (!__ballot(active)) break;
+        if (!WBALLOT(active)) break;
         // ---- one or two symbols per lane: straight-line select code on the common path
         const uint32_t win = cur_peek(cur);
         const bool isdc = k == 0;
         const uint32_t widx = win >> (32 - JS_L1_BITS);
+        // Both tables are read unconditionally and side by side (some lane of the wave is at a DC symbol in nearly every step: a DC
+        // read behind a branch is a second, dependent LDS round trip per step); the DC entry has the AC entry's format in 16 bits
+        // (code length | size << 4, bit 15 = escape to the second level, 0 = no code), widened without a branch.
         const uint32_t e_dc = *reinterpret_cast<const uint16_t*>(l1b + ((wb & 0xFFFFu) + (widx << 1)));
-        uint32_t e = *reinterpret_cast<const uint32_t*>(l1b + ((wb >> 16) + (widx << 2)));   // AC: this symbol and, where visible, the one behind it
-        if (isdc) { const uint32_t l = (e_dc >> 8) & 31u; e = (e_dc & 0x8000u) ? (0x80000000u | (e_dc & 0x7FFFu)) : (l ? (l | ((e_dc & 15u) << 4)) : 0xC0000000u); }
+        const uint32_t e_ac = *reinterpret_cast<const uint32_t*>(l1b + ((wb >> 16) + (widx << 2)));   // AC: this symbol and, where visible, the one behind it
+        const uint32_t e_dcw = (e_dc & 0x7FFFu) | ((e_dc & 0x8000u) << 16);
+        uint32_t e = isdc ? e_dcw : e_ac;
         uint32_t len = e & 15u, size = (e >> 4) & 15u, run = (e >> 8) & 15u;
-        if (__ballot(active && (int32_t)e < 0)) {                // some lane holds a code longer than JS_L1_BITS bits (a few % of symbols), or no code
+        if (WBALLOT(active && (int32_t)e < 0)) {                // some lane holds a code longer than JS_L1_BITS bits (a few % of symbols), or no code
             if ((int32_t)e < 0) {
                 if (e & 0x40000000u) { len = 0; size = 0; run = 0; }
                 else { const uint32_t nbx = (e >> 12) & 7u; const uint32_t e2 = W.lut2[(e & 0xFFFu) + ((win >> (32 - JS_L1_BITS - nbx)) & ((1u << nbx) - 1u))];
@@ -1627,7 +1634,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         // ---- anything out of the ordinary sits behind one vote: no code, the end of the interval inside the code or its value
         //      bits, a run past the 64th coefficient
         bool norm = active;
-        if (__ballot(active && (len == 0 || cur.p + tot > seg_end || k2 > 64u))) {
+        if (WBALLOT(active && (len == 0 || cur.p + tot > seg_end || k2 > 64u))) {
             if (active && (len == 0 || cur.p + len > seg_end)) {  // interval / stream end, or a code that matches nothing
                 const bool more = walk_slow<true, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, blk, !captured, rstf, fl);
                 if (!more) { if (!captured) { captured = true; res_p = P_END; res_s = 0; res_n = nblk; } active = false; }
@@ -1675,7 +1682,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         // Up to FOUR finished blocks per trip: 16 lanes move one block (8 bytes each), so a trip is one LDS read and one
         // 512-byte store instruction -- few, wide stores keep the count of outstanding memory operations (which the next
         // bit-window refill has to wait for) low.
-        uint64_t fm = SIDE ? 0ull : __ballot(flush);
+        uint64_t fm = SIDE ? 0ull : WBALLOT(flush);
         while (fm) {
             const uint32_t s0 = (uint32_t)__builtin_ctzll(fm); fm &= fm - 1;
             const uint32_t s1 = fm ? (uint32_t)__builtin_ctzll(fm) : 64u; fm &= fm - 1;

@@ -97,7 +97,7 @@ void js_build_parallel_luts(JsTableSet* ts, uint32_t ncomp)
             lp[w] = v;
         }
     }
-    // value form of the AC tables for the write pass, rows numbered per class
+    // value form of the tables for the write pass, rows numbered per class
     memset(ts->lutw, 0, sizeof ts->lutw); memset(ts->row_sub, 0, sizeof ts->row_sub); ts->n_dc_rows = ts->n_ac_rows = 0;
     bool seen[6] = { false, false, false, false, false, false };
     for (uint32_t slot = 0; slot < ncomp * 2; slot++) {
@@ -105,8 +105,14 @@ void js_build_parallel_luts(JsTableSet* ts, uint32_t ncomp)
         if (seen[row]) continue;
         seen[row] = true;
         ts->row_sub[row] = is_dc ? ts->n_dc_rows++ : ts->n_ac_rows++;
-        if (is_dc) continue;
         const uint16_t* l1 = ts->lut1[row]; uint32_t* lw = ts->lutw[row];
+        if (is_dc) {                                               // DC rows: single-symbol entries, 16 bits -- [3:0] code length, [7:4] size (the symbol), escape as in lut1
+            for (uint32_t w = 0; w < (1u << JS_L1_BITS); w++) {
+                const uint32_t e1 = l1[w], len1 = (e1 >> 8) & 31u;
+                lw[w] = (e1 & 0x8000u) ? (0x8000u | (e1 & 0x7FFFu)) : (len1 ? (len1 | ((e1 & 15u) << 4)) : 0u);     // 16 significant bits: bit 15 = escape, 0 = no code
+            }
+            continue;
+        }
         for (uint32_t w = 0; w < (1u << JS_L1_BITS); w++) {
             const uint32_t e1 = l1[w], len1 = (e1 >> 8) & 31u;
             if (e1 & 0x8000u) { lw[w] = 0x80000000u | (e1 & 0x7FFFu); continue; }

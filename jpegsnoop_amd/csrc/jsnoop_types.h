@@ -47,7 +47,7 @@ struct JsTableSet {
     //     same form; bits 31 and 30: no code starts with these bits.
     uint32_t lutp[6][1 << JS_L1_BITS];
     uint32_t lut2p[JS_LUT2_MAX];
-    // --- value form for the write pass (AC tables only; DC tables use their lut1 row): the symbol at the window and, when its
+    // --- value form for the write pass (DC tables: single-symbol entries, [3:0] code length, [7:4] size): the symbol at the window and, when its
     //     code is visible in the same window, the AC symbol behind it -- [3:0] code length, [7:4] size, [11:8] run of symbol 1,
     //     [15:12] / [19:16] / [23:20] the same of symbol 2, [24] a second symbol is described.  Bit 31 = escape as in lutp.
     uint32_t lutw[6][1 << JS_L1_BITS];
