@@ -1595,16 +1595,22 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
     const uint32_t wb0 = W.wb0, wb1 = W.wb1, wb2 = W.wb2;       // per component: byte offset of its DC row | of its AC row << 16
     const char* l1b = W.rows;
     uint32_t comp = comp_of(T, c), wb = comp == 0 ? wb0 : (comp == 1 ? wb1 : wb2);
+    uint64_t amask = ~0ull;
     for (;;) {
         // ---- end of the owned range: report the state there; keep going only to finish a block this lane started
+        // Votes: the lane mask of `active` is formed once per step (amask) and ANDed with votes on plain register compares -- a vote on
+        // "active && ..." makes the compiler materialise the loop-carried flag as 0 / 1 and compare it again, two half-rate VALU
+        // instructions per vote.  amask may still hold lanes that went inactive late in the previous step: such a vote only enters a
+        // block in which no lane acts.
         const bool at_end = active && cur.p >= own_end;
-        if (WBALLOT(at_end)) {
+        if (WBALLOT(cur.p >= own_end) & amask) {
             if (at_end) {
                 if (!captured) { res_p = cur.p; res_s = ST_MAKE(seg, c, k); res_n = nblk; captured = true; }
                 if (k == 0 || skip) active = false;
             }
         }
-        if (!WBALLOT(active)) break;
+        amask = WBALLOT(active);
+        if (!amask) break;
         // ---- one or two symbols per lane: straight-line select code on the common path
         const uint32_t win = cur_peek(cur);
         const bool isdc = k == 0;
@@ -1617,7 +1623,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         const uint32_t e_dcw = (e_dc & 0x7FFFu) | ((e_dc & 0x8000u) << 16);
         uint32_t e = isdc ? e_dcw : e_ac;
         uint32_t len = e & 15u, size = (e >> 4) & 15u, run = (e >> 8) & 15u;
-        if (WBALLOT(active && (int32_t)e < 0)) {                // some lane holds a code longer than JS_L1_BITS bits (a few % of symbols), or no code
+        if (WBALLOT((int32_t)e < 0) & amask) {                // some lane holds a code longer than JS_L1_BITS bits (a few % of symbols), or no code
             if ((int32_t)e < 0) {
                 if (e & 0x40000000u) { len = 0; size = 0; run = 0; }
                 else { const uint32_t nbx = (e >> 12) & 7u; const uint32_t e2 = W.lut2[(e & 0xFFFu) + ((win >> (32 - JS_L1_BITS - nbx)) & ((1u << nbx) - 1u))];
@@ -1634,7 +1640,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         // ---- anything out of the ordinary sits behind one vote: no code, the end of the interval inside the code or its value
         //      bits, a run past the 64th coefficient
         bool norm = active;
-        if (WBALLOT(active && (len == 0 || cur.p + tot > seg_end || k2 > 64u))) {
+        if (WBALLOT(len == 0 || cur.p + tot > seg_end || k2 > 64u) & amask) {
             if (active && (len == 0 || cur.p + len > seg_end)) {  // interval / stream end, or a code that matches nothing
                 const bool more = walk_slow<true, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, blk, !captured, rstf, fl);
                 if (!more) { if (!captured) { captured = true; res_p = P_END; res_s = 0; res_n = nblk; } active = false; }

@@ -221,6 +221,14 @@ int js_selftest_tables(unsigned seed, unsigned rounds)
                     if (vis2 != (b12 != 0)) bad++;
                     if (vis2 && (b12 != bits1 + len2 + size2 || (pe >> 24) != adv1 + adv2)) bad++;
                 }
+                // write pass: DC rows hold single-symbol entries in 16 bits (code length | size << 4, bit 15 = escape, 0 = no code)
+                if (is_dc) {
+                    const uint32_t we = ts->lutw[row][w];
+                    if (we >> 16) bad++;
+                    if (we & 0x8000u) { if (len1 && len1 <= JS_L1_BITS) bad++; if ((we & 0x7FFFu) != (ts->lut1[row][w] & 0x7FFFu)) bad++; }
+                    else if (!len1 || len1 > JS_L1_BITS) { if (we != 0u && !(ts->lut1[row][w] & 0x8000u)) bad++; }
+                    else if ((we & 15u) != len1 || ((we >> 4) & 15u) != size1 || (we >> 8)) bad++;
+                }
                 // value-pair entries of the write pass (AC tables)
                 if (!is_dc) {
                     const uint32_t we = ts->lutw[row][w];
