@@ -1688,21 +1688,25 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         // Up to FOUR finished blocks per trip: 16 lanes move one block (8 bytes each), so a trip is one LDS read and one
         // 512-byte store instruction -- few, wide stores keep the count of outstanding memory operations (which the next
         // bit-window refill has to wait for) low.
-        uint64_t fm = SIDE ? 0ull : WBALLOT(flush);
-        while (fm) {
-            const uint32_t s0 = (uint32_t)__builtin_ctzll(fm); fm &= fm - 1;
-            const uint32_t s1 = fm ? (uint32_t)__builtin_ctzll(fm) : 64u; fm &= fm - 1;
-            const uint32_t s2 = fm ? (uint32_t)__builtin_ctzll(fm) : 64u; fm &= fm - 1;
-            const uint32_t s3 = fm ? (uint32_t)__builtin_ctzll(fm) : 64u; fm &= fm - 1;
-            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)fblk, s0), b1 = (uint32_t)__builtin_amdgcn_readlane((int)fblk, s1 & 63u),
-                           b2 = (uint32_t)__builtin_amdgcn_readlane((int)fblk, s2 & 63u), b3 = (uint32_t)__builtin_amdgcn_readlane((int)fblk, s3 & 63u);
-            const uint32_t g = lane >> 4;
-            const uint32_t src = g == 0 ? s0 : (g == 1 ? s1 : (g == 2 ? s2 : s3)), b = g == 0 ? b0 : (g == 1 ? b1 : (g == 2 ? b2 : b3));
-            if (src < 64u) {
-                uint32_t* sb = reinterpret_cast<uint32_t*>(s_blk[wave0 + src]) + (lane & 15u) * 2u;
-                const uint32_t lo = sb[0], hi = sb[1];
-                sb[0] = 0u; sb[1] = 0u;
-                *reinterpret_cast<uint2*>(cbase + (size_t)b * 64 + (lane & 15u) * 4u) = make_uint2(lo, hi);
+        // The flushing lanes are ranked (mbcnt) and one wave permute hands lane j the id of the j-th flushing lane; per trip a group of
+        // 16 lanes fetches "its" source lane and that lane's block number with two more permutes -- no scalar loop over the vote mask
+        // (find-first-set, readlane and per-group selects cost 25 scalar + 21 vector instructions per trip).
+        const uint64_t fm = SIDE ? 0ull : WBALLOT(flush);
+        if (fm) {
+            const uint32_t nfl = (uint32_t)__builtin_popcountll(fm);
+            const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+            const uint32_t dst = flush ? rk : nfl + lane - rk;                       // a full permutation: flushing lanes first, in lane order
+            const uint32_t ent = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)lane);
+            for (uint32_t t0 = 0; t0 < nfl; t0 += 4u) {
+                const uint32_t idx = t0 + (lane >> 4);
+                const uint32_t src = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)ent);
+                const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)fblk);
+                if (idx < nfl) {
+                    uint32_t* sb = reinterpret_cast<uint32_t*>(s_blk[wave0 + src]) + (lane & 15u) * 2u;
+                    const uint32_t lo = sb[0], hi = sb[1];
+                    sb[0] = 0u; sb[1] = 0u;
+                    *reinterpret_cast<uint2*>(cbase + (size_t)b * 64 + (lane & 15u) * 4u) = make_uint2(lo, hi);
+                }
             }
         }
     }
@@ -1716,6 +1720,192 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         uint32_t* ho = side + im.side_off + JS_SIDE_HISTO;
         for (uint32_t q = threadIdx.x; q < 2 * 4 * 17; q += SY_THREADS) { const uint32_t v = s_histo[q]; if (v) atomicAdd(&ho[q], v); }
     } else if (fl) atomicOr(&flags[img], fl);
+}
+
+// WRITE pass, second form (the one the main path launches; k_write<., true> above stays the side-output pass and k_write<., false> the
+// cross-check, JSNOOP_WRITE_V1=1).  Same walk, same results -- written against the instruction-cost table of DESIGN.md §4.7:
+//  * every per-lane flag that lives across steps (active, skip, captured) is a 64-bit lane MASK in scalar registers; votes are compares
+//    written straight into a scalar pair and combined there, a lane reads its bit back as a predicate (inverse ballot) -- the compiler
+//    never has to turn a flag into 0 / 1 in a vector register and compare it again;
+//  * the rare events (end of the own range, codes longer than the first level, interval ends and errors) each sit behind ONE vote, and
+//    they leave the lane in a state in which the straight-line code of the step does nothing for it (no bits consumed, index kept);
+//  * zero-valued coefficients (ZRL, EOB) are simply stored: they land on positions that are zero and are never written twice;
+//  * the DC difference of a finished block is read back from the lane's block instead of being carried through every step.
+#define IBAL(m) __builtin_amdgcn_inverse_ballot_w64(m)
+// EXTEND (HuffmanDc2Signed :859) of the `size` bits that follow `skipbits` bits of the window; size == 0 -> 0
+__device__ __forceinline__ int32_t extend_bits(uint32_t win, uint32_t skipbits, uint32_t size)
+{
+    const uint32_t x = win << skipbits;
+    const uint32_t vraw = __builtin_amdgcn_ubfe(x, 32u - size, size);
+    const uint32_t neglim = (0xFFFFFFFFu << size) + 1u;          // -(2^size - 1)
+    return (int32_t)x < 0 ? (int32_t)vraw : (int32_t)(vraw + neglim);
+}
+template <int WL>
+__global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sy_base, uint32_t nimg,
+                                                       const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr,
+                                                       const uint32_t* __restrict__ seg_tab, uint32_t* __restrict__ side, SubArrays A,
+                                                       int16_t* __restrict__ coef, int16_t* __restrict__ dccum, uint8_t* __restrict__ mcu_rst, uint32_t* __restrict__ flags,
+                                                       uint32_t tab_rows, uint32_t tab_lut2)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    __shared__ __attribute__((aligned(16))) int16_t s_blk[SY_THREADS][WR_STRIDE];
+    const uint32_t wg = blockIdx.x;
+    const uint32_t img = find_image(sy_base, nimg, wg);
+    const JsImage& im = imgs[img];
+    if (!tables[im.tableset].lut_ok) return;
+    const uint32_t* sd = side + im.side_off;
+    const uint32_t total_bits = sd[10] * 8, nseg = min(sd[11], im.seg_cap - 1);
+    const uint32_t lane = threadIdx.x & 63, wave0 = threadIdx.x & ~63u;
+    const uint32_t sub0 = (wg - sy_base[img]) * SY_THREADS, i = sub0 + threadIdx.x;
+    if (sub0 * SUB_BITS >= total_bits) return;
+    const JsTableSet& tset = tables[im.tableset];
+    SubTabs T; T.nb = im.blk_per_mcu; T.n1 = im.samp_h[1] * im.samp_v[1]; T.n2 = im.ncomp == 3 ? T.n1 + im.samp_h[2] * im.samp_v[2] : T.nb;
+    WriteTabs W; load_wtabs(W, s_dyn, tset, tab_rows, tab_lut2, im.ncomp, threadIdx.x, SY_THREADS);
+    { uint32_t* z = reinterpret_cast<uint32_t*>(s_blk[threadIdx.x]); for (int j = 0; j < WR_STRIDE / 2; j++) z[j] = 0u; }
+    __syncthreads();
+
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);
+    const uint32_t* st = seg_tab + im.seg_off;
+    int16_t* cbase = coef + im.coef_off * 64; int16_t* dbase = dccum + im.coef_off; uint8_t* rstf = mcu_rst + im.mcu_off;
+    char* lbuf = reinterpret_cast<char*>(s_blk[threadIdx.x]);
+    const uint32_t nblocks = im.total_blocks, prec_shift = im.precision >= 8 ? ((im.precision - 8) & 31) : 0;
+    const uint64_t acmask = im.decode_ac ? ~0ull : 0ull;        // DC-only mode: AC coefficients are parsed, not stored
+    const bool in_data = i * SUB_BITS < total_bits;
+    const size_t g = im.subseq_off + i;
+    uint32_t fl = 0, nblk = 0, seg = 0, c = 0, k = 0, seg_end = 0, blk = 0;
+    uint32_t res_p = 0, res_s = 0, res_n = 0;                // what this lane reports for verification
+    bool verify = false, check_n = false, active0 = false, skip0 = false;
+    const uint32_t own_end = min((i + 1) * SUB_BITS, total_bits);
+    Cursor cur; cur.words = words; cur.widx = 0; cur.w0 = cur.w1 = cur.nxt = 0; cur.sh = 0; cur.p = 0;
+    if (in_data) {
+        const uint32_t p0 = i ? A.out_p[g - 1] : 0u, s0 = i ? A.out_s[g - 1] : 0u;
+        blk = A.base[g]; seg = ST_SEG(s0); c = ST_C(s0); k = ST_K(s0);
+        verify = true;
+        if (p0 != P_END && p0 >= own_end) { res_p = p0; res_s = s0; }                          // owns no symbol: passes through
+        else if (p0 == P_END || (p0 >= total_bits && seg + 1 >= nseg)) { res_p = P_END; res_s = 0; check_n = true; }
+        else if (blk >= nblocks) verify = false;                                                // everything owned lies past the last MCU
+        else { active0 = true; check_n = true; seg_end = st[seg + 1] * 8; skip0 = k != 0; cur_init<WL>(cur, words, p0); }
+    }
+    const uint32_t wb0 = W.wb0, wb1 = W.wb1, wb2 = W.wb2;       // per component: byte offset of its DC row | of its AC row << 16
+    const char* l1b = W.rows;
+    const char* qzb = reinterpret_cast<const char*>(W.qz);
+    uint32_t comp = comp_of(T, c), wb = comp == 0 ? wb0 : (comp == 1 ? wb1 : wb2);
+    uint64_t m_act = WBALLOT(active0), m_skip = WBALLOT(skip0), m_cap = 0ull;
+    for (;;) {
+        // ---- end of the owned range: report the state there; keep going only to finish a block this lane started
+        const uint64_t m_end = WBALLOT(cur.p >= own_end) & m_act;
+        if (m_end) {
+            if (IBAL(m_end & ~m_cap)) { res_p = cur.p; res_s = ST_MAKE(seg, c, k); res_n = nblk; }
+            m_cap |= m_end;
+            m_act &= ~(m_end & (WBALLOT(k == 0) | m_skip));
+        }
+        if (!m_act) break;
+        // ---- table entry: both tables read side by side (some lane of the wave is at a DC symbol in nearly every step)
+        const uint32_t win = cur_peek(cur);
+        const uint32_t widx = win >> (32 - JS_L1_BITS);
+        const uint64_t m_dc = WBALLOT(k == 0);
+        const uint32_t e_dc = (uint32_t)(int32_t)*reinterpret_cast<const int16_t*>(l1b + ((wb & 0xFFFFu) + (widx << 1)));   // escape (bit 15) becomes the sign
+        const uint32_t e_ac = *reinterpret_cast<const uint32_t*>(l1b + ((wb >> 16) + (widx << 2)));
+        uint32_t e = IBAL(m_dc) ? e_dc : e_ac;
+        uint32_t len = e & 15u, size = (e >> 4) & 15u, run = (e >> 8) & 15u;
+        const uint64_t m_esc = WBALLOT((int32_t)e < 0) & m_act;
+        if (m_esc) {                                             // a code longer than JS_L1_BITS bits (a few % of symbols), or no code
+            if (IBAL(m_esc)) {
+                const uint32_t nbx = (e >> 12) & 7u;
+                const uint32_t e2 = W.lut2[(e & 0xFFFu) + __builtin_amdgcn_ubfe(win, 32u - JS_L1_BITS - nbx, nbx)];
+                const bool nocode = e == 0xC0000000u;            // (AC rows; a DC row says 0, which is "length 0" already)
+                len = nocode ? 0u : (e2 >> 8) & 31u; run = nocode ? 0u : (e2 >> 4) & 15u; size = nocode ? 0u : e2 & 15u;
+                e = 0;                                           // a single symbol
+            }
+        }
+        uint32_t tot = len + size;
+        uint32_t k2 = k + run + 1u;                              // coefficient index behind this symbol (DC: k = 0, run = 0)
+        // the AC symbol behind it goes along when the first one does not end the lane's own range, and nothing out of the ordinary can
+        // happen on the way (interval end, coefficient overflow); an entry without a visible second symbol has zero bits there
+        const uint32_t len2 = (e >> 12) & 15u, size2 = (e >> 16) & 15u, run2 = (e >> 20) & 15u, tot2 = len2 + size2, k3 = k2 + run2 + 1u;
+        const uint32_t p1 = cur.p + tot, p2 = p1 + tot2;
+        uint64_t m_two = WBALLOT(tot2 != 0u) & WBALLOT(k3 <= 64u) & WBALLOT(p1 < own_end) & WBALLOT(p2 <= seg_end) & m_act;
+        // ---- anything out of the ordinary sits behind one vote: no code, the end of the interval inside the code or its value
+        //      bits, a run past the 64th coefficient
+        uint64_t m_norm = m_act, m_nost = 0ull;
+        const uint64_t m_abn = (WBALLOT(len == 0u) | WBALLOT(p1 > seg_end) | WBALLOT(k2 > 64u)) & m_act;
+        if (m_abn) {
+            const uint64_t m_slow = (WBALLOT(len == 0u) | WBALLOT(cur.p + len > seg_end)) & m_act;
+            bool over = false;                                   // (lane masks change in wave-uniform code only)
+            if (IBAL(m_slow)) {                                  // interval / stream end, or a code that matches nothing
+                const bool notcap = !IBAL(m_cap);
+                const bool more = walk_slow<true, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, blk, notcap, rstf, fl);
+                if (!more && notcap) { res_p = P_END; res_s = 0; res_n = nblk; }
+                over = !more;
+                comp = comp_of(T, c); wb = comp == 0 ? wb0 : (comp == 1 ? wb1 : wb2);
+                tot = 0; size = 0; k2 = k;                       // the step below does nothing for this lane
+            } else if (IBAL(m_act)) {
+                if (blk < nblocks) { if (p1 > seg_end) fl |= F_OVERRUN; if (k2 > 64u) fl |= F_COEF_OVERFLOW; }
+            }
+            const uint64_t m_over = WBALLOT(over);
+            m_cap |= m_over; m_act &= ~m_over;
+            m_norm &= ~m_slow; m_two &= ~m_slow;
+            m_nost = WBALLOT(k2 > 64u);
+        }
+        // ---- value bits: EXTEND (HuffmanDc2Signed :859), precision divide (:1234-1238), dequantise (:2278), de-zigzag
+        int32_t val = extend_bits(win, len, size), val2 = extend_bits(win, tot + len2, size2);
+        if (prec_shift) { val /= (int32_t)(1u << prec_shift); val2 /= (int32_t)(1u << prec_shift); }
+        const char* qrow = qzb + comp * 256u;
+        const uint32_t qz = *reinterpret_cast<const uint32_t*>(qrow + (((k2 - 1u) & 63u) << 2));           // DC: 0, AC: k + run
+        const uint32_t qz2 = *reinterpret_cast<const uint32_t*>(qrow + (((k3 - 1u) & 63u) << 2));
+        const uint64_t m_st = m_norm & ~m_skip & ~m_nost & (m_dc | acmask);
+        if (IBAL(m_st)) *reinterpret_cast<int16_t*>(lbuf + ((qz >> 16) << 1)) = (int16_t)((int32_t)(int16_t)val * (int32_t)(qz & 0xFFFFu));
+        if (IBAL(m_two & ~m_skip & acmask)) *reinterpret_cast<int16_t*>(lbuf + ((qz2 >> 16) << 1)) = (int16_t)((int32_t)(int16_t)val2 * (int32_t)(qz2 & 0xFFFFu));
+        // ---- advance
+        const bool two = IBAL(m_two);
+        { const uint32_t adv = tot + (two ? tot2 : 0u); cur.sh -= (int32_t)adv; cur.p += adv; }
+        if (IBAL(WBALLOT(cur.sh < 0) & m_act)) {                 // (lanes that are not active compute on whatever they hold: they must not load)
+            cur.sh += 32; cur.w0 = cur.w1; cur.w1 = bswap32(cur.nxt); cur.nxt = words[phys_word<WL>(cur.widx++)];
+        }
+        const uint32_t kn = two ? k3 : k2;
+        const uint64_t m_eob = (m_two & WBALLOT((run2 | size2) == 0u)) | (~m_two & WBALLOT((run | size) == 0u));
+        const uint64_t m_done = m_norm & ~m_dc & (m_eob | WBALLOT(kn >= 64u));
+        k = IBAL(m_done) ? 0u : kn;
+        if (m_done) {
+            const uint64_t m_flush = m_done & ~m_skip & WBALLOT(blk < nblocks);
+            const uint32_t fblk = blk;
+            if (IBAL(m_done)) {
+                c = c + 1 == T.nb ? 0u : c + 1; comp = comp_of(T, c); wb = comp == 0 ? wb0 : (comp == 1 ? wb1 : wb2);
+                nblk += IBAL(m_cap) ? 0u : 1u;
+                blk++;
+            }
+            m_skip &= ~m_done;
+            // ---- the whole wave moves every block that completed in this step: 16 lanes x 8 bytes per block, four blocks per store
+            // instruction.  The flushing lanes are ranked (mbcnt); two wave permutes hand lane j the id and the block number of the j-th
+            // flushing lane, and per trip a group of 16 lanes fetches "its" pair with two more permutes -- no scalar loop over the vote.
+            if (m_flush) {
+                const bool flush = IBAL(m_flush);
+                if (flush) dbase[fblk] = *reinterpret_cast<const int16_t*>(lbuf);      // the block's DC difference (natural index 0)
+                const uint32_t nfl = (uint32_t)__builtin_popcountll(m_flush);
+                const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_flush >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_flush, 0u));
+                const uint32_t dst = (flush ? rk : nfl + lane - rk) << 2;                // a full permutation: flushing lanes first, in lane order
+                const uint32_t ent_l = (uint32_t)__builtin_amdgcn_ds_permute((int)dst, (int)lane);
+                const uint32_t ent_b = (uint32_t)__builtin_amdgcn_ds_permute((int)dst, (int)fblk);
+                for (uint32_t t0 = 0; t0 < nfl; t0 += 4u) {
+                    const uint32_t idx = t0 + (lane >> 4);
+                    const uint32_t src = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)ent_l);
+                    const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)ent_b);
+                    if (idx < nfl) {
+                        uint32_t* sb = reinterpret_cast<uint32_t*>(s_blk[wave0 + src]) + (lane & 15u) * 2u;
+                        const uint32_t lo = sb[0], hi = sb[1];
+                        sb[0] = 0u; sb[1] = 0u;
+                        *reinterpret_cast<uint2*>(cbase + (size_t)b * 64 + (lane & 15u) * 4u) = make_uint2(lo, hi);
+                    }
+                }
+            }
+        }
+    }
+    if (verify) {
+        if (check_n && !IBAL(m_cap) && res_p != P_END) { res_p = cur.p; res_s = cur.p == P_END ? 0u : ST_MAKE(seg, c, k); res_n = nblk; }
+        // the chain must be at its fixed point, and the block count that fed the prefix sum must be the real one
+        if (res_p != A.out_p[g] || res_s != A.out_s[g] || (check_n && res_n != A.nblk[g])) fl |= F_NOSYNC;
+    }
+    if (fl) atomicOr(&flags[img], fl);
 }
 
 // One workgroup (1024 lanes) per image: DC differences (in dccum, decode order) -> cumulative DC per block.
@@ -1843,6 +2033,14 @@ void js_launch_write(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut
                      int16_t* coef, int16_t* dccum, uint8_t* mcu_rst, uint32_t* flags)
 {
     if (!total_wgs) return;
+    static const bool v1 = getenv("JSNOOP_WRITE_V1") != nullptr;     // the first form of the kernel, kept as a cross-check
+    if (!v1) {
+        if (wl == 7) hipLaunchKernelGGL((k_write2<7>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                           sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2);
+        else hipLaunchKernelGGL((k_write2<5>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                           sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2);
+        return;
+    }
     if (wl == 7) hipLaunchKernelGGL((k_write<7, false>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2, 0u, (uint32_t*)nullptr);
     else hipLaunchKernelGGL((k_write<5, false>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
