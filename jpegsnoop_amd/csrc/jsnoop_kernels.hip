@@ -1352,9 +1352,11 @@ __device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, co
     Cursor cur; cur_init<WL>(cur, words, p_io);
     const char* lp = reinterpret_cast<const char*>(T.lutp);
     uint32_t rb = c < T.n1 ? T.rb0 : (c < T.n2 ? T.rb1 : T.rb2);
+    // Votes are compares written into scalar pairs and combined there (a vote on "act && ..." makes the compiler turn the flag into 0 / 1 in
+    // a vector register and compare it again); a lane reads its bit back as a predicate.
     for (;;) {
-        const bool act = cur.p < own_end;
-        if (!WBALLOT(act)) break;
+        const uint64_t m_act = WBALLOT(cur.p < own_end);
+        if (!m_act) break;
         const uint32_t win = cur_peek(cur);
         // One table entry describes the symbol at the cursor and, where its code was visible in the same window, the AC symbol
         // behind it: byte 0 = bits of symbol 1 (code + value), byte 1 = its advance of the coefficient index (64 for EOB: ends the
@@ -1362,17 +1364,17 @@ __device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, co
         uint32_t pe = *reinterpret_cast<const uint32_t*>(lp + ((k ? rb >> 16 : rb & 0xFFFFu) + ((win >> (32 - JS_L1_BITS)) << 2)));
         // A code longer than the window: a few % of symbols, but SOME lane of the wave holds one nearly every step.  One read of
         // the second level replaces the entry by a single-symbol one and the lane stays on the common path.
-        const bool esc = act && (pe >> 30) == 2u;
-        if (WBALLOT(esc)) {
-            if (esc) { const uint32_t nbx = (pe >> 12) & 7u; pe = T.lut2p[(pe & 0xFFFu) + ((win >> (32 - JS_L1_BITS - nbx)) & ((1u << nbx) - 1u))]; }
+        const uint64_t m_esc = WBALLOT((int32_t)pe < (int32_t)0xC0000000u) & m_act;       // top bits 10
+        if (m_esc) {
+            if (__builtin_amdgcn_inverse_ballot_w64(m_esc)) { const uint32_t nbx = (pe >> 12) & 7u; pe = T.lut2p[(pe & 0xFFFu) + ((win >> (32 - JS_L1_BITS - nbx)) & ((1u << nbx) - 1u))]; }
         }
         const uint32_t b1 = pe & 255u, k1 = k + ((pe >> 8) & 255u), b12 = (pe >> 16) & 255u;
         // both symbols together when the first one does not end the block and the second one starts inside this lane's own range
         const bool two = b12 != 0u && k1 < 64u && cur.p + b1 < own_end;
         const uint32_t adv = two ? b12 : b1;
-        const bool slow = act && ((int32_t)pe < 0 || cur.p + adv > seg_end);
-        if (WBALLOT(slow)) {
-            if (slow) {                                          // no code here, or the end of the restart interval / of the data is near:
+        const uint64_t m_slow = (WBALLOT((int32_t)pe < 0) | WBALLOT(cur.p + adv > seg_end)) & m_act;
+        if (m_slow) {
+            if (__builtin_amdgcn_inverse_ballot_w64(m_slow)) {   // no code here, or the end of the restart interval / of the data is near:
                 const uint32_t row = (k ? rb >> 16 : rb & 0xFFFFu) >> (JS_L1_BITS + 2);     // one symbol the careful way
                 const uint32_t e = sym_lookup(T, win, row, 0u);
                 const uint32_t len = (e >> 8) & 31u, run = (e >> 4) & 15u, size = e & 15u;
@@ -1388,10 +1390,12 @@ __device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, co
                 rb = c < T.n1 ? T.rb0 : (c < T.n2 ? T.rb1 : T.rb2);
             }
         }
-        const bool go = act && !slow;
+        const uint64_t m_go = m_act & ~m_slow;
+        const bool go = __builtin_amdgcn_inverse_ballot_w64(m_go);
         cur_skip<WL>(cur, go ? adv : 0u);
         const uint32_t kn = two ? k + (pe >> 24) : k1;
-        const bool dn = go && kn >= 64u;
+        const uint64_t m_dn = m_go & WBALLOT(kn >= 64u);
+        const bool dn = __builtin_amdgcn_inverse_ballot_w64(m_dn);
         k = dn ? 0u : (go ? kn : k);
         if (dn) { c = c + 1 == T.nb ? 0u : c + 1; nblk++; rb = c < T.n1 ? T.rb0 : (c < T.n2 ? T.rb1 : T.rb2); }
     }
