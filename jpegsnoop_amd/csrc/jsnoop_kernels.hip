@@ -1882,9 +1882,9 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
             // ---- the whole wave moves every block that completed in this step: 16 lanes x 8 bytes per block, four blocks per store
             // instruction.  The flushing lanes are ranked (mbcnt); two wave permutes hand lane j the id and the block number of the j-th
             // flushing lane, and per trip a group of 16 lanes fetches "its" pair with two more permutes -- no scalar loop over the vote.
+            // The first lane of a group also stores the block's DC difference (the first coefficient it holds).
             if (m_flush) {
                 const bool flush = IBAL(m_flush);
-                if (flush) dbase[fblk] = *reinterpret_cast<const int16_t*>(lbuf);      // the block's DC difference (natural index 0)
                 const uint32_t nfl = (uint32_t)__builtin_popcountll(m_flush);
                 const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_flush >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_flush, 0u));
                 const uint32_t dst = (flush ? rk : nfl + lane - rk) << 2;                // a full permutation: flushing lanes first, in lane order
@@ -1895,10 +1895,11 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
                     const uint32_t src = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)ent_l);
                     const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)ent_b);
                     if (idx < nfl) {
-                        uint32_t* sb = reinterpret_cast<uint32_t*>(s_blk[wave0 + src]) + (lane & 15u) * 2u;
-                        const uint32_t lo = sb[0], hi = sb[1];
-                        sb[0] = 0u; sb[1] = 0u;
-                        *reinterpret_cast<uint2*>(cbase + (size_t)b * 64 + (lane & 15u) * 4u) = make_uint2(lo, hi);
+                        uint2* sb = reinterpret_cast<uint2*>(s_blk[wave0 + src]) + (lane & 15u);
+                        const uint2 v = *sb;
+                        *sb = make_uint2(0u, 0u);
+                        *reinterpret_cast<uint2*>(cbase + (size_t)b * 64 + (lane & 15u) * 4u) = v;
+                        if ((lane & 15u) == 0u) dbase[b] = (int16_t)v.x;
                     }
                 }
             }
