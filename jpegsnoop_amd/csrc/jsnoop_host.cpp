@@ -307,7 +307,7 @@ int JsnoopBatch::upload()
     // sub-sequence length: long (512 B) when the batch still yields plenty of lanes, short (128 B) for small jobs
     uint64_t scan_total = 0; for (const JsImage& im : imgs) scan_total += im.scan_len;
     sub_wl = scan_total >= (96ull << 20) ? 7 : 5;
-    if (const char* e = getenv("JSNOOP_SUB_WL")) sub_wl = atoi(e) == 7 ? 7 : 5;
+    if (const char* e = getenv("JSNOOP_SUB_WL")) { const int w = atoi(e); sub_wl = (w >= 5 && w <= 8) ? w : 5; }
     const uint32_t sub_bytes = 4u << sub_wl;
     uint32_t wgs = 0; max_mcu_h = 8; max_mcu_w = 8;
     for (size_t i = 0; i < n; i++) {

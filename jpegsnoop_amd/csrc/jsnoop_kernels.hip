@@ -1015,7 +1015,7 @@ void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, 
 #define SY_THREADS 256
 // sub-sequence length is a per-batch choice: WL = log2(32-bit words per sub-sequence) = 5 (128 B) or 7 (512 B)
 #define SUB_BITS   (32u << WL)
-#define SYNC_SPEC_TAIL (WL == 7 ? 2048u : 1024u)   // bits at the end of a sub-sequence the first (speculative) walk covers
+#define SYNC_SPEC_TAIL (WL >= 7 ? 2048u : 1024u)   // bits at the end of a sub-sequence the first (speculative) walk covers
 
 #define F_BAD_CODE      0x0001u
 #define F_OVERRUN       0x0002u
@@ -1034,6 +1034,13 @@ template <int WL> __device__ __forceinline__ uint32_t phys_byte(uint32_t B) { re
 struct UsBytes { uint32_t keep_mask, rst_mask; };
 
 // Classifies the 16 bytes at absolute raw offset `o16` of image `im` (scan range [s,e)).
+// Four "byte is zero" flags of a word, gathered into bits 0..3 (exact: no borrow crosses a byte; the multiply lines the four flag bits
+// up in the top nibble, every partial product lands on a bit of its own).
+__device__ __forceinline__ uint32_t us_zero_bytes(uint32_t x)
+{
+    const uint32_t nz = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;          // bit 7 of every byte: byte != 0
+    return (((~nz & 0x80808080u) >> 7) * 0x10204080u) >> 28;
+}
 __device__ __forceinline__ UsBytes us_classify(const uint8_t* __restrict__ raw, uint64_t o16, uint64_t s, uint64_t e)
 {
     UsBytes r; r.keep_mask = 0; r.rst_mask = 0;
@@ -1042,6 +1049,18 @@ __device__ __forceinline__ UsBytes us_classify(const uint8_t* __restrict__ raw, 
     const uint32_t w[4] = { v.x, v.y, v.z, v.w };
     uint32_t prev = o16 > s ? raw[o16 - 1] : 0u;             // bytes before the scan start never count as FF
     const uint32_t next16 = (o16 + 16 < e) ? raw[o16 + 16] : 0u;
+    if (o16 > s && o16 + 17 <= e) {
+        // All sixteen bytes, the one before and the one after lie inside the scan (everything but the first and last few threads of an
+        // image): the byte rules as word arithmetic.  ff = bytes that are FF, rc = bytes D0..D7 (bit j = byte j of the sixteen).
+        uint32_t ff = 0, rc = 0;
+        #pragma unroll
+        for (int q = 0; q < 4; q++) { ff |= us_zero_bytes(~w[q]) << (4 * q); rc |= us_zero_bytes((w[q] & 0xF8F8F8F8u) ^ 0xD0D0D0D0u) << (4 * q); }
+        const uint32_t rc_next = (next16 & 0xF8u) == 0xD0u ? 1u : 0u;
+        const uint32_t is_rst = ff & ((rc >> 1) | (rc_next << 15));            // FF followed by D0..D7
+        const uint32_t after_ff = ((ff << 1) | (prev == 0xFFu ? 1u : 0u)) & 0xFFFFu;   // the byte after an FF: stuffed 00 or the RSTn code
+        r.keep_mask = ~(after_ff | is_rst) & 0xFFFFu; r.rst_mask = is_rst;
+        return r;
+    }
     #pragma unroll
     for (int j = 0; j < 16; j++) {
         const uint64_t o = o16 + j;
@@ -2009,7 +2028,9 @@ void js_launch_unstuff(hipStream_t st, int wl, const JsImage* imgs, const uint32
     hipLaunchKernelGGL(k_unstuff_count, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst);
     hipLaunchKernelGGL(k_unstuff_scan, dim3(nimg), dim3(256), 0, st, imgs, us_base, chunk_keep, chunk_rst, seg_tab, side, flags);
     hipLaunchKernelGGL(k_unstuff_write, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, ustr_lin, seg_tab, 0u, (uint32_t*)nullptr);
-    if (wl == 7) hipLaunchKernelGGL(k_interleave<7>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
+    if (wl == 6) hipLaunchKernelGGL(k_interleave<6>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
+    else if (wl == 8) hipLaunchKernelGGL(k_interleave<8>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
+    else if (wl == 7) hipLaunchKernelGGL(k_interleave<7>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
     else hipLaunchKernelGGL(k_interleave<5>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
 }
 static SubArrays sub_arrays(uint32_t* sub, uint64_t n) { SubArrays a; a.out_p = sub; a.out_s = sub + n; a.in_p = sub + 2 * n; a.in_s = sub + 3 * n; a.nblk = sub + 4 * n; a.base = sub + 5 * n; return a; }
@@ -2019,7 +2040,11 @@ void js_launch_sync(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2
                     const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub, int first_pass)
 {
     if (!total_wgs) return;
-    if (wl == 7) hipLaunchKernelGGL(k_sync<7>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2, true), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+    if (wl == 6) hipLaunchKernelGGL(k_sync<6>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2, true), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                       sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2);
+    else if (wl == 8) hipLaunchKernelGGL(k_sync<8>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2, true), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                       sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2);
+    else if (wl == 7) hipLaunchKernelGGL(k_sync<7>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2, true), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2);
     else hipLaunchKernelGGL(k_sync<5>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2, true), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2);
@@ -2028,9 +2053,13 @@ void js_launch_block_scan(hipStream_t st, int wl, const JsImage* imgs, uint32_t 
 {
     if (!nimg) return;
     if (nimg <= 8) {                                             // a few (large) images: wide workgroups, fewer serial steps
-        if (wl == 7) hipLaunchKernelGGL((k_block_scan<7, 1024>), dim3(nimg), dim3(1024), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
+        if (wl == 6) hipLaunchKernelGGL((k_block_scan<6, 1024>), dim3(nimg), dim3(1024), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
+    else if (wl == 8) hipLaunchKernelGGL((k_block_scan<8, 1024>), dim3(nimg), dim3(1024), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
+    else if (wl == 7) hipLaunchKernelGGL((k_block_scan<7, 1024>), dim3(nimg), dim3(1024), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
         else hipLaunchKernelGGL((k_block_scan<5, 1024>), dim3(nimg), dim3(1024), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
-    } else if (wl == 7) hipLaunchKernelGGL((k_block_scan<7, 256>), dim3(nimg), dim3(256), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
+    } else if (wl == 6) hipLaunchKernelGGL((k_block_scan<6, 256>), dim3(nimg), dim3(256), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
+    else if (wl == 8) hipLaunchKernelGGL((k_block_scan<8, 256>), dim3(nimg), dim3(256), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
+    else if (wl == 7) hipLaunchKernelGGL((k_block_scan<7, 256>), dim3(nimg), dim3(256), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
     else hipLaunchKernelGGL((k_block_scan<5, 256>), dim3(nimg), dim3(256), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
 }
 void js_launch_write(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
@@ -2040,13 +2069,21 @@ void js_launch_write(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut
     if (!total_wgs) return;
     static const bool v1 = getenv("JSNOOP_WRITE_V1") != nullptr;     // the first form of the kernel, kept as a cross-check
     if (!v1) {
-        if (wl == 7) hipLaunchKernelGGL((k_write2<7>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+        if (wl == 6) hipLaunchKernelGGL((k_write2<6>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                           sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2);
+    else if (wl == 8) hipLaunchKernelGGL((k_write2<8>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                           sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2);
+    else if (wl == 7) hipLaunchKernelGGL((k_write2<7>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                            sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2);
         else hipLaunchKernelGGL((k_write2<5>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                            sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2);
         return;
     }
-    if (wl == 7) hipLaunchKernelGGL((k_write<7, false>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+    if (wl == 6) hipLaunchKernelGGL((k_write<6, false>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                       sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2, 0u, (uint32_t*)nullptr);
+    else if (wl == 8) hipLaunchKernelGGL((k_write<8, false>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                       sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2, 0u, (uint32_t*)nullptr);
+    else if (wl == 7) hipLaunchKernelGGL((k_write<7, false>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2, 0u, (uint32_t*)nullptr);
     else hipLaunchKernelGGL((k_write<5, false>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2, 0u, (uint32_t*)nullptr);
@@ -2180,7 +2217,11 @@ void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab
 {
     if (!us_wgs || !sy_wgs) return;
     hipLaunchKernelGGL(k_unstuff_write, dim3(us_wgs), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, (uint8_t*)nullptr, seg_tab, us_wg0, us_out);
-    if (wl == 7) hipLaunchKernelGGL((k_write<7, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+    if (wl == 6) hipLaunchKernelGGL((k_write<6, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                       sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos);
+    else if (wl == 8) hipLaunchKernelGGL((k_write<8, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                       sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos);
+    else if (wl == 7) hipLaunchKernelGGL((k_write<7, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos);
     else hipLaunchKernelGGL((k_write<5, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos);
