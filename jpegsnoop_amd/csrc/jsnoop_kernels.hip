@@ -1357,45 +1357,60 @@ __device__ __forceinline__ bool walk_slow(const JsImage& im, const uint32_t* __r
     return false;
 }
 
+// LDS through its own 32-bit addresses: an address kept in a register goes into the ds instruction as it is (no base added per access)
+typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_u8_t*)p; }
+__device__ __forceinline__ uint32_t lds_r32(uint32_t a) { return *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)a; }
+__device__ __forceinline__ uint2 lds_r64(uint32_t a) { const u32x2_t v = *(const __attribute__((address_space(3))) u32x2_t*)(uintptr_t)a; return make_uint2(v.x, v.y); }
+
 // SYNC flavour: state only.  Walks the symbols that start inside [entry position, own_end).
 // The lanes of a wave step together (one table entry per lane and step); everything a lane rarely needs -- a code longer than
-// the first-level window, the end of a restart interval, a code that matches nothing -- sits behind a wave-level vote, so the
-// common step is one straight run of select code.
+// the first-level window, the end of a restart interval, a code that matches nothing, the end of its range -- sits behind a wave-level
+// vote, and leaves the lane in a state in which the straight-line code of the step does nothing for it: the common step has no
+// "is this lane still going" selects.  Votes are compares written into scalar pairs and combined there; a lane reads its bit back as
+// a predicate.  a_ctab: LDS address of the per-block-of-the-MCU table {address of its DC row, address of its AC row} in lutp.
 template <int WL>
-__device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, const uint32_t* __restrict__ words, const uint32_t* __restrict__ st,
+__device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, uint32_t a_ctab, const uint32_t* __restrict__ words, const uint32_t* __restrict__ st,
                                           uint32_t nseg, uint32_t total_bits, uint32_t own_end, uint32_t& p_io, uint32_t& s_io, uint32_t& nblk_out)
 {
     uint32_t seg = ST_SEG(s_io), c = ST_C(s_io), k = ST_K(s_io), nblk = 0, fl = 0;
     if (p_io == P_END || (p_io >= total_bits && seg + 1 >= nseg)) { p_io = P_END; s_io = 0; nblk_out = 0; return; }
     uint32_t seg_end = st[seg + 1] * 8;
     Cursor cur; cur_init<WL>(cur, words, p_io);
-    const char* lp = reinterpret_cast<const char*>(T.lutp);
-    uint32_t rb = c < T.n1 ? T.rb0 : (c < T.n2 ? T.rb1 : T.rb2);
-    // Votes are compares written into scalar pairs and combined there (a vote on "act && ..." makes the compiler turn the flag into 0 / 1 in
-    // a vector register and compare it again); a lane reads its bit back as a predicate.
+    const uint32_t a_lp = lds_addr(T.lutp), a_l2p = lds_addr(T.lut2p);
+    uint2 ct = lds_r64(a_ctab + (c < T.nb ? c : 0u) * 8u);
+    uint32_t row = k ? ct.y : ct.x;                              // LDS address of the table row the next symbol is read from
+    uint32_t res_p = cur.p, res_s = s_io, res_n = 0;
+    uint64_t m_live = WBALLOT(true);                             // lanes still inside their range
     for (;;) {
-        const uint64_t m_act = WBALLOT(cur.p < own_end);
+        // a lane that has left its range reports the state it left with; from then on it computes on whatever it holds
+        const uint64_t m_act = m_live & WBALLOT(cur.p < own_end);
+        if (m_act != m_live) {
+            if (__builtin_amdgcn_inverse_ballot_w64(m_live & ~m_act)) { res_p = cur.p; res_s = cur.p == P_END ? 0u : ST_MAKE(seg, c, k); res_n = nblk; }
+            m_live = m_act;
+        }
         if (!m_act) break;
         const uint32_t win = cur_peek(cur);
         // One table entry describes the symbol at the cursor and, where its code was visible in the same window, the AC symbol
         // behind it: byte 0 = bits of symbol 1 (code + value), byte 1 = its advance of the coefficient index (64 for EOB: ends the
         // block from any index), byte 2 = bits of both (0: no second symbol), byte 3 = index advance of both.
-        uint32_t pe = *reinterpret_cast<const uint32_t*>(lp + ((k ? rb >> 16 : rb & 0xFFFFu) + ((win >> (32 - JS_L1_BITS)) << 2)));
+        uint32_t pe = lds_r32(row + ((win >> (32 - JS_L1_BITS)) << 2));
         // A code longer than the window: a few % of symbols, but SOME lane of the wave holds one nearly every step.  One read of
         // the second level replaces the entry by a single-symbol one and the lane stays on the common path.
         const uint64_t m_esc = WBALLOT((int32_t)pe < (int32_t)0xC0000000u) & m_act;       // top bits 10
         if (m_esc) {
-            if (__builtin_amdgcn_inverse_ballot_w64(m_esc)) { const uint32_t nbx = (pe >> 12) & 7u; pe = T.lut2p[(pe & 0xFFFu) + ((win >> (32 - JS_L1_BITS - nbx)) & ((1u << nbx) - 1u))]; }
+            if (__builtin_amdgcn_inverse_ballot_w64(m_esc)) { const uint32_t nbx = (pe >> 12) & 7u; pe = lds_r32(a_l2p + (((pe & 0xFFFu) + __builtin_amdgcn_ubfe(win, 32u - JS_L1_BITS - nbx, nbx)) << 2)); }
         }
-        const uint32_t b1 = pe & 255u, k1 = k + ((pe >> 8) & 255u), b12 = (pe >> 16) & 255u;
+        uint32_t b1 = pe & 255u, k1 = k + ((pe >> 8) & 255u);
+        const uint32_t b12 = (pe >> 16) & 255u;
         // both symbols together when the first one does not end the block and the second one starts inside this lane's own range
-        const bool two = b12 != 0u && k1 < 64u && cur.p + b1 < own_end;
-        const uint32_t adv = two ? b12 : b1;
-        const uint64_t m_slow = (WBALLOT((int32_t)pe < 0) | WBALLOT(cur.p + adv > seg_end)) & m_act;
+        uint64_t m_two = WBALLOT(b12 != 0u) & WBALLOT(k1 < 64u) & WBALLOT(cur.p + b1 < own_end);
+        const uint64_t m_slow = (WBALLOT((int32_t)pe < 0) | WBALLOT(cur.p + (__builtin_amdgcn_inverse_ballot_w64(m_two) ? b12 : b1) > seg_end)) & m_act;
         if (m_slow) {
             if (__builtin_amdgcn_inverse_ballot_w64(m_slow)) {   // no code here, or the end of the restart interval / of the data is near:
-                const uint32_t row = (k ? rb >> 16 : rb & 0xFFFFu) >> (JS_L1_BITS + 2);     // one symbol the careful way
-                const uint32_t e = sym_lookup(T, win, row, 0u);
+                const uint32_t lrow = (row - a_lp) >> (JS_L1_BITS + 2);                     // one symbol the careful way
+                const uint32_t e = sym_lookup(T, win, lrow, 0u);
                 const uint32_t len = (e >> 8) & 31u, run = (e >> 4) & 15u, size = e & 15u;
                 if (len == 0 || cur.p + len > seg_end) {
                     walk_slow<false, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, 0, false, nullptr, fl);   // end of the data: p = P_END
@@ -1406,19 +1421,26 @@ __device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, co
                     k = dn ? 0u : kn;
                     if (dn) { c = c + 1 == T.nb ? 0u : c + 1; nblk++; }
                 }
-                rb = c < T.n1 ? T.rb0 : (c < T.n2 ? T.rb1 : T.rb2);
+                ct = lds_r64(a_ctab + c * 8u);
+                b1 = 0; k1 = k;                                  // the rest of the step does nothing for this lane
             }
+            m_two &= ~m_slow;
         }
-        const uint64_t m_go = m_act & ~m_slow;
-        const bool go = __builtin_amdgcn_inverse_ballot_w64(m_go);
-        cur_skip<WL>(cur, go ? adv : 0u);
+        const bool two = __builtin_amdgcn_inverse_ballot_w64(m_two);
+        { const uint32_t adv = two ? b12 : b1; cur.sh -= (int32_t)adv; cur.p += adv; }
+        if (__builtin_amdgcn_inverse_ballot_w64(WBALLOT(cur.sh < 0) & m_act)) {          // (lanes out of their range must not load)
+            cur.sh += 32; cur.w0 = cur.w1; cur.w1 = bswap32(cur.nxt);
+            cur.nxt = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(words) + (phys_word<WL>(cur.widx++) << 2));
+        }
         const uint32_t kn = two ? k + (pe >> 24) : k1;
-        const uint64_t m_dn = m_go & WBALLOT(kn >= 64u);
-        const bool dn = __builtin_amdgcn_inverse_ballot_w64(m_dn);
-        k = dn ? 0u : (go ? kn : k);
-        if (dn) { c = c + 1 == T.nb ? 0u : c + 1; nblk++; rb = c < T.n1 ? T.rb0 : (c < T.n2 ? T.rb1 : T.rb2); }
+        const uint64_t m_dn = WBALLOT(kn >= 64u) & m_act;
+        k = __builtin_amdgcn_inverse_ballot_w64(m_dn) ? 0u : kn;
+        if (m_dn) {
+            if (__builtin_amdgcn_inverse_ballot_w64(m_dn)) { c = c + 1 == T.nb ? 0u : c + 1; nblk++; ct = lds_r64(a_ctab + c * 8u); }
+        }
+        row = k ? ct.y : ct.x;
     }
-    p_io = cur.p; s_io = cur.p == P_END ? 0u : ST_MAKE(seg, c, k); nblk_out = nblk;
+    p_io = res_p; s_io = res_s; nblk_out = res_n;
 }
 
 // upper_bound(seg table, byte) - 1 : the interval a speculative start position lies in
@@ -1443,6 +1465,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
     __shared__ uint16_t s_act[SY_THREADS];
     __shared__ uint32_t s_wcount[SY_THREADS / 64];
     __shared__ int s_changed;
+    __shared__ __attribute__((aligned(8))) uint2 s_ctab[JS_MAX_BLK_PER_MCU];   // per block of the MCU: LDS address of its DC row, of its AC row (lutp)
     const uint32_t img = find_image(sy_base, nimg, blockIdx.x);
     const JsImage& im = imgs[img];
     if (!tables[im.tableset].lut_ok) return;
@@ -1470,6 +1493,8 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
         if (!go) return;
     }
     SubTabs T; load_subtabs<true>(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, t, SY_THREADS);
+    if (t < T.nb) { const uint32_t rbc = t < T.n1 ? T.rb0 : (t < T.n2 ? T.rb1 : T.rb2); s_ctab[t] = make_uint2(lds_addr(T.lutp) + (rbc & 0xFFFFu), lds_addr(T.lutp) + (rbc >> 16)); }
+    const uint32_t a_ctab = lds_addr(s_ctab);                    // (visible after the barrier below)
     const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);
     const uint32_t* st = seg_tab + im.seg_off;
     const size_t gs = g0 + t - 1;                                // this thread's slot (not for the halo thread of the first workgroup)
@@ -1514,7 +1539,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
             uint32_t p = s_inp[u], s = s_ins[u], nblk = 0;
             const uint32_t own_end = min((iu + 1) * SUB_BITS, total_bits);
             if (!(p != P_END && p >= own_end))                   // else: owns no symbol, the state passes through
-                walk_sync<WL>(im, T, words, st, nseg, total_bits, own_end, p, s, nblk);
+                walk_sync<WL>(im, T, a_ctab, words, st, nseg, total_bits, own_end, p, s, nblk);
             if (p != s_outp[u] || s != s_outs[u]) { s_outp[u] = p; s_outs[u] = s; s_changed = 1; }
             s_nblk[u] = nblk;
         }
