@@ -1,0 +1,78 @@
+"""GPU: the tunable forms of the parallel entropy path give the answer of the default one.
+
+* every sub-sequence length the kernels are instantiated for (JSNOOP_SUB_WL = 5, 6, 7, 8: 128 B ... 1 KiB per lane; the library
+  picks 5 or 7 by batch size on its own) -- same DIBs, same side outputs, parallel path taken;
+* the first form of the write pass (k_write<., false>, JSNOOP_WRITE_V1=1: read once per process, hence the subprocess) against the
+  second (k_write2, the one the main path launches): the checksums of a mixed batch, RSTn streams and 4:4:4 / 4:2:2 / 4:2:0 / gray
+  layouts included, must be identical and equal to the oracle's.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KWS = [dict(width=640, height=480, hs=1, vs=1), dict(width=1280, height=720, hs=2, vs=2), dict(width=800, height=600, hs=2, vs=1, restart_interval=25),
+       dict(width=512, height=512, gray=1), dict(width=1000, height=700, hs=2, vs=2, restart_interval=1), dict(width=333, height=217, hs=1, vs=2, quality=97),
+       dict(width=1920, height=1080, hs=2, vs=2, quality=30)]
+
+
+def _files(harness):
+    return [harness.synth_jpeg(seed=900 + i, **kw) for i, kw in enumerate(KWS)]
+
+
+@pytest.mark.parametrize("wl", [5, 6, 7, 8])
+def test_every_subsequence_length(harness, oracle, monkeypatch, wl):
+    import jpegsnoop_amd as J
+    monkeypatch.setenv("JSNOOP_SUB_WL", str(wl))
+    files = _files(harness)
+    b = J.JpegBatch()
+    for f in files:
+        b.add_jpeg(f)
+    b.tile(3 * len(files))
+    b.upload(); b.decode(); b.sync()
+    for i in range(3 * len(files)):
+        harness.drive(oracle, files[i % len(files)])
+        assert b.info(i)["path"] == 1 and b.info(i)["flags"] == 0, (wl, i)
+        assert np.array_equal(b.dib(i), oracle.dib()), (wl, i, KWS[i % len(files)])
+    b.close()
+
+
+_CHILD = r"""
+import json, sys
+sys.path.insert(0, sys.argv[1])
+import jpegsnoop_amd as J
+from oracle import harness as H
+kws = json.loads(sys.argv[2])
+b = J.JpegBatch()
+for i, kw in enumerate(kws):
+    b.add_jpeg(H.synth_jpeg(seed=900 + i, **kw))
+b.tile(4 * len(kws))
+b.upload(); b.decode(); b.sync()
+print(json.dumps({"sums": [int(x) for x in b.dib_checksums()], "paths": [b.info(i)["path"] for i in range(4 * len(kws))],
+                  "flags": [b.info(i)["flags"] for i in range(4 * len(kws))]}))
+"""
+
+
+def _run_child(extra_env):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env.pop("JSNOOP_WRITE_V1", None); env.pop("JSNOOP_SUB_WL", None); env.update(extra_env)
+    out = subprocess.run([sys.executable, "-c", _CHILD, root, json.dumps(KWS)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_write_pass_first_and_second_form_agree(harness, oracle):
+    import jpegsnoop_amd as J
+    v2 = _run_child({})
+    v1 = _run_child({"JSNOOP_WRITE_V1": "1"})
+    assert v1["sums"] == v2["sums"]
+    assert set(v1["paths"]) == {1} and set(v2["paths"]) == {1} and not any(v1["flags"]) and not any(v2["flags"])
+    for j, f in enumerate(_files(harness)):
+        harness.drive(oracle, f)
+        want = J.dib_checksum_numpy(oracle.dib())
+        assert all(s == want for s in v2["sums"][j::len(KWS)]), KWS[j]
