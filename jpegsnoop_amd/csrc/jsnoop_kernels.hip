@@ -427,13 +427,13 @@ __device__ __forceinline__ float idct_terms(int cv16, const WaveList L, uint32_t
     const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_popcountll(mask));   // wave-uniform: the exit tests are scalar compares
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     const uint32_t zrank = lane - rank;                          // zero lanes: how many zero lanes lie below
-    if (nz || zrank < 3u) L.coef[nz ? rank : n + zrank] = (float)cv16;          // zero lanes write the 0.0f padding
-    if (nz) L.rowh[rank] = (uint16_t)(lane << 8);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     float acc = 0.0f;
     const uint32_t li = lane & 15u;
 #ifndef JS_EXP_NOTERMS
-    if (n) {
+    if (n) {                                                     // (a block without AC coefficients: no list, no terms)
+        if (nz || zrank < 3u) L.coef[nz ? rank : n + zrank] = (float)cv16;          // zero lanes write the 0.0f padding
+        if (nz) L.rowh[rank] = (uint16_t)(lane << 8);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         const uint32_t rows2 = reinterpret_cast<const uint32_t*>(L.rowh)[lane & 31u];  // lane q (< 32): rows of terms 2q, 2q+1
         float a0, a1, a2, a3, b0, b1, b2, b3; uint32_t sp0, sp1;
         { const float ey = L.coef[li]; const uint32_t nl = n; IDCT_ROUND(0, 1, 2, 3, 4, 5, 6, 7); }
