@@ -1806,6 +1806,9 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
     const uint32_t lane = threadIdx.x & 63, wave0 = threadIdx.x & ~63u;
     const uint32_t sub0 = (wg - sy_base[img]) * SY_THREADS, i = sub0 + threadIdx.x;
     if (sub0 * SUB_BITS >= total_bits) return;
+    // block rows are addressed with 32-bit byte offsets from the image's first row: an image of 2^25 blocks or more (2 Gpixel of
+    // grayscale) is left to the exact kernel
+    if (im.total_blocks >= (1u << 25)) { if (threadIdx.x == 0) atomicOr(&flags[img], F_SHORT); return; }
     const JsTableSet& tset = tables[im.tableset];
     SubTabs T; T.nb = im.blk_per_mcu; T.n1 = im.samp_h[1] * im.samp_v[1]; T.n2 = im.ncomp == 3 ? T.n1 + im.samp_h[2] * im.samp_v[2] : T.nb;
     WriteTabs W; load_wtabs(W, s_dyn, tset, tab_rows, tab_lut2, im.ncomp, threadIdx.x, SY_THREADS);
@@ -1922,7 +1925,8 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
         const bool two = IBAL(m_two);
         { const uint32_t adv = tot + (two ? tot2 : 0u); cur.sh -= (int32_t)adv; cur.p += adv; }
         if (IBAL(WBALLOT(cur.sh < 0) & m_act)) {                 // (lanes that are not active compute on whatever they hold: they must not load)
-            cur.sh += 32; cur.w0 = cur.w1; cur.w1 = bswap32(cur.nxt); cur.nxt = words[phys_word<WL>(cur.widx++)];
+            cur.sh += 32; cur.w0 = cur.w1; cur.w1 = bswap32(cur.nxt);
+            cur.nxt = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(words) + (phys_word<WL>(cur.widx++) << 2));
         }
         const uint32_t kn = two ? k3 : k2;
         const uint64_t m_eob = (m_two & WBALLOT((run2 | size2) == 0u)) | (~m_two & WBALLOT((run | size) == 0u));
@@ -1955,7 +1959,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
                         uint2* sb = reinterpret_cast<uint2*>(s_blk[wave0 + src]) + (lane & 15u);
                         const uint2 v = *sb;
                         *sb = make_uint2(0u, 0u);
-                        *reinterpret_cast<uint2*>(cbase + (size_t)b * 64 + (lane & 15u) * 4u) = v;
+                        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(cbase) + ((b << 7) | ((lane & 15u) << 3))) = v;   // 32-bit offset: scalar base + vector offset
                     }
                 }
                 if (flush) {
