@@ -1959,7 +1959,9 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
                         uint2* sb = reinterpret_cast<uint2*>(s_blk[wave0 + src]) + (lane & 15u);
                         const uint2 v = *sb;
                         *sb = make_uint2(0u, 0u);
-                        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(cbase) + ((b << 7) | ((lane & 15u) << 3))) = v;   // 32-bit offset: scalar base + vector offset
+                        // (written once, read once by a later kernel, 6.4 GB per 1024 images: kept out of the caches' way -- 3.42 -> 3.31 ms)
+                        { typedef uint32_t u32x2_nt __attribute__((ext_vector_type(2))); u32x2_nt t; t.x = v.x; t.y = v.y;
+                          __builtin_nontemporal_store(t, reinterpret_cast<u32x2_nt*>(reinterpret_cast<char*>(cbase) + ((b << 7) | ((lane & 15u) << 3)))); }   // scalar base + 32-bit vector offset
                     }
                 }
                 if (flush) {
