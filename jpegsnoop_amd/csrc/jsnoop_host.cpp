@@ -304,10 +304,10 @@ int JsnoopBatch::upload()
     strips_per_wg = 0; uint64_t total_mcus = 0; for (const JsImage& im : imgs) total_mcus += (uint64_t)im.mcu_xmax * im.mcu_ymax;
     // back end: 8 waves per workgroup; enough MCUs per wave to amortise a workgroup's table load, enough workgroups (>= ~1500) to fill 256 CUs
     const uint32_t mcus_per_wave = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (total_mcus + 8 * 1536 - 1) / (8 * 1536)));
-    // sub-sequence length: long (512 B) when the batch still yields plenty of lanes, short (128 B) for small jobs
+    // sub-sequence length: long (512 B) when the batch still yields plenty of lanes, short (128 B, 64 B) for small jobs
     uint64_t scan_total = 0; for (const JsImage& im : imgs) scan_total += im.scan_len;
-    sub_wl = scan_total >= (96ull << 20) ? 7 : 5;
-    if (const char* e = getenv("JSNOOP_SUB_WL")) { const int w = atoi(e); sub_wl = (w >= 5 && w <= 8) ? w : 5; }
+    sub_wl = scan_total >= (96ull << 20) ? 7 : (scan_total < (4ull << 20) ? 4 : 5);    // (a single image / a handful: 64-byte pieces give the write pass more lanes)
+    if (const char* e = getenv("JSNOOP_SUB_WL")) { const int w = atoi(e); sub_wl = (w >= 4 && w <= 8) ? w : 5; }
     const uint32_t sub_bytes = 4u << sub_wl;
     uint32_t wgs = 0; max_mcu_h = 8; max_mcu_w = 8;
     for (size_t i = 0; i < n; i++) {

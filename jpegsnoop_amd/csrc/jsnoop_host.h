@@ -76,7 +76,7 @@ struct JsnoopBatch {
     JsDeviceArenas dev; JsArenaCaps cap;
     bool uploaded;
     uint64_t total_blocks, dib_bytes, side_words, total_subseq, ustr_bytes, seg_words, mcu_bytes; uint32_t total_wgs, strips_per_wg, us_chunks, sy_wgs, sn_wgs, max_mcu_h, max_mcu_w;
-    int sync_launches; int sub_wl;   // log2(words per sub-sequence): 5 = 128-byte, 7 = 512-byte sub-sequences (chosen per batch)
+    int sync_launches; int sub_wl;   // log2(words per sub-sequence): 4 / 5 / 7 = 64- / 128- / 512-byte sub-sequences (chosen per batch; 6 and 8 through JSNOOP_SUB_WL)
     uint32_t tab_rows, tab_lut2, tab_rows_w;     // largest decode-table footprint in the batch (sizes the kernels' LDS); _w: DC rows | AC rows << 8
     hipEvent_t ev[JSNOOP_NUM_STAGES + 1];
     // helper streams for work that forks inside one decode (independent scans of a progressive file), created on first use

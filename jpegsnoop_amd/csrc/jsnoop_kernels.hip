@@ -1013,7 +1013,8 @@ void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, 
 #define US_THREADS 256
 #define US_CHUNK   (US_THREADS * 16)
 #define SY_THREADS 256
-// sub-sequence length is a per-batch choice: WL = log2(32-bit words per sub-sequence) = 5 (128 B) or 7 (512 B)
+// sub-sequence length is a per-batch choice: WL = log2(32-bit words per sub-sequence) = 4 (64 B, a handful of images), 5 (128 B) or 7 (512 B, large batches);
+// 6 and 8 are instantiated for experiments (JSNOOP_SUB_WL)
 #define SUB_BITS   (32u << WL)
 #define SYNC_SPEC_TAIL (WL >= 7 ? 2048u : 1024u)   // bits at the end of a sub-sequence the first (speculative) walk covers
 
@@ -2077,7 +2078,8 @@ void js_launch_unstuff(hipStream_t st, int wl, const JsImage* imgs, const uint32
     hipLaunchKernelGGL(k_unstuff_count, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst);
     hipLaunchKernelGGL(k_unstuff_scan, dim3(nimg), dim3(256), 0, st, imgs, us_base, chunk_keep, chunk_rst, seg_tab, side, flags);
     hipLaunchKernelGGL(k_unstuff_write, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, ustr_lin, seg_tab, 0u, (uint32_t*)nullptr);
-    if (wl == 6) hipLaunchKernelGGL(k_interleave<6>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
+    if (wl == 4) hipLaunchKernelGGL(k_interleave<4>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
+    else if (wl == 6) hipLaunchKernelGGL(k_interleave<6>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
     else if (wl == 8) hipLaunchKernelGGL(k_interleave<8>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
     else if (wl == 7) hipLaunchKernelGGL(k_interleave<7>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
     else hipLaunchKernelGGL(k_interleave<5>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
@@ -2089,7 +2091,9 @@ void js_launch_sync(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2
                     const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub, int first_pass)
 {
     if (!total_wgs) return;
-    if (wl == 6) hipLaunchKernelGGL(k_sync<6>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2, true), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+    if (wl == 4) hipLaunchKernelGGL(k_sync<4>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2, true), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                       sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2);
+    else if (wl == 6) hipLaunchKernelGGL(k_sync<6>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2, true), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2);
     else if (wl == 8) hipLaunchKernelGGL(k_sync<8>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2, true), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2);
@@ -2102,11 +2106,13 @@ void js_launch_block_scan(hipStream_t st, int wl, const JsImage* imgs, uint32_t 
 {
     if (!nimg) return;
     if (nimg <= 8) {                                             // a few (large) images: wide workgroups, fewer serial steps
-        if (wl == 6) hipLaunchKernelGGL((k_block_scan<6, 1024>), dim3(nimg), dim3(1024), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
+        if (wl == 4) hipLaunchKernelGGL((k_block_scan<4, 1024>), dim3(nimg), dim3(1024), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
+    else if (wl == 6) hipLaunchKernelGGL((k_block_scan<6, 1024>), dim3(nimg), dim3(1024), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
     else if (wl == 8) hipLaunchKernelGGL((k_block_scan<8, 1024>), dim3(nimg), dim3(1024), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
     else if (wl == 7) hipLaunchKernelGGL((k_block_scan<7, 1024>), dim3(nimg), dim3(1024), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
         else hipLaunchKernelGGL((k_block_scan<5, 1024>), dim3(nimg), dim3(1024), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
-    } else if (wl == 6) hipLaunchKernelGGL((k_block_scan<6, 256>), dim3(nimg), dim3(256), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
+    } else if (wl == 4) hipLaunchKernelGGL((k_block_scan<4, 256>), dim3(nimg), dim3(256), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
+    else if (wl == 6) hipLaunchKernelGGL((k_block_scan<6, 256>), dim3(nimg), dim3(256), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
     else if (wl == 8) hipLaunchKernelGGL((k_block_scan<8, 256>), dim3(nimg), dim3(256), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
     else if (wl == 7) hipLaunchKernelGGL((k_block_scan<7, 256>), dim3(nimg), dim3(256), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
     else hipLaunchKernelGGL((k_block_scan<5, 256>), dim3(nimg), dim3(256), 0, st, imgs, tables, sub_arrays(sub, nsub), side, flags);
@@ -2118,7 +2124,9 @@ void js_launch_write(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut
     if (!total_wgs) return;
     static const bool v1 = getenv("JSNOOP_WRITE_V1") != nullptr;     // the first form of the kernel, kept as a cross-check
     if (!v1) {
-        if (wl == 6) hipLaunchKernelGGL((k_write2<6>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+        if (wl == 4) hipLaunchKernelGGL((k_write2<4>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                           sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2);
+    else if (wl == 6) hipLaunchKernelGGL((k_write2<6>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                            sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2);
     else if (wl == 8) hipLaunchKernelGGL((k_write2<8>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                            sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2);
@@ -2128,7 +2136,9 @@ void js_launch_write(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut
                            sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2);
         return;
     }
-    if (wl == 6) hipLaunchKernelGGL((k_write<6, false>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+    if (wl == 4) hipLaunchKernelGGL((k_write<4, false>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                       sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2, 0u, (uint32_t*)nullptr);
+    else if (wl == 6) hipLaunchKernelGGL((k_write<6, false>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2, 0u, (uint32_t*)nullptr);
     else if (wl == 8) hipLaunchKernelGGL((k_write<8, false>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2, 0u, (uint32_t*)nullptr);
@@ -2266,7 +2276,9 @@ void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab
 {
     if (!us_wgs || !sy_wgs) return;
     hipLaunchKernelGGL(k_unstuff_write, dim3(us_wgs), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, (uint8_t*)nullptr, seg_tab, us_wg0, us_out);
-    if (wl == 6) hipLaunchKernelGGL((k_write<6, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+    if (wl == 4) hipLaunchKernelGGL((k_write<4, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                       sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos);
+    else if (wl == 6) hipLaunchKernelGGL((k_write<6, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos);
     else if (wl == 8) hipLaunchKernelGGL((k_write<8, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos);

@@ -1,6 +1,6 @@
 """GPU: the tunable forms of the parallel entropy path give the answer of the default one.
 
-* every sub-sequence length the kernels are instantiated for (JSNOOP_SUB_WL = 5, 6, 7, 8: 128 B ... 1 KiB per lane; the library
+* every sub-sequence length the kernels are instantiated for (JSNOOP_SUB_WL = 4 ... 8: 64 B ... 1 KiB per lane; the library
   picks 5 or 7 by batch size on its own) -- same DIBs, same side outputs, parallel path taken;
 * the first form of the write pass (k_write<., false>, JSNOOP_WRITE_V1=1: read once per process, hence the subprocess) against the
   second (k_write2, the one the main path launches): the checksums of a mixed batch, RSTn streams and 4:4:4 / 4:2:2 / 4:2:0 / gray
@@ -25,7 +25,7 @@ def _files(harness):
     return [harness.synth_jpeg(seed=900 + i, **kw) for i, kw in enumerate(KWS)]
 
 
-@pytest.mark.parametrize("wl", [5, 6, 7, 8])
+@pytest.mark.parametrize("wl", [4, 5, 6, 7, 8])
 def test_every_subsequence_length(harness, oracle, monkeypatch, wl):
     import jpegsnoop_amd as J
     monkeypatch.setenv("JSNOOP_SUB_WL", str(wl))
