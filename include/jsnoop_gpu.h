@@ -209,6 +209,10 @@ int          jsnoop_batch_add_progressive(JsnoopBatch*, const uint8_t* file, siz
 /* Tiles already-added images so the batch holds `total` images (image i reuses the
  * bytes of image i % n): the bench's "N distinct seeds tiled to 1024".               */
 int          jsnoop_batch_tile(JsnoopBatch*, int total);
+/* Beyond the reference: parts = 2 makes the following decodes run the two halves of the batch on two streams side by side (same
+   arenas, same results; the kernels of one half fill the thinly populated phases of the other: about 4 % more throughput on
+   1024 x 1080p).  Off by default -- with it the per-kernel timings are those of launches that share the chip.  0 / -1. */
+int          jsnoop_batch_set_split(JsnoopBatch*, int parts);
 int          jsnoop_batch_count(const JsnoopBatch*);
 int          jsnoop_batch_upload(JsnoopBatch*);      /* pinned host -> HBM (async), builds device descriptors */
 int          jsnoop_batch_decode(JsnoopBatch*);      /* HBM -> HBM, asynchronous on the batch stream          */

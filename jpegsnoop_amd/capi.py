@@ -85,6 +85,7 @@ SIGNATURES = {
     "jsnoop_batch_add": (_i, [_p, _p, _p, _sz, _u]),
     "jsnoop_batch_add_jpeg": (_i, [_p, _p, _sz]),
     "jsnoop_batch_tile": (_i, [_p, _i]),
+    "jsnoop_batch_set_split": (_i, [_p, _i]),
     "jsnoop_batch_count": (_i, [_p]),
     "jsnoop_batch_upload": (_i, [_p]),
     "jsnoop_batch_decode": (_i, [_p]),

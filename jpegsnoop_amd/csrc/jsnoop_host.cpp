@@ -161,6 +161,7 @@ JsnoopBatch::JsnoopBatch(void* user_stream)
     pinned = nullptr; pinned_cap = 0; raw_bytes = 0; uploaded = false; sync_launches = 2;
     if (const char* e = getenv("JSNOOP_SYNC_LAUNCHES")) sync_launches = std::max(1, atoi(e));
     for (auto& e : ev) e = nullptr;
+    for (auto& e : ev2) e = nullptr;
     d_lut = nullptr;
 }
 int JsnoopBatch::init()
@@ -168,6 +169,7 @@ int JsnoopBatch::init()
     HIP_TRY(hipSetDevice(device));
     if (!stream) { HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
     for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    for (auto& e : ev2) HIP_TRY(hipEventCreate(&e));
     // PrecalcIdct :2313-2351: built once on the host in fp32, then transposed to [vu][yx] for lane-contiguous reads
     const float pi = (float)3.141592654, rh = (float)0.707106781;
     for (unsigned y = 0; y < 8; y++) for (unsigned x = 0; x < 8; x++) for (unsigned v = 0; v < 8; v++) for (unsigned u = 0; u < 8; u++) {
@@ -194,6 +196,7 @@ JsnoopBatch::~JsnoopBatch()
     js_prog_free(this);
     if (pinned) hipHostFree(pinned);
     for (auto& e : ev) if (e) hipEventDestroy(e);
+    for (auto& e : ev2) if (e) hipEventDestroy(e);
     for (auto& e : aux_ev) if (e) hipEventDestroy(e);
     for (auto& a : aux) if (a) hipStreamDestroy(a);
     if (own_stream && stream) hipStreamDestroy(stream);
@@ -353,7 +356,9 @@ int JsnoopBatch::upload()
     HIP_TRY(hipMemcpyAsync(dev.us_base, usb.data(), (n + 1) * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(dev.sy_base, syb.data(), 2 * (n + 1) * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));          // host vectors above may go out of scope
-    h_us_base = usb; h_sy_base.assign(syb.begin(), syb.begin() + n + 1);
+    h_us_base = usb; h_sy_base.assign(syb.begin(), syb.begin() + n + 1); h_sn_base.assign(syb.begin() + n + 1, syb.end()); h_wg_base = wg;
+    if (const char* e = getenv("JSNOOP_SPLIT")) opt_split = atoi(e) == 2 ? 2 : 1;
+    split_parts = (opt_split == 2 && n >= 2) ? 2 : 1;
     uploaded = true;
     return 0;
 }
@@ -377,6 +382,22 @@ int JsnoopBatch::decode(bool timed)
     HIP_TRY(hipMemsetAsync(dev.flags, 0, (size_t)n * 4, stream));
     if (event_words) HIP_TRY(hipMemsetAsync(dev.events, 0, event_words * 4, stream));
     if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
+    last_timed_split = false;
+    if (split_parts == 2 && parallel_ok && !event_words) {
+        // two halves of the batch on two streams, launches interleaved stage by stage
+        if (ensure_aux()) return -1;
+        const uint32_t n0 = n / 2; hipStream_t s2 = aux[0];
+        HIP_TRY(hipEventRecord(aux_ev[0], stream)); HIP_TRY(hipStreamWaitEvent(s2, aux_ev[0], 0));
+        if (timed) { HIP_TRY(hipEventRecord(ev2[0], s2)); HIP_TRY(hipEventRecord(ev2[1], s2)); }
+        if (js_parallel_entropy_part(this, stream, 0, n0, timed ? ev : nullptr) < 0 || js_parallel_entropy_part(this, s2, n0, n - n0, timed ? ev2 : nullptr) < 0) return -1;
+        last_used_parallel = true;
+        if (timed) { HIP_TRY(hipEventRecord(ev[7], stream)); HIP_TRY(hipEventRecord(ev2[7], s2)); }
+        { JsRange r2_("jsnoop:idct+colour"); if (launch_back_end_part(stream, 0, n0) || launch_back_end_part(s2, n0, n - n0)) return -1; }
+        if (timed) { HIP_TRY(hipEventRecord(ev[8], stream)); HIP_TRY(hipEventRecord(ev2[8], s2)); last_timed_split = true; }
+        HIP_TRY(hipEventRecord(aux_ev[1], s2)); HIP_TRY(hipStreamWaitEvent(stream, aux_ev[1], 0));
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     // parallel path stages 1..5 (k_unstuff .. k_dc_scan) are launched by js_parallel_entropy
     int used_parallel = opt_force_exact ? 0 : js_parallel_entropy(this, timed);
     if (used_parallel < 0) return -1;
@@ -389,11 +410,13 @@ int JsnoopBatch::decode(bool timed)
     HIP_TRY(hipGetLastError());
     return 0;
 }
-int JsnoopBatch::launch_back_end(uint32_t nimg)
+int JsnoopBatch::launch_back_end(uint32_t nimg) { return launch_back_end_part(stream, 0, nimg); }
+int JsnoopBatch::launch_back_end_part(hipStream_t st, uint32_t i0, uint32_t nimg)
 {
     uint32_t tile = 16;
-    for (uint32_t i = 0; i < nimg && i < imgs.size(); i++) tile = std::max(tile, js_tile_bytes(imgs[i]));
-    const int rc = js_launch_idct_color(stream, dev.imgs, dev.wg_base, nimg, total_wgs, tile, d_lut, dev.coef, dev.dccum, dev.dib, dev.planes, dev.side);
+    for (uint32_t i = i0; i < i0 + nimg && i < imgs.size(); i++) tile = std::max(tile, js_tile_bytes(imgs[i]));
+    const uint32_t wgs = h_wg_base.size() > i0 + nimg ? h_wg_base[i0 + nimg] - h_wg_base[i0] : total_wgs;
+    const int rc = js_launch_idct_color(st, dev.imgs + i0, dev.wg_base + i0, nimg, wgs, tile, d_lut, dev.coef, dev.dccum, dev.dib, dev.planes, dev.side);
     if (rc == -2) { js_set_error("back end: an MCU tile of %u bytes per wave does not fit the 160 KiB LDS", tile); return -1; }
     if (rc) { js_set_error("back end launch failed (%d): %s", rc, hipGetErrorString(hipGetLastError())); return -1; }
     return 0;
@@ -685,6 +708,12 @@ int jsnoop_batch_add_jpeg(JsnoopBatch* b, const uint8_t* file, size_t len)
     return b->add(&tmp, file, len, scan_start, 1);
 }
 int jsnoop_batch_tile(JsnoopBatch* b, int total) { return b->tile(total); }
+int jsnoop_batch_set_split(JsnoopBatch* b, int parts)
+{
+    if (!b || (parts != 1 && parts != 2)) { js_set_error("jsnoop_batch_set_split: parts must be 1 or 2"); return -1; }
+    b->opt_split = parts; b->split_parts = (parts == 2 && b->imgs.size() >= 2) ? 2 : 1;
+    return 0;
+}
 int jsnoop_batch_count(const JsnoopBatch* b) { return (int)b->imgs.size(); }
 int jsnoop_batch_upload(JsnoopBatch* b) { return b->upload(); }
 int jsnoop_batch_decode(JsnoopBatch* b) { return b->decode(false); }
@@ -697,8 +726,14 @@ double jsnoop_batch_decode_timed(JsnoopBatch* b, int reps, double* stage_ms)
     for (int r = 0; r < reps; r++) {
         if (b->decode(true)) return -1;
         if (hipStreamSynchronize(b->stream) != hipSuccess) { js_set_error("stream sync failed"); return -1; }
-        for (int s = 0; s < JSNOOP_NUM_STAGES; s++) { float ms = 0; hipEventElapsedTime(&ms, b->ev[s], b->ev[s + 1]); tot[s] += ms; }
-        float ms = 0; hipEventElapsedTime(&ms, b->ev[0], b->ev[JSNOOP_NUM_STAGES]); whole += ms;
+        for (int s = 0; s < JSNOOP_NUM_STAGES; s++) {
+            float ms = 0; hipEventElapsedTime(&ms, b->ev[s], b->ev[s + 1]);
+            if (b->last_timed_split && s >= 1) { float m2 = 0; hipEventElapsedTime(&m2, b->ev2[s], b->ev2[s + 1]); ms = 0.5f * (ms + m2); }   // two halves side by side: the mean of their stage times
+            tot[s] += ms;
+        }
+        float ms = 0; hipEventElapsedTime(&ms, b->ev[0], b->ev[JSNOOP_NUM_STAGES]);
+        if (b->last_timed_split) { float m2 = 0; hipEventElapsedTime(&m2, b->ev[0], b->ev2[JSNOOP_NUM_STAGES]); ms = std::max(ms, m2); }
+        whole += ms;
     }
     if (stage_ms) for (int s = 0; s < JSNOOP_NUM_STAGES; s++) stage_ms[s] = tot[s] / reps;
     return whole / reps;

@@ -69,7 +69,13 @@ struct JsnoopBatch {
     int opt_decode_ac, opt_want_planes, opt_force_exact, opt_events = 0;   // opt_events: keep the decoder's event log (single-image API)
     uint64_t event_words = 0;
     std::vector<JsImage> imgs; std::vector<JsTableSet> tables;
-    std::vector<uint32_t> host_flags, host_path, h_us_base, h_sy_base;
+    std::vector<uint32_t> host_flags, host_path, h_us_base, h_sy_base, h_sn_base, h_wg_base;
+    // A large batch decodes as two halves on two streams (stream, aux[0]): the kernels of one half fill the tails and the thinly
+    // populated phases (second synchronisation launch, DC scan) of the other -- 14.2 -> 13.7 ms per 1024 images.  Both halves live in
+    // the same arenas; a launch over a half passes pointers to its first image and its first prefix entry.
+    int opt_split = 1, split_parts = 1;                           // opt-in (jsnoop_batch_set_split / JSNOOP_SPLIT=2): the per-kernel timings of a split decode are those of launches that share the chip
+    hipEvent_t ev2[JSNOOP_NUM_STAGES + 1];                        // stage events of the second half (timed decodes)
+    bool last_timed_split = false;
     bool last_used_parallel = false;                              // false: no table set of the batch fits the parallel path, the exact-mirror kernel decoded everything
     uint32_t* d_side_tmp = nullptr; size_t side_tmp_cap = 0;      // scratch of the side-output pass (one image at a time)
     uint8_t* pinned; size_t pinned_cap; uint64_t raw_bytes;
@@ -102,6 +108,7 @@ struct JsnoopBatch {
     int  read_dib(int i, uint8_t* dst);
     int  read_planes(int i, int16_t* y, int16_t* cb, int16_t* cr);
     int  run_exact(const std::vector<uint32_t>& which);
+    int  launch_back_end_part(hipStream_t st, uint32_t i0, uint32_t n);   // ... over images [i0, i0 + n) on stream st
     int  launch_back_end(uint32_t nimg);        // k_idct_color over the first nimg images (tile size from their CURRENT preview state)
 };
 
@@ -116,6 +123,7 @@ void js_emit_decode_events(JsnoopDecoder* d);                      // jsnoop_rep
 void js_emit_report(JsnoopDecoder* d, bool display, bool quiet);
 void js_build_parallel_luts(JsTableSet* ts, uint32_t ncomp);          // jsnoop_parallel.cpp
 int js_selftest_tables(unsigned seed, unsigned rounds);                // jsnoop_parallel.cpp (host only)
+int  js_parallel_entropy_part(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32_t n, hipEvent_t* evs /*stage events or null*/);   // images [i0, i0 + n)
 int  js_parallel_entropy(JsnoopBatch* b, bool timed);                 // 1 = launched, 0 = not applicable, <0 error
 int  js_parallel_fixup(JsnoopBatch* b);
 int  js_side_only(JsnoopBatch* b, uint32_t i);

@@ -695,7 +695,8 @@ __global__ void __launch_bounds__(BK_THREADS, JS_BK_OCC) k_idct_color(const JsIm
     if ((uint32_t)(size_t)s_dyn != 0u) __builtin_trap();
 
     uint32_t lo = 0, hi = nimg;                                  // wg_base is an exclusive prefix, nimg+1 entries
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (wg_base[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+    const uint32_t bx = blockIdx.x + wg_base[0];
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (wg_base[mid] <= bx) lo = mid; else hi = mid; }
     const JsImage& im = imgs[lo];
 
     for (uint32_t i = tid; i < 64 * 64; i += BK_THREADS) s_lut[i] = lut_t[i];
@@ -704,7 +705,7 @@ __global__ void __launch_bounds__(BK_THREADS, JS_BK_OCC) k_idct_color(const JsIm
     BackEndCtx C;
     C.im = &im; C.cbase = coef + im.coef_off * 64; C.dccum = dccum; C.dibp = dib + im.dib_off; C.planes = planes;
     C.L.coef = reinterpret_cast<float*>(wave_mem); C.L.rowh = reinterpret_cast<uint16_t*>(wave_mem + 68 * 4); C.tile = reinterpret_cast<int16_t*>(wave_mem + LIST_BYTES);
-    C.s_meta = s_meta; C.lane = lane; C.wave = wave; C.wg_in_img = blockIdx.x - wg_base[lo]; C.wgs_in_img = wg_base[lo + 1] - wg_base[lo];
+    C.s_meta = s_meta; C.lane = lane; C.wave = wave; C.wg_in_img = bx - wg_base[lo]; C.wgs_in_img = wg_base[lo + 1] - wg_base[lo];
     list_init(C.L, lane);
     __syncthreads();
 
@@ -1088,17 +1089,20 @@ __device__ __forceinline__ uint32_t find_image(const uint32_t* __restrict__ base
 __global__ void __launch_bounds__(US_THREADS) k_unstuff_count(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ us_base, uint32_t nimg,
                                                               const uint8_t* __restrict__ raw, uint32_t* __restrict__ chunk_keep, uint32_t* __restrict__ chunk_rst)
 {
-    const uint32_t img = find_image(us_base, nimg, blockIdx.x);
+    // (a launch may cover a sub-range of the batch's images: imgs / us_base then point at its first image, the prefix values stay the
+    // batch's own, and the first workgroup of the launch is workgroup us_base[0] of the batch -- the same in every kernel below)
+    const uint32_t wg = blockIdx.x + us_base[0];
+    const uint32_t img = find_image(us_base, nimg, wg);
     const JsImage& im = imgs[img];
     const uint64_t s = im.file_off + im.scan_start, e = s + im.scan_len;
-    const uint64_t o16 = (s & ~15ull) + (uint64_t)(blockIdx.x - us_base[img]) * US_CHUNK + threadIdx.x * 16;
+    const uint64_t o16 = (s & ~15ull) + (uint64_t)(wg - us_base[img]) * US_CHUNK + threadIdx.x * 16;
     const UsBytes c = us_classify(raw, o16, s, e);
     uint32_t nk = __popc(c.keep_mask), nr = __popc(c.rst_mask);
     for (int off = 32; off > 0; off >>= 1) { nk += __shfl_down(nk, off); nr += __shfl_down(nr, off); }
     __shared__ uint32_t sk[US_THREADS / 64], sr[US_THREADS / 64];
     if ((threadIdx.x & 63) == 0) { sk[threadIdx.x >> 6] = nk; sr[threadIdx.x >> 6] = nr; }
     __syncthreads();
-    if (threadIdx.x == 0) { chunk_keep[blockIdx.x] = sk[0] + sk[1] + sk[2] + sk[3]; chunk_rst[blockIdx.x] = sr[0] + sr[1] + sr[2] + sr[3]; }
+    if (threadIdx.x == 0) { chunk_keep[wg] = sk[0] + sk[1] + sk[2] + sk[3]; chunk_rst[wg] = sr[0] + sr[1] + sr[2] + sr[3]; }
 }
 
 // One workgroup per image: exclusive scan over its chunks (in place), totals into the side block,
@@ -1141,7 +1145,7 @@ __global__ void __launch_bounds__(US_THREADS) k_unstuff_write(const JsImage* __r
                                                               const uint32_t* __restrict__ chunk_rst, uint8_t* __restrict__ ustr, uint32_t* __restrict__ seg_tab,
                                                               uint32_t wg0, uint32_t* __restrict__ us_out)
 {
-    const uint32_t wg = blockIdx.x + wg0;
+    const uint32_t wg = blockIdx.x + wg0 + us_base[0];
     const uint32_t img = find_image(us_base, nimg, wg);
     const JsImage& im = imgs[img];
     const uint64_t s = im.file_off + im.scan_start, e = s + im.scan_len;
@@ -1195,9 +1199,10 @@ __global__ void __launch_bounds__(256) k_interleave(const JsImage* __restrict__ 
 {
     constexpr uint32_t WPS = 1u << WL, GW = 64u * WPS;               // words per sub-sequence / per group
     __shared__ uint32_t s_w[64 * (WPS + 1)];                          // +1: the transposed read walks a column without bank conflicts
-    const uint32_t img = find_image(sy_base, nimg, blockIdx.x / 4);
+    const uint32_t bx = blockIdx.x + sy_base[0] * 4;
+    const uint32_t img = find_image(sy_base, nimg, bx / 4);
     const JsImage& im = imgs[img];
-    const uint32_t g = blockIdx.x - sy_base[img] * 4;                 // group index inside the image (4 groups per 256 sub-sequences)
+    const uint32_t g = bx - sy_base[img] * 4;                         // group index inside the image (4 groups per 256 sub-sequences)
     if (g * 64 >= im.n_subseq) return;
     const uint32_t len_words = (side[im.side_off + 10] + 3) / 4 + 4;  // un-stuffed length (+ cursor look-ahead)
     if (g * GW >= len_words) return;
@@ -1467,7 +1472,8 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
     __shared__ uint32_t s_wcount[SY_THREADS / 64];
     __shared__ int s_changed;
     __shared__ __attribute__((aligned(8))) uint2 s_ctab[JS_MAX_BLK_PER_MCU];   // per block of the MCU: LDS address of its DC row, of its AC row (lutp)
-    const uint32_t img = find_image(sy_base, nimg, blockIdx.x);
+    const uint32_t bx = blockIdx.x + sy_base[0];
+    const uint32_t img = find_image(sy_base, nimg, bx);
     const JsImage& im = imgs[img];
     if (!tables[im.tableset].lut_ok) return;
     const uint32_t* sd = side + im.side_off;
@@ -1476,7 +1482,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
     // Threads 1..255 own one sub-sequence each; thread 0 walks the one BEFORE the workgroup's first, speculatively and only in
     // the first iteration of the first launch: its exit state is where the first owned sub-sequence really starts in all but a
     // few % of the cases, so the later launches (which carry the true states across workgroup boundaries) find next to nothing to do.
-    const uint32_t own0 = (blockIdx.x - sy_base[img]) * (SY_THREADS - 1);
+    const uint32_t own0 = (bx - sy_base[img]) * (SY_THREADS - 1);
     if (own0 * SUB_BITS >= total_bits && own0) return;          // whole workgroup lies past the end of the data
     const size_t g0 = im.subseq_off + own0;                      // slot of the first owned sub-sequence
     const bool halo = t == 0;
@@ -1603,7 +1609,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     __shared__ __attribute__((aligned(16))) int16_t s_blk[SY_THREADS][WR_STRIDE];
     __shared__ uint32_t s_histo[SIDE ? 2 * 4 * 17 : 1];
-    const uint32_t wg = blockIdx.x + wg0;
+    const uint32_t wg = blockIdx.x + wg0 + sy_base[0];
     const uint32_t img = find_image(sy_base, nimg, wg);
     const JsImage& im = imgs[img];
     if (!tables[im.tableset].lut_ok) return;
@@ -1798,7 +1804,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     __shared__ __attribute__((aligned(16))) int16_t s_blk[SY_THREADS][WR_STRIDE];
-    const uint32_t wg = blockIdx.x;
+    const uint32_t wg = blockIdx.x + sy_base[0];
     const uint32_t img = find_image(sy_base, nimg, wg);
     const JsImage& im = imgs[img];
     if (!tables[im.tableset].lut_ok) return;

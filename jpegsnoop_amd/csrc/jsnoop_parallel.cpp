@@ -245,34 +245,44 @@ int js_selftest_tables(unsigned seed, unsigned rounds)
     return usable ? bad : -1;
 }
 
-// Launches stages 1..5 (unstuff, sync, block scan, write, DC scan) for the whole batch.
+// Launches stages 1..5 (unstuff, sync, block scan, write, DC scan) for images [i0, i0 + n) of the batch on stream st.  The arenas and
+// the prefix tables are the batch's: a part passes pointers to its first image / first prefix entry (the kernels add the first
+// entry to their block index) and the number of workgroups its images own.
+int js_parallel_entropy_part(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32_t n, hipEvent_t* evs)
+{
+    const uint32_t N = (uint32_t)b->imgs.size();
+    uint32_t* sub = (uint32_t*)b->dev.sub;
+    const JsImage* imgs = b->dev.imgs + i0;
+    const uint32_t* us_base = b->dev.us_base + i0; const uint32_t* sy_base = b->dev.sy_base + i0; const uint32_t* sn_base = b->dev.sy_base + (N + 1) + i0;
+    uint32_t* flags = b->dev.flags + i0;
+    const uint32_t us_chunks = b->h_us_base[i0 + n] - b->h_us_base[i0], sy_wgs = b->h_sy_base[i0 + n] - b->h_sy_base[i0], sn_wgs = b->h_sn_base[i0 + n] - b->h_sn_base[i0];
+    roctxRangePushA("jsnoop:unstuff");
+    js_launch_unstuff(st, b->sub_wl, imgs, us_base, n, us_chunks, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst,
+                      b->dev.ustr_lin, b->dev.ustr, b->dev.seg, b->dev.side, flags, sy_base, sy_wgs);
+    roctxRangePop();
+    if (evs) HIP_TRY(hipEventRecord(evs[2], st));
+    roctxRangePushA("jsnoop:sub-sequence sync");
+    for (int l = 0; l < b->sync_launches; l++)
+        js_launch_sync(st, b->sub_wl, b->tab_rows, b->tab_lut2, imgs, sn_base, n, sn_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, l == 0);
+    roctxRangePop();
+    if (evs) HIP_TRY(hipEventRecord(evs[3], st));
+    roctxRangePushA("jsnoop:block scan + coefficient write + DC scan");
+    js_launch_block_scan(st, b->sub_wl, imgs, n, b->dev.tables, sub, b->total_subseq, b->dev.side, flags);
+    if (evs) HIP_TRY(hipEventRecord(evs[4], st));
+    js_launch_write(st, b->sub_wl, b->tab_rows_w, b->tab_lut2, imgs, sy_base, n, sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
+                    b->dev.coef, b->dev.dccum, b->dev.mcu_rst, flags);
+    if (evs) HIP_TRY(hipEventRecord(evs[5], st));
+    js_launch_dc_scan(st, imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst, n == N ? b->dev.dc_parts : nullptr);   // (one scratch area: whole-batch launches only)
+    roctxRangePop();
+    if (evs) HIP_TRY(hipEventRecord(evs[6], st));
+    return 1;
+}
 int js_parallel_entropy(JsnoopBatch* b, bool timed)
 {
-    const uint32_t n = (uint32_t)b->imgs.size();
     bool any = false;
     for (const JsTableSet& t : b->tables) any = any || t.lut_ok;
     if (!any) return 0;
-    uint32_t* sub = (uint32_t*)b->dev.sub;
-    roctxRangePushA("jsnoop:unstuff");
-    js_launch_unstuff(b->stream, b->sub_wl, b->dev.imgs, b->dev.us_base, n, b->us_chunks, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst,
-                      b->dev.ustr_lin, b->dev.ustr, b->dev.seg, b->dev.side, b->dev.flags, b->dev.sy_base, b->sy_wgs);
-    roctxRangePop();
-    if (timed) HIP_TRY(hipEventRecord(b->ev[2], b->stream));
-    roctxRangePushA("jsnoop:sub-sequence sync");
-    for (int l = 0; l < b->sync_launches; l++)
-        js_launch_sync(b->stream, b->sub_wl, b->tab_rows, b->tab_lut2, b->dev.imgs, b->dev.sy_base + (n + 1), n, b->sn_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, l == 0);
-    roctxRangePop();
-    if (timed) HIP_TRY(hipEventRecord(b->ev[3], b->stream));
-    roctxRangePushA("jsnoop:block scan + coefficient write + DC scan");
-    js_launch_block_scan(b->stream, b->sub_wl, b->dev.imgs, n, b->dev.tables, sub, b->total_subseq, b->dev.side, b->dev.flags);
-    if (timed) HIP_TRY(hipEventRecord(b->ev[4], b->stream));
-    js_launch_write(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
-                    b->dev.coef, b->dev.dccum, b->dev.mcu_rst, b->dev.flags);
-    if (timed) HIP_TRY(hipEventRecord(b->ev[5], b->stream));
-    js_launch_dc_scan(b->stream, b->dev.imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst, b->dev.dc_parts);
-    roctxRangePop();
-    if (timed) { HIP_TRY(hipEventRecord(b->ev[6], b->stream)); }
-    return 1;
+    return js_parallel_entropy_part(b, b->stream, 0, (uint32_t)b->imgs.size(), timed ? b->ev : nullptr);
 }
 
 // Sequential exact-mirror decode of the listed images (their intermediate ranges are cleared first),

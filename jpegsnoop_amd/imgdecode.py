@@ -172,6 +172,9 @@ class JpegBatch:
         return self._chk(self._lib.jsnoop_batch_add_jpeg(self._h, C.cast(buf, C.c_void_p), len(data)), "batch_add_jpeg")
 
     def tile(self, total: int) -> int: return self._chk(self._lib.jsnoop_batch_tile(self._h, total), "batch_tile")
+    def set_split(self, parts: int) -> None:
+        """parts = 2: later decodes run the two halves of the batch on two streams side by side (same results); 1: one stream."""
+        self._chk(self._lib.jsnoop_batch_set_split(self._h, parts), "batch_set_split")
     def clear(self): self._lib.jsnoop_batch_clear(self._h)
     def __len__(self): return self._lib.jsnoop_batch_count(self._h)
     def upload(self): self._chk(self._lib.jsnoop_batch_upload(self._h), "batch_upload")

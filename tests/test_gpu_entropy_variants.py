@@ -76,3 +76,32 @@ def test_write_pass_first_and_second_form_agree(harness, oracle):
         harness.drive(oracle, f)
         want = J.dib_checksum_numpy(oracle.dib())
         assert all(s == want for s in v2["sums"][j::len(KWS)]), KWS[j]
+
+
+def test_two_stream_split_gives_the_same_batch(harness, oracle):
+    """jsnoop_batch_set_split(2): the two halves of a batch on two streams, same arenas -- every DIB as with one stream, flags clean,
+    a stream with restart markers and a grayscale image among them; then back to one stream."""
+    import jpegsnoop_amd as J
+    files = _files(harness)
+    n = 5 * len(files) + 3                                          # an odd count: halves of different size
+    b = J.JpegBatch()
+    for f in files:
+        b.add_jpeg(f)
+    b.tile(n)
+    b.upload(); b.decode(); b.sync()
+    one = b.dib_checksums().copy()
+    b.set_split(2)
+    for _ in range(3):
+        b.decode()
+    b.sync()
+    assert np.array_equal(b.dib_checksums(), one)
+    assert all(b.info(i)["path"] == 1 and b.info(i)["flags"] == 0 for i in range(n))
+    ms, stages = b.decode_timed(2)                                  # the timed form of a split decode: mean of the halves' stage times
+    assert ms > 0 and all(v >= 0 for v in stages.values())
+    assert np.array_equal(b.dib_checksums(), one)
+    for j, f in enumerate(files):
+        harness.drive(oracle, f)
+        assert int(one[j]) == J.dib_checksum_numpy(oracle.dib()), KWS[j]
+    b.set_split(1); b.decode(); b.sync()
+    assert np.array_equal(b.dib_checksums(), one)
+    b.close()
