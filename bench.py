@@ -381,9 +381,9 @@ def main():
             extra["two_stream_split"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not stub and not args.no_extras:
         try:
-            extra = extras_single_gpu(J, H, orc, np)
+            extra.update(extras_single_gpu(J, H, orc, np))
         except Exception as e:                                       # beside the headline, never a reason to lose it
-            extra = {"extras_error": repr(e)}
+            extra["extras_error"] = repr(e)
         try:
             extra["staging_pipeline"] = staging_pipeline(J, files, args.images)
         except Exception as e:
