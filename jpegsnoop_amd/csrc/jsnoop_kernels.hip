@@ -1785,7 +1785,9 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
 //  * the rare events (end of the own range, codes longer than the first level, interval ends and errors) each sit behind ONE vote, and
 //    they leave the lane in a state in which the straight-line code of the step does nothing for it (no bits consumed, index kept);
 //  * zero-valued coefficients (ZRL, EOB) are simply stored: they land on positions that are zero and are never written twice;
-//  * the DC difference of a finished block is read back from the lane's block instead of being carried through every step.
+//  * the flush has no scalar loop (ranks + wave permutes), its block rows leave as non-temporal stores through a scalar base and a
+//    32-bit offset, and the DC differences of finished blocks wait in registers and leave eight at a time: what the vector memory
+//    pipe is charged for is the number of store instructions, not their bytes.
 #define IBAL(m) __builtin_amdgcn_inverse_ballot_w64(m)
 // EXTEND (HuffmanDc2Signed :859) of the `size` bits that follow `skipbits` bits of the window; size == 0 -> 0
 __device__ __forceinline__ int32_t extend_bits(uint32_t win, uint32_t skipbits, uint32_t size)
