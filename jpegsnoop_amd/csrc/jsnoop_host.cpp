@@ -164,6 +164,15 @@ JsnoopBatch::JsnoopBatch(void* user_stream)
     for (auto& e : ev2) e = nullptr;
     d_lut = nullptr;
 }
+int JsnoopDecoder::Pinned::ensure(size_t need)
+{
+    if (need <= cap && p) return 0;
+    if (p) { hipHostFree(p); p = nullptr; cap = 0; }
+    if (hipHostMalloc(&p, need ? need : 1, hipHostMallocDefault) != hipSuccess) { p = nullptr; js_set_error("page-locked host buffer of %zu bytes: allocation failed", need); return -1; }
+    cap = need;
+    return 0;
+}
+JsnoopDecoder::Pinned::~Pinned() { if (p) hipHostFree(p); }
 int JsnoopBatch::init()
 {
     HIP_TRY(hipSetDevice(device));
@@ -195,6 +204,7 @@ JsnoopBatch::~JsnoopBatch()
     if (d_side_tmp) hipFree(d_side_tmp);
     js_prog_free(this);
     if (pinned) hipHostFree(pinned);
+    if (d2h_land) hipHostFree(d2h_land);
     for (auto& e : ev) if (e) hipEventDestroy(e);
     for (auto& e : ev2) if (e) hipEventDestroy(e);
     for (auto& e : aux_ev) if (e) hipEventDestroy(e);
@@ -573,11 +583,10 @@ const uint8_t* jsnoop_get_bitmap_ptr(JsnoopDecoder* d)
     if (!d->have_image) return nullptr;
     if (!(d->host_valid & 1)) {
         const JsImage& im = d->batch->imgs[0];
-        d->h_dib.resize((size_t)im.img_x * im.img_y * 4);
-        if (d->batch->read_dib(0, d->h_dib.data())) return nullptr;
+        if (d->h_dib.ensure((size_t)im.img_x * im.img_y * 4) || d->batch->read_dib(0, (uint8_t*)d->h_dib.p)) return nullptr;
         d->host_valid |= 1;
     }
-    return d->h_dib.data();
+    return (const uint8_t*)d->h_dib.p;
 }
 const void* jsnoop_get_bitmap_dev(JsnoopDecoder* d) { return d->have_image ? d->batch->dev.dib + d->batch->imgs[0].dib_off : nullptr; }
 void jsnoop_get_pixmap_ptrs(JsnoopDecoder* d, const int16_t** y, const int16_t** cb, const int16_t** cr)
@@ -586,13 +595,16 @@ void jsnoop_get_pixmap_ptrs(JsnoopDecoder* d, const int16_t** y, const int16_t**
     if (!d->have_image) return;
     const JsImage& im = d->batch->imgs[0];
     const size_t psz = (size_t)im.blk_xmax * 8 * im.blk_ymax * 8;
+    int16_t* hp = nullptr;
     if (!(d->host_valid & 2)) {
-        d->h_planes.assign(psz * 3, 0);
-        if (d->batch->read_planes(0, d->h_planes.data(), d->h_planes.data() + psz, d->h_planes.data() + 2 * psz)) return;
+        if (d->h_planes.ensure(psz * 3 * sizeof(int16_t))) return;
+        hp = (int16_t*)d->h_planes.p; memset(hp, 0, psz * 3 * sizeof(int16_t));
+        if (d->batch->read_planes(0, hp, hp + psz, hp + 2 * psz)) return;
         d->host_valid |= 2;
     }
-    *y = d->h_planes.data();
-    if (im.ncomp == 3) { *cb = d->h_planes.data() + psz; *cr = d->h_planes.data() + 2 * psz; }
+    hp = (int16_t*)d->h_planes.p;
+    *y = hp;
+    if (im.ncomp == 3) { *cb = hp + psz; *cr = hp + 2 * psz; }
 }
 void jsnoop_lookup_file_pos_mcu(JsnoopDecoder* d, unsigned mx, unsigned my, unsigned* byte, unsigned* bit)
 {
@@ -755,8 +767,7 @@ int jsnoop_batch_read_coefs(JsnoopBatch* b, int i, int16_t* dst, size_t max_bloc
     if (i < 0 || (size_t)i >= b->imgs.size()) return -1;
     const JsImage& im = b->imgs[i]; size_t nb = std::min<size_t>(max_blocks, im.total_blocks);
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipMemcpyAsync(dst, b->dev.coef + im.coef_off * 64, nb * 128, hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (b->d2h_staged(dst, b->dev.coef + im.coef_off * 64, nb * 128)) return -1;
     return (int)nb;
 }
 int jsnoop_batch_dib_hashes(JsnoopBatch* b, uint64_t* dst)
@@ -783,8 +794,25 @@ int JsnoopBatch::read_dib(int i, uint8_t* dst)
     const JsImage& im = imgs[i];
     JsRange r_("jsnoop:read_dib (D2H)");
     HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipMemcpyAsync(dst, dev.dib + im.dib_off, (size_t)im.img_x * im.img_y * 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    return d2h_staged(dst, dev.dib + im.dib_off, (size_t)im.img_x * im.img_y * 4);
+}
+// Device -> caller's (pageable) memory through a page-locked landing buffer of this batch, in chunks: a direct asynchronous copy into
+// pageable memory is slower and, once the runtime has taken that path, makes every later synchronisation of the process dearer.
+int JsnoopBatch::d2h_staged(void* dst, const void* src, size_t bytes)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, dst) == hipSuccess && at.type == hipMemoryTypeHost) {          // already page-locked: straight there
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream)); HIP_TRY(hipStreamSynchronize(stream)); return 0;
+    }
+    (void)hipGetLastError();                                                                          // (pageable pointers make the query fail: not an error)
+    const size_t chunk = 32u << 20;
+    if (!d2h_land) { HIP_TRY(hipHostMalloc((void**)&d2h_land, chunk, hipHostMallocDefault)); }
+    for (size_t o = 0; o < bytes; o += chunk) {
+        const size_t nb = std::min(chunk, bytes - o);
+        HIP_TRY(hipMemcpyAsync(d2h_land, (const uint8_t*)src + o, nb, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        memcpy((uint8_t*)dst + o, d2h_land, nb);
+    }
     return 0;
 }
 int JsnoopBatch::read_planes(int i, int16_t* y, int16_t* cb, int16_t* cr)
@@ -793,8 +821,7 @@ int JsnoopBatch::read_planes(int i, int16_t* y, int16_t* cb, int16_t* cr)
     const JsImage& im = imgs[i]; const size_t psz = (size_t)im.blk_xmax * 8 * im.blk_ymax * 8;
     int16_t* dst[3] = { y, cb, cr };
     HIP_TRY(hipSetDevice(device));
-    for (uint32_t c = 0; c < im.ncomp; c++) if (dst[c]) HIP_TRY(hipMemcpyAsync(dst[c], dev.planes + im.plane_off + c * psz, psz * 2, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    for (uint32_t c = 0; c < im.ncomp; c++) if (dst[c] && d2h_staged(dst[c], dev.planes + im.plane_off + c * psz, psz * 2)) return -1;
     return 0;
 }
 void JsnoopDecoder::ensure_side()
@@ -807,8 +834,7 @@ void JsnoopDecoder::fetch_side()
     const JsImage& im = batch->imgs[0];
     h_side.assign(js_side_words(im.mcu_xmax * im.mcu_ymax, im.blk_xmax * im.blk_ymax), 0);
     hipSetDevice(batch->device);
-    HIP_NOTE(hipMemcpyAsync(h_side.data(), batch->dev.side + im.side_off, h_side.size() * 4, hipMemcpyDeviceToHost, batch->stream));
-    HIP_NOTE(hipStreamSynchronize(batch->stream));
+    if (batch->d2h_staged(h_side.data(), batch->dev.side + im.side_off, h_side.size() * 4)) log(2, "*** ERROR: reading the side block back failed: %s", g_err.c_str());
 }
 void JsnoopDecoder::rerender()                                  // CalcChannelPreview :4965 on the retained data: colour kernel only
 {

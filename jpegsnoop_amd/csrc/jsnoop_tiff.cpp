@@ -79,10 +79,9 @@ extern "C" int jsnoop_export_tiff(JsnoopDecoder* d, const char* path, int mode)
     if (hipMalloc((void**)&dpack, strip + 64) != hipSuccess) { js_set_error("jsnoop_export_tiff: hipMalloc failed"); return -1; }
     js_launch_tiff_pack(b->stream, b->dev.imgs, 0, b->dev.dib, b->dev.planes, mode, dpack);
     std::vector<uint8_t> host(strip);
-    hipError_t e = hipMemcpyAsync(host.data(), dpack, strip, hipMemcpyDeviceToHost, b->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    const int rc = b->d2h_staged(host.data(), dpack, strip);
     hipFree(dpack);
-    if (e != hipSuccess) { js_set_error("jsnoop_export_tiff: device error: %s", hipGetErrorString(e)); return -1; }
+    if (rc) return -1;
     FILE* f = fopen(path, "wb");
     if (!f) { js_set_error("ERROR: Couldn't open file for write [%s]", path); return -1; }
     const bool ok = fwrite(head.v.data(), 1, head.v.size(), f) == head.v.size() && fwrite(host.data(), 1, strip, f) == strip;
