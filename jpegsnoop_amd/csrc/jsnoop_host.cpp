@@ -776,8 +776,7 @@ int jsnoop_batch_dib_hashes(JsnoopBatch* b, uint64_t* dst)
     const uint32_t n = (uint32_t)b->imgs.size();
     HIP_TRY(hipMemsetAsync(b->dev.sums, 0, n * 8, b->stream));
     js_launch_dib_checksum(b->stream, b->dev.imgs, n, b->dev.dib, (unsigned long long*)b->dev.sums);
-    HIP_TRY(hipMemcpyAsync(dst, b->dev.sums, n * 8, hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (b->d2h_staged(dst, b->dev.sums, n * 8)) return -1;
     return 0;
 }
 uint64_t jsnoop_batch_algorithmic_bytes(const JsnoopBatch* b)

@@ -323,8 +323,7 @@ static int js_parallel_resume(JsnoopBatch* b, int extra_launches)
                     b->dev.coef, b->dev.dccum, b->dev.mcu_rst, b->dev.flags);
     js_launch_dc_scan(b->stream, b->dev.imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst, b->dev.dc_parts);
     if (b->launch_back_end(n)) return -1;
-    HIP_TRY(hipMemcpyAsync(b->host_flags.data(), b->dev.flags, (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (b->d2h_staged(b->host_flags.data(), b->dev.flags, (size_t)n * 4)) return -1;      // (through the page-locked landing buffer)
     return 0;
 }
 
@@ -337,8 +336,7 @@ int js_parallel_fixup(JsnoopBatch* b)
         for (uint32_t i = 0; i < n; i++) { b->host_flags[i] = JSNOOP_FLAG_TABLES; b->host_path[i] = 2; }   // outside the parallel path's LUT form)
         return 0;
     }
-    HIP_TRY(hipMemcpyAsync(b->host_flags.data(), b->dev.flags, (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (b->d2h_staged(b->host_flags.data(), b->dev.flags, (size_t)n * 4)) return -1;      // (through the page-locked landing buffer)
     // An unconverged chain is not a malformed stream: give it more synchronisation rounds first.
     for (int attempt = 0, extra = 4; attempt < 4; attempt++, extra *= 4) {
         bool nosync = false;
