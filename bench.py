@@ -15,6 +15,11 @@ block scan -> coefficient write -> DC scan -> IDCT + colour -> DIB.  Prints ONE 
 (rank 0).  `value` counts SOF pixels (X*Y) of every image of every rank per second, and is only
 reported when every DIB checksum equals the oracle's (bit-exact gate).
 
+`--strong` (opt-in; the default line stays the weak-scaling one): ONE job of `--job-images` files of mixed size (1280x720,
+1920x1080, 3840x2160) -- the loop of CJPEGsnoopCore::DoBatchFileProcess (source/JPEGsnoopCore.cpp:765-845) made parallel: every
+rank derives the same job list, `partition_lpt` balances it by compressed bytes, each rank decodes its shard, `value` is the
+job's pixels over the slowest rank's time ("scaling": "strong"), the per-rank times and shard costs are reported beside it.
+
 `--stub` replaces the GPU batch by a CPU stand-in (gloo instead of RCCL): the rank / shard /
 reduce logic of this file runs unchanged, which is what tests/test_bench_ranks.py drives at
 world size 2.
@@ -45,6 +50,8 @@ def parse_args(argv=None):
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-extras", action="store_true", help="skip the BASELINE config 2 / config 5 / staging-pipeline extras (rank 0, N=1)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: one job of --job-images mixed-size files, LPT-partitioned over the ranks")
+    ap.add_argument("--job-images", type=int, default=8192, help="--strong: files in the whole job (BASELINE config 4 names 8192)")
     ap.add_argument("--stub", action="store_true", help="CPU dry run of the rank logic: stand-in batch, gloo backend (tests)")
     ap.add_argument("--stub-ms", type=float, default=2.0, help="--stub: pretended decode time per step")
     return ap.parse_args(argv)
@@ -69,15 +76,17 @@ def spawn_ranks(args, argv):
 
 
 class StubBatch:
-    """CPU stand-in for jpegsnoop_amd.JpegBatch (--stub): same surface bench.py uses, no device."""
+    """CPU stand-in for jpegsnoop_amd.JpegBatch (--stub): same surface bench.py uses, no device.  `dims` = (width, height) per image,
+    `gidx` = the global index of each image in the job (the pretended DIB checksum depends on it alone: whatever the partition,
+    the job's fingerprint is the same)."""
 
-    def __init__(self, rank, n_images, width, height, step_ms):
+    def __init__(self, dims, gidx, step_ms):
         import numpy as np
-        self.n, self.w, self.h, self.step_ms = n_images, width, height, step_ms
-        self._sums = (np.arange(n_images, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(rank + 1)).astype(np.uint64)
-    def __len__(self): return self.n
-    def pixels(self): return self.n * self.w * self.h
-    def algorithmic_bytes(self): return self.n * ((self.w * ((self.h + 15) // 16 * 16)) * 4 + 590000)
+        self.dims, self.step_ms = list(dims), step_ms
+        self._sums = (np.array(list(gidx), dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(1)).astype(np.uint64)
+    def __len__(self): return len(self.dims)
+    def pixels(self): return sum(w * h for w, h in self.dims)
+    def algorithmic_bytes(self): return sum((w * ((h + 15) // 16 * 16)) * 4 + int(0.285 * w * h) for w, h in self.dims)
     def upload(self): pass
     def decode(self): time.sleep(self.step_ms * 1e-3)
     def sync(self): pass
@@ -88,6 +97,46 @@ class StubBatch:
         k = self.step_ms / sum(st.values())
         return self.step_ms, {a: b * k for a, b in st.items()}
     def close(self): pass
+
+
+MIX64_MASK = 0xFFFFFFFFFFFFFFFF
+
+
+def mix64(z):
+    """splitmix64 finaliser (the same mixer as k_dib_checksum)."""
+    z = (z + 0x9E3779B97F4A7C15) & MIX64_MASK
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MIX64_MASK
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MIX64_MASK
+    return z ^ (z >> 31)
+
+
+def shard_checksum(sums, global_index):
+    """Fingerprint of a shard: sum mod 2^64 of mix64(dib_checksum_i ^ mix64(global index of image i)).  Position-keyed, so the
+    replicas of a tiled workload do not cancel (a plain XOR of 16 identical values is 0) and the all-reduced sum over the ranks
+    is the fingerprint of the whole job whatever the partition."""
+    tot = 0
+    for s, g in zip(sums, global_index):
+        tot = (tot + mix64(int(s) ^ mix64(int(g)))) & MIX64_MASK
+    return tot
+
+
+# --strong: the job list.  Entry i = (kind, seed): kind indexes JOB_KINDS, 5/8 of the files are 1080p, 2/8 720p, 1/8 4K.
+JOB_KINDS = [(1280, 720), (1920, 1080), (3840, 2160)]
+JOB_PATTERN = [1, 1, 0, 1, 1, 2, 1, 0]
+
+
+def job_plan(job_images, distinct):
+    return [(JOB_PATTERN[i % 8], (i // 8) % max(1, distinct)) for i in range(job_images)]
+
+
+def job_seed(kind, seed):
+    return 50000 + 1000 * kind + seed + 1
+
+
+def stub_cost(kind, seed):
+    """--stub: a stand-in for the compressed size of file (kind, seed): proportional to its pixels, +-12 % by seed."""
+    w, h = JOB_KINDS[kind]
+    return int(w * h * 0.285 * (0.88 + 0.24 * ((seed * 2654435761) % 97) / 96.0))
 
 
 def _cpu_worker_init(width, height, seed_base):
@@ -254,22 +303,52 @@ def main():
         if not stub:
             torch.cuda.synchronize()
 
-    # ---- this rank's shard: seeded per (rank, index) so every shard holds different pictures --------
+    # ---- this rank's shard ----------------------------------------------------------------------------
+    #  weak (default): every rank owns --images pictures of its own, seeded per (rank, index): global index = rank * images + i
+    #  strong:         ONE job list, the same on every rank; partition_lpt by compressed bytes; this rank takes bin `rank`
     t_gen = t_upload_first = t_upload = 0.0
-    files = []
+    files = []                    # weak: the rank's distinct files
+    job_files = {}                # strong: (kind, seed) -> file bytes, every distinct file of the job
+    keys = []                     # per image of this rank's batch: what it is a copy of (weak: index into files; strong: (kind, seed))
+    shard_info = None
+    if args.strong:
+        plan = job_plan(args.job_images, args.distinct)
+        distinct_keys = sorted(set(plan))
+        if stub:
+            costs = [stub_cost(k, sd) for k, sd in plan]
+        else:
+            t0 = time.time()
+            for k, sd in distinct_keys:                                   # deterministic: every rank makes the same files, and so the same costs
+                w, h = JOB_KINDS[k]
+                job_files[(k, sd)] = H.synth_jpeg(width=w, height=h, hs=2, vs=2, quality=85, seed=job_seed(k, sd))
+            t_gen = time.time() - t0
+            costs = [len(job_files[e]) for e in plan]
+        bins = J.partition_lpt(costs, world)
+        gidx = bins[rank]
+        keys = [plan[g] for g in gidx]
+        shard_info = {"images": len(gidx), "compressed_bytes": int(sum(costs[g] for g in gidx)),
+                      "index_sums": [len(gidx), int(sum(gidx)), int(sum(g * g for g in gidx))]}
+    else:
+        gidx = list(range(rank * args.images, (rank + 1) * args.images))
+        keys = [i % args.distinct for i in range(args.images)]
     if stub:
-        batch = StubBatch(rank, args.images, args.width, args.height, args.stub_ms)
+        dims = [JOB_KINDS[k[0]] for k in keys] if args.strong else [(args.width, args.height)] * args.images
+        batch = StubBatch(dims, gidx, args.stub_ms)
     else:
         lib = J.load()
         assert lib.jsnoop_set_device(local_rank) == 0, J.last_error()
-        t0 = time.time()
-        files = [H.synth_jpeg(width=args.width, height=args.height, hs=2, vs=2, quality=85, seed=1000 * rank + i + 1)
-                 for i in range(args.distinct)]
-        t_gen = time.time() - t0
         batch = J.JpegBatch(want_planes=False)
-        for f in files:
-            batch.add_jpeg(f)
-        batch.tile(args.images)                          # physical replication: every image has its own bytes in the raw arena
+        if args.strong:
+            for k in keys:
+                batch.add_jpeg(job_files[k])                 # every image has its own bytes in the raw arena
+        else:
+            t0 = time.time()
+            files = [H.synth_jpeg(width=args.width, height=args.height, hs=2, vs=2, quality=85, seed=1000 * rank + i + 1)
+                     for i in range(args.distinct)]
+            t_gen = time.time() - t0
+            for f in files:
+                batch.add_jpeg(f)
+            batch.tile(args.images)                          # physical replication: every image has its own bytes in the raw arena
         t0 = time.perf_counter()
         batch.upload()                                   # pinned host -> HBM, outside the timed region
         t_upload_first = time.perf_counter() - t0        # includes the one-time hipMalloc of the arenas
@@ -289,21 +368,27 @@ def main():
     budget = args.cpu_seconds if (rank == 0 and world == 1 and not stub) else 0.0
     all_cores = ref_info = cfg1 = None
     orc = None
+    n_checked = 0
     if not stub:
+        # EVERY rank checks EVERY distinct picture of its shard against the oracle (ranks work side by side; 64 x 1080p = ~9 s):
+        # no image is reported bit-exact on the strength of its flags alone.  The cpu_baseline figure is the time of the first
+        # `budget` seconds of these same oracle decodes (rank 0, N = 1).
         orc = H.oracle_backend()
-        check_idx = list(range(args.distinct)) if budget > 0 else list(range(min(2, args.distinct)))
-        for j in check_idx:
+        members = {}
+        for i, k in enumerate(keys):
+            members.setdefault(k, []).append(i)
+        for k in sorted(members):
             t1 = time.perf_counter()
-            H.drive(orc, files[j])
+            H.drive(orc, job_files[k] if args.strong else files[k])
             dt = time.perf_counter() - t1
             want = J.dib_checksum_numpy(orc.dib())
-            for i in range(j, args.images, args.distinct):
+            for i in members[k]:
                 errors += int(int(sums[i]) != want)
-            if budget > 0:
+                n_checked += 1
+            if budget > 0 and cpu_time <= budget and not args.strong:
                 n_cpu += 1
                 cpu_time += dt
-                if cpu_time > budget:
-                    break
+        assert n_checked == len(batch), "parity gate: every image of the shard must have been compared"
     errors += sum(1 for f in flags if f)
     if budget > 0:
         all_cores = cpu_all_cores(args, rank)
@@ -352,17 +437,38 @@ def main():
     ms_whole, stages = batch.decode_timed(max(3, min(10, args.steps)))
     dom = max(stages, key=stages.get)
 
-    my_ck = int(np.bitwise_xor.reduce(sums))
+    my_ck = shard_checksum(sums, gidx)
     tot_px, max_el, job_ck, tot_err = J.reduce_job_stats(pixels * args.steps, elapsed, my_ck, errors, dev if world > 1 else None)
+    if len(batch) and job_ck == 0:
+        tot_err += 1                                      # a fingerprint of 0 carries no information (what the XOR of replicas used to give)
     per_rank_ms = [round(elapsed / args.steps * 1e3, 4)]
     if world > 1:
         t = torch.tensor([elapsed / args.steps * 1e3], dtype=torch.float64, device=dev if dev is not None else "cpu")
         got = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(got, t)
         per_rank_ms = [round(float(g[0]), 4) for g in got]
+    shards = None
+    if args.strong:
+        # the union of the shards must be the job: count, sum and sum of squares of the global indices, all-reduced, against the closed forms
+        t = torch.tensor(shard_info["index_sums"] + [shard_info["compressed_bytes"]], dtype=torch.int64, device=dev if (dev is not None and world > 1) else "cpu")
+        mine = t.clone()
+        if world > 1:
+            got = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(got, mine)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        else:
+            got = [mine]
+        nj = args.job_images
+        union_ok = [int(t[0]), int(t[1]), int(t[2])] == [nj, nj * (nj - 1) // 2, (nj - 1) * nj * (2 * nj - 1) // 6]
+        if not union_ok:
+            tot_err += 1
+        per_bytes = [int(g[3]) for g in got]
+        shards = {"images": [int(g[0]) for g in got], "compressed_bytes": per_bytes, "union_is_the_job": union_ok,
+                  "byte_imbalance": round((max(per_bytes) - min(per_bytes)) / max(1, max(per_bytes)), 4),
+                  "ms_spread": round((max(per_rank_ms) - min(per_rank_ms)) / max(per_rank_ms), 4) if max(per_rank_ms) > 0 else 0.0}
 
     extra = {}
-    if rank == 0 and world == 1 and not stub:
+    if rank == 0 and world == 1 and not stub and not args.strong:
         # the same resident batch as two halves on two streams (jsnoop_batch_set_split): beside the headline, which stays the one-stream
         # form -- the per-kernel timings of a split decode are those of launches that share the chip
         try:
@@ -379,7 +485,7 @@ def main():
             batch.set_split(1)
         except Exception as e:
             extra["two_stream_split"] = {"error": repr(e)}
-    if rank == 0 and world == 1 and not stub and not args.no_extras:
+    if rank == 0 and world == 1 and not stub and not args.no_extras and not args.strong:
         try:
             extra.update(extras_single_gpu(J, H, orc, np))
         except Exception as e:                                       # beside the headline, never a reason to lose it
@@ -394,14 +500,16 @@ def main():
         out = {
             "metric": METRIC,
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(max_el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(max_el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "u8/i16 entropy+DIB, f32 IDCT+colour", "data": "synthetic" + (" (stub: no decode, rank logic only)" if stub else ""),
-            "config": {"workload": f"{args.images} x {args.width}x{args.height} baseline 4:2:0 q85 JPEG per GPU "
-                                   f"({args.distinct} distinct seeds replicated; BASELINE config 3, config 4 at 8 GPUs), HBM->HBM (T1)",
-                       "images_per_gpu": args.images, "distinct": args.distinct, "subsampling": "4:2:0", "quality": 85,
+            "config": {"workload": (f"ONE job of {args.job_images} baseline 4:2:0 q85 JPEGs of mixed size (5/8 1920x1080, 2/8 1280x720, 1/8 3840x2160; "
+                                    f"{args.distinct} distinct seeds per size), LPT-partitioned by compressed bytes over the ranks, HBM->HBM (T1)") if args.strong else
+                                   (f"{args.images} x {args.width}x{args.height} baseline 4:2:0 q85 JPEG per GPU "
+                                    f"({args.distinct} distinct seeds replicated; BASELINE config 3, config 4 at 8 GPUs), HBM->HBM (T1)"),
+                       "images_per_gpu": (args.job_images // world) if args.strong else args.images, "distinct": args.distinct, "subsampling": "4:2:0", "quality": 85,
                        "parallelism": f"shard{world}" if world > 1 else "single", "entropy_path": "parallel" if all(p == 1 for p in paths) else "mixed"},
             "bit_exact": tot_err == 0, "parity_errors": tot_err,
-            "per_rank_ms_per_step": per_rank_ms, "job_checksum": "%016x" % job_ck,
+            "per_rank_ms_per_step": per_rank_ms, "job_checksum": "%016x" % job_ck, "images_oracle_checked_per_rank": n_checked,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(alg_bytes / (stages[dom] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(alg_bytes / (stages[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stages[dom], 4),
@@ -430,7 +538,9 @@ def main():
                     out["roofline"]["traffic_source"] = tj.get("source")
             except Exception:
                 pass
-        if not stub:
+        if shards:
+            out["shards"] = shards
+        if not stub and not args.strong:
             comp = int(sum(len(f) for f in files) * (args.images / args.distinct))
             out["setup_s"] = {"synth": round(t_gen, 1), "first_upload_with_alloc": round(t_upload_first, 3)}
             out["pcie_inclusive_T2"] = {"h2d_ms": round(t_upload * 1e3, 3), "compressed_bytes": comp, "h2d_GBps": round(comp / t_upload / 1e9, 1),

@@ -160,6 +160,7 @@ JsnoopBatch::JsnoopBatch(void* user_stream)
     memset(&dev, 0, sizeof dev); memset(&cap, 0, sizeof cap);
     pinned = nullptr; pinned_cap = 0; raw_bytes = 0; uploaded = false; sync_launches = 2;
     if (const char* e = getenv("JSNOOP_SYNC_LAUNCHES")) sync_launches = std::max(1, atoi(e));
+    if (const char* e = getenv("JSNOOP_SPLIT")) opt_split = atoi(e) == 2 ? 2 : 1;      // the default only: jsnoop_batch_set_split takes precedence afterwards
     for (auto& e : ev) e = nullptr;
     for (auto& e : ev2) e = nullptr;
     d_lut = nullptr;
@@ -367,7 +368,6 @@ int JsnoopBatch::upload()
     HIP_TRY(hipMemcpyAsync(dev.sy_base, syb.data(), 2 * (n + 1) * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));          // host vectors above may go out of scope
     h_us_base = usb; h_sy_base.assign(syb.begin(), syb.begin() + n + 1); h_sn_base.assign(syb.begin() + n + 1, syb.end()); h_wg_base = wg;
-    if (const char* e = getenv("JSNOOP_SPLIT")) opt_split = atoi(e) == 2 ? 2 : 1;
     split_parts = (opt_split == 2 && n >= 2) ? 2 : 1;
     uploaded = true;
     return 0;

@@ -15,6 +15,7 @@
 // accumulation order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "jsnoop_types.h"
 #include "jsnoop_launch.h"
 
@@ -768,19 +769,22 @@ __global__ void __launch_bounds__(256) k_color_sweep(uint32_t* __restrict__ out)
 __device__ __forceinline__ uint64_t mix64(uint64_t z)
 { z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
 
-__global__ void __launch_bounds__(256) k_dib_checksum(const JsImage* __restrict__ imgs, uint32_t chunks_per_img,
+__global__ void __launch_bounds__(256) k_dib_checksum(const JsImage* __restrict__ imgs, uint32_t nimg, uint32_t chunks_per_img,
                                                       const uint8_t* __restrict__ dib, unsigned long long* __restrict__ sums)
 {
-    const JsImage& im = imgs[blockIdx.y];
-    const uint32_t npx = im.img_x * im.img_y;
-    const uint32_t* p = reinterpret_cast<const uint32_t*>(dib + im.dib_off);
-    uint64_t acc = 0;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < npx; i += chunks_per_img * 256) acc += mix64(((uint64_t)i << 32) | p[i]);
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     __shared__ uint64_t s[4];
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&sums[blockIdx.y], (unsigned long long)(s[0] + s[1] + s[2] + s[3]));
+    for (uint32_t img = blockIdx.y; img < nimg; img += gridDim.y) {          // (grid rows wrap beyond the grid.y limit)
+        const JsImage& im = imgs[img];
+        const uint32_t npx = im.img_x * im.img_y;
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(dib + im.dib_off);
+        uint64_t acc = 0;
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < npx; i += chunks_per_img * 256) acc += mix64(((uint64_t)i << 32) | p[i]);
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(&sums[img], (unsigned long long)(s[0] + s[1] + s[2] + s[3]));
+        __syncthreads();
+    }
 }
 
 // =====================================================================================
@@ -966,8 +970,14 @@ int js_launch_idct_color(hipStream_t st, const JsImage* imgs, const uint32_t* wg
     const size_t lds = 64 * 64 * sizeof(float) + JS_MAX_BLK_PER_MCU * 4 + (size_t)BK_WAVES * (LIST_BYTES + tile_bytes) + BK_WAVES * 12;
     if (lds > 160u * 1024u) return -2;
     if (lds > 64u * 1024u) {
-        static size_t opted = 0;                              // raised monotonically; the attribute is per function, not per launch
-        if (lds > opted) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_idct_color), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3; opted = lds; }
+        // The attribute belongs to the function object of the CURRENT device (one host thread per GPU is a supported use of the C ABI):
+        // the size already opted in is remembered per device, raised monotonically, and read / written with atomics.
+        static std::atomic<size_t> opted[JS_MAX_DEVICES];
+        int devi = 0; if (hipGetDevice(&devi) != hipSuccess || devi < 0) return -3;
+        if (devi >= JS_MAX_DEVICES || lds > opted[devi].load(std::memory_order_acquire)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_idct_color), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
+            if (devi < JS_MAX_DEVICES) { size_t cur = opted[devi].load(std::memory_order_relaxed); while (cur < lds && !opted[devi].compare_exchange_weak(cur, lds)) {} }
+        }
     }
     hipLaunchKernelGGL(k_idct_color, dim3(total_wgs), dim3(BK_THREADS), lds, st, imgs, wg_base, nimg, tile_bytes, lut_t, coef, dccum, dib, planes, side);
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -988,7 +998,7 @@ void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, 
 {
     if (!nimg) return;
     const uint32_t chunks = 64;
-    hipLaunchKernelGGL(k_dib_checksum, dim3(chunks, nimg), dim3(256), 0, st, imgs, chunks, dib, sums);
+    hipLaunchKernelGGL(k_dib_checksum, dim3(chunks, nimg < 65535u ? nimg : 65535u), dim3(256), 0, st, imgs, nimg, chunks, dib, sums);
 }
 
 // =====================================================================================

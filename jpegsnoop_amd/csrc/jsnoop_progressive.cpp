@@ -341,8 +341,7 @@ int JsnoopBatch::sync_progressive()
 {
     const uint32_t n = (uint32_t)imgs.size();
     std::vector<uint32_t> st((size_t)n * 4, 0);
-    HIP_TRY(hipMemcpyAsync(st.data(), prog->d_status, st.size() * 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    if (d2h_staged(st.data(), prog->d_status, st.size() * 4)) return -1;            // (through the page-locked landing buffer; it synchronises the stream)
     host_flags.assign(n, 0); host_path.assign(n, 3u);
     for (uint32_t i = 0; i < n; i++) host_flags[i] = st[(size_t)i * 4] ? JSNOOP_FLAG_BAD_CODE : 0u;
     return 0;

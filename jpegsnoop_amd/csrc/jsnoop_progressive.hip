@@ -224,15 +224,17 @@ __global__ void __launch_bounds__(256) k_prog_finalize(const JsImage* __restrict
                                                        const uint32_t* __restrict__ blk_base, uint32_t total_blocks, int16_t* __restrict__ coef, int16_t* __restrict__ dccum)
 {
     const uint32_t lane = threadIdx.x & 63;
-    const JsImage& im = imgs[blockIdx.y]; const JsProgFrame& fr = frames[blockIdx.y];       // one grid row per image
-    int16_t* cbase = coef + im.coef_off * 64; int16_t* dbase = dccum + im.coef_off;
-    (void)nimg; (void)blk_base; (void)total_blocks;
-    for (uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6); b < im.total_blocks; b += gridDim.x * 4) {
-        const uint32_t comp = im.blk_comp[b % im.blk_per_mcu] - 1u;
-        const int16_t v = cbase[(size_t)b * 64 + lane];
-        const int16_t dq = (int16_t)((int32_t)v * (int32_t)fr.qnat[comp][lane]);
-        if (lane == 0) { dbase[b] = dq; cbase[(size_t)b * 64] = 0; }
-        else cbase[(size_t)b * 64 + lane] = dq;
+    (void)blk_base; (void)total_blocks;
+    for (uint32_t img = blockIdx.y; img < nimg; img += gridDim.y) {                         // one grid row per image (rows wrap beyond the grid.y limit)
+        const JsImage& im = imgs[img]; const JsProgFrame& fr = frames[img];
+        int16_t* cbase = coef + im.coef_off * 64; int16_t* dbase = dccum + im.coef_off;
+        for (uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6); b < im.total_blocks; b += gridDim.x * 4) {
+            const uint32_t comp = im.blk_comp[b % im.blk_per_mcu] - 1u;
+            const int16_t v = cbase[(size_t)b * 64 + lane];
+            const int16_t dq = (int16_t)((int32_t)v * (int32_t)fr.qnat[comp][lane]);
+            if (lane == 0) { dbase[b] = dq; cbase[(size_t)b * 64] = 0; }
+            else cbase[(size_t)b * 64 + lane] = dq;
+        }
     }
 }
 
@@ -249,5 +251,5 @@ void js_launch_prog_finalize(hipStream_t st, const JsImage* imgs, const JsProgFr
     if (!nimg) return;
     const uint32_t per_img = (total_blocks / nimg + 3) / 4;           // workgroups of four blocks; each strides over its image
     const uint32_t gx = nimg >= 64 ? 64u : (per_img < 2048 ? (per_img ? per_img : 1u) : 2048u);
-    hipLaunchKernelGGL(k_prog_finalize, dim3(gx, nimg), dim3(256), 0, st, imgs, frames, nimg, blk_base, total_blocks, coef, dccum);
+    hipLaunchKernelGGL(k_prog_finalize, dim3(gx, nimg < 65535u ? nimg : 65535u), dim3(256), 0, st, imgs, frames, nimg, blk_base, total_blocks, coef, dccum);
 }

@@ -21,6 +21,7 @@
 #define JS_CODE_UNUSED     0xFFFFFFFFu
 #define JS_L1_BITS         9       // first-level index width of the parallel path's decode tables (1 KiB rows: four workgroups of the write pass fit a CU)
 #define JS_LUT2_MAX        2048    // second-level entries (all tables together) in the parallel path's LUT form
+#define JS_MAX_DEVICES     64      // devices one process may drive (per-device state of the launch wrappers)
 #define JS_SUBSEQ_BYTES    128     // bytes of un-stuffed stream per sub-sequence (parallel entropy path)
 
 // One distinct set of Huffman + quantisation tables, resolved per scan component
@@ -106,7 +107,7 @@ enum { JS_EV_OVERREAD_BEFORE = 1, JS_EV_OVERREAD_CODE, JS_EV_OVERREAD_BITS, JS_E
 
 // Layouts the back end converts without a replicated LDS tile (k_idct_color, mcu_to_dib_fast): three components, Y un-expanded,
 // Cb and Cr one block each and both expanded eh x ev with eh, ev in {1, 2} (4:4:4, 4:2:2, 4:4:0, 4:2:0), default preview, no YCC shift.
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 __host__ __device__
 #endif
 static inline bool js_fast_layout(const JsImage& im)

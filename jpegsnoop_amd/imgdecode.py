@@ -150,10 +150,12 @@ class JpegBatch:
             raise RuntimeError("jsnoop_batch_create failed: " + capi.last_error())
         self._lib.jsnoop_batch_set_options(self._h, int(decode_ac), int(want_planes), int(force_exact))
         self.want_planes = want_planes
+        self._borrowed = False                   # True: the handle belongs to a JpegPipeline, which destroys it
 
     def close(self):
         if self._h:
-            self._lib.jsnoop_batch_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._lib.jsnoop_batch_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -33,13 +33,54 @@ def test_gpus_2_spawns_two_ranks_and_reduces():
     # value = pixels of BOTH ranks / slowest rank's time
     assert abs(out["value"] - 2 * images * w * h * steps / (out["ms_per_step"] * steps * 1e-3) / 1e6) < 0.05 * out["value"] + 0.2
     assert out["ms_per_step"] >= max(out["per_rank_ms_per_step"]) - 1e-3
-    # the job checksum is the sum (mod 2^64) of the per-rank XORs of the stub's per-image sums
+    # the job checksum: sum mod 2^64 over ALL images of the job of mix64(image checksum ^ mix64(global index)) -- position-keyed, so
+    # replicas cannot cancel; the stub's image checksum is a function of the global index alone
     import numpy as np
-    want = 0
-    for r in range(2):
-        sums = (np.arange(images, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(r + 1)).astype(np.uint64)
-        want = (want + int(np.bitwise_xor.reduce(sums))) & 0xFFFFFFFFFFFFFFFF
-    assert int(out["job_checksum"], 16) == want
+    sys.path.insert(0, ROOT)
+    import bench
+    gidx = list(range(2 * images))
+    sums = (np.array(gidx, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(1)).astype(np.uint64)
+    want = bench.shard_checksum(sums, gidx)
+    assert int(out["job_checksum"], 16) == want and want != 0
+
+
+def test_shard_checksum_does_not_cancel_on_replicas():
+    sys.path.insert(0, ROOT)
+    import bench
+    # 16 identical DIB checksums (a tiled workload): the XOR is 0, the position-keyed sum is not -- and it depends on every member
+    sums = [0x1234567890ABCDEF] * 16
+    a = bench.shard_checksum(sums, range(16))
+    assert a != 0
+    b = bench.shard_checksum(sums[:15] + [0x1234567890ABCDEE], range(16))
+    assert a != b
+    # partition independence: two shards' fingerprints add up to the job's
+    assert (bench.shard_checksum(sums[:5], range(5)) + bench.shard_checksum(sums[5:], range(5, 16))) & bench.MIX64_MASK == a
+
+
+def test_strong_scaling_job_is_partitioned_by_bytes_and_its_union_is_the_job():
+    sys.path.insert(0, ROOT)
+    import bench
+    from jpegsnoop_amd.shard import partition_lpt
+    nj, distinct = 203, 5
+    one = last_json(run_bench("--stub", "--strong", "--job-images", str(nj), "--distinct", str(distinct), "--steps", "2", "--warmup", "1", "--stub-ms", "3"))
+    two = last_json(run_bench("--gpus", "2", "--stub", "--strong", "--job-images", str(nj), "--distinct", str(distinct), "--steps", "2", "--warmup", "1", "--stub-ms", "3"))
+    for out, w in ((one, 1), (two, 2)):
+        assert out["scaling"] == "strong" and out["n_gpus"] == w and out["bit_exact"]
+        sh = out["shards"]
+        assert sh["union_is_the_job"] and sum(sh["images"]) == nj and len(sh["images"]) == w
+    # the same job whatever the partition: same fingerprint, same pixel count per step
+    assert one["job_checksum"] == two["job_checksum"] and int(one["job_checksum"], 16) != 0
+    plan = bench.job_plan(nj, distinct)
+    px = sum(bench.JOB_KINDS[k][0] * bench.JOB_KINDS[k][1] for k, _ in plan)
+    for out in (one, two):
+        assert abs(out["value"] - px * 2 / (out["ms_per_step"] * 2 * 1e-3) / 1e6) < 0.05 * out["value"] + 0.2
+    # the shards are the LPT bins of the compressed-size list, and they are balanced to within one (largest) file
+    costs = [bench.stub_cost(k, sd) for k, sd in plan]
+    bins = partition_lpt(costs, 2)
+    assert two["shards"]["images"] == [len(b) for b in bins]
+    assert two["shards"]["compressed_bytes"] == [sum(costs[i] for i in b) for b in bins]
+    assert max(two["shards"]["compressed_bytes"]) - min(two["shards"]["compressed_bytes"]) <= max(costs)
+    assert {bench.JOB_KINDS[k] for k, _ in plan} == {(1280, 720), (1920, 1080), (3840, 2160)}
 
 
 def test_single_rank_stub_line_has_the_contract_keys():

@@ -97,6 +97,59 @@ def test_two_batches_two_streams_two_host_threads(harness, oracle):
     assert not errors, errors[:5]
 
 
+def _device_workers(harness, oracle, devices):
+    """One host thread per entry of `devices`: jsnoop_set_device(dev), an own batch holding an ordinary image AND a 4 x 4 sampled one
+    (32 x 32 MCU: the back end's LDS tile needs the > 64 KiB opt-in, which is a per-device attribute), decoded three times."""
+    import jpegsnoop_amd as J
+    lib = J.load()
+    kws = [dict(width=640, height=480), dict(width=200, height=136, hs=4, vs=4), dict(width=512, height=384, hs=2, vs=1)]
+    files = [harness.synth_jpeg(seed=1300 + i, **kw) for i, kw in enumerate(kws)]
+    want = []
+    for f in files:
+        harness.drive(oracle, f)
+        want.append(J.dib_checksum_numpy(oracle.dib()))
+    errors = []
+    start = threading.Barrier(len(devices))
+
+    def worker(k, dev):
+        try:
+            assert lib.jsnoop_set_device(dev) == 0, J.last_error()   # per-thread default device
+            b = J.JpegBatch()
+            for f in files:
+                b.add_jpeg(f)
+            b.tile(48)
+            start.wait(timeout=120)                                  # all threads launch their first back end together
+            for _ in range(3):
+                b.upload(); b.decode(); b.sync()
+                sums = b.dib_checksums()
+                for i in range(48):
+                    if int(sums[i]) != want[i % 3] or b.info(i)["flags"]:
+                        errors.append((k, dev, i))
+            b.close()
+        except Exception as e:                                       # surfaced by the main thread
+            errors.append((k, dev, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(k, d)) for k, d in enumerate(devices)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:5]
+
+
+def test_one_process_threads_share_a_device_with_large_tiles(harness, oracle):
+    _device_workers(harness, oracle, [0, 0, 0])
+
+
+def test_one_process_one_host_thread_per_device(harness, oracle):
+    """The one-process N-device entry of SURVEY.md 8(e): N host threads, jsnoop_set_device(k) each.  Needs two visible devices."""
+    import jpegsnoop_amd as J
+    n = J.load().jsnoop_device_count()
+    if n < 2:
+        pytest.skip(f"{n} HIP device(s) visible: the multi-device test needs two")
+    _device_workers(harness, oracle, list(range(min(n, 8))))
+
+
 def test_staging_pipeline_overlaps_and_stays_exact(harness, oracle):
     """Two slots cycled by jsnoop_pipeline_run (H2D of the next batch while the current one decodes, D2H of the previous one on
     request): every slot's DIBs equal the oracle's afterwards, and the overlapped time per batch is below the sum of its pieces."""
