@@ -365,7 +365,7 @@ def main():
     flags = [batch.info(i)["flags"] for i in range(len(batch))]
     paths = [batch.info(i)["path"] for i in range(len(batch))]
     n_cpu, cpu_time, errors = 0, 0.0, 0
-    budget = args.cpu_seconds if (rank == 0 and world == 1 and not stub) else 0.0
+    budget = args.cpu_seconds if (rank == 0 and world == 1 and not stub and not args.strong) else 0.0
     all_cores = ref_info = cfg1 = None
     orc = None
     n_checked = 0
@@ -385,7 +385,7 @@ def main():
             for i in members[k]:
                 errors += int(int(sums[i]) != want)
                 n_checked += 1
-            if budget > 0 and cpu_time <= budget and not args.strong:
+            if budget > 0 and cpu_time <= budget:
                 n_cpu += 1
                 cpu_time += dt
         assert n_checked == len(batch), "parity gate: every image of the shard must have been compared"

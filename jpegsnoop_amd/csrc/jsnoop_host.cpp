@@ -423,10 +423,17 @@ int JsnoopBatch::decode(bool timed)
 int JsnoopBatch::launch_back_end(uint32_t nimg) { return launch_back_end_part(stream, 0, nimg); }
 int JsnoopBatch::launch_back_end_part(hipStream_t st, uint32_t i0, uint32_t nimg)
 {
-    uint32_t tile = 16;
-    for (uint32_t i = i0; i < i0 + nimg && i < imgs.size(); i++) tile = std::max(tile, js_tile_bytes(imgs[i]));
+    uint32_t tile = 16; int layout = -1;                          // layout: the one fast layout all images of the launch share, else 0
+    for (uint32_t i = i0; i < i0 + nimg && i < imgs.size(); i++) {
+        tile = std::max(tile, js_tile_bytes(imgs[i]));
+        const JsImage& im = imgs[i];
+        const int l = !js_fast_layout(im) ? 0 : (im.expand_h[2] == 2 ? (im.expand_v[2] == 2 ? 1 : 2) : (im.expand_v[2] == 2 ? 3 : 4));
+        layout = layout < 0 ? l : (layout == l ? l : 0);
+    }
+    static const bool generic_only = getenv("JSNOOP_BACKEND_GENERIC") != nullptr;   // (cross-check: the all-layouts kernel for every launch)
+    if (layout < 0 || generic_only) layout = 0;
     const uint32_t wgs = h_wg_base.size() > i0 + nimg ? h_wg_base[i0 + nimg] - h_wg_base[i0] : total_wgs;
-    const int rc = js_launch_idct_color(st, dev.imgs + i0, dev.wg_base + i0, nimg, wgs, tile, d_lut, dev.coef, dev.dccum, dev.dib, dev.planes, dev.side);
+    const int rc = js_launch_idct_color(st, dev.imgs + i0, dev.wg_base + i0, nimg, wgs, tile, d_lut, dev.coef, dev.dccum, dev.dib, dev.planes, dev.side, layout);
     if (rc == -2) { js_set_error("back end: an MCU tile of %u bytes per wave does not fit the 160 KiB LDS", tile); return -1; }
     if (rc) { js_set_error("back end launch failed (%d): %s", rc, hipGetErrorString(hipGetLastError())); return -1; }
     return 0;

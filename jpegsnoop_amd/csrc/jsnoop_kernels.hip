@@ -680,6 +680,10 @@ __device__ __forceinline__ void back_end_mcus(const BackEndCtx& C, uint64_t& bri
 #ifndef JS_BK_OCC
 #define JS_BK_OCC 8     // 64 VGPRs: with the small tiles of the common layouts four workgroups (32 waves) fit a CU
 #endif
+// LAYOUT: 0 = any image (the layout is read from the descriptor, every path is in the kernel); 1..4 = every image of the launch has the
+// fast layout with chroma expansion (2,2) / (2,1) / (1,2) / (1,1) -- the host checks -- and the kernel holds that one path only: a
+// quarter of the code (the four-layout kernel is 20 k instructions, its 4:2:0 loop alone 4.5 k) and registers allocated for it alone.
+template <int LAYOUT>
 __global__ void __launch_bounds__(BK_THREADS, JS_BK_OCC) k_idct_color(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ wg_base, uint32_t nimg,
                                                            uint32_t tile_bytes, const float* __restrict__ lut_t /*[vu][yx]*/,
                                                            const int16_t* __restrict__ coef, const int16_t* __restrict__ dccum,
@@ -712,13 +716,19 @@ __global__ void __launch_bounds__(BK_THREADS, JS_BK_OCC) k_idct_color(const JsIm
 
     uint64_t bright = 0; uint32_t sum_y = 0;
     // the common layouts take the short colour path: Y un-expanded, Cb and Cr one block each, both expanded EH x EV with EH, EV in {1, 2}
-    const uint32_t eh = im.expand_h[2], ev = im.expand_v[2];
-    const bool fast = js_fast_layout(im);
-    if (fast && eh == 2 && ev == 2) back_end_mcus<true, 2, 2>(C, bright, sum_y);
-    else if (fast && eh == 2) back_end_mcus<true, 2, 1>(C, bright, sum_y);
-    else if (fast && ev == 2) back_end_mcus<true, 1, 2>(C, bright, sum_y);
-    else if (fast) back_end_mcus<true, 1, 1>(C, bright, sum_y);
-    else back_end_mcus<false, 1, 1>(C, bright, sum_y);
+    if (LAYOUT == 1) back_end_mcus<true, 2, 2>(C, bright, sum_y);
+    else if (LAYOUT == 2) back_end_mcus<true, 2, 1>(C, bright, sum_y);
+    else if (LAYOUT == 3) back_end_mcus<true, 1, 2>(C, bright, sum_y);
+    else if (LAYOUT == 4) back_end_mcus<true, 1, 1>(C, bright, sum_y);
+    else {
+        const uint32_t eh = im.expand_h[2], ev = im.expand_v[2];
+        const bool fast = js_fast_layout(im);
+        if (fast && eh == 2 && ev == 2) back_end_mcus<true, 2, 2>(C, bright, sum_y);
+        else if (fast && eh == 2) back_end_mcus<true, 2, 1>(C, bright, sum_y);
+        else if (fast && ev == 2) back_end_mcus<true, 1, 2>(C, bright, sum_y);
+        else if (fast) back_end_mcus<true, 1, 1>(C, bright, sum_y);
+        else back_end_mcus<false, 1, 1>(C, bright, sum_y);
+    }
 
     for (int off = 32; off > 0; off >>= 1) {
         const uint64_t ob = __shfl_down(bright, off); bright = ob > bright ? ob : bright;
@@ -962,7 +972,7 @@ void js_launch_entropy_exact(hipStream_t st, const JsImage* imgs, const uint32_t
     hipLaunchKernelGGL(k_entropy_exact, dim3(nsel), dim3(64), 0, st, imgs, sel, nsel, tables, raw, coef, dccum, side, side_only, events);
 }
 int js_launch_idct_color(hipStream_t st, const JsImage* imgs, const uint32_t* wg_base, uint32_t nimg, uint32_t total_wgs, uint32_t tile_bytes,
-                         const float* lut_t, const int16_t* coef, const int16_t* dccum, uint8_t* dib, int16_t* planes, uint32_t* side)
+                         const float* lut_t, const int16_t* coef, const int16_t* dccum, uint8_t* dib, int16_t* planes, uint32_t* side, int layout)
 {
     if (!total_wgs) return 0;
     // tile_bytes: the largest per-wave tile any image of the launch needs (js_tile_bytes).  Ordinary images leave room for four
@@ -974,12 +984,19 @@ int js_launch_idct_color(hipStream_t st, const JsImage* imgs, const uint32_t* wg
         // the size already opted in is remembered per device, raised monotonically, and read / written with atomics.
         static std::atomic<size_t> opted[JS_MAX_DEVICES];
         int devi = 0; if (hipGetDevice(&devi) != hipSuccess || devi < 0) return -3;
+        layout = 0;                                            // (the fast layouts never need it: their tiles are at most 16 x 16 samples)
         if (devi >= JS_MAX_DEVICES || lds > opted[devi].load(std::memory_order_acquire)) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_idct_color), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_idct_color<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
             if (devi < JS_MAX_DEVICES) { size_t cur = opted[devi].load(std::memory_order_relaxed); while (cur < lds && !opted[devi].compare_exchange_weak(cur, lds)) {} }
         }
     }
-    hipLaunchKernelGGL(k_idct_color, dim3(total_wgs), dim3(BK_THREADS), lds, st, imgs, wg_base, nimg, tile_bytes, lut_t, coef, dccum, dib, planes, side);
+    switch (layout) {
+    case 1: hipLaunchKernelGGL(k_idct_color<1>, dim3(total_wgs), dim3(BK_THREADS), lds, st, imgs, wg_base, nimg, tile_bytes, lut_t, coef, dccum, dib, planes, side); break;
+    case 2: hipLaunchKernelGGL(k_idct_color<2>, dim3(total_wgs), dim3(BK_THREADS), lds, st, imgs, wg_base, nimg, tile_bytes, lut_t, coef, dccum, dib, planes, side); break;
+    case 3: hipLaunchKernelGGL(k_idct_color<3>, dim3(total_wgs), dim3(BK_THREADS), lds, st, imgs, wg_base, nimg, tile_bytes, lut_t, coef, dccum, dib, planes, side); break;
+    case 4: hipLaunchKernelGGL(k_idct_color<4>, dim3(total_wgs), dim3(BK_THREADS), lds, st, imgs, wg_base, nimg, tile_bytes, lut_t, coef, dccum, dib, planes, side); break;
+    default: hipLaunchKernelGGL(k_idct_color<0>, dim3(total_wgs), dim3(BK_THREADS), lds, st, imgs, wg_base, nimg, tile_bytes, lut_t, coef, dccum, dib, planes, side); break;
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 void js_launch_idct_probe(hipStream_t st, const float* lut_t, const int16_t* coef64, float* out64)

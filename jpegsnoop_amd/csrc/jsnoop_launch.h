@@ -7,7 +7,8 @@
 void js_launch_entropy_exact(hipStream_t st, const JsImage* imgs, const uint32_t* sel, uint32_t nsel, const JsTableSet* tables,
                              const uint8_t* raw, int16_t* coef, int16_t* dccum, uint32_t* side, int side_only, uint32_t* events);
 int  js_launch_idct_color(hipStream_t st, const JsImage* imgs, const uint32_t* wg_base, uint32_t nimg, uint32_t total_wgs, uint32_t tile_bytes,
-                          const float* lut_t, const int16_t* coef, const int16_t* dccum, uint8_t* dib, int16_t* planes, uint32_t* side);
+                          const float* lut_t, const int16_t* coef, const int16_t* dccum, uint8_t* dib, int16_t* planes, uint32_t* side,
+                          int layout /* 0 = mixed; 1..4 = every image has the fast layout with chroma expansion (2,2) / (2,1) / (1,2) / (1,1) */);
 void js_launch_idct_probe(hipStream_t st, const float* lut_t, const int16_t* coef64, float* out64);
 void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, const uint8_t* dib, unsigned long long* sums);
 void js_launch_color_probe(hipStream_t st, int y, int cb, int cr, uint32_t* out);
