@@ -236,6 +236,23 @@ int          jsnoop_batch_read_coefs(JsnoopBatch*, int i, int16_t* dst, size_t m
  * bHistoEn (histo_en != 0) or only bStatClipEn (histo_en == 0) would leave them */
 int          jsnoop_batch_color_stats(JsnoopBatch*, int i, int histo_en, uint32_t* out);
 int          jsnoop_batch_dib_hashes(JsnoopBatch*, uint64_t* host_dst);
+/* ---- everything else DecodeScanImg leaves behind, per image of a decoded batch: what the per-file pass of the reference's batch loop
+ *      produces (CJPEGsnoopCore::DoBatchFileProcess -> AnalyzeFile -> DoLogSave, source/JPEGsnoopCore.cpp:765-845; the log body of this
+ *      path is source/ImgDecode.cpp:3021-3025, :3126-3135 and :3630-3745).  Same code as the single-image API, addressed at image i.
+ *  jsnoop_batch_side_outputs: any pointer may be NULL.  mcu_map [mcu_ymax*mcu_xmax] (m_pMcuFileMap :3229), dc_* [blk_ymax*blk_xmax]
+ *      (m_pBlkDcValY/Cb/Cr :3524-3608; Cb / Cr untouched for a one-component image), dht_histo [2][4][17] (m_anDhtHisto :1190), status8 as
+ *      jsnoop_scan_status, bright_avg10 as jsnoop_bright_avg (three-component images: needs want_planes).  Produced on request by the
+ *      parallel side pass (about 1 ms per image), without touching coefficients or pixels.
+ *  jsnoop_batch_enable_log: keep the decoder's event records of every image (24 KiB of HBM each); call before upload.
+ *  jsnoop_batch_log: the text DecodeScanImg(nStart, bDisplay = TRUE, bQuiet = quiet) of a fresh CimgDecode writes to CDocLog for image i
+ *      under bHistoEn = histo_en / bStatClipEn = stat_clip_en, through `fn` (needs jsnoop_batch_enable_log, and want_planes for
+ *      three-component images and the statistics).
+ *  jsnoop_batch_export_tiff: jsnoop_export_tiff for image i.   All four: 0 on success, -1 + jsnoop_last_error().                    */
+int          jsnoop_batch_enable_log(JsnoopBatch*, int on);
+int          jsnoop_batch_side_outputs(JsnoopBatch*, int i, uint32_t* mcu_map, int16_t* dc_y, int16_t* dc_cb, int16_t* dc_cr, uint32_t* dht_histo,
+                                       unsigned* status8, int* bright_avg10);
+int          jsnoop_batch_log(JsnoopBatch*, int i, int histo_en, int stat_clip_en, int quiet, jsnoop_log_fn fn, void* user);
+int          jsnoop_batch_export_tiff(JsnoopBatch*, int i, const char* path, int mode);
 uint64_t     jsnoop_batch_algorithmic_bytes(const JsnoopBatch*);                   /* sum(scan bytes + DIB bytes), SURVEY.md 8(d) */
 uint64_t     jsnoop_batch_pixels(const JsnoopBatch*);                              /* sum(SOF X*Y) */
 

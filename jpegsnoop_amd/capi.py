@@ -99,6 +99,10 @@ SIGNATURES = {
     "jsnoop_batch_read_coefs": (_i, [_p, _i, _p, _sz]),
     "jsnoop_batch_color_stats": (_i, [_p, _i, _i, _p]),
     "jsnoop_batch_dib_hashes": (_i, [_p, _p]),
+    "jsnoop_batch_enable_log": (_i, [_p, _i]),
+    "jsnoop_batch_side_outputs": (_i, [_p, _i, _p, _p, _p, _p, _p, _PU, _PI]),
+    "jsnoop_batch_log": (_i, [_p, _i, _i, _i, _i, LOG_FN, _p]),
+    "jsnoop_batch_export_tiff": (_i, [_p, _i, C.c_char_p, _i]),
     "jsnoop_batch_algorithmic_bytes": (C.c_uint64, [_p]),
     "jsnoop_batch_add_progressive": (_i, [_p, _p, _sz]),
     "jsnoop_pipeline_create": (_p, [_i]),

@@ -222,7 +222,7 @@ int JsnoopBatch::ensure_aux()
 }
 void JsnoopBatch::clear()
 {
-    imgs.clear(); tables.clear(); raw_bytes = 0; uploaded = false; host_flags.clear();
+    imgs.clear(); hinfo.clear(); tables.clear(); raw_bytes = 0; uploaded = false; host_flags.clear();
     js_prog_clear(this);
 }
 int JsnoopBatch::reserve_pinned(size_t need)
@@ -261,6 +261,8 @@ int JsnoopBatch::add(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned
     delete ts;
     im.tableset = tsi;
     imgs.push_back(im); uploaded = false;
+    JsImgHost hi; hi.dht_setmax[0] = d->t.dht_setmax[0]; hi.dht_setmax[1] = d->t.dht_setmax[1]; hi.err_max = d->opt_err_max; hi.display = display != 0;
+    hinfo.resize(imgs.size() - 1); hinfo.push_back(hi);
     return (int)imgs.size() - 1;
 }
 // Stages a file whose image descriptor the caller built itself (progressive path): no scan-length search, no decode tables.
@@ -292,6 +294,7 @@ int JsnoopBatch::tile(int total)
         memcpy(pinned + off, pinned + im.file_off, im.file_len); memset(pinned + off + im.file_len, 0, 16);
         raw_bytes = off + im.file_len + 16; im.file_off = off;
         imgs.push_back(im);
+        if (hinfo.size() > i % n) { hinfo.resize(i); hinfo.push_back(hinfo[i % n]); }
         if (js_prog_count(this)) js_prog_dup(this, (uint32_t)(i % n), (uint32_t)i);
     }
     uploaded = false;
@@ -379,6 +382,7 @@ int JsnoopBatch::decode(bool timed)
     HIP_TRY(hipSetDevice(device));
     if (!uploaded && upload()) return -1;
     const uint32_t n = (uint32_t)imgs.size();
+    side_done.assign(n, 0);
     JsRange r_("jsnoop:decode (enqueue)");
     if (js_prog_count(this)) return decode_progressive(timed);     // SOF2 files: every scan of every image, one launch per dependency level
     if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
@@ -589,24 +593,24 @@ const uint8_t* jsnoop_get_bitmap_ptr(JsnoopDecoder* d)
 {
     if (!d->have_image) return nullptr;
     if (!(d->host_valid & 1)) {
-        const JsImage& im = d->batch->imgs[0];
-        if (d->h_dib.ensure((size_t)im.img_x * im.img_y * 4) || d->batch->read_dib(0, (uint8_t*)d->h_dib.p)) return nullptr;
+        const JsImage& im = d->batch->imgs[d->img];
+        if (d->h_dib.ensure((size_t)im.img_x * im.img_y * 4) || d->batch->read_dib(d->img, (uint8_t*)d->h_dib.p)) return nullptr;
         d->host_valid |= 1;
     }
     return (const uint8_t*)d->h_dib.p;
 }
-const void* jsnoop_get_bitmap_dev(JsnoopDecoder* d) { return d->have_image ? d->batch->dev.dib + d->batch->imgs[0].dib_off : nullptr; }
+const void* jsnoop_get_bitmap_dev(JsnoopDecoder* d) { return d->have_image ? d->batch->dev.dib + d->batch->imgs[d->img].dib_off : nullptr; }
 void jsnoop_get_pixmap_ptrs(JsnoopDecoder* d, const int16_t** y, const int16_t** cb, const int16_t** cr)
 {
     *y = *cb = *cr = nullptr;
     if (!d->have_image) return;
-    const JsImage& im = d->batch->imgs[0];
+    const JsImage& im = d->batch->imgs[d->img];
     const size_t psz = (size_t)im.blk_xmax * 8 * im.blk_ymax * 8;
     int16_t* hp = nullptr;
     if (!(d->host_valid & 2)) {
         if (d->h_planes.ensure(psz * 3 * sizeof(int16_t))) return;
         hp = (int16_t*)d->h_planes.p; memset(hp, 0, psz * 3 * sizeof(int16_t));
-        if (d->batch->read_planes(0, hp, hp + psz, hp + 2 * psz)) return;
+        if (d->batch->read_planes(d->img, hp, hp + psz, hp + 2 * psz)) return;
         d->host_valid |= 2;
     }
     hp = (int16_t*)d->h_planes.p;
@@ -628,7 +632,7 @@ void jsnoop_blk_dc_ptrs(JsnoopDecoder* d, const int16_t** y, const int16_t** cb,
     *y = *cb = *cr = nullptr; if (!d->have_image) return;
     const uint32_t nmcu = d->geom[2] * d->geom[3], nblk = d->geom[4] * d->geom[5], w = 2 * ((nblk + 1) / 2);
     const int16_t* base = (const int16_t*)(d->h_side.data() + JS_SIDE_MCUMAP + nmcu);
-    *y = base; if (d->batch->imgs[0].ncomp == 3) { *cb = base + w; *cr = base + 2 * w; }
+    *y = base; if (d->batch->imgs[d->img].ncomp == 3) { *cb = base + w; *cr = base + 2 * w; }
 }
 void jsnoop_lookup_blk_ycc(JsnoopDecoder* d, unsigned bx, unsigned by, int* y, int* cb, int* cr)      // :5037-5047
 {
@@ -642,14 +646,23 @@ void jsnoop_bright_avg(JsnoopDecoder* d, int* o)
 {
     memset(o, 0, 10 * sizeof(int)); o[1] = o[2] = o[3] = -32768;
     if (!d->have_image || !d->preview_is_jpeg) return;
-    const JsImage& im = d->batch->imgs[0];
+    const JsImage& im = d->batch->imgs[d->img];
     const uint64_t key = ((uint64_t)d->h_side[13] << 32) | d->h_side[12];
     const uint32_t yk = (uint32_t)(key >> 32), idx = 0xFFFFFFFFu - (uint32_t)key;
     o[0] = 1;
     if (yk != 0) {            // some pixel beat the -32768 start value (:4723-4730)
-        const int16_t *py, *pcb, *pcr; jsnoop_get_pixmap_ptrs(d, &py, &pcb, &pcr);
         const uint32_t px = idx % im.img_x, pyy = idx / im.img_x; const size_t pi = (size_t)pyy * im.blk_xmax * 8 + px;
-        o[1] = (int)yk - 32768; o[2] = pcb ? pcb[pi] : 0; o[3] = pcr ? pcr[pi] : 0; o[7] = (int)(px / im.mcu_w); o[8] = (int)(pyy / im.mcu_h);
+        o[1] = (int)yk - 32768; o[2] = o[3] = 0; o[7] = (int)(px / im.mcu_w); o[8] = (int)(pyy / im.mcu_h);   // (one component: Cb = Cr = 0, :4709-4715)
+        if (im.ncomp == 3) {
+            if (d->host_valid & 2) { const int16_t* hp = (const int16_t*)d->h_planes.p; const size_t psz = (size_t)im.blk_xmax * 8 * im.blk_ymax * 8; o[2] = hp[psz + pi]; o[3] = hp[2 * psz + pi]; }
+            else if (d->batch->opt_want_planes) {                   // the two chroma samples of that pixel straight from HBM (not the whole planes)
+                const size_t psz = (size_t)im.blk_xmax * 8 * im.blk_ymax * 8; int16_t c2[2] = { 0, 0 };
+                hipSetDevice(d->batch->device);
+                if (d->batch->d2h_staged(&c2[0], d->batch->dev.planes + im.plane_off + psz + pi, 2) || d->batch->d2h_staged(&c2[1], d->batch->dev.planes + im.plane_off + 2 * psz + pi, 2))
+                    d->log(2, "*** ERROR: reading the brightest pixel's chroma back failed: %s", g_err.c_str());
+                o[2] = c2[0]; o[3] = c2[1];
+            }
+        }
     }
     {   // RGB of the brightest pixel through the device colour routine (:4805-4811)
         JsnoopBatch* b = d->batch; uint32_t bgra = 0; hipSetDevice(b->device);
@@ -759,7 +772,7 @@ double jsnoop_batch_decode_timed(JsnoopBatch* b, int reps, double* stage_ms)
 }
 int jsnoop_batch_image_info(const JsnoopBatch* b, int i, unsigned* o)
 {
-    if (i < 0 || (size_t)i >= b->imgs.size()) return -1;
+    if (i < 0 || (size_t)i >= b->imgs.size()) { js_set_error("jsnoop_batch_image_info: image index out of range"); return -1; }
     const JsImage& im = b->imgs[i];
     unsigned v[16] = { im.dim_x, im.dim_y, im.img_x, im.img_y, im.mcu_w, im.mcu_h, im.mcu_xmax, im.mcu_ymax, im.blk_xmax, im.blk_ymax,
                        im.scan_len, (size_t)i < b->host_flags.size() ? b->host_flags[i] : 0u, (size_t)i < b->host_path.size() ? b->host_path[i] : 0u,
@@ -785,6 +798,86 @@ int jsnoop_batch_dib_hashes(JsnoopBatch* b, uint64_t* dst)
     js_launch_dib_checksum(b->stream, b->dev.imgs, n, b->dev.dib, (unsigned long long*)b->dev.sums);
     if (b->d2h_staged(dst, b->dev.sums, n * 8)) return -1;
     return 0;
+}
+// ---- per-image results of a batch beyond pixels (what DoBatchFileProcess's per-file pass produces, source/JPEGsnoopCore.cpp:805-808):
+//      a JsnoopDecoder *view* onto image i of the caller's batch runs the very code of the single-image API (side pass on request,
+//      statistics pass, event records, report text, TIFF writer) -- one implementation, two entry points.
+static int js_batch_view(JsnoopBatch* b, int i, JsnoopDecoder& v, const char* who)
+{
+    if (!b || i < 0 || (size_t)i >= b->imgs.size()) { js_set_error("%s: image index out of range", who); return -1; }
+    if (!b->uploaded || b->host_path.size() != b->imgs.size()) { js_set_error("%s: the batch has not been decoded (upload / decode / sync first)", who); return -1; }
+    const JsImage& im = b->imgs[i];
+    v.batch = b; v.img = i; v.have_image = true; v.host_valid = 0;
+    v.last_path = (int)b->host_path[i]; v.last_flags = b->host_flags[i];
+    const bool display = (size_t)i < b->hinfo.size() ? b->hinfo[i].display : true;
+    v.preview_is_jpeg = display; v.opt_decode_ac = (int)im.decode_ac; v.opt_err_max = im.err_max;
+    if ((size_t)i < b->hinfo.size()) { v.t.dht_setmax[0] = b->hinfo[i].dht_setmax[0]; v.t.dht_setmax[1] = b->hinfo[i].dht_setmax[1]; }
+    v.preview_mode = im.preview_mode; v.shift_y = im.shift_y; v.shift_cb = im.shift_cb; v.shift_cr = im.shift_cr; v.shift_mcu_x = im.shift_mcu_x; v.shift_mcu_y = im.shift_mcu_y;
+    v.geom[0] = im.mcu_w; v.geom[1] = im.mcu_h; v.geom[2] = im.mcu_xmax; v.geom[3] = im.mcu_ymax; v.geom[4] = im.blk_xmax; v.geom[5] = im.blk_ymax; v.geom[6] = im.img_x; v.geom[7] = im.img_y;
+    v.side_ready = v.last_path != 1 || ((size_t)i < b->side_done.size() && b->side_done[i]);   // the exact-mirror kernel fills the side block as it goes; a progressive image has none (zeros + the back end's reductions)
+    if (hipSetDevice(b->device) != hipSuccess) { js_set_error("%s: device error", who); return -1; }
+    return 0;
+}
+int jsnoop_batch_enable_log(JsnoopBatch* b, int on)
+{
+    if (!b) { js_set_error("jsnoop_batch_enable_log: bad argument"); return -1; }
+    if (b->opt_events != (on ? 1 : 0)) { b->opt_events = on ? 1 : 0; b->uploaded = false; }
+    return 0;
+}
+int jsnoop_batch_side_outputs(JsnoopBatch* b, int i, uint32_t* mcu_map, int16_t* dc_y, int16_t* dc_cb, int16_t* dc_cr, uint32_t* dht_histo, unsigned* status8, int* bright_avg10)
+{
+    JsnoopDecoder v;
+    if (js_batch_view(b, i, v, "jsnoop_batch_side_outputs")) return -1;
+    const JsImage& im = b->imgs[i];
+    if (bright_avg10 && im.ncomp == 3 && !b->opt_want_planes) { js_set_error("jsnoop_batch_side_outputs: the brightest pixel's Cb / Cr / RGB need the planes (want_planes)"); return -1; }
+    v.ensure_side();
+    if (!v.side_ready) return -1;
+    if (v.h_side.empty()) v.fetch_side();
+    const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax, nblk = im.blk_xmax * im.blk_ymax, w = 2 * ((nblk + 1) / 2);
+    const uint32_t* sd = v.h_side.data();
+    if (mcu_map) memcpy(mcu_map, sd + JS_SIDE_MCUMAP, (size_t)nmcu * 4);
+    const int16_t* base = (const int16_t*)(sd + JS_SIDE_MCUMAP + nmcu);
+    if (dc_y) memcpy(dc_y, base, (size_t)nblk * 2);
+    if (im.ncomp == 3) { if (dc_cb) memcpy(dc_cb, base + w, (size_t)nblk * 2); if (dc_cr) memcpy(dc_cr, base + 2 * w, (size_t)nblk * 2); }
+    if (dht_histo) memcpy(dht_histo, sd + JS_SIDE_HISTO, 2 * 4 * 17 * 4);
+    if (status8) for (int k = 0; k < 8; k++) status8[k] = sd[k];
+    if (bright_avg10) jsnoop_bright_avg(&v, bright_avg10);
+    return 0;
+}
+int jsnoop_batch_log(JsnoopBatch* b, int i, int histo_en, int stat_clip_en, int quiet, jsnoop_log_fn fn, void* user)
+{
+    JsnoopDecoder v;
+    if (js_batch_view(b, i, v, "jsnoop_batch_log")) return -1;
+    if (!fn) { js_set_error("jsnoop_batch_log: no log sink"); return -1; }
+    if (v.last_path == 3) { js_set_error("jsnoop_batch_log: a progressive image has no DecodeScanImg log (the reference refuses SOF2, source/JfifDecode.cpp:4827-4833)"); return -1; }
+    if (!b->event_words) { js_set_error("jsnoop_batch_log: the decoder's event records were not kept (jsnoop_batch_enable_log before upload)"); return -1; }
+    const JsImage& im = b->imgs[i];
+    const bool display = v.preview_is_jpeg;
+    if (display && !b->opt_want_planes && (im.ncomp == 3 || histo_en || stat_clip_en)) { js_set_error("jsnoop_batch_log: the report quotes plane samples (want_planes)"); return -1; }
+    v.log_fn = fn; v.log_user = user;
+    if (!quiet) {                                                   // the lines DecodeScanImg writes before its MCU loop (:3021-3025, :3126-3135)
+        v.log(0, "*** Decoding SCAN Data ***"); v.log(0, "  OFFSET: 0x%08X", im.scan_start);
+        if (display && im.decode_ac) v.log(0, "  Scan Decode Mode: Full IDCT (AC + DC)");
+        else { v.log(0, "  Scan Decode Mode: No IDCT (DC only)");
+               v.log(1, "    NOTE: Low-resolution DC component shown. Can decode full-res with [Options->Scan Segment->Full IDCT]"); }
+        v.log(0, "");
+    }
+    v.hist_latched = histo_en != 0; v.clip_latched = stat_clip_en != 0;
+    v.fetch_side();
+    if (display) v.stats_pass();
+    v.ensure_side();
+    js_emit_decode_events(&v);
+    if (!quiet) v.log(0, "");
+    v.flush_pending_log();
+    js_emit_report(&v, display, quiet != 0);
+    return 0;
+}
+int jsnoop_batch_export_tiff(JsnoopBatch* b, int i, const char* path, int mode)
+{
+    JsnoopDecoder v;
+    if (js_batch_view(b, i, v, "jsnoop_batch_export_tiff")) return -1;
+    if (mode == 2 && !b->opt_want_planes) { js_set_error("jsnoop_batch_export_tiff: YCC export needs the planes (want_planes)"); return -1; }
+    return jsnoop_export_tiff(&v, path, mode);
 }
 uint64_t jsnoop_batch_algorithmic_bytes(const JsnoopBatch* b)
 { uint64_t s = 0; for (const JsImage& im : b->imgs) s += (uint64_t)im.scan_len + (uint64_t)im.img_x * im.img_y * 4; return s; }
@@ -833,11 +926,11 @@ int JsnoopBatch::read_planes(int i, int16_t* y, int16_t* cb, int16_t* cr)
 void JsnoopDecoder::ensure_side()
 {
     if (!have_image || side_ready) return;
-    if (js_side_only(batch, 0) == 0) { side_ready = true; fetch_side(); }
+    if (js_side_only(batch, (uint32_t)img) == 0) { side_ready = true; fetch_side(); }
 }
 void JsnoopDecoder::fetch_side()
 {
-    const JsImage& im = batch->imgs[0];
+    const JsImage& im = batch->imgs[img];
     h_side.assign(js_side_words(im.mcu_xmax * im.mcu_ymax, im.blk_xmax * im.blk_ymax), 0);
     hipSetDevice(batch->device);
     if (batch->d2h_staged(h_side.data(), batch->dev.side + im.side_off, h_side.size() * 4)) log(2, "*** ERROR: reading the side block back failed: %s", g_err.c_str());
@@ -863,7 +956,7 @@ void JsnoopDecoder::stats_pass()
     if (!have_image || !preview_is_jpeg || !(hist_latched || clip_latched)) return;   // CalcChannelPreview needs the DIB (:4971-4974)
     const bool want_notes = log_fn != nullptr;
     if (want_notes) ensure_side();                                  // the warning text quotes the reader's final position (GetScanBufPos)
-    if (batch->color_stats_pass(0, hist_latched, stats, &warn_ycc_clip, want_notes ? &pending_log : nullptr, want_notes ? h_side[4] : 0, want_notes ? h_side[5] : 0))
+    if (batch->color_stats_pass(img, hist_latched, stats, &warn_ycc_clip, want_notes ? &pending_log : nullptr, want_notes ? h_side[4] : 0, want_notes ? h_side[5] : 0))
         log(2, "*** ERROR: colour statistics pass failed: %s", g_err.c_str());
 }
 void JsnoopDecoder::flush_pending_log()

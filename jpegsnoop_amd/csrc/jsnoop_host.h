@@ -32,6 +32,7 @@ struct JsnoopDecoder {
     std::vector<Overlay> overlays;
     jsnoop_log_fn log_fn; void* log_user;
     JsnoopBatch* batch;                         // private batch of one image (single-image API)
+    int img = 0;                                // index of this object's image in `batch` (0 there; a view onto image i of a caller's batch otherwise)
     unsigned preview_mode; int shift_y, shift_cb, shift_cr; unsigned shift_mcu_x, shift_mcu_y;
     unsigned ins_mcu_x = 0, ins_mcu_y = 0, ins_mcu_len = 0;      // m_nPreviewInsMcu* (:682-699), stored only
     bool preview_is_jpeg, have_image; int host_valid; int last_path; uint32_t last_flags;
@@ -73,6 +74,9 @@ struct JsnoopBatch {
     int opt_decode_ac, opt_want_planes, opt_force_exact, opt_events = 0;   // opt_events: keep the decoder's event log (single-image API)
     uint64_t event_words = 0;
     std::vector<JsImage> imgs; std::vector<JsTableSet> tables;
+    struct JsImgHost { uint32_t dht_setmax[2] = { 0, 0 }; unsigned err_max = 20; bool display = true; };   // what the per-image report needs beyond the descriptor
+    std::vector<JsImgHost> hinfo;
+    std::vector<uint8_t> side_done;                               // per image: the side-output pass has run since the last decode
     std::vector<uint32_t> host_flags, host_path, h_us_base, h_sy_base, h_sn_base, h_wg_base;
     // A large batch decodes as two halves on two streams (stream, aux[0]): the kernels of one half fill the tails and the thinly
     // populated phases (second synchronisation launch, DC scan) of the other -- 14.2 -> 13.7 ms per 1024 images.  Both halves live in

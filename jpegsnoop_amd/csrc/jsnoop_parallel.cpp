@@ -379,6 +379,7 @@ int js_side_only(JsnoopBatch* b, uint32_t i)
         }
         uint32_t* mcu_pos = b->d_side_tmp; uint32_t* us_out = mcu_pos + (((size_t)nmcu + 1 + 15) & ~(size_t)15);
         HIP_TRY(hipMemsetAsync(mcu_pos, 0, ((size_t)nmcu + 1) * 4, b->stream));
+        if (b->event_words) HIP_TRY(hipMemsetAsync(b->dev.events + im.ev_off, 0, 4, b->stream));   // the pass logs the end-of-scan markers: a repeated pass must not log them twice
         js_launch_side_pass(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.us_base, b->dev.sy_base, (uint32_t)b->imgs.size(), i, us0, usn, sy0, syn,
                             b->dev.tables, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst, b->dev.ustr, b->dev.seg, b->dev.side, (uint32_t*)b->dev.sub, b->total_subseq,
                             b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out, b->event_words ? b->dev.events : nullptr);
@@ -388,5 +389,7 @@ int js_side_only(JsnoopBatch* b, uint32_t i)
     }
     HIP_TRY(hipStreamSynchronize(b->stream));
     HIP_TRY(hipGetLastError());
+    if (b->side_done.size() != b->imgs.size()) b->side_done.assign(b->imgs.size(), 0);
+    b->side_done[i] = 1;
     return 0;
 }

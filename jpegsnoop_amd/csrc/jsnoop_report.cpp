@@ -62,7 +62,7 @@ void js_emit_decode_events(JsnoopDecoder* d)
 {
     JsnoopBatch* b = d->batch;
     if (!d->have_image || !b->event_words) return;
-    const JsImage& im = b->imgs[0];
+    const JsImage& im = b->imgs[d->img];
     hipSetDevice(b->device);
     std::vector<uint32_t> raw(1 + (size_t)JS_EV_WORDS * JS_EV_MAX);
     if (b->d2h_staged(raw.data(), b->dev.events + im.ev_off, raw.size() * 4)) {   /* page-locked landing buffer: no pageable asynchronous copies */ d->log(2, "*** ERROR: reading the decoder's event log back from the device failed ***"); return; }
@@ -110,7 +110,7 @@ void js_emit_decode_events(JsnoopDecoder* d)
 void js_emit_report(JsnoopDecoder* d, bool display, bool quiet)
 {
     if (!d->have_image) return;
-    const JsImage& im = d->batch->imgs[0];
+    const JsImage& im = d->batch->imgs[d->img];
     const JsTables& t = d->t;
     const uint32_t* sd = d->h_side.data();
     if (!quiet) {

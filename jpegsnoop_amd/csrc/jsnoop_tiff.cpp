@@ -62,7 +62,7 @@ extern "C" int jsnoop_export_tiff(JsnoopDecoder* d, const char* path, int mode)
 {
     if (!d || !path || mode < 0 || mode > 2) { js_set_error("jsnoop_export_tiff: bad argument"); return -1; }
     if (!d->have_image || !d->preview_is_jpeg) { js_set_error("jsnoop_export_tiff: no decoded image"); return -1; }
-    JsnoopBatch* b = d->batch; const JsImage& im = b->imgs[0];
+    JsnoopBatch* b = d->batch; const JsImage& im = b->imgs[d->img];
     const bool ycc = mode == 2, b16 = mode == 1;
     if (ycc && im.ncomp != 3) { js_set_error("jsnoop_export_tiff: YCC export needs three components"); return -1; }
     const unsigned w = im.img_x, h = im.img_y;
@@ -77,7 +77,7 @@ extern "C" int jsnoop_export_tiff(JsnoopDecoder* d, const char* path, int mode)
     if (hipSetDevice(b->device) != hipSuccess) { js_set_error("jsnoop_export_tiff: device error"); return -1; }
     uint8_t* dpack = nullptr;
     if (hipMalloc((void**)&dpack, strip + 64) != hipSuccess) { js_set_error("jsnoop_export_tiff: hipMalloc failed"); return -1; }
-    js_launch_tiff_pack(b->stream, b->dev.imgs, 0, b->dev.dib, b->dev.planes, mode, dpack);
+    js_launch_tiff_pack(b->stream, b->dev.imgs, (uint32_t)d->img, b->dev.dib, b->dev.planes, mode, dpack);
     std::vector<uint8_t> host(strip);
     const int rc = b->d2h_staged(host.data(), dpack, strip);
     hipFree(dpack);

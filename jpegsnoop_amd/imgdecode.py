@@ -226,6 +226,40 @@ class JpegBatch:
         self._chk(self._lib.jsnoop_batch_dib_hashes(self._h, out.ctypes.data), "batch_dib_hashes")
         return out
 
+    # --- what DecodeScanImg leaves behind besides pixels, per image (the per-file pass of DoBatchFileProcess) -----------------
+    def add(self, tables: "CimgDecode", data: bytes, scan_start: int) -> int:
+        """Adds one image under the table / frame state `tables` holds (after the setter calls of its header), like jsnoop_batch_add."""
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        h = getattr(tables, "_h", None) or getattr(tables, "h", None) or tables
+        return self._chk(self._lib.jsnoop_batch_add(self._h, h, C.cast(buf, C.c_void_p), len(data), scan_start), "batch_add")
+
+    def enable_log(self, on=True): self._chk(self._lib.jsnoop_batch_enable_log(self._h, int(on)), "batch_enable_log")
+
+    def side_outputs(self, i, bright=True):
+        """MCU file map, block-DC maps, Huffman code-length histogram, status words, brightest pixel / average Y of image i."""
+        inf = self.info(i)
+        nmcu, nblk = inf["mcu_xmax"] * inf["mcu_ymax"], inf["blk_xmax"] * inf["blk_ymax"]
+        mcu = np.zeros(nmcu, np.uint32)
+        dcs = [np.zeros(nblk, np.int16) for _ in range(3)]
+        histo = np.zeros(2 * 4 * 17, np.uint32)
+        st, ba = (C.c_uint * 8)(), (C.c_int * 10)()
+        self._chk(self._lib.jsnoop_batch_side_outputs(self._h, i, mcu.ctypes.data, dcs[0].ctypes.data, dcs[1].ctypes.data, dcs[2].ctypes.data, histo.ctypes.data,
+                                                      st, ba if bright else None), "batch_side_outputs")
+        keys = "scan_bad scan_end rst_count num_pixels pos0 align warn_bad first".split()
+        return {"mcu_map": mcu.reshape(inf["mcu_ymax"], inf["mcu_xmax"]),
+                "blk_dc": [d.reshape(inf["blk_ymax"], inf["blk_xmax"]) if (c == 0 or inf["ncomp"] == 3) else None for c, d in enumerate(dcs)],
+                "dht_histo": histo.reshape(2, 4, 17), "status": dict(zip(keys, st)), "bright_avg": list(ba) if bright else None}
+
+    def log_lines(self, i, histo_en=False, stat_clip_en=False, quiet=False):
+        """The text DecodeScanImg writes to CDocLog for image i, as (level, line) pairs."""
+        out = []
+        cb = capi.LOG_FN(lambda _u, lvl, txt: out.append((lvl, txt.decode(errors="replace"))))
+        self._chk(self._lib.jsnoop_batch_log(self._h, i, int(histo_en), int(stat_clip_en), int(quiet), cb, None), "batch_log")
+        return out
+
+    def export_tiff(self, i, path: str, mode: int = 0):
+        self._chk(self._lib.jsnoop_batch_export_tiff(self._h, i, path.encode(), mode), "batch_export_tiff")
+
     def algorithmic_bytes(self): return int(self._lib.jsnoop_batch_algorithmic_bytes(self._h))
     def pixels(self): return int(self._lib.jsnoop_batch_pixels(self._h))
 
