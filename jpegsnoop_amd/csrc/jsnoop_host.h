@@ -122,6 +122,8 @@ struct JsnoopBatch {
     int  launch_back_end(uint32_t nimg);        // k_idct_color over the first nimg images (tile size from their CURRENT preview state)
 };
 
+// flags that leave coefficients, planes and DIB of the parallel path reference-exact (bookkeeping differs: status words, warning counter, log)
+#define JS_FLAGS_PIXEL_EXACT (JSNOOP_FLAG_COEF_OVERFLOW)
 void js_set_error(const char* fmt, ...);
 // roctx ranges around the host-side stages (rocprofv3 --marker-trace makes a timeline self-describing: upload / clear / entropy
 // stages / back end / read-back).  One push and pop per stage and call: nothing per image.

@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
     r.file = raw + im.file_off; r.flen = im.file_len; r.ts = tables + im.tableset; r.histo = s_histo; r.fast = s_fast; r.meta = s_meta; r.q = s_q; r.zz = s_zz; r.win_at = 0xFFFFFFFFu; r.win = 0;
     r.rst_interval = im.rst_interval; r.precision = im.precision; r.err_max = im.err_max; r.warn_bad = 0;
     r.rst_count = 0; r.rst_last = 0; r.rst_expect = 0; r.rst_handled = 0;
-    r.ev = (im.ev_cap && !side_only) ? events + im.ev_off : nullptr; r.ev_cap = im.ev_cap; r.ev_only = 0;
+    r.ev = (im.ev_cap && events) ? events + im.ev_off : nullptr; r.ev_cap = im.ev_cap; r.ev_only = 0;       // (side-only passes log when the caller hands the event area over)
     ex_restart_scan_buf(r, im.scan_start, false);
     int16_t dc_y = 0, dc_cb = 0, dc_cr = 0;
     int16_t css[3][16];

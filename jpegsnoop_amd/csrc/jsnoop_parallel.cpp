@@ -344,8 +344,13 @@ int js_parallel_fixup(JsnoopBatch* b)
         if (!nosync) break;
         if (js_parallel_resume(b, extra)) return -1;
     }
+    // What the flags mean for the PIXELS: a run past the 64th coefficient (JSNOOP_FLAG_COEF_OVERFLOW) ends the block without a store in the
+    // reference (:1723-1735: "ncoef > 64 -> done", the value bits are consumed) exactly as in the parallel walks -- coefficients, planes
+    // and DIB of such an image are already the reference's; what the flag stands for is bookkeeping (scan_bad, the warning counter, two
+    // log lines per event), which the side pass produces on request (js_side_only: exact-mirror reader in side-only mode).  It is by far
+    // the most common trace a damaged byte leaves (tools/damage_survey.py: 85 % of the flagged files) and no reason for a 1.2 s decode.
     std::vector<uint32_t> bad;
-    for (uint32_t i = 0; i < n; i++) if (b->host_flags[i]) { bad.push_back(i); b->host_path[i] = 2; }
+    for (uint32_t i = 0; i < n; i++) if (b->host_flags[i] & ~JS_FLAGS_PIXEL_EXACT) { bad.push_back(i); b->host_path[i] = 2; }
     if (bad.empty()) return 0;
     // The back end already ran on the flagged images' (partial) coefficients; their sums in the side block
     // (brightest pixel, sum of Y) are cleared together with the side block in run_exact and recomputed.
@@ -384,8 +389,11 @@ int js_side_only(JsnoopBatch* b, uint32_t i)
                             b->dev.tables, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst, b->dev.ustr, b->dev.seg, b->dev.side, (uint32_t*)b->dev.sub, b->total_subseq,
                             b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out, b->event_words ? b->dev.events : nullptr);
     } else {
+        // (an image of the parallel path whose flags are bookkeeping only: the mirror reader's messages are part of that bookkeeping)
+        const bool with_events = b->event_words && i < b->host_path.size() && b->host_path[i] == 1;
+        if (with_events) HIP_TRY(hipMemsetAsync(b->dev.events + im.ev_off, 0, 4, b->stream));
         HIP_TRY(hipMemcpyAsync(b->dev.sel, &i, 4, hipMemcpyHostToDevice, b->stream));
-        js_launch_entropy_exact(b->stream, b->dev.imgs, b->dev.sel, 1, b->dev.tables, b->dev.raw, b->dev.coef, b->dev.dccum, b->dev.side, 1, nullptr);
+        js_launch_entropy_exact(b->stream, b->dev.imgs, b->dev.sel, 1, b->dev.tables, b->dev.raw, b->dev.coef, b->dev.dccum, b->dev.side, 1, with_events ? b->dev.events : nullptr);
     }
     HIP_TRY(hipStreamSynchronize(b->stream));
     HIP_TRY(hipGetLastError());

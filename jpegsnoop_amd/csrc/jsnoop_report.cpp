@@ -69,12 +69,16 @@ void js_emit_decode_events(JsnoopDecoder* d)
     std::vector<Ev> evs;
     const uint32_t n = std::min<uint32_t>(raw[0], JS_EV_MAX);
     const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax;
+    // clean image of the parallel path: only the end-of-scan markers come from the device (parallel side pass), the restart bookkeeping is
+    // derived below; otherwise the exact-mirror reader wrote every message itself (at decode time, or in the side-only pass of an
+    // image whose flags are bookkeeping only)
+    const bool derived = d->last_path == 1 && d->last_flags == 0;
     for (uint32_t i = 0; i < n; i++) {
         Ev e; e.kind = raw[1 + i * JS_EV_WORDS]; for (int k = 0; k < 5; k++) e.a[k] = raw[2 + i * JS_EV_WORDS + k];
-        e.order = ((uint64_t)(d->last_path == 1 ? nmcu : 0) << 32) | (2u << 28) | i;     // parallel path: only the end-of-scan markers come from the device
+        e.order = ((uint64_t)(derived ? nmcu : 0) << 32) | (2u << 28) | i;
         evs.push_back(e);
     }
-    if (d->last_path == 1) {
+    if (derived) {
         // Restart bookkeeping of a well-formed scan, from the marker bytes and the per-MCU restart flags: an RSTn whose
         // number is not the expected one (:1416-1423, logged when the refill meets it, i.e. before the MCU behind it), and
         // an elapsed restart interval with no marker in the stream (:3180-3200, logged at the top of that MCU).
