@@ -239,15 +239,17 @@ def extras_single_gpu(J, H, orc, np):
                                                       "bit_exact_vs_baseline_encoding": ok5,
                                                       "note": "single file, per call: host parse + H2D + scan launches (one wave per restart interval) + back end"}
     dec.close()
-    # ... and as a batch citizen: 64 such files, every scan of every image decoded together (one launch per dependency level)
-    p5 = J.JpegBatch(); p5.add_jpeg(prog5); p5.tile(64); p5.upload(); p5.decode(); p5.sync()
+    # ... and as a batch citizen: N such files, every scan of every image decoded together (one launch per dependency level).  64 files
+    # decode one restart interval per wave; from ~100 files on the library switches to one interval per LANE (k_prog_scan_lanes)
     want5 = J.dib_checksum_numpy(orc.dib())
-    ok5b = bool(all(int(s) == want5 for s in p5.dib_checksums()))
-    ms5b, st5b = p5.decode_timed(5)
-    extra["config5_progressive_batch64"] = {"ms_per_batch": round(ms5b, 3), "ms_per_image": round(ms5b / 64, 4), "mpix_per_s": round(64 * 1920 * 1080 / ms5b / 1e3, 1),
-                                            "bit_exact_vs_baseline_encoding": ok5b, "speedup_vs_single_call": round(ms5 / (ms5b / 64), 1),
-                                            "stages_ms": {"scans": round(st5b["write"], 3), "finalize": round(st5b["dcscan"], 3), "idct_color": round(st5b["idct_color"], 3)}}
-    p5.close()
+    for nb5 in (64, 512):
+        p5 = J.JpegBatch(); p5.add_jpeg(prog5); p5.tile(nb5); p5.upload(); p5.decode(); p5.sync()
+        ok5b = bool(all(int(s) == want5 for s in p5.dib_checksums()))
+        ms5b, st5b = p5.decode_timed(3)
+        extra["config5_progressive_batch%d" % nb5] = {"ms_per_batch": round(ms5b, 3), "ms_per_image": round(ms5b / nb5, 4), "mpix_per_s": round(nb5 * 1920 * 1080 / ms5b / 1e3, 1),
+                                                      "bit_exact_vs_baseline_encoding": ok5b, "speedup_vs_single_call": round(ms5 / (ms5b / nb5), 1),
+                                                      "stages_ms": {"scans": round(st5b["write"], 3), "finalize": round(st5b["dcscan"], 3), "idct_color": round(st5b["idct_color"], 3)}}
+        p5.close()
     # the baseline (SOF0) form of config 5 through the batch path, oracle-checked directly
     b5 = J.JpegBatch(); b5.add_jpeg(base5); b5.upload(); b5.decode(); b5.sync()
     msb, _ = b5.decode_timed(10)

@@ -287,8 +287,13 @@ static int js_prog_upload(JsnoopBatch* b)
     // per level: the scans of that level over all images, and the exclusive prefix of their workgroup counts
     // a single file leaves the chip mostly idle: one interval per wave; a batch that fills it packs several (JSNOOP_PG_LANES overrides)
     size_t total_iv = 0; for (const JsProgScan& sc : g->scans) total_iv += sc.nseg;
-    g->pg_lanes = total_iv > 32768 ? 8u : 1u;
-    if (const char* e = getenv("JSNOOP_PG_LANES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) g->pg_lanes = (uint32_t)v; }
+    // Scans cut into many restart intervals decode one interval per LANE (k_prog_scan_lanes: 64 sequential decoders abreast in
+    // predicated straight-line code); with few intervals per scan the wave-per-interval kernel keeps the lanes of a wave on one
+    // block (AC refinement) or leaves them idle.  64 = lanes; 1 / 8 = intervals per wave of the wave-per-interval kernel.
+    // (a lane-per-interval wave is a latency chain of its own: below ~64 x 1080p files with a marker per MCU row the chip is not full of
+    //  them and the wave-per-interval kernel is as fast; 128 files: 20 against 12 Gpixel/s, 1024 files: 35 against 13)
+    g->pg_lanes = (nsc && total_iv / nsc >= 16 && total_iv >= 98304) ? 64u : (total_iv > 32768 ? 8u : 1u);
+    if (const char* e = getenv("JSNOOP_PG_LANES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 64) g->pg_lanes = (uint32_t)v; }
     std::vector<uint32_t> ls, lw; g->lvl_first.clear(); g->lvl_count.clear(); g->lvl_wgs.clear();
     for (int lv = 0; lv < g->nlev; lv++) {
         g->lvl_first.push_back((uint32_t)ls.size()); uint32_t acc = 0; const size_t w0 = lw.size();

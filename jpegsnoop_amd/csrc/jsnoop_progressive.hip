@@ -238,11 +238,231 @@ __global__ void __launch_bounds__(256) k_prog_finalize(const JsImage* __restrict
     }
 }
 
-uint32_t js_prog_wgs_of(const JsProgScan& sc, uint32_t pg_lanes) { const uint32_t per = (sc.ss != 0 && sc.ah != 0) ? 1u : pg_lanes; return (sc.nseg + per - 1) / per; }
+// =====================================================================================================================================
+//  Lane-per-interval form of the scan kernels (pg_lanes == 64): one LANE per restart interval, the 64 lanes of a wave step through
+//  64 intervals of ONE scan together.  The wave-per-interval kernel above spends a whole wave's issue slots on one to eight sequential
+//  decoders (profiles/r03_prog_*: 3.7 G wave instructions per 64 images for one level of refinement scans, 1800 per block); here the
+//  same decoders run 64 abreast in straight-line, predicated code:
+//    * DC scans: a uniform loop over the units of the interval (every lane decodes "its" j-th unit in the same iteration);
+//    * AC first scans: one symbol per lane and iteration, end-of-band runs skip whole blocks;
+//    * AC refinement scans: a uniform loop over the blocks of the interval and, inside, over the band positions k = Ss..Se -- every lane
+//      is at the SAME zig-zag position of its own block in every iteration (a position takes exactly one iteration whatever happens at
+//      it: a correction bit for a non-zero history, a zero counted towards the run, the placement of the new value, or the tail of
+//      an end-of-band run), so the position's natural index is wave-uniform; the block sits in LDS dword-interleaved across the lanes
+//      (dword d of lane l at [d][l]: conflict-free), changes go through to HBM as 2-byte stores of the band positions only (other
+//      scans of the level may own other bands of the same block).
+//  The bit reader keeps 64 bits per lane and is topped up to >= 32 before every symbol (a code of <= 16 bits plus <= 15 value bits).
+// =====================================================================================================================================
+namespace {
+// The file bytes come through a 128-byte ring per lane in LDS (dword-interleaved across the lanes), topped up in WAVE-UNIFORM code: a
+// wave of sequential decoders has nothing else to run while a load is in flight, and a load issued inside a lane's own branch is waited
+// for on the spot (one lane or another crosses a window boundary in nearly every step: 0.7 us per step, measured).  When some lane
+// runs low, EVERY lane takes as many 32-byte chunks as its ring has room for -- one round of loads and one wait per ~60 steps.
+struct LReader { const uint8_t* base; uint32_t pos, end, wr, limit; uint64_t acc; int n; uint32_t over; };
+typedef uint32_t LRing[32][64];
+__device__ __forceinline__ void lr_refill(LReader& r, bool live, LRing& ring, uint32_t lane)
+{
+    for (int c = 0; c < 4; c++) {
+        const bool take = live && r.wr < r.limit && (r.wr - (r.pos & ~31u)) <= 96u;
+        if (!__any(take)) break;
+        if (take) {
+            const uint4* p = reinterpret_cast<const uint4*>(r.base + r.wr);
+            const uint4 a = p[0], b = p[1];
+            const uint32_t d = (r.wr >> 2) & 31u;
+            ring[d][lane] = a.x; ring[d + 1][lane] = a.y; ring[d + 2][lane] = a.z; ring[d + 3][lane] = a.w;
+            ring[d + 4][lane] = b.x; ring[d + 5][lane] = b.y; ring[d + 6][lane] = b.z; ring[d + 7][lane] = b.w;
+            r.wr += 32u;
+        }
+    }
+}
+__device__ __forceinline__ void lr_init(LReader& r, const uint8_t* file, uint32_t s, uint32_t e, uint32_t file_len, bool live, LRing& ring, uint32_t lane)
+{
+    r.base = file; r.pos = s; r.end = e; r.acc = 0; r.n = 0; r.over = 0; r.wr = s & ~31u; r.limit = (file_len + 31u) & ~31u;   // (file images are 16-byte aligned, padded, and the arena has slack)
+    lr_refill(r, live, ring, lane);
+}
+__device__ __forceinline__ uint32_t lr_byte(const LReader& r, uint32_t i, const LRing& ring, uint32_t lane) { return (ring[(i >> 2) & 31u][lane] >> ((i & 3u) * 8u)) & 255u; }
+// every live lane leaves with at least 32 bits; a pass appends one byte to every live lane that has room for it
+__device__ __forceinline__ void lr_fill(LReader& r, bool live, LRing& ring, uint32_t lane)
+{
+    while (__any(live && r.n < 32)) {
+        if (__any(live && r.wr < r.limit && r.wr - r.pos < 24u)) lr_refill(r, live, ring, lane);
+        if (live && r.n <= 56) {
+            uint32_t b = 0;
+            if (r.pos < r.end) { b = lr_byte(r, r.pos++, ring, lane); if (b == 0xFF && r.pos < r.end && lr_byte(r, r.pos, ring, lane) == 0x00) r.pos++; }    // FF00 -> FF (B.1.1.5)
+            else r.over++;                                                                 // past the interval: zero bits, counted
+            r.acc |= (uint64_t)b << (56 - r.n); r.n += 8;
+        }
+    }
+}
+__device__ __forceinline__ void lr_skip(LReader& r, int k) { r.acc <<= k; r.n -= k; }
+__device__ __forceinline__ uint32_t lr_bits(LReader& r, int k) { if (!k) return 0u; const uint32_t v = (uint32_t)(r.acc >> (64 - k)); lr_skip(r, k); return v; }
+__device__ __forceinline__ bool lr_overrun(const LReader& r) { return r.over * 8 > (uint32_t)(r.n > 0 ? r.n : 0); }
+// canonical Huffman decode of the code at the top of the register (>= 16 bits present); consumes it for lanes in `take`
+__device__ __forceinline__ int lr_huff(LReader& r, const JsProgTable& t, bool take)
+{
+    const uint32_t la = (uint32_t)(r.acc >> 48);
+    const uint32_t e = t.look[la >> 8];
+    int sym = -1, len = 16;
+    if (e) { len = (int)(e >> 8); sym = (int)(e & 255u); }
+    if (__any(take && !e)) {                                     // a code longer than eight bits in some lane
+        if (!e) for (int l = 9; l <= 16; l++) {
+            const int32_t code = (int32_t)(la >> (16 - l));
+            if (code <= t.maxcode[l]) { len = l; sym = t.sym[(code + t.valoff[l]) & 255]; break; }
+        }
+    }
+    if (take) lr_skip(r, len);
+    return sym;
+}
+}  // namespace
+
+__global__ void __launch_bounds__(64) k_prog_scan_lanes(const JsImage* __restrict__ imgs, const JsProgFrame* __restrict__ frames, const JsProgScan* __restrict__ scans,
+                                                        const uint32_t* __restrict__ lvl_scans, const uint32_t* __restrict__ lvl_wg, uint32_t nsc,
+                                                        const JsProgTable* __restrict__ tabs, const JsProgSeg* __restrict__ segs, const uint8_t* __restrict__ raw,
+                                                        int16_t* __restrict__ coef, uint32_t* __restrict__ status_all)
+{
+    uint32_t lo = 0, hi = nsc;                                   // lvl_wg is an exclusive prefix, nsc + 1 entries
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (lvl_wg[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+    const JsProgScan& sc = scans[lvl_scans[lo]];                 // wave-uniform, read through the scalar cache (a by-value copy of a struct that is
+    const uint32_t wg_in_scan = blockIdx.x - lvl_wg[lo];          // indexed dynamically anywhere ends up in scratch memory, every field of it)
+    const JsProgFrame& fr = frames[sc.img];
+    uint32_t* status = status_all + sc.img * 4u;
+    const uint32_t SS = sc.ss, SE = sc.se, AH = sc.ah, NBX = sc.nbx, NCOMP = sc.ncomp;      // the fields the loops live on, in registers
+    __shared__ JsProgTable s_tab[4];
+    __shared__ uint8_t s_zz[64];
+    __shared__ uint32_t s_blk[32][64];                           // AC refinement: the lanes' current blocks, dword-interleaved
+    __shared__ LRing s_ring;                                     // the lanes' file bytes
+    const uint32_t lane = threadIdx.x;
+    s_zz[lane] = c_zz_nat[lane];
+    for (uint32_t t = 0; t < sc.ntabs; t++) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(tabs + sc.tab[t]); uint32_t* dst = reinterpret_cast<uint32_t*>(&s_tab[t]);
+        for (uint32_t i = lane; i < sizeof(JsProgTable) / 4; i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    const JsImage& im = imgs[sc.img];
+    const uint32_t iv = wg_in_scan * 64u + lane;
+    const bool have = iv < sc.nseg;
+    const JsProgSeg sg = segs[sc.seg_first + (have ? iv : 0u)];
+    LReader r; lr_init(r, raw + im.file_off, sg.start, have ? sg.end : sg.start, im.file_len, have, s_ring, lane);
+    int16_t* cbase = coef + im.coef_off * 64;
+    const uint32_t units = sc.ncomp > 1 ? im.mcu_xmax * im.mcu_ymax : sc.nbx * sc.nby;     // MCUs of the scan (A.2.2 / A.2.3)
+    const uint32_t ri = sc.rst_interval ? sc.rst_interval : units;
+    const uint32_t u0 = min(units, iv * ri), u1 = have ? min(units, u0 + ri) : u0;
+    const uint32_t nu = u1 - u0;
+    uint32_t bad = 0;
+    const int al = (int)sc.al;
+
+    if (SS == 0) {
+        // ---- DC scans (G.1.2.1): the j-th unit of every interval in the same iteration
+        int pred[3] = { 0, 0, 0 };
+        for (uint32_t j = 0; __any(j < nu && !bad); j++) {
+            const bool live0 = j < nu;
+            const uint32_t u = u0 + j;
+            for (uint32_t ci = 0; ci < NCOMP; ci++) {
+                const uint32_t comp = sc.comp[ci];
+                const uint32_t hs = NCOMP > 1 ? fr.hs[comp] : 1u, vs = NCOMP > 1 ? fr.vs[comp] : 1u;
+                for (uint32_t v = 0; v < vs; v++) for (uint32_t h = 0; h < hs; h++) {
+                    const bool live = live0 && !bad;
+                    const uint32_t bx = NCOMP > 1 ? (u % im.mcu_xmax) * hs + h : u % NBX;
+                    const uint32_t by = NCOMP > 1 ? (u / im.mcu_xmax) * vs + v : u / NBX;
+                    int16_t* blk = cbase + block_row(im, fr, comp, live ? bx : 0u, live ? by : 0u) * 64;
+                    lr_fill(r, live, s_ring, lane);
+                    if (AH == 0) {
+                        const int s = lr_huff(r, s_tab[sc.dc_slot[ci]], live);
+                        if (live) {
+                            if (s < 0 || s > 15) bad = 1;
+                            else { const int diff = s ? extend(lr_bits(r, s), s) : 0; pred[ci] += diff; blk[0] = (int16_t)(pred[ci] * (1 << al)); }
+                        }
+                    } else if (live) { if (lr_bits(r, 1)) blk[0] = (int16_t)(blk[0] | (1 << al)); }
+                }
+            }
+        }
+    } else if (AH == 0) {
+        // ---- AC first scan (G.1.2.2): one symbol per lane and iteration; an end-of-band run skips whole blocks
+        const uint32_t comp = sc.comp[0]; const JsProgTable& T = s_tab[sc.ac_slot[0]];
+        uint32_t j = 0, k = SS, eobrun = 0;
+        int16_t* blk = cbase; bool newblk = true;               // the block of unit j: its row is worked out when j moves, not per symbol
+        while (__any(j < nu && !bad)) {
+            if (j < nu && eobrun && k == SS) { const uint32_t sk = min(eobrun, nu - j); j += sk; eobrun -= sk; newblk = true; }
+            const bool live = j < nu && !bad;
+            if (__any(live && newblk)) {
+                if (live && newblk) { const uint32_t u = u0 + j; blk = cbase + block_row(im, fr, comp, u % NBX, u / NBX) * 64; newblk = false; }
+            }
+            lr_fill(r, live, s_ring, lane);
+            const int rs = lr_huff(r, T, live);
+            if (live) {
+                if (rs < 0) bad = 1;
+                else {
+                    const uint32_t run = (uint32_t)rs >> 4, s = (uint32_t)rs & 15u;
+                    if (s) {
+                        k += run;
+                        if (k > SE) bad = 1;
+                        else { blk[s_zz[k]] = (int16_t)(extend(lr_bits(r, (int)s), (int)s) * (1 << al)); k++; }
+                    } else if (run == 15) k += 16;                                          // ZRL
+                    else { eobrun = (1u << run) + lr_bits(r, (int)run) - 1u; k = SE + 1u; }    // EOBn: this block ends here, eobrun more follow
+                    if (k > SE) { j++; k = SS; newblk = true; }
+                }
+            }
+        }
+    } else {
+        // ---- AC refinement scan (G.1.2.3), the decoding procedure of libjpeg's decode_mcu_AC_refine position by position
+        const uint32_t comp = sc.comp[0]; const JsProgTable& T = s_tab[sc.ac_slot[0]];
+        const int p1 = 1 << al, m1 = -(1 << al);
+        uint32_t eobrun = 0;
+        for (uint32_t j = 0; __any(j < nu && !bad); j++) {
+            const bool inb = j < nu;
+            const uint32_t u = u0 + (inb ? j : 0u);
+            int16_t* gblk = cbase + block_row(im, fr, comp, u % NBX, u / NBX) * 64;
+            if (inb) {
+                #pragma unroll
+                for (int q = 0; q < 8; q++) { const uint4 x = reinterpret_cast<const uint4*>(gblk)[q]; s_blk[4 * q][lane] = x.x; s_blk[4 * q + 1][lane] = x.y; s_blk[4 * q + 2][lane] = x.z; s_blk[4 * q + 3][lane] = x.w; }
+            }
+            bool adv = false, has_new = false; int newv = 0; uint32_t run = 0;
+            for (uint32_t k = SS; k <= SE; k++) {                // k is wave-uniform
+                const bool live = inb && !bad;
+                const uint32_t nat = s_zz[k];
+                lr_fill(r, live, s_ring, lane);
+                const bool need = live && !eobrun && !adv;
+                if (__any(need)) {
+                    const int rs = lr_huff(r, T, need);
+                    if (need) {
+                        if (rs < 0) bad = 1;
+                        else {
+                            run = (uint32_t)rs >> 4; const uint32_t s = (uint32_t)rs & 15u;
+                            if (s) { if (s != 1) bad = 1; newv = lr_bits(r, 1) ? p1 : m1; has_new = true; adv = true; }
+                            else if (run == 15) { has_new = false; adv = true; }
+                            else eobrun = (1u << run) + lr_bits(r, (int)run);                // EOBn (this block included): the rest of the band takes correction bits only
+                        }
+                    }
+                }
+                if (live && !bad) {
+                    const uint32_t w = s_blk[nat >> 1][lane];
+                    int v = (nat & 1u) ? (int)w >> 16 : (int)(int16_t)w;
+                    bool changed = false;
+                    if (v != 0) {                                // a coefficient with history: one correction bit
+                        if (lr_bits(r, 1) && !(v & p1)) { v += (v >= 0 ? p1 : m1); changed = true; }
+                    } else if (!eobrun && adv) {                 // a zero: counts towards the run, or takes the new value
+                        if (run == 0) { if (has_new) { v = newv; changed = true; } adv = false; }
+                        else run--;
+                    }
+                    if (changed) {
+                        s_blk[nat >> 1][lane] = (nat & 1u) ? (w & 0xFFFFu) | ((uint32_t)v << 16) : (w & 0xFFFF0000u) | ((uint32_t)v & 0xFFFFu);
+                        gblk[nat] = (int16_t)v;                  // the band position only: other scans of the level own the rest of the block
+                    }
+                }
+            }
+            if (inb && eobrun) eobrun--;
+        }
+    }
+    if (bad) atomicOr(&status[0], 1u);                              // a code that matches nothing / illegal symbol
+    if (have && lr_overrun(r)) atomicOr(&status[0], 2u);            // the interval ended before its blocks did
+}
+
+uint32_t js_prog_wgs_of(const JsProgScan& sc, uint32_t pg_lanes) { const uint32_t per = pg_lanes >= 64u ? 64u : ((sc.ss != 0 && sc.ah != 0) ? 1u : pg_lanes); return (sc.nseg + per - 1) / per; }
 void js_launch_prog_level(hipStream_t st, const JsImage* imgs, const JsProgFrame* frames, const JsProgScan* scans, const uint32_t* lvl_scans, const uint32_t* lvl_wg,
                           uint32_t nsc, uint32_t total_wgs, uint32_t pg_lanes, const JsProgTable* tabs, const JsProgSeg* segs, const uint8_t* raw, int16_t* coef, uint32_t* status)
 {
     if (!nsc || !total_wgs) return;
+    if (pg_lanes >= 64u) { hipLaunchKernelGGL(k_prog_scan_lanes, dim3(total_wgs), dim3(64), 0, st, imgs, frames, scans, lvl_scans, lvl_wg, nsc, tabs, segs, raw, coef, status); return; }
     hipLaunchKernelGGL(k_prog_scan, dim3(total_wgs), dim3(64), 0, st, imgs, frames, scans, lvl_scans, lvl_wg, nsc, pg_lanes, tabs, segs, raw, coef, status);
 }
 void js_launch_prog_finalize(hipStream_t st, const JsImage* imgs, const JsProgFrame* frames, uint32_t nimg, const uint32_t* blk_base, uint32_t total_blocks,
