@@ -254,21 +254,21 @@ __global__ void __launch_bounds__(256) k_prog_finalize(const JsImage* __restrict
 //  The bit reader keeps 64 bits per lane and is topped up to >= 32 before every symbol (a code of <= 16 bits plus <= 15 value bits).
 // =====================================================================================================================================
 namespace {
-// The file bytes come through a 128-byte ring per lane in LDS (dword-interleaved across the lanes), topped up in WAVE-UNIFORM code: a
+// The file bytes come through a 64-byte ring per lane in LDS (dword-interleaved across the lanes), topped up in WAVE-UNIFORM code: a
 // wave of sequential decoders has nothing else to run while a load is in flight, and a load issued inside a lane's own branch is waited
-// for on the spot (one lane or another crosses a window boundary in nearly every step: 0.7 us per step, measured).  When some lane
-// runs low, EVERY lane takes as many 32-byte chunks as its ring has room for -- one round of loads and one wait per ~60 steps.
+// for on the spot.  When some lane runs low, EVERY lane of the wave takes a 32-byte chunk if its ring has room for one -- one round of
+// loads and one wait per few dozen steps.
 struct LReader { const uint8_t* base; uint32_t pos, end, wr, limit; uint64_t acc; int n; uint32_t over; };
-typedef uint32_t LRing[32][64];
+typedef uint32_t LRing[16][64];
 __device__ __forceinline__ void lr_refill(LReader& r, bool live, LRing& ring, uint32_t lane)
 {
-    for (int c = 0; c < 4; c++) {
-        const bool take = live && r.wr < r.limit && (r.wr - (r.pos & ~31u)) <= 96u;
+    for (int c = 0; c < 2; c++) {
+        const bool take = live && r.wr < r.limit && (r.wr - (r.pos & ~31u)) <= 32u;
         if (!__any(take)) break;
         if (take) {
             const uint4* p = reinterpret_cast<const uint4*>(r.base + r.wr);
             const uint4 a = p[0], b = p[1];
-            const uint32_t d = (r.wr >> 2) & 31u;
+            const uint32_t d = (r.wr >> 2) & 15u;
             ring[d][lane] = a.x; ring[d + 1][lane] = a.y; ring[d + 2][lane] = a.z; ring[d + 3][lane] = a.w;
             ring[d + 4][lane] = b.x; ring[d + 5][lane] = b.y; ring[d + 6][lane] = b.z; ring[d + 7][lane] = b.w;
             r.wr += 32u;
@@ -280,12 +280,13 @@ __device__ __forceinline__ void lr_init(LReader& r, const uint8_t* file, uint32_
     r.base = file; r.pos = s; r.end = e; r.acc = 0; r.n = 0; r.over = 0; r.wr = s & ~31u; r.limit = (file_len + 31u) & ~31u;   // (file images are 16-byte aligned, padded, and the arena has slack)
     lr_refill(r, live, ring, lane);
 }
-__device__ __forceinline__ uint32_t lr_byte(const LReader& r, uint32_t i, const LRing& ring, uint32_t lane) { return (ring[(i >> 2) & 31u][lane] >> ((i & 3u) * 8u)) & 255u; }
-// every live lane leaves with at least 32 bits; a pass appends one byte to every live lane that has room for it
+__device__ __forceinline__ uint32_t lr_byte(const LReader& r, uint32_t i, const LRing& ring, uint32_t lane) { return (ring[(i >> 2) & 15u][lane] >> ((i & 3u) * 8u)) & 255u; }
+// every live lane leaves with at least 32 bits; a pass appends one byte to every live lane that has room for it (a pass takes at most two
+// file bytes from a lane's ring, which is topped up whenever some lane has fewer than eight left)
 __device__ __forceinline__ void lr_fill(LReader& r, bool live, LRing& ring, uint32_t lane)
 {
-    while (__any(live && r.n < 32)) {
-        if (__any(live && r.wr < r.limit && r.wr - r.pos < 24u)) lr_refill(r, live, ring, lane);
+    while (__any(live && r.n < 32)) {          // (topping every lane up beyond 48 bits once some lane is short -- bursts of passes instead of one per step -- measured slower)
+        if (__any(live && r.wr < r.limit && r.wr - r.pos < 8u)) lr_refill(r, live, ring, lane);
         if (live && r.n <= 56) {
             uint32_t b = 0;
             if (r.pos < r.end) { b = lr_byte(r, r.pos++, ring, lane); if (b == 0xFF && r.pos < r.end && lr_byte(r, r.pos, ring, lane) == 0x00) r.pos++; }    // FF00 -> FF (B.1.1.5)
@@ -315,7 +316,29 @@ __device__ __forceinline__ int lr_huff(LReader& r, const JsProgTable& t, bool ta
 }
 }  // namespace
 
-__global__ void __launch_bounds__(64) k_prog_scan_lanes(const JsImage* __restrict__ imgs, const JsProgFrame* __restrict__ frames, const JsProgScan* __restrict__ scans,
+#define PL_THREADS 256                                           // four waves per workgroup share the scan's tables (an LDS ring per wave): eight waves per SIMD fit
+// zig-zag position -> natural index as compile-time constants (the mask builder below is unrolled over them)
+__device__ constexpr uint8_t kZzNat[64] = {
+     0, 1, 8,16, 9, 2, 3,10, 17,24,32,25,18,11, 4, 5, 12,19,26,33,40,48,41,34, 27,20,13, 6, 7,14,21,28,
+    35,42,49,56,57,50,43,36, 29,22,15,23,30,37,44,51, 58,59,52,45,38,31,39,46, 53,60,61,54,47,55,62,63 };
+// History of a block for a refinement scan, one bit per zig-zag position: coefficient non-zero / negative.
+__device__ __forceinline__ void history_masks(const int16_t* __restrict__ gblk, uint64_t& nz, uint64_t& neg)
+{
+    uint32_t w[32];
+    #pragma unroll
+    for (int q = 0; q < 8; q++) { const uint4 x = reinterpret_cast<const uint4*>(gblk)[q]; w[4 * q] = x.x; w[4 * q + 1] = x.y; w[4 * q + 2] = x.z; w[4 * q + 3] = x.w; }
+    uint32_t nzl = 0, nzh = 0, ngl = 0, ngh = 0;
+    #pragma unroll
+    for (int k = 0; k < 64; k++) {
+        const int nat = kZzNat[k];
+        const uint32_t c = (nat & 1) ? w[nat >> 1] >> 16 : w[nat >> 1] & 0xFFFFu;
+        const uint32_t one = min(c, 1u), sg = c >> 15;
+        if (k < 32) { nzl |= one << k; ngl |= sg << k; } else { nzh |= one << (k - 32); ngh |= sg << (k - 32); }
+    }
+    nz = ((uint64_t)nzh << 32) | nzl; neg = ((uint64_t)ngh << 32) | ngl;
+}
+
+__global__ void __launch_bounds__(PL_THREADS) k_prog_scan_lanes(const JsImage* __restrict__ imgs, const JsProgFrame* __restrict__ frames, const JsProgScan* __restrict__ scans,
                                                         const uint32_t* __restrict__ lvl_scans, const uint32_t* __restrict__ lvl_wg, uint32_t nsc,
                                                         const JsProgTable* __restrict__ tabs, const JsProgSeg* __restrict__ segs, const uint8_t* __restrict__ raw,
                                                         int16_t* __restrict__ coef, uint32_t* __restrict__ status_all)
@@ -329,17 +352,18 @@ __global__ void __launch_bounds__(64) k_prog_scan_lanes(const JsImage* __restric
     const uint32_t SS = sc.ss, SE = sc.se, AH = sc.ah, NBX = sc.nbx, NCOMP = sc.ncomp;      // the fields the loops live on, in registers
     __shared__ JsProgTable s_tab[4];
     __shared__ uint8_t s_zz[64];
-    __shared__ uint32_t s_blk[32][64];                           // AC refinement: the lanes' current blocks, dword-interleaved
-    __shared__ LRing s_ring;                                     // the lanes' file bytes
-    const uint32_t lane = threadIdx.x;
-    s_zz[lane] = c_zz_nat[lane];
+    __shared__ LRing s_rings[PL_THREADS / 64];                   // the lanes' file bytes, one ring set per wave
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    LRing& s_ring = s_rings[wave];
+    if (threadIdx.x < 64) s_zz[threadIdx.x] = c_zz_nat[threadIdx.x];
     for (uint32_t t = 0; t < sc.ntabs; t++) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(tabs + sc.tab[t]); uint32_t* dst = reinterpret_cast<uint32_t*>(&s_tab[t]);
-        for (uint32_t i = lane; i < sizeof(JsProgTable) / 4; i += 64) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < sizeof(JsProgTable) / 4; i += PL_THREADS) dst[i] = src[i];
     }
     __syncthreads();
+    // (from here on the waves of the workgroup go their own ways: no further barrier)
     const JsImage& im = imgs[sc.img];
-    const uint32_t iv = wg_in_scan * 64u + lane;
+    const uint32_t iv = wg_in_scan * PL_THREADS + threadIdx.x;
     const bool have = iv < sc.nseg;
     const JsProgSeg sg = segs[sc.seg_first + (have ? iv : 0u)];
     LReader r; lr_init(r, raw + im.file_off, sg.start, have ? sg.end : sg.start, im.file_len, have, s_ring, lane);
@@ -404,7 +428,13 @@ __global__ void __launch_bounds__(64) k_prog_scan_lanes(const JsImage* __restric
             }
         }
     } else {
-        // ---- AC refinement scan (G.1.2.3), the decoding procedure of libjpeg's decode_mcu_AC_refine position by position
+        // ---- AC refinement scan (G.1.2.3), the decoding procedure of libjpeg's decode_mcu_AC_refine position by position.
+        // What the procedure needs of a block is its history -- which coefficients are non-zero, and their signs: two 64-bit masks per
+        // lane, built when the block is entered.  A coefficient with history is a multiple of 2 << Al (every earlier scan of its band had
+        // a larger point transform), so a correction bit adds +-(1 << Al) to it, and a new coefficient adds its value to a zero: both
+        // leave as ONE 32-bit atomic add on the dword that holds the coefficient (no value comes back: nothing to wait for).  The low
+        // half takes the addend sign-extended when the coefficient is non-zero (it grows away from zero: no carry, no borrow reaches
+        // the neighbour) and as its 16-bit pattern when it is zero; other scans of the level may own the other half of the dword.
         const uint32_t comp = sc.comp[0]; const JsProgTable& T = s_tab[sc.ac_slot[0]];
         const int p1 = 1 << al, m1 = -(1 << al);
         uint32_t eobrun = 0;
@@ -412,10 +442,9 @@ __global__ void __launch_bounds__(64) k_prog_scan_lanes(const JsImage* __restric
             const bool inb = j < nu;
             const uint32_t u = u0 + (inb ? j : 0u);
             int16_t* gblk = cbase + block_row(im, fr, comp, u % NBX, u / NBX) * 64;
-            if (inb) {
-                #pragma unroll
-                for (int q = 0; q < 8; q++) { const uint4 x = reinterpret_cast<const uint4*>(gblk)[q]; s_blk[4 * q][lane] = x.x; s_blk[4 * q + 1][lane] = x.y; s_blk[4 * q + 2][lane] = x.z; s_blk[4 * q + 3][lane] = x.w; }
-            }
+            uint64_t nz = 0, neg = 0;
+            if (__any(inb)) { if (inb) history_masks(gblk, nz, neg); }
+            uint32_t* gw = reinterpret_cast<uint32_t*>(gblk);
             bool adv = false, has_new = false; int newv = 0; uint32_t run = 0;
             for (uint32_t k = SS; k <= SE; k++) {                // k is wave-uniform
                 const bool live = inb && !bad;
@@ -435,18 +464,17 @@ __global__ void __launch_bounds__(64) k_prog_scan_lanes(const JsImage* __restric
                     }
                 }
                 if (live && !bad) {
-                    const uint32_t w = s_blk[nat >> 1][lane];
-                    int v = (nat & 1u) ? (int)w >> 16 : (int)(int16_t)w;
-                    bool changed = false;
-                    if (v != 0) {                                // a coefficient with history: one correction bit
-                        if (lr_bits(r, 1) && !(v & p1)) { v += (v >= 0 ? p1 : m1); changed = true; }
+                    const bool hist = (nz >> k) & 1ull;
+                    int delta = 0; bool was_zero = false;
+                    if (hist) {                                  // a coefficient with history: one correction bit
+                        if (lr_bits(r, 1)) delta = ((neg >> k) & 1ull) ? m1 : p1;
                     } else if (!eobrun && adv) {                 // a zero: counts towards the run, or takes the new value
-                        if (run == 0) { if (has_new) { v = newv; changed = true; } adv = false; }
+                        if (run == 0) { if (has_new) { delta = newv; was_zero = true; } adv = false; }
                         else run--;
                     }
-                    if (changed) {
-                        s_blk[nat >> 1][lane] = (nat & 1u) ? (w & 0xFFFFu) | ((uint32_t)v << 16) : (w & 0xFFFF0000u) | ((uint32_t)v & 0xFFFFu);
-                        gblk[nat] = (int16_t)v;                  // the band position only: other scans of the level own the rest of the block
+                    if (delta) {
+                        const uint32_t add = (nat & 1u) ? (uint32_t)delta << 16 : (was_zero ? (uint32_t)delta & 0xFFFFu : (uint32_t)delta);
+                        atomicAdd(gw + (nat >> 1), add);
                     }
                 }
             }
@@ -457,12 +485,12 @@ __global__ void __launch_bounds__(64) k_prog_scan_lanes(const JsImage* __restric
     if (have && lr_overrun(r)) atomicOr(&status[0], 2u);            // the interval ended before its blocks did
 }
 
-uint32_t js_prog_wgs_of(const JsProgScan& sc, uint32_t pg_lanes) { const uint32_t per = pg_lanes >= 64u ? 64u : ((sc.ss != 0 && sc.ah != 0) ? 1u : pg_lanes); return (sc.nseg + per - 1) / per; }
+uint32_t js_prog_wgs_of(const JsProgScan& sc, uint32_t pg_lanes) { const uint32_t per = pg_lanes >= 64u ? (uint32_t)PL_THREADS : ((sc.ss != 0 && sc.ah != 0) ? 1u : pg_lanes); return (sc.nseg + per - 1) / per; }
 void js_launch_prog_level(hipStream_t st, const JsImage* imgs, const JsProgFrame* frames, const JsProgScan* scans, const uint32_t* lvl_scans, const uint32_t* lvl_wg,
                           uint32_t nsc, uint32_t total_wgs, uint32_t pg_lanes, const JsProgTable* tabs, const JsProgSeg* segs, const uint8_t* raw, int16_t* coef, uint32_t* status)
 {
     if (!nsc || !total_wgs) return;
-    if (pg_lanes >= 64u) { hipLaunchKernelGGL(k_prog_scan_lanes, dim3(total_wgs), dim3(64), 0, st, imgs, frames, scans, lvl_scans, lvl_wg, nsc, tabs, segs, raw, coef, status); return; }
+    if (pg_lanes >= 64u) { hipLaunchKernelGGL(k_prog_scan_lanes, dim3(total_wgs), dim3(PL_THREADS), 0, st, imgs, frames, scans, lvl_scans, lvl_wg, nsc, tabs, segs, raw, coef, status); return; }
     hipLaunchKernelGGL(k_prog_scan, dim3(total_wgs), dim3(64), 0, st, imgs, frames, scans, lvl_scans, lvl_wg, nsc, pg_lanes, tabs, segs, raw, coef, status);
 }
 void js_launch_prog_finalize(hipStream_t st, const JsImage* imgs, const JsProgFrame* frames, uint32_t nimg, const uint32_t* blk_base, uint32_t total_blocks,
