@@ -356,7 +356,7 @@ int JsnoopBatch::upload()
         grow(&dev.sub, &cap.sub, subs * 24 + 64) || grow(&dev.probe, &cap.probe, 1024) || grow(&dev.seg, &cap.seg, segw * 4 + 64) ||
         grow(&dev.chunk_keep, &cap.chunk_keep, (size_t)usc * 4 + 64) || grow(&dev.chunk_rst, &cap.chunk_rst, (size_t)usc * 4 + 64) ||
         grow(&dev.us_base, &cap.us_base, (n + 1) * 4) || grow(&dev.sy_base, &cap.sy_base, 2 * (n + 1) * 4) ||
-        grow(&dev.mcu_rst, &cap.mcu_rst, mcub + 64) || grow(&dev.dc_parts, &cap.dc_parts, JS_DC_PARTS_BYTES) || grow(&dev.ustr_lin, &cap.ustr_lin, ustr + 64) || grow(&dev.flags, &cap.flags, n * 4 + 64)) return -1;
+        grow(&dev.mcu_rst, &cap.mcu_rst, mcub + 64) || grow(&dev.dc_parts, &cap.dc_parts, JS_DC_PARTS_BYTES) || grow(&dev.ustr_lin, &cap.ustr_lin, ustr + 64) || grow(&dev.flags, &cap.flags, n * 16 + 64)) return -1;
     if (opt_want_planes && grow(&dev.planes, &cap.planes, plane * 2)) return -1;
     event_words = opt_events ? (uint64_t)n * (1 + JS_EV_WORDS * JS_EV_MAX) : 0;
     if (event_words && grow(&dev.events, &cap.events, event_words * 4)) return -1;
@@ -372,6 +372,7 @@ int JsnoopBatch::upload()
     HIP_TRY(hipStreamSynchronize(stream));          // host vectors above may go out of scope
     h_us_base = usb; h_sy_base.assign(syb.begin(), syb.begin() + n + 1); h_sn_base.assign(syb.begin() + n + 1, syb.end()); h_wg_base = wg;
     split_parts = (opt_split == 2 && n >= 2) ? 2 : 1;
+    flags_init_dev = false;
     uploaded = true;
     return 0;
 }
@@ -393,7 +394,7 @@ int JsnoopBatch::decode(bool timed)
     }
     HIP_TRY(hipMemsetAsync(dev.side, 0, side_words * 4, stream));
     HIP_TRY(hipMemsetAsync(dev.mcu_rst, 0, mcu_bytes, stream));
-    HIP_TRY(hipMemsetAsync(dev.flags, 0, (size_t)n * 4, stream));
+    if (js_clear_flags(this)) return -1;
     if (event_words) HIP_TRY(hipMemsetAsync(dev.events, 0, event_words * 4, stream));
     if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
     last_timed_split = false;

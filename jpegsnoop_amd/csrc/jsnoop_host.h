@@ -77,6 +77,8 @@ struct JsnoopBatch {
     struct JsImgHost { uint32_t dht_setmax[2] = { 0, 0 }; unsigned err_max = 20; bool display = true; };   // what the per-image report needs beyond the descriptor
     std::vector<JsImgHost> hinfo;
     std::vector<uint8_t> side_done;                               // per image: the side-output pass has run since the last decode
+    std::vector<uint32_t> flags_init; bool flags_init_dev = false; // clear pattern of the flag arena (kept behind it on the device)
+    std::vector<uint32_t> host_anom;                              // per image: first block (decode order) the parallel path could not vouch for (0xFFFFFFFF: none)
     std::vector<uint32_t> host_flags, host_path, h_us_base, h_sy_base, h_sn_base, h_wg_base;
     // A large batch decodes as two halves on two streams (stream, aux[0]): the kernels of one half fill the tails and the thinly
     // populated phases (second synchronisation launch, DC scan) of the other -- 14.2 -> 13.7 ms per 1024 images.  Both halves live in
@@ -124,6 +126,8 @@ struct JsnoopBatch {
 
 // flags that leave coefficients, planes and DIB of the parallel path reference-exact (bookkeeping differs: status words, warning counter, log)
 #define JS_FLAGS_PIXEL_EXACT (JSNOOP_FLAG_COEF_OVERFLOW)
+int  js_clear_flags(JsnoopBatch* b);                              // flag arena: {0, 0xFFFFFFFF} per image (flags, first anomalous block)
+int  js_read_flags(JsnoopBatch* b);                               // -> host_flags, host_anom
 void js_set_error(const char* fmt, ...);
 // roctx ranges around the host-side stages (rocprofv3 --marker-trace makes a timeline self-describing: upload / clear / entropy
 // stages / back end / read-back).  One push and pop per stage and call: nothing per image.

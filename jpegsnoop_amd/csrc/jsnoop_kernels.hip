@@ -210,10 +210,20 @@ __device__ int16_t ex_decode_block(ExactReader& r, uint32_t comp, uint32_t decod
     return dct0;
 }
 
+// Tail mode (tail.flags != nullptr; one image, sel[0]): the parallel path has decoded the image and vouches for every block before
+// flags[2 * img + 1] (the first block at which it saw something other than a coefficient-index overflow).  The mirror reader takes over
+// at the top of the MCU that holds that block -- seeded from the MCU's bit position (side walk: mcu_pos) and the cumulative DC values the
+// parallel path left for the MCU before it -- and decodes from there to the last MCU, writing coefficients and cumulative DC only.  At
+// an MCU top the part of the reader's state that decides WHAT is decoded (bit register after its refill, next byte to load, "restart
+// marker seen") is a function of the bit position alone; what is not (slots of its position array, a pending bad-marker latch) only
+// shows in the MCU file map and the messages, which such an image gets from a side-only pass of the whole mirror on request.
+struct ExactTail { const uint32_t* flags; const uint32_t* seg_tab; const uint8_t* mcu_rst; const uint32_t* mcu_pos; const uint32_t* us_out; uint32_t us_threads; };
+__device__ uint32_t raw_of_compacted(const JsImage& im, const uint8_t* __restrict__ raw, const uint32_t* __restrict__ us_out, uint32_t nthreads, uint32_t u);
+
 __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sel, uint32_t nsel,
                                                       const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ raw,
                                                       int16_t* __restrict__ coef, int16_t* __restrict__ dccum, uint32_t* __restrict__ side, int side_only,
-                                                      uint32_t* __restrict__ events)
+                                                      uint32_t* __restrict__ events, ExactTail tail)
 {
     // side_only: recompute only the decoder's side outputs (MCU file map, block-DC maps, code-length
     // histogram, status words) for an image whose pixels came from the parallel path.
@@ -236,9 +246,34 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
         if (threadIdx.x < 64) s_zz[threadIdx.x] = c_zigzag[threadIdx.x];
     }
     __syncthreads();
-    if (threadIdx.x) return;
     uint32_t* sd = side + im.side_off;
     const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax, nblk = im.blk_xmax * im.blk_ymax;
+    __shared__ uint32_t s_m0;
+    if (tail.flags) {
+        // Tail mode: the MCU the mirror takes over at, and everything from there on emptied first -- the mirror stores what it decodes, and
+        // MCUs it never reaches (the scan-stop logic after an overread, :3623-3625) must read as the cleared arrays of the reference.
+        if (threadIdx.x == 0) {
+            uint32_t m0 = min(tail.flags[2u * sel[j] + 1u] / im.blk_per_mcu, nmcu);
+            while (m0 && tail.mcu_pos[m0] == 0u) m0--;             // (an MCU top the side walk did not reach: fall back to an earlier one)
+            s_m0 = m0;
+        }
+        __syncthreads();
+        const size_t b0 = (size_t)s_m0 * im.blk_per_mcu, b1 = im.total_blocks;
+        uint4* zc = reinterpret_cast<uint4*>(coef + (im.coef_off + b0) * 64); const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+        for (size_t q = threadIdx.x; q < (b1 - b0) * 8; q += blockDim.x) zc[q] = zero;
+        int16_t* zd = dccum + im.coef_off;
+        for (size_t q = b0 + threadIdx.x; q < b1; q += blockDim.x) zd[q] = 0;
+        __syncthreads();
+    }
+    // Periodic tail (tail mode): once the reader has run out of file -- every byte it will ever load is the zero CwindowBuf::Buf returns
+    // past the end (WindowBuf.cpp:639), its register holds zero bits only, nothing is pending -- every further MCU decodes to the same
+    // blocks and moves the DC predictors by the same amounts.  The mirror decodes ONE such MCU; the lanes of the wave replicate it over
+    // the rest of the image (a truncated file: the common case of a carved one) instead of 0.6 ms of sequential decode per MCU.
+    __shared__ uint32_t s_fill_from;                               // MCU index of the template, 0xFFFFFFFF: none
+    __shared__ int s_dc_after[3], s_dc_step[3]; __shared__ int s_dc_in[JS_MAX_BLK_PER_MCU];
+    __shared__ __attribute__((aligned(16))) int16_t s_tpl[JS_MAX_BLK_PER_MCU * 64];
+    if (threadIdx.x == 0) s_fill_from = 0xFFFFFFFFu;
+    auto serial = [&]() {
     uint32_t* mcu_map = sd + JS_SIDE_MCUMAP;
     int16_t* bdc[3]; bdc[0] = (int16_t*)(mcu_map + nmcu); bdc[1] = bdc[0] + 2 * ((nblk + 1) / 2); bdc[2] = bdc[1] + 2 * ((nblk + 1) / 2);
 
@@ -255,13 +290,37 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
     uint32_t num_pixels = 0;
     int16_t* cbase = coef + im.coef_off * 64;
     int16_t* dbase = dccum + im.coef_off;
+    uint32_t m_first = 0;
+    const bool tail_mode = tail.flags != nullptr;
+    if (tail_mode) {
+        const uint32_t nb = im.blk_per_mcu;
+        const uint32_t m0 = s_m0;
+        m_first = m0;
+        if (m0) {
+            const uint32_t p = tail.mcu_pos[m0];
+            r.ev = nullptr;
+            // The reader is seeded at the byte that holds the LAST bit consumed before the MCU top and walks the remaining 1..8 bits of it:
+            // when the top sits on a restart-interval boundary that byte is the last one in front of the marker(s), the refill meets the
+            // marker, and the reader arrives with an empty register and "restart marker seen" -- it handles the restart (or two markers
+            // back to back, whose second one the reference meets inside the retry of :1644-1680) exactly as the reference does.
+            const uint32_t ub = (p - 1u) >> 3;
+            ex_restart_scan_buf(r, raw_of_compacted(im, raw, tail.us_out, tail.us_threads, ub), true); ex_topup(r); ex_consume(r, p - 8u * ub);
+            const uint32_t n1 = im.samp_h[1] * im.samp_v[1], n2 = im.ncomp == 3 ? n1 + im.samp_h[2] * im.samp_v[2] : nb;
+            const int16_t* dprev = dbase + (size_t)(m0 - 1) * nb;   // cumulative DC of the last block of each component in the MCU before
+            dc_y = dprev[n1 - 1]; if (im.ncomp == 3) { dc_cb = dprev[n2 - 1]; dc_cr = dprev[nb - 1]; }
+            r.ptr_first = im.scan_start;
+        }
+    }
 
-    for (uint32_t my = 0; my < im.mcu_ymax; my++) {
+    for (uint32_t my = m_first / im.mcu_xmax; my < im.mcu_ymax; my++) {
         bool stop = false;
-        for (uint32_t mx = 0; mx < im.mcu_xmax && !stop; mx++) {
+        for (uint32_t mx = (my == m_first / im.mcu_xmax ? m_first % im.mcu_xmax : 0u); mx < im.mcu_xmax && !stop; mx++) {
             const uint32_t mi = my * im.mcu_xmax + mx;
             if (im.rst_en && r.mcus_left == 0 && !r.restart_read) ex_event(r, JS_EV_RST_NOT_DETECTED, r.pos0, r.align);   // :3180-3200
-            mcu_map[mi] = (r.pos0 << 4) + r.align;                        // PackFileOffset :5104
+            if (!tail_mode) mcu_map[mi] = (r.pos0 << 4) + r.align;        // PackFileOffset :5104
+            const bool zero_state = tail_mode && mi + 1 < nmcu && r.buff == 0u && r.ptr >= r.flen && !r.restart_read && !r.scan_end && r.latch == SB_OK &&
+                                    r.err0 == SB_OK && r.err1 == SB_OK && r.err2 == SB_OK && r.err3 == SB_OK;
+            const int dc_in0 = dc_y, dc_in1 = dc_cb, dc_in2 = dc_cr;
             for (uint32_t c = 0; c < im.blk_per_mcu; c++) {
                 const uint32_t comp = im.blk_comp[c];
                 const size_t b = (size_t)mi * im.blk_per_mcu + c;
@@ -277,7 +336,7 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
                 if (!side_only) dbase[b] = *acc;
                 if (comp == 1) num_pixels += 64;
             }
-            {   // per-block cumulative DC maps :3524-3608 (sequential overwrite order preserved)
+            if (!tail_mode) {   // per-block cumulative DC maps :3524-3608 (sequential overwrite order preserved)
                 uint32_t lin = (my * im.expand_v[1]) * im.blk_xmax + mx * im.expand_h[1];
                 for (uint32_t cv = 0; cv < im.samp_v[1]; cv++) for (uint32_t ch = 0; ch < im.samp_h[1]; ch++) {
                     uint32_t bi = lin + cv * im.blk_xmax + ch; if (bi < nblk) bdc[0][bi] = css[0][cv * 4 + ch]; }
@@ -288,11 +347,40 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
             }
             if (im.rst_en) r.mcus_left--;
             if (r.scan_end && r.scan_bad) stop = true;                    // :3623-3625
+            if (zero_state && !stop && r.buff == 0u) {                    // this MCU is the template of all that follow
+                const uint32_t nb = im.blk_per_mcu;
+                const int din[3] = { dc_in0, dc_in1, dc_in2 };
+                s_dc_after[0] = dc_y; s_dc_after[1] = dc_cb; s_dc_after[2] = dc_cr;
+                s_dc_step[0] = dc_y - dc_in0; s_dc_step[1] = dc_cb - dc_in1; s_dc_step[2] = dc_cr - dc_in2;
+                for (uint32_t c = 0; c < nb; c++) {
+                    s_dc_in[c] = (int)dbase[(size_t)mi * nb + c] - din[im.blk_comp[c] - 1];   // the predictor's gain inside the MCU up to and including block c
+                    const uint4* src = reinterpret_cast<const uint4*>(cbase + ((size_t)mi * nb + c) * 64); uint4* dst = reinterpret_cast<uint4*>(s_tpl + c * 64);
+                    for (int q = 0; q < 8; q++) dst[q] = src[q];
+                }
+                s_fill_from = mi;
+                return;
+            }
         }
     }
+    if (tail_mode) return;                                        // (status words, histogram and maps: the side-only pass, on request)
     sd[0] = r.scan_bad; sd[1] = r.scan_end; sd[2] = r.rst_count; sd[3] = num_pixels;
     sd[4] = r.pos0; sd[5] = r.align; sd[6] = r.warn_bad; sd[7] = r.ptr_first; if (!side_only) sd[9] = 2;
     for (uint32_t i = 0; i < 2 * 4 * 17; i++) sd[JS_SIDE_HISTO + i] = s_histo[i];
+    };
+    if (threadIdx.x == 0) serial();
+    __syncthreads();
+    if (s_fill_from != 0xFFFFFFFFu) {
+        const uint32_t nb = im.blk_per_mcu, mt = s_fill_from;
+        const size_t rows = (size_t)(nmcu - mt - 1) * nb;            // block rows behind the template MCU
+        uint4* dst = reinterpret_cast<uint4*>(coef + (im.coef_off + (size_t)(mt + 1) * nb) * 64);
+        const uint4* tpl = reinterpret_cast<const uint4*>(s_tpl);
+        for (size_t q = threadIdx.x; q < rows * 8; q += blockDim.x) dst[q] = tpl[((q >> 3) % nb) * 8 + (q & 7)];
+        int16_t* dd = dccum + im.coef_off + (size_t)(mt + 1) * nb;
+        for (size_t q = threadIdx.x; q < rows; q += blockDim.x) {
+            const uint32_t c = (uint32_t)(q % nb), comp0 = im.blk_comp[c] - 1u; const int n = (int)(q / nb);   // n whole MCUs lie between the template and this one
+            dd[q] = (int16_t)(s_dc_after[comp0] + n * s_dc_step[comp0] + s_dc_in[c]);
+        }
+    }
 }
 
 // =====================================================================================
@@ -969,7 +1057,8 @@ void js_launch_entropy_exact(hipStream_t st, const JsImage* imgs, const uint32_t
                              const uint8_t* raw, int16_t* coef, int16_t* dccum, uint32_t* side, int side_only, uint32_t* events)
 {
     if (!nsel) return;
-    hipLaunchKernelGGL(k_entropy_exact, dim3(nsel), dim3(64), 0, st, imgs, sel, nsel, tables, raw, coef, dccum, side, side_only, events);
+    ExactTail none; none.flags = nullptr; none.seg_tab = nullptr; none.mcu_rst = nullptr; none.mcu_pos = nullptr; none.us_out = nullptr; none.us_threads = 0;
+    hipLaunchKernelGGL(k_entropy_exact, dim3(nsel), dim3(64), 0, st, imgs, sel, nsel, tables, raw, coef, dccum, side, side_only, events, none);
 }
 int js_launch_idct_color(hipStream_t st, const JsImage* imgs, const uint32_t* wg_base, uint32_t nimg, uint32_t total_wgs, uint32_t tile_bytes,
                          const float* lut_t, const int16_t* coef, const int16_t* dccum, uint8_t* dib, int16_t* planes, uint32_t* side, int layout)
@@ -1046,6 +1135,11 @@ void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, 
 #define SUB_BITS   (32u << WL)
 #define SYNC_SPEC_TAIL (WL >= 7 ? 2048u : 1024u)   // bits at the end of a sub-sequence the first (speculative) walk covers
 
+// flag arena: two words per image -- [2 * img] the F_* bits, [2 * img + 1] the first block (decode order) at which something other than a
+// coefficient-index overflow was seen (0xFFFFFFFF: none): everything before it is what the reference decodes, and the exact-mirror
+// reader can take over from the MCU that holds it (k_entropy_exact, tail mode) instead of from the first byte of the scan.
+#define FLAG_OR(flags, img, bits) atomicOr(&(flags)[2u * (img)], (bits))
+#define ANOM_MIN(flags, img, blk) atomicMin(&(flags)[2u * (img) + 1u], (blk))
 #define F_BAD_CODE      0x0001u
 #define F_OVERRUN       0x0002u
 #define F_COEF_OVERFLOW 0x0004u
@@ -1160,7 +1254,7 @@ __global__ void __launch_bounds__(256) k_unstuff_scan(const JsImage* __restrict_
         uint32_t* sd = side + im.side_off; uint32_t* st = seg_tab + im.seg_off;
         sd[10] = run_k; sd[11] = run_r + 1;
         st[0] = 0;
-        if (run_r + 2 <= im.seg_cap) st[run_r + 1] = run_k; else atomicOr(&flags[img], F_OVERRUN);
+        if (run_r + 2 <= im.seg_cap) st[run_r + 1] = run_k; else { FLAG_OR(flags, img, F_OVERRUN); ANOM_MIN(flags, img, 0u); }
     }
 }
 
@@ -1365,27 +1459,27 @@ __device__ __forceinline__ uint32_t sym_lookup(const SubTabs& T, uint32_t win, u
 template <bool WRITE, int WL>
 __device__ __forceinline__ bool walk_slow(const JsImage& im, const uint32_t* __restrict__ words, const uint32_t* __restrict__ st, uint32_t nseg,
                                        Cursor& cur, uint32_t len, uint32_t& seg, uint32_t& seg_end, uint32_t& c, uint32_t& k,
-                                       uint32_t blk, bool mark, uint8_t* __restrict__ mcu_rst, uint32_t& flags)
+                                       uint32_t blk, bool mark, uint8_t* __restrict__ mcu_rst, uint32_t& flags, uint32_t& anom)
 {
     const uint32_t remain = seg_end > cur.p ? seg_end - cur.p : 0u;
     if (len == 0 && remain >= 16) {
         // No code matches although a whole code could still fit: a corrupt stream (the reference skips one bit
         // and reports it, :1178-1186) -- or simply a speculative walk that is not synchronised yet.
-        if (WRITE && blk < im.total_blocks) flags |= F_BAD_CODE;
+        if (WRITE && blk < im.total_blocks) { flags |= F_BAD_CODE; anom = min(anom, blk); }
         cur_skip<WL>(cur, 1);
         return true;
     }
     if (seg + 1 < nseg) {
         if (WRITE) {
-            if (k != 0 || c != 0 || remain >= 8) flags |= F_RST_MISALIGN;   // well-formed: < 8 pad bits, on an MCU boundary
+            if (k != 0 || c != 0 || remain >= 8) { flags |= F_RST_MISALIGN; anom = min(anom, blk); }   // well-formed: < 8 pad bits, on an MCU boundary
             if (mark && blk < im.total_blocks) mcu_rst[blk / im.blk_per_mcu] = 1;
         }
         seg++; const uint32_t np = seg_end; seg_end = st[seg + 1] * 8; c = 0; k = 0;
-        if (WRITE && seg_end == np && seg + 1 < nseg) flags |= F_RST_MISALIGN;       // back-to-back RSTn
+        if (WRITE && seg_end == np && seg + 1 < nseg) { flags |= F_RST_MISALIGN; anom = min(anom, blk); }       // back-to-back RSTn
         cur_init<WL>(cur, words, np);
         return true;
     }
-    if (WRITE && blk < im.total_blocks) flags |= F_SHORT;
+    if (WRITE && blk < im.total_blocks) { flags |= F_SHORT; anom = min(anom, blk); }
     cur.p = P_END; c = 0; k = 0; seg = 0;
     return false;
 }
@@ -1446,7 +1540,7 @@ __device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, ui
                 const uint32_t e = sym_lookup(T, win, lrow, 0u);
                 const uint32_t len = (e >> 8) & 31u, run = (e >> 4) & 15u, size = e & 15u;
                 if (len == 0 || cur.p + len > seg_end) {
-                    walk_slow<false, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, 0, false, nullptr, fl);   // end of the data: p = P_END
+                    walk_slow<false, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, 0, false, nullptr, fl, fl);   // end of the data: p = P_END
                 } else {
                     cur_skip<WL>(cur, len + size);
                     const uint32_t kn = k == 0 ? 1u : k + run + 1u;
@@ -1591,7 +1685,7 @@ __global__ void __launch_bounds__(THREADS) k_block_scan(const JsImage* __restric
                                                         SubArrays A, uint32_t* side, uint32_t* __restrict__ flags)
 {
     const uint32_t img = blockIdx.x; const JsImage& im = imgs[img];
-    if (!tables[im.tableset].lut_ok) { if (threadIdx.x == 0) atomicOr(&flags[img], 0x0020u); return; }
+    if (!tables[im.tableset].lut_ok) { if (threadIdx.x == 0) { FLAG_OR(flags, img, 0x0020u); ANOM_MIN(flags, img, 0u); } return; }
     const uint32_t total_bits = side[im.side_off + 10] * 8;
     const uint32_t n = min(im.n_subseq, (total_bits + SUB_BITS - 1) / SUB_BITS);
     // THREADS sub-sequences per step: inclusive scan inside each wave (shuffles), the wave totals through LDS, a running carry
@@ -1611,7 +1705,7 @@ __global__ void __launch_bounds__(THREADS) k_block_scan(const JsImage* __restric
         if (i < n) A.base[im.subseq_off + i] = run + pre + inc - v;
         run += tot;
     }
-    if (threadIdx.x == 0) { side[im.side_off + 14] = run; if (run < im.total_blocks) atomicOr(&flags[img], F_SHORT); }
+    if (threadIdx.x == 0) { side[im.side_off + 14] = run; if (run < im.total_blocks) { FLAG_OR(flags, img, F_SHORT); ANOM_MIN(flags, img, run); } }
 }
 
 // WRITE pass.  Every 8x8 block is written by exactly one lane -- the one that decodes its DC symbol.  A lane entering
@@ -1659,7 +1753,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
     const uint32_t nblocks = im.total_blocks, decode_ac = im.decode_ac, prec_shift = im.precision >= 8 ? ((im.precision - 8) & 31) : 0;
     const bool in_data = i * SUB_BITS < total_bits;
     const size_t g = im.subseq_off + i;
-    uint32_t fl = 0, nblk = 0, seg = 0, c = 0, k = 0, seg_end = 0, blk = 0;
+    uint32_t fl = 0, an = 0xFFFFFFFFu, nblk = 0, seg = 0, c = 0, k = 0, seg_end = 0, blk = 0;
     uint32_t res_p = 0, res_s = 0, res_n = 0;                // what this lane reports for verification
     bool verify = false, check_n = false, active = false, captured = false, skip = false;
     const uint32_t own_end = min((i + 1) * SUB_BITS, total_bits);
@@ -1724,12 +1818,12 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         bool norm = active;
         if (WBALLOT(len == 0 || cur.p + tot > seg_end || k2 > 64u) & amask) {
             if (active && (len == 0 || cur.p + len > seg_end)) {  // interval / stream end, or a code that matches nothing
-                const bool more = walk_slow<true, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, blk, !captured, rstf, fl);
+                const bool more = walk_slow<true, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, blk, !captured, rstf, fl, an);
                 if (!more) { if (!captured) { captured = true; res_p = P_END; res_s = 0; res_n = nblk; } active = false; }
                 comp = comp_of(T, c); wb = comp == 0 ? wb0 : (comp == 1 ? wb1 : wb2);
                 norm = false;
             } else if (active && blk < nblocks) {
-                if (cur.p + tot > seg_end) fl |= F_OVERRUN;
+                if (cur.p + tot > seg_end) { fl |= F_OVERRUN; an = min(an, blk); }
                 if (k2 > 64u) fl |= F_COEF_OVERFLOW;
             }
         }
@@ -1801,7 +1895,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         __syncthreads();
         uint32_t* ho = side + im.side_off + JS_SIDE_HISTO;
         for (uint32_t q = threadIdx.x; q < 2 * 4 * 17; q += SY_THREADS) { const uint32_t v = s_histo[q]; if (v) atomicAdd(&ho[q], v); }
-    } else if (fl) atomicOr(&flags[img], fl);
+    } else if (fl) { FLAG_OR(flags, img, fl); if (an != 0xFFFFFFFFu) ANOM_MIN(flags, img, an); }
 }
 
 // WRITE pass, second form (the one the main path launches; k_write<., true> above stays the side-output pass and k_write<., false> the
@@ -1844,7 +1938,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
     if (sub0 * SUB_BITS >= total_bits) return;
     // block rows are addressed with 32-bit byte offsets from the image's first row: an image of 2^25 blocks or more (2 Gpixel of
     // grayscale) is left to the exact kernel
-    if (im.total_blocks >= (1u << 25)) { if (threadIdx.x == 0) atomicOr(&flags[img], F_SHORT); return; }
+    if (im.total_blocks >= (1u << 25)) { if (threadIdx.x == 0) { FLAG_OR(flags, img, F_SHORT); ANOM_MIN(flags, img, 0u); } return; }
     const JsTableSet& tset = tables[im.tableset];
     SubTabs T; T.nb = im.blk_per_mcu; T.n1 = im.samp_h[1] * im.samp_v[1]; T.n2 = im.ncomp == 3 ? T.n1 + im.samp_h[2] * im.samp_v[2] : T.nb;
     WriteTabs W; load_wtabs(W, s_dyn, tset, tab_rows, tab_lut2, im.ncomp, threadIdx.x, SY_THREADS);
@@ -1859,7 +1953,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
     const uint64_t acmask = im.decode_ac ? ~0ull : 0ull;        // DC-only mode: AC coefficients are parsed, not stored
     const bool in_data = i * SUB_BITS < total_bits;
     const size_t g = im.subseq_off + i;
-    uint32_t fl = 0, nblk = 0, seg = 0, c = 0, k = 0, seg_end = 0, blk = 0;
+    uint32_t fl = 0, an = 0xFFFFFFFFu, nblk = 0, seg = 0, c = 0, k = 0, seg_end = 0, blk = 0;
     uint32_t res_p = 0, res_s = 0, res_n = 0;                // what this lane reports for verification
     bool verify = false, check_n = false, active0 = false, skip0 = false;
     const uint32_t own_end = min((i + 1) * SUB_BITS, total_bits);
@@ -1933,13 +2027,13 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
             bool over = false;                                   // (lane masks change in wave-uniform code only)
             if (IBAL(m_slow)) {                                  // interval / stream end, or a code that matches nothing
                 const bool notcap = !IBAL(m_cap);
-                const bool more = walk_slow<true, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, blk, notcap, rstf, fl);
+                const bool more = walk_slow<true, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, blk, notcap, rstf, fl, an);
                 if (!more && notcap) { res_p = P_END; res_s = 0; res_n = nblk; }
                 over = !more;
                 comp = comp_of(T, c); wb = comp == 0 ? wb0 : (comp == 1 ? wb1 : wb2);
                 tot = 0; size = 0; k2 = k;                       // the step below does nothing for this lane
             } else if (IBAL(m_act)) {
-                if (blk < nblocks) { if (p1 > seg_end) fl |= F_OVERRUN; if (k2 > 64u) fl |= F_COEF_OVERFLOW; }
+                if (blk < nblocks) { if (p1 > seg_end) { fl |= F_OVERRUN; an = min(an, blk); } if (k2 > 64u) fl |= F_COEF_OVERFLOW; }
             }
             const uint64_t m_over = WBALLOT(over);
             m_cap |= m_over; m_act &= ~m_over;
@@ -2014,7 +2108,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
         // the chain must be at its fixed point, and the block count that fed the prefix sum must be the real one
         if (res_p != A.out_p[g] || res_s != A.out_s[g] || (check_n && res_n != A.nblk[g])) fl |= F_NOSYNC;
     }
-    if (fl) atomicOr(&flags[img], fl);
+    if (fl) { FLAG_OR(flags, img, fl); if (an != 0xFFFFFFFFu) ANOM_MIN(flags, img, an); }
 }
 
 // One workgroup (1024 lanes) per image: DC differences (in dccum, decode order) -> cumulative DC per block.
@@ -2322,6 +2416,22 @@ void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab
     else hipLaunchKernelGGL((k_write<5, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos);
     hipLaunchKernelGGL(k_side_maps, dim3(64), dim3(256), 0, st, imgs, img, tables, raw, seg_tab, dccum, mcu_rst, mcu_pos, us_out, us_wgs * US_THREADS, side, events);
+}
+// Tail take-over for image `img` of a decoded batch (see ExactTail): the inverse byte map and the MCU bit positions through the first two
+// kernels of the side pass, then the mirror reader from the MCU that holds the first block the parallel path could not vouch for.
+void js_launch_tail_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* us_base, const uint32_t* sy_base, uint32_t nimg,
+                         uint32_t us_wg0, uint32_t us_wgs, uint32_t sy_wg0, uint32_t sy_wgs, const JsTableSet* tables, const uint8_t* raw,
+                         const uint32_t* chunk_keep, const uint32_t* chunk_rst, const uint8_t* ustr, uint32_t* seg_tab, uint32_t* side, uint32_t* sub, uint64_t nsub,
+                         int16_t* coef, int16_t* dccum, uint8_t* mcu_rst, uint32_t* mcu_pos, uint32_t* us_out, const uint32_t* flags, const uint32_t* sel1)
+{
+    if (!us_wgs || !sy_wgs) return;
+    hipLaunchKernelGGL(k_unstuff_write, dim3(us_wgs), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, (uint8_t*)nullptr, seg_tab, us_wg0, us_out);
+#define JS_TAIL_WALK(W) hipLaunchKernelGGL((k_write<W, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side, \
+                       sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos)
+    if (wl == 4) JS_TAIL_WALK(4); else if (wl == 6) JS_TAIL_WALK(6); else if (wl == 8) JS_TAIL_WALK(8); else if (wl == 7) JS_TAIL_WALK(7); else JS_TAIL_WALK(5);
+#undef JS_TAIL_WALK
+    ExactTail t; t.flags = flags; t.seg_tab = seg_tab; t.mcu_rst = mcu_rst; t.mcu_pos = mcu_pos; t.us_out = us_out; t.us_threads = us_wgs * US_THREADS;
+    hipLaunchKernelGGL(k_entropy_exact, dim3(1), dim3(64), 0, st, imgs, sel1, 1u, tables, raw, coef, dccum, side, 0, (uint32_t*)nullptr, t);
 }
 void js_launch_dc_scan(hipStream_t st, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, int16_t* dccum, const uint8_t* mcu_rst, void* parts_scratch)
 {

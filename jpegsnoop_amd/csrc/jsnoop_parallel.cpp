@@ -1,6 +1,7 @@
 // jsnoop_parallel.cpp -- host side of the parallel (self-synchronising) entropy path:
 // LUT construction from the DHT code lists, stage launches, and the re-decode of flagged
 // images on the sequential exact-mirror kernel (all on the device; no CPU decode).
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -254,7 +255,7 @@ int js_parallel_entropy_part(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32
     uint32_t* sub = (uint32_t*)b->dev.sub;
     const JsImage* imgs = b->dev.imgs + i0;
     const uint32_t* us_base = b->dev.us_base + i0; const uint32_t* sy_base = b->dev.sy_base + i0; const uint32_t* sn_base = b->dev.sy_base + (N + 1) + i0;
-    uint32_t* flags = b->dev.flags + i0;
+    uint32_t* flags = b->dev.flags + 2 * (size_t)i0;             // two words per image
     const uint32_t us_chunks = b->h_us_base[i0 + n] - b->h_us_base[i0], sy_wgs = b->h_sy_base[i0 + n] - b->h_sy_base[i0], sn_wgs = b->h_sn_base[i0 + n] - b->h_sn_base[i0];
     roctxRangePushA("jsnoop:unstuff");
     js_launch_unstuff(st, b->sub_wl, imgs, us_base, n, us_chunks, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst,
@@ -314,7 +315,7 @@ static int js_parallel_resume(JsnoopBatch* b, int extra_launches)
     HIP_TRY(hipMemsetAsync(b->dev.coef, 0, b->total_blocks * 128, b->stream));
     HIP_TRY(hipMemsetAsync(b->dev.dccum, 0, b->total_blocks * 2, b->stream));
     HIP_TRY(hipMemsetAsync(b->dev.mcu_rst, 0, b->mcu_bytes, b->stream));
-    HIP_TRY(hipMemsetAsync(b->dev.flags, 0, (size_t)n * 4, b->stream));
+    if (js_clear_flags(b)) return -1;
     for (uint32_t i = 0; i < n; i++) HIP_TRY(hipMemsetAsync(b->dev.side + b->imgs[i].side_off + 12, 0, 16, b->stream));
     for (int l = 0; l < extra_launches; l++)
         js_launch_sync(b->stream, b->sub_wl, b->tab_rows, b->tab_lut2, b->dev.imgs, b->dev.sy_base + (n + 1), n, b->sn_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, 0);
@@ -323,7 +324,28 @@ static int js_parallel_resume(JsnoopBatch* b, int extra_launches)
                     b->dev.coef, b->dev.dccum, b->dev.mcu_rst, b->dev.flags);
     js_launch_dc_scan(b->stream, b->dev.imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst, b->dev.dc_parts);
     if (b->launch_back_end(n)) return -1;
-    if (b->d2h_staged(b->host_flags.data(), b->dev.flags, (size_t)n * 4)) return -1;      // (through the page-locked landing buffer)
+    return js_read_flags(b);
+}
+
+static int js_side_scratch(JsnoopBatch* b, uint32_t i, uint32_t** mcu_pos, uint32_t** us_out);
+int js_clear_flags(JsnoopBatch* b)
+{
+    const size_t n = b->imgs.size();
+    if (b->flags_init.size() != 2 * n) { b->flags_init.assign(2 * n, 0u); for (size_t i = 0; i < n; i++) b->flags_init[2 * i + 1] = 0xFFFFFFFFu; b->flags_init_dev = false; }
+    if (!b->flags_init_dev) {                                     // the pattern lives behind the arena itself: clearing is one device-to-device copy
+        HIP_TRY(hipMemcpyAsync(b->dev.flags + 2 * n, b->flags_init.data(), 2 * n * 4, hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream)); b->flags_init_dev = true;
+    }
+    HIP_TRY(hipMemcpyAsync(b->dev.flags, b->dev.flags + 2 * n, 2 * n * 4, hipMemcpyDeviceToDevice, b->stream));
+    return 0;
+}
+int js_read_flags(JsnoopBatch* b)
+{
+    const size_t n = b->imgs.size();
+    std::vector<uint32_t> both(2 * n);
+    if (b->d2h_staged(both.data(), b->dev.flags, 2 * n * 4)) return -1;          // (through the page-locked landing buffer)
+    b->host_flags.resize(n); b->host_anom.resize(n);
+    for (size_t i = 0; i < n; i++) { b->host_flags[i] = both[2 * i]; b->host_anom[i] = both[2 * i + 1]; }
     return 0;
 }
 
@@ -336,7 +358,7 @@ int js_parallel_fixup(JsnoopBatch* b)
         for (uint32_t i = 0; i < n; i++) { b->host_flags[i] = JSNOOP_FLAG_TABLES; b->host_path[i] = 2; }   // outside the parallel path's LUT form)
         return 0;
     }
-    if (b->d2h_staged(b->host_flags.data(), b->dev.flags, (size_t)n * 4)) return -1;      // (through the page-locked landing buffer)
+    if (js_read_flags(b)) return -1;
     // An unconverged chain is not a malformed stream: give it more synchronisation rounds first.
     for (int attempt = 0, extra = 4; attempt < 4; attempt++, extra *= 4) {
         bool nosync = false;
@@ -349,8 +371,48 @@ int js_parallel_fixup(JsnoopBatch* b)
     // and DIB of such an image are already the reference's; what the flag stands for is bookkeeping (scan_bad, the warning counter, two
     // log lines per event), which the side pass produces on request (js_side_only: exact-mirror reader in side-only mode).  It is by far
     // the most common trace a damaged byte leaves (tools/damage_survey.py: 85 % of the flagged files) and no reason for a 1.2 s decode.
-    std::vector<uint32_t> bad;
-    for (uint32_t i = 0; i < n; i++) if (b->host_flags[i] & ~JS_FLAGS_PIXEL_EXACT) { bad.push_back(i); b->host_path[i] = 2; }
+    // Anything else: the parallel path vouches for the blocks before the first anomaly it saw (host_anom); the exact-mirror reader takes over
+    // at the top of the MCU that holds it and decodes from there to the end (k_entropy_exact in tail mode) -- a damaged byte near the end of a
+    // file, a scan that ends a few blocks early or late: milliseconds instead of a sequential decode of the whole file.  An anomaly in the
+    // first MCU (or none recorded), tables outside the LUT form: the whole image through the mirror, as before.
+    static const bool no_tail = getenv("JSNOOP_NO_TAIL") != nullptr;     // (cross-check: every flagged image through the whole mirror)
+    std::vector<uint32_t> bad, tails;
+    for (uint32_t i = 0; i < n; i++) {
+        if (!(b->host_flags[i] & ~JS_FLAGS_PIXEL_EXACT)) continue;
+        const JsImage& im = b->imgs[i];
+        const bool tail_ok = !no_tail && !(b->host_flags[i] & (JSNOOP_FLAG_TABLES | JSNOOP_FLAG_NOSYNC | JSNOOP_FLAG_FORCED)) && b->tables[im.tableset].lut_ok &&
+                             b->host_anom[i] != 0xFFFFFFFFu && b->host_anom[i] / im.blk_per_mcu >= 1u && b->host_anom[i] < im.total_blocks;
+        if (getenv("JSNOOP_DEBUG_TAIL")) fprintf(stderr, "[tail] image %u flags 0x%04x first anomalous block %u (MCU %u of %u) -> %s\n", i, b->host_flags[i], b->host_anom[i],
+                                                 b->host_anom[i] / im.blk_per_mcu, im.mcu_xmax * im.mcu_ymax, tail_ok ? "tail take-over" : "whole mirror");
+        if (tail_ok) tails.push_back(i); else { bad.push_back(i); b->host_path[i] = 2; }
+    }
+    if (!tails.empty()) {
+        HIP_TRY(hipSetDevice(b->device));
+        for (uint32_t i : tails) {
+            const JsImage& im = b->imgs[i];
+            uint32_t *mcu_pos = nullptr, *us_out = nullptr;
+            if (js_side_scratch(b, i, &mcu_pos, &us_out)) return -1;
+            const uint32_t us0 = b->h_us_base[i], usn = b->h_us_base[i + 1] - us0, sy0 = b->h_sy_base[i], syn = b->h_sy_base[i + 1] - sy0;
+            HIP_TRY(hipMemsetAsync(mcu_pos, 0, ((size_t)im.mcu_xmax * im.mcu_ymax + 1) * 4, b->stream));
+            HIP_TRY(hipMemcpyAsync(b->dev.sel, &i, 4, hipMemcpyHostToDevice, b->stream));
+            js_launch_tail_pass(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.us_base, b->dev.sy_base, n, us0, usn, sy0, syn, b->dev.tables, b->dev.raw,
+                                b->dev.chunk_keep, b->dev.chunk_rst, b->dev.ustr, b->dev.seg, b->dev.side, (uint32_t*)b->dev.sub, b->total_subseq,
+                                b->dev.coef, b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out, b->dev.flags, b->dev.sel);
+            HIP_TRY(hipStreamSynchronize(b->stream));              // (dev.sel and the scratch area are reused by the next image)
+            if (getenv("JSNOOP_DEBUG_TAIL")) {
+                const uint32_t ma = b->host_anom[i] / im.blk_per_mcu; uint32_t pos[3] = { 0, 0, 0 };
+                hipMemcpy(pos, mcu_pos + (ma ? ma - 1 : 0), 12, hipMemcpyDeviceToHost);
+                fprintf(stderr, "[tail] image %u: bit positions of MCU tops %u..%u: %u %u %u\n", i, ma ? ma - 1 : 0, (ma ? ma - 1 : 0) + 2, pos[0], pos[1], pos[2]);
+            }
+        }
+        if (bad.empty()) {                                          // pixels of the patched images (and the reductions of all: see below)
+            for (uint32_t i = 0; i < n; i++) { HIP_TRY(hipMemsetAsync(b->dev.side + b->imgs[i].side_off + 12, 0, 16, b->stream)); }
+            if (b->launch_back_end(n)) return -1;
+            HIP_TRY(hipStreamSynchronize(b->stream));
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
+    }
     if (bad.empty()) return 0;
     // The back end already ran on the flagged images' (partial) coefficients; their sums in the side block
     // (brightest pixel, sum of Y) are cleared together with the side block in run_exact and recomputed.
@@ -364,6 +426,21 @@ int js_parallel_fixup(JsnoopBatch* b)
 // request without touching the coefficient / pixel data.  Images the parallel path decoded get them from the
 // parallel side pass (k_write<.., true> + k_side_maps + k_side_tail); images that went through the exact-mirror
 // kernel already have them, and that kernel remains the producer for anything flagged.
+// scratch of the side walk of image i: bit position of every MCU top, then the inverse byte map of the un-stuffing pass
+static int js_side_scratch(JsnoopBatch* b, uint32_t i, uint32_t** mcu_pos, uint32_t** us_out)
+{
+    const JsImage& im = b->imgs[i];
+    const size_t nmcu = (size_t)im.mcu_xmax * im.mcu_ymax, usn = b->h_us_base[i + 1] - b->h_us_base[i];
+    const size_t need = (nmcu + 1 + usn * 256 + 64) * 4;
+    if (need > b->side_tmp_cap) {
+        if (b->d_side_tmp) hipFree(b->d_side_tmp);
+        b->d_side_tmp = nullptr; b->side_tmp_cap = 0;
+        HIP_TRY(hipMalloc((void**)&b->d_side_tmp, need + need / 8));
+        b->side_tmp_cap = need + need / 8;
+    }
+    *mcu_pos = b->d_side_tmp; *us_out = *mcu_pos + ((nmcu + 1 + 15) & ~(size_t)15);
+    return 0;
+}
 int js_side_only(JsnoopBatch* b, uint32_t i)
 {
     HIP_TRY(hipSetDevice(b->device));
@@ -375,14 +452,8 @@ int js_side_only(JsnoopBatch* b, uint32_t i)
     const bool parallel = i < b->host_path.size() && b->host_path[i] == 1 && b->host_flags[i] == 0 && !getenv("JSNOOP_SIDE_EXACT");
     if (parallel) {
         const uint32_t us0 = b->h_us_base[i], usn = b->h_us_base[i + 1] - us0, sy0 = b->h_sy_base[i], syn = b->h_sy_base[i + 1] - sy0;
-        const size_t need = ((size_t)nmcu + 1 + (size_t)usn * 256 + 64) * 4;
-        if (need > b->side_tmp_cap) {
-            if (b->d_side_tmp) hipFree(b->d_side_tmp);
-            b->d_side_tmp = nullptr; b->side_tmp_cap = 0;
-            HIP_TRY(hipMalloc((void**)&b->d_side_tmp, need + need / 8));
-            b->side_tmp_cap = need + need / 8;
-        }
-        uint32_t* mcu_pos = b->d_side_tmp; uint32_t* us_out = mcu_pos + (((size_t)nmcu + 1 + 15) & ~(size_t)15);
+        uint32_t *mcu_pos = nullptr, *us_out = nullptr;
+        if (js_side_scratch(b, i, &mcu_pos, &us_out)) return -1;
         HIP_TRY(hipMemsetAsync(mcu_pos, 0, ((size_t)nmcu + 1) * 4, b->stream));
         if (b->event_words) HIP_TRY(hipMemsetAsync(b->dev.events + im.ev_off, 0, 4, b->stream));   // the pass logs the end-of-scan markers: a repeated pass must not log them twice
         js_launch_side_pass(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.us_base, b->dev.sy_base, (uint32_t)b->imgs.size(), i, us0, usn, sy0, syn,

@@ -1,0 +1,89 @@
+"""GPU: damaged files at device speed.  What the parallel path can vouch for stays (every block before the first anomaly it saw); the
+exact-mirror reader takes over at the top of the MCU that holds the anomaly (k_entropy_exact in tail mode), and once it has run out of
+file bytes ONE decoded MCU is replicated over the rest of the image (a truncated file decodes zeros: CwindowBuf::Buf returns 0 past the
+end, source/WindowBuf.cpp:639).  Everything is compared with the oracle: DIB, planes, and -- through the side-only pass of the whole
+mirror -- MCU file map, block-DC maps, code-length histogram, status words.  Reference behaviour mirrored: coefficient-index overflow
+source/ImgDecode.cpp:1723-1735, bad codes :1178-1186, markers inside the scan :1486-1561, restart handling :1644-1680, scan stop :3623-3625."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _damage(harness, base, kind, frac):
+    p = harness.parse_jpeg(base)
+    d = bytearray(base)
+    i = p.scan_start + int((p.scan_end - p.scan_start) * frac)
+    if kind == "cut":
+        d = d[:i]
+    elif kind == "marker":
+        d[i:i + 2] = b"\xff\xe3"
+    elif kind == "rst":
+        d[i:i] = b"\xff\xd5"
+    elif kind == "rst2":                                              # two restart markers back to back
+        j = next(k for k in range(i, p.scan_end - 1) if d[k] == 0xFF and 0xD0 <= d[k + 1] <= 0xD7)
+        d[j:j] = b"\xff\xd2"
+    elif kind == "delete":
+        del d[i:i + 3]
+    elif kind == "zeros":
+        d[i:i + 40] = bytes(40)
+    elif kind == "ones":
+        d[i:i + 6] = b"\xff\x00" * 3
+    return bytes(d)
+
+
+CASES = [(dict(width=1920, height=1080), "cut", 0.5), (dict(width=1920, height=1080, restart_interval=120), "cut", 0.93),
+         (dict(width=640, height=480), "marker", 0.8), (dict(width=640, height=480, restart_interval=40), "rst", 0.6),
+         (dict(width=640, height=480, hs=1, vs=1, restart_interval=1), "rst2", 0.5), (dict(width=800, height=600, hs=2, vs=1), "delete", 0.9),
+         (dict(width=640, height=480), "zeros", 0.7), (dict(width=640, height=480, gray=1), "ones", 0.85),
+         (dict(width=333, height=217, restart_interval=5), "cut", 0.4)]
+
+
+@pytest.mark.parametrize("kw,kind,frac", CASES)
+def test_damaged_file_is_exact_and_stays_on_the_device_fast_path(harness, oracle, gpu, kw, kind, frac):
+    from fuzz_util import differs
+    base = harness.synth_jpeg(seed=17, **kw)
+    data = _damage(harness, base, kind, frac)
+    harness.drive(oracle, data)
+    harness.drive(gpu, data)
+    if kind not in ("delete", "ones", "zeros"):                       # (lost or overwritten bytes may leave a stream that still parses: nothing to flag)
+        assert gpu.lib.jsnoop_last_flags(gpu.h) != 0, "the damage must leave a trace"
+    assert gpu.lib.jsnoop_last_path(gpu.h) == 1, "the parallel path's blocks must have been kept"
+    assert differs(oracle, gpu) is None
+
+
+def test_truncated_1080p_decodes_in_milliseconds(harness, oracle):
+    import jpegsnoop_amd as J
+    base = harness.synth_jpeg(width=1920, height=1080, seed=23)
+    data = _damage(harness, base, "cut", 0.5)
+    b = J.JpegBatch(); b.add_jpeg(data); b.upload(); b.decode(); b.sync()
+    t = time.perf_counter(); b.decode(); b.sync(); ms = (time.perf_counter() - t) * 1e3
+    harness.drive(oracle, data)
+    assert b.info(0)["path"] == 1 and b.info(0)["flags"] != 0
+    assert np.array_equal(b.dib(0), oracle.dib())
+    assert ms < 100.0, f"{ms:.1f} ms: the sequential mirror over half a 1080p picture of zero bits takes seconds"
+    b.close()
+
+
+def test_damaged_images_inside_a_batch(harness, oracle):
+    import jpegsnoop_amd as J
+    base = harness.synth_jpeg(width=640, height=480, seed=29)
+    files = [base, _damage(harness, base, "cut", 0.6), _damage(harness, base, "marker", 0.3), base, _damage(harness, base, "delete", 0.5),
+             _damage(harness, harness.synth_jpeg(width=640, height=480, seed=30, restart_interval=40), "rst", 0.45)]
+    b = J.JpegBatch(want_planes=True)
+    for f in files:
+        b.add_jpeg(f)
+    b.upload(); b.decode(); b.sync()
+    for i, f in enumerate(files):
+        harness.drive(oracle, f)
+        assert np.array_equal(b.dib(i), oracle.dib()), i
+        for pa, pb in zip(oracle.planes(), b.planes(i)):
+            if pa is not None:
+                assert np.array_equal(pa, pb), i
+        so = b.side_outputs(i)
+        assert np.array_equal(so["mcu_map"], oracle.mcu_map()), i
+        assert {k: int(v) for k, v in so["status"].items()} == {("rst_count" if k == "restart_read" else k): int(v) for k, v in oracle.status().items()}, i
+    assert b.info(0)["flags"] == 0 and all(b.info(i)["path"] == 1 for i in range(len(files)))
+    b.close()

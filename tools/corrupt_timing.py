@@ -12,9 +12,14 @@ for label, kw in (("1080p", dict(width=1920, height=1080)), ("1080p rst", dict(w
                   ("4K", dict(width=3840, height=2160)), ("4K rst", dict(width=3840, height=2160, restart_interval=240))):
     base = H.synth_jpeg(seed=9, **kw)
     p = H.parse_jpeg(base)
-    for where in (None, 0.5, 0.05, 0.95):
+    for where in (None, 0.5, 0.05, 0.95, "cut 0.5", "cut 0.9", "marker 0.3", "delete 0.7"):
         d = bytearray(base)
-        if where is not None:
+        if isinstance(where, str):
+            kind, frac = where.split(); i = p.scan_start + int((p.scan_end - p.scan_start) * float(frac))
+            if kind == "cut": d = d[:i]                                   # a truncated (carved) file
+            elif kind == "marker": d[i:i + 2] = b"\xff\xe3"              # two bytes overwritten by a stray marker
+            else: del d[i:i + 3]                                          # three bytes lost
+        elif where is not None:
             i = p.scan_start + int((p.scan_end - p.scan_start) * where)
             while d[i] == 0xFF or d[i - 1] == 0xFF or (d[i] ^ 0x10) == 0xFF: i += 1     # keep the damage a plain data byte
             d[i] ^= 0x10
