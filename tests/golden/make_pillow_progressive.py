@@ -26,15 +26,16 @@ CASES = [
     dict(name="p420_rst_128x96", w=128, h=96, sub="4:2:0", q=85, restart_rows=1),
     dict(name="p422_rstblk_112x64", w=112, h=64, sub="4:2:2", q=50, restart_blocks=3),
     dict(name="p420_q100_64x48", w=64, h=48, sub="4:2:0", q=100),
+    dict(name="p422_rst_1920x1080", w=1920, h=1080, sub="4:2:2", q=80, restart_rows=1, noise=6),   # BASELINE config 5's shape, written by libjpeg-turbo
 ]
 
 
-def picture(w, h, gray, seed):
+def picture(w, h, gray, seed, noise=14):
     rng = np.random.default_rng(seed)
     yy, xx = np.mgrid[0:h, 0:w]
     chans = []
     for c in range(1 if gray else 3):
-        f = 128 + 90 * np.sin(xx / (7.0 + 3 * c) + c) * np.cos(yy / (5.0 + 2 * c)) + rng.normal(0, 14, (h, w))
+        f = 128 + 90 * np.sin(xx / (7.0 + 3 * c) + c) * np.cos(yy / (5.0 + 2 * c)) + rng.normal(0, noise, (h, w))
         chans.append(np.clip(f, 0, 255).astype(np.uint8))
     return Image.fromarray(chans[0], "L") if gray else Image.fromarray(np.dstack(chans), "RGB")
 
@@ -43,7 +44,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     manifest = []
     for i, c in enumerate(CASES):
-        im = picture(c["w"], c["h"], c["sub"] is None, 1000 + i)
+        im = picture(c["w"], c["h"], c["sub"] is None, 1000 + i, c.get("noise", 14))
         kw = dict(quality=c["q"])
         if c["sub"] is not None:
             kw["subsampling"] = c["sub"]
