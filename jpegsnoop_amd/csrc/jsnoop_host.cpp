@@ -201,6 +201,7 @@ JsnoopBatch::~JsnoopBatch()
                       (void**)&dev.side, (void**)&dev.imgs, (void**)&dev.tables, (void**)&dev.wg_base, (void**)&dev.sel, (void**)&dev.sums,
                       (void**)&dev.sub, (void**)&dev.probe, (void**)&dev.seg, (void**)&dev.chunk_keep, (void**)&dev.chunk_rst, (void**)&dev.us_base,
                       (void**)&dev.sy_base, (void**)&dev.mcu_rst, (void**)&dev.dc_parts, (void**)&dev.flags, (void**)&dev.ustr_lin, (void**)&dev.events }) if (*p) hipFree(*p);
+    delete helper; helper = nullptr;
     if (d_lut) hipFree(d_lut);
     if (d_side_tmp) hipFree(d_side_tmp);
     js_prog_free(this);
@@ -280,6 +281,26 @@ int JsnoopBatch::add_described(const JsImage& desc, const uint8_t* file, size_t 
     imgs.push_back(im); uploaded = false;
     return (int)imgs.size() - 1;
 }
+int JsnoopBatch::add_clone(const JsnoopBatch* src, uint32_t i, bool through_markers)
+{
+    if (i >= src->imgs.size()) { js_set_error("add_clone: image index out of range"); return -1; }
+    JsImage im = src->imgs[i];
+    const JsTableSet& ts = src->tables[im.tableset];
+    const uint8_t* file = src->pinned + im.file_off; const size_t len = im.file_len;
+    if (through_markers) im.scan_len = im.scan_start < im.file_len ? im.file_len - im.scan_start : 0u;
+    const uint64_t off = align_up(raw_bytes, 16);
+    if (reserve_pinned(off + len + 16)) return -1;
+    memset(pinned + raw_bytes, 0, off - raw_bytes);
+    memcpy(pinned + off, file, len); memset(pinned + off + len, 0, 16);
+    raw_bytes = off + len + 16; im.file_off = off;
+    uint32_t tsi = (uint32_t)tables.size();
+    for (uint32_t k = 0; k < tables.size(); k++) if (!memcmp(&tables[k], &ts, sizeof ts)) { tsi = k; break; }
+    if (tsi == tables.size()) tables.push_back(ts);
+    im.tableset = tsi;
+    imgs.push_back(im); uploaded = false;
+    hinfo.resize(imgs.size() - 1); hinfo.push_back((size_t)i < src->hinfo.size() ? src->hinfo[i] : JsImgHost());
+    return (int)imgs.size() - 1;
+}
 int JsnoopBatch::tile(int total)
 {
     // Replicates the batch PHYSICALLY up to `total` images: every copy gets its own file bytes in the pinned staging area
@@ -356,7 +377,7 @@ int JsnoopBatch::upload()
         grow(&dev.sub, &cap.sub, subs * 24 + 64) || grow(&dev.probe, &cap.probe, 1024) || grow(&dev.seg, &cap.seg, segw * 4 + 64) ||
         grow(&dev.chunk_keep, &cap.chunk_keep, (size_t)usc * 4 + 64) || grow(&dev.chunk_rst, &cap.chunk_rst, (size_t)usc * 4 + 64) ||
         grow(&dev.us_base, &cap.us_base, (n + 1) * 4) || grow(&dev.sy_base, &cap.sy_base, 2 * (n + 1) * 4) ||
-        grow(&dev.mcu_rst, &cap.mcu_rst, mcub + 64) || grow(&dev.dc_parts, &cap.dc_parts, JS_DC_PARTS_BYTES) || grow(&dev.ustr_lin, &cap.ustr_lin, ustr + 64) || grow(&dev.flags, &cap.flags, n * 16 + 64)) return -1;
+        grow(&dev.mcu_rst, &cap.mcu_rst, mcub + 64) || grow(&dev.dc_parts, &cap.dc_parts, JS_DC_PARTS_BYTES) || grow(&dev.ustr_lin, &cap.ustr_lin, ustr + 64) || grow(&dev.flags, &cap.flags, n * 8 + 64)) return -1;
     if (opt_want_planes && grow(&dev.planes, &cap.planes, plane * 2)) return -1;
     event_words = opt_events ? (uint64_t)n * (1 + JS_EV_WORDS * JS_EV_MAX) : 0;
     if (event_words && grow(&dev.events, &cap.events, event_words * 4)) return -1;
@@ -372,7 +393,6 @@ int JsnoopBatch::upload()
     HIP_TRY(hipStreamSynchronize(stream));          // host vectors above may go out of scope
     h_us_base = usb; h_sy_base.assign(syb.begin(), syb.begin() + n + 1); h_sn_base.assign(syb.begin() + n + 1, syb.end()); h_wg_base = wg;
     split_parts = (opt_split == 2 && n >= 2) ? 2 : 1;
-    flags_init_dev = false;
     uploaded = true;
     return 0;
 }

@@ -77,7 +77,6 @@ struct JsnoopBatch {
     struct JsImgHost { uint32_t dht_setmax[2] = { 0, 0 }; unsigned err_max = 20; bool display = true; };   // what the per-image report needs beyond the descriptor
     std::vector<JsImgHost> hinfo;
     std::vector<uint8_t> side_done;                               // per image: the side-output pass has run since the last decode
-    std::vector<uint32_t> flags_init; bool flags_init_dev = false; // clear pattern of the flag arena (kept behind it on the device)
     std::vector<uint32_t> host_anom;                              // per image: first block (decode order) the parallel path could not vouch for (0xFFFFFFFF: none)
     std::vector<uint32_t> host_flags, host_path, h_us_base, h_sy_base, h_sn_base, h_wg_base;
     // A large batch decodes as two halves on two streams (stream, aux[0]): the kernels of one half fill the tails and the thinly
@@ -113,6 +112,10 @@ struct JsnoopBatch {
     int  reserve_pinned(size_t need);
     int  add(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned scan_start, int display, int quiet = 1);
     int  add_described(const JsImage& desc, const uint8_t* file, size_t len);
+    // Image i of `src` once more in this batch (same bytes, tables, geometry, options); through_markers: its scan runs to the end of the
+    // file, markers that are no RSTn and FF FF pairs staying in the stream as the data the reference reads them as (BuffAddByte :1486-1561).
+    int  add_clone(const JsnoopBatch* src, uint32_t i, bool through_markers);
+    JsnoopBatch* helper = nullptr; bool is_helper = false;       // a private one-image batch for second attempts at flagged images (js_parallel_fixup)
     int  tile(int total);
     int  upload();
     int  decode(bool timed);
@@ -126,7 +129,7 @@ struct JsnoopBatch {
 
 // flags that leave coefficients, planes and DIB of the parallel path reference-exact (bookkeeping differs: status words, warning counter, log)
 #define JS_FLAGS_PIXEL_EXACT (JSNOOP_FLAG_COEF_OVERFLOW)
-int  js_clear_flags(JsnoopBatch* b);                              // flag arena: {0, 0xFFFFFFFF} per image (flags, first anomalous block)
+int  js_clear_flags(JsnoopBatch* b);                              // flag arena: two words per image (flags, complement of the first anomalous block)
 int  js_read_flags(JsnoopBatch* b);                               // -> host_flags, host_anom
 void js_set_error(const char* fmt, ...);
 // roctx ranges around the host-side stages (rocprofv3 --marker-trace makes a timeline self-describing: upload / clear / entropy

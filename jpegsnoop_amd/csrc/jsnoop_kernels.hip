@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
         // Tail mode: the MCU the mirror takes over at, and everything from there on emptied first -- the mirror stores what it decodes, and
         // MCUs it never reaches (the scan-stop logic after an overread, :3623-3625) must read as the cleared arrays of the reference.
         if (threadIdx.x == 0) {
-            uint32_t m0 = min(tail.flags[2u * sel[j] + 1u] / im.blk_per_mcu, nmcu);
+            uint32_t m0 = min(~tail.flags[2u * sel[j] + 1u] / im.blk_per_mcu, nmcu);
             while (m0 && tail.mcu_pos[m0] == 0u) m0--;             // (an MCU top the side walk did not reach: fall back to an earlier one)
             s_m0 = m0;
         }
@@ -1136,10 +1136,10 @@ void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, 
 #define SYNC_SPEC_TAIL (WL >= 7 ? 2048u : 1024u)   // bits at the end of a sub-sequence the first (speculative) walk covers
 
 // flag arena: two words per image -- [2 * img] the F_* bits, [2 * img + 1] the first block (decode order) at which something other than a
-// coefficient-index overflow was seen (0xFFFFFFFF: none): everything before it is what the reference decodes, and the exact-mirror
+// coefficient-index overflow was seen (stored complemented; 0 = none): everything before it is what the reference decodes, and the exact-mirror
 // reader can take over from the MCU that holds it (k_entropy_exact, tail mode) instead of from the first byte of the scan.
 #define FLAG_OR(flags, img, bits) atomicOr(&(flags)[2u * (img)], (bits))
-#define ANOM_MIN(flags, img, blk) atomicMin(&(flags)[2u * (img) + 1u], (blk))
+#define ANOM_MIN(flags, img, blk) atomicMax(&(flags)[2u * (img) + 1u], ~(uint32_t)(blk))   // kept as the maximum of ~block: "none" is 0, one memset clears the arena
 #define F_BAD_CODE      0x0001u
 #define F_OVERRUN       0x0002u
 #define F_COEF_OVERFLOW 0x0004u
@@ -1175,12 +1175,15 @@ __device__ __forceinline__ UsBytes us_classify(const uint8_t* __restrict__ raw, 
     if (o16 > s && o16 + 17 <= e) {
         // All sixteen bytes, the one before and the one after lie inside the scan (everything but the first and last few threads of an
         // image): the byte rules as word arithmetic.  ff = bytes that are FF, rc = bytes D0..D7 (bit j = byte j of the sixteen).
-        uint32_t ff = 0, rc = 0;
+        uint32_t ff = 0, rc = 0, zb = 0;
         #pragma unroll
-        for (int q = 0; q < 4; q++) { ff |= us_zero_bytes(~w[q]) << (4 * q); rc |= us_zero_bytes((w[q] & 0xF8F8F8F8u) ^ 0xD0D0D0D0u) << (4 * q); }
+        for (int q = 0; q < 4; q++) { ff |= us_zero_bytes(~w[q]) << (4 * q); rc |= us_zero_bytes((w[q] & 0xF8F8F8F8u) ^ 0xD0D0D0D0u) << (4 * q); zb |= us_zero_bytes(w[q]) << (4 * q); }
         const uint32_t rc_next = (next16 & 0xF8u) == 0xD0u ? 1u : 0u;
         const uint32_t is_rst = ff & ((rc >> 1) | (rc_next << 15));            // FF followed by D0..D7
-        const uint32_t after_ff = ((ff << 1) | (prev == 0xFFu ? 1u : 0u)) & 0xFFFFu;   // the byte after an FF: stuffed 00 or the RSTn code
+        // the byte after an FF is dropped when it is the stuffed 00 or the RSTn code; anything else behind an FF (another FF: :1486-1525, a
+        // marker that is no RSTn: :1527-1561) stays in the stream as data, exactly as BuffAddByte keeps it ("skip 1") -- inside a well-formed
+        // scan such bytes do not occur; a scan decoded THROUGH its stray markers (js_parallel_fixup) relies on it
+        const uint32_t after_ff = ((ff << 1) | (prev == 0xFFu ? 1u : 0u)) & 0xFFFFu & (zb | rc);
         r.keep_mask = ~(after_ff | is_rst) & 0xFFFFu; r.rst_mask = is_rst;
         return r;
     }
@@ -1191,7 +1194,7 @@ __device__ __forceinline__ UsBytes us_classify(const uint8_t* __restrict__ raw, 
         const uint32_t nb = j < 15 ? ((w[(j + 1) >> 2] >> (((j + 1) & 3) * 8)) & 255u) : next16;
         const bool in = o >= s && o < e;
         const bool is_rst = in && b == 0xFF && (o + 1 < e) && nb >= 0xD0 && nb <= 0xD7;
-        const bool drop = (prev == 0xFF && o > s) || is_rst;    // the byte after an FF is a stuffed 00 or the RSTn code
+        const bool drop = (prev == 0xFF && o > s && (b == 0x00 || (b >= 0xD0 && b <= 0xD7))) || is_rst;    // the byte after an FF: dropped when it is the stuffed 00 or the RSTn code
         if (in && !drop) r.keep_mask |= 1u << j;
         if (is_rst) r.rst_mask |= 1u << j;
         prev = b;

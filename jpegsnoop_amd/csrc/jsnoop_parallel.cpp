@@ -330,13 +330,7 @@ static int js_parallel_resume(JsnoopBatch* b, int extra_launches)
 static int js_side_scratch(JsnoopBatch* b, uint32_t i, uint32_t** mcu_pos, uint32_t** us_out);
 int js_clear_flags(JsnoopBatch* b)
 {
-    const size_t n = b->imgs.size();
-    if (b->flags_init.size() != 2 * n) { b->flags_init.assign(2 * n, 0u); for (size_t i = 0; i < n; i++) b->flags_init[2 * i + 1] = 0xFFFFFFFFu; b->flags_init_dev = false; }
-    if (!b->flags_init_dev) {                                     // the pattern lives behind the arena itself: clearing is one device-to-device copy
-        HIP_TRY(hipMemcpyAsync(b->dev.flags + 2 * n, b->flags_init.data(), 2 * n * 4, hipMemcpyHostToDevice, b->stream));
-        HIP_TRY(hipStreamSynchronize(b->stream)); b->flags_init_dev = true;
-    }
-    HIP_TRY(hipMemcpyAsync(b->dev.flags, b->dev.flags + 2 * n, 2 * n * 4, hipMemcpyDeviceToDevice, b->stream));
+    HIP_TRY(hipMemsetAsync(b->dev.flags, 0, b->imgs.size() * 8, b->stream));
     return 0;
 }
 int js_read_flags(JsnoopBatch* b)
@@ -345,7 +339,7 @@ int js_read_flags(JsnoopBatch* b)
     std::vector<uint32_t> both(2 * n);
     if (b->d2h_staged(both.data(), b->dev.flags, 2 * n * 4)) return -1;          // (through the page-locked landing buffer)
     b->host_flags.resize(n); b->host_anom.resize(n);
-    for (size_t i = 0; i < n; i++) { b->host_flags[i] = both[2 * i]; b->host_anom[i] = both[2 * i + 1]; }
+    for (size_t i = 0; i < n; i++) { b->host_flags[i] = both[2 * i]; b->host_anom[i] = ~both[2 * i + 1]; }      // (the arena keeps the complement: 0 = none)
     return 0;
 }
 
@@ -376,10 +370,34 @@ int js_parallel_fixup(JsnoopBatch* b)
     // file, a scan that ends a few blocks early or late: milliseconds instead of a sequential decode of the whole file.  An anomaly in the
     // first MCU (or none recorded), tables outside the LUT form: the whole image through the mirror, as before.
     static const bool no_tail = getenv("JSNOOP_NO_TAIL") != nullptr;     // (cross-check: every flagged image through the whole mirror)
+    // Second attempt first, for an image whose entropy data "ended" before its MCUs did although the file goes on: the scan was cut at a
+    // marker that is no RSTn (or at an FF FF pair) -- which the reference does not stop at: it keeps the FF as data, reports it and reads on
+    // (BuffAddByte :1486-1561).  A private one-image batch decodes the same file with the scan running to the end of the file and those
+    // bytes left in the stream (us_classify); its coefficients and cumulative DC replace the image's.  What such bytes change besides
+    // the data is bookkeeping (scan_bad, messages): the side-only pass of the mirror, on request, like for every flagged image.
+    bool patched = false;
+    if (!b->is_helper && !no_tail) for (uint32_t i = 0; i < n; i++) {
+        const JsImage& im = b->imgs[i];
+        if (!(b->host_flags[i] & JSNOOP_FLAG_SHORT) || (b->host_flags[i] & (JSNOOP_FLAG_TABLES | JSNOOP_FLAG_NOSYNC | JSNOOP_FLAG_FORCED))) continue;
+        if ((uint64_t)im.scan_start + im.scan_len + 2 > im.file_len || !b->tables[im.tableset].lut_ok) continue;      // the data really ends with the file
+        if (!b->helper) { b->helper = new JsnoopBatch(nullptr); b->helper->device = b->device; b->helper->is_helper = true; if (b->helper->init()) return -1; }
+        JsnoopBatch* h = b->helper;
+        h->clear(); h->opt_decode_ac = (int)im.decode_ac; h->opt_want_planes = 0; h->opt_force_exact = 0;
+        if (h->add_clone(b, i, true) < 0 || h->upload() || h->decode(false) || h->sync()) return -1;
+        const JsImage& hm = h->imgs[0];
+        if (hm.total_blocks != im.total_blocks) { js_set_error("second attempt: geometry mismatch"); return -1; }
+        HIP_TRY(hipMemcpyAsync(b->dev.coef + im.coef_off * 64, h->dev.coef + hm.coef_off * 64, (size_t)im.total_blocks * 128, hipMemcpyDeviceToDevice, b->stream));
+        HIP_TRY(hipMemcpyAsync(b->dev.dccum + im.coef_off, h->dev.dccum + hm.coef_off, (size_t)im.total_blocks * 2, hipMemcpyDeviceToDevice, b->stream));
+        if (getenv("JSNOOP_DEBUG_TAIL")) fprintf(stderr, "[tail] image %u flags 0x%04x: decoded through the markers of its scan (second attempt: path %u, flags 0x%04x)\n", i, b->host_flags[i], h->host_path[0], h->host_flags[0]);
+        b->host_flags[i] = (b->host_flags[i] & JS_FLAGS_PIXEL_EXACT) | JSNOOP_FLAG_MARKER | (h->host_flags[0] & ~(uint32_t)JSNOOP_FLAG_FORCED);
+        b->host_anom[i] = 0xFFFFFFFFu;                              // nothing left for the tail pass below: the second attempt had its own
+        patched = true;
+    }
     std::vector<uint32_t> bad, tails;
     for (uint32_t i = 0; i < n; i++) {
         if (!(b->host_flags[i] & ~JS_FLAGS_PIXEL_EXACT)) continue;
         const JsImage& im = b->imgs[i];
+        if ((b->host_flags[i] & JSNOOP_FLAG_MARKER) && b->host_anom[i] == 0xFFFFFFFFu) continue;    // resolved by the second attempt
         const bool tail_ok = !no_tail && !(b->host_flags[i] & (JSNOOP_FLAG_TABLES | JSNOOP_FLAG_NOSYNC | JSNOOP_FLAG_FORCED)) && b->tables[im.tableset].lut_ok &&
                              b->host_anom[i] != 0xFFFFFFFFu && b->host_anom[i] / im.blk_per_mcu >= 1u && b->host_anom[i] < im.total_blocks;
         if (getenv("JSNOOP_DEBUG_TAIL")) fprintf(stderr, "[tail] image %u flags 0x%04x first anomalous block %u (MCU %u of %u) -> %s\n", i, b->host_flags[i], b->host_anom[i],
@@ -405,6 +423,9 @@ int js_parallel_fixup(JsnoopBatch* b)
                 fprintf(stderr, "[tail] image %u: bit positions of MCU tops %u..%u: %u %u %u\n", i, ma ? ma - 1 : 0, (ma ? ma - 1 : 0) + 2, pos[0], pos[1], pos[2]);
             }
         }
+        patched = true;
+    }
+    if (patched) {
         if (bad.empty()) {                                          // pixels of the patched images (and the reductions of all: see below)
             for (uint32_t i = 0; i < n; i++) { HIP_TRY(hipMemsetAsync(b->dev.side + b->imgs[i].side_off + 12, 0, 16, b->stream)); }
             if (b->launch_back_end(n)) return -1;
