@@ -50,6 +50,7 @@ def parse_args(argv=None):
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-extras", action="store_true", help="skip the BASELINE config 2 / config 5 / staging-pipeline extras (rank 0, N=1)")
+    ap.add_argument("--no-split", action="store_true", help="skip the two-streams variant of the same batch (profiling runs: keeps the per-kernel averages those of whole-batch launches)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: one job of --job-images mixed-size files, LPT-partitioned over the ranks")
     ap.add_argument("--job-images", type=int, default=8192, help="--strong: files in the whole job (BASELINE config 4 names 8192)")
     ap.add_argument("--stub", action="store_true", help="CPU dry run of the rank logic: stand-in batch, gloo backend (tests)")
@@ -156,6 +157,16 @@ def _cpu_worker(reps):
     return reps, time.perf_counter() - t, time.process_time() - c
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_all_cores(args, rank):
     """The same CPU path on every host core: independent decoder instances, one per process (the reference is single-threaded,
     DoBatchFileProcess run N-wide is N instances) -- bounded to a few seconds."""
@@ -250,6 +261,36 @@ def extras_single_gpu(J, H, orc, np):
                                                       "bit_exact_vs_baseline_encoding": ok5b, "speedup_vs_single_call": round(ms5 / (ms5b / nb5), 1),
                                                       "stages_ms": {"scans": round(st5b["write"], 3), "finalize": round(st5b["dcscan"], 3), "idct_color": round(st5b["idct_color"], 3)}}
         p5.close()
+    # damaged files (JPEGsnoop's daily input): one 1080p file each, decode + sync of a resident batch of one, DIB checked against the oracle.
+    # "flip": the scan bit flips of tools/corrupt_timing.py that leave a trace (coefficient-index overflow); "cut": truncated at half its
+    # scan (the rest decodes as the zero bytes CwindowBuf::Buf returns past the end); "marker": two bytes overwritten by a stray marker
+    dmg = {}
+    for label, kwd in (("1080p", dict(width=1920, height=1080)), ("1080p_rst", dict(width=1920, height=1080, restart_interval=120))):
+        based = H.synth_jpeg(seed=9, **kwd)
+        pd = H.parse_jpeg(based)
+        for kind, frac in (("flip", 0.95), ("cut", 0.5), ("marker", 0.3)):
+            d = bytearray(based)
+            i = pd.scan_start + int((pd.scan_end - pd.scan_start) * frac)
+            if kind == "flip":
+                while d[i] == 0xFF or d[i - 1] == 0xFF or (d[i] ^ 0x10) == 0xFF:
+                    i += 1
+                d[i] ^= 0x10
+            elif kind == "cut":
+                d = d[:i]
+            else:
+                d[i:i + 2] = b"\xff\xe3"
+            d = bytes(d)
+            bd = J.JpegBatch(); bd.add_jpeg(d); bd.upload(); bd.decode(); bd.sync()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                bd.decode(); bd.sync()
+            msd = (time.perf_counter() - t0) / 3 * 1e3
+            H.drive(orc, d)
+            inf = bd.info(0)
+            dmg["%s_%s" % (label, kind)] = {"ms": round(msd, 3), "path": int(inf["path"]), "flags": "0x%04x" % inf["flags"],
+                                            "bit_exact": bool(int(bd.dib_checksums()[0]) == J.dib_checksum_numpy(orc.dib()))}
+            bd.close()
+    extra["damaged_files"] = dmg
     # the baseline (SOF0) form of config 5 through the batch path, oracle-checked directly
     b5 = J.JpegBatch(); b5.add_jpeg(base5); b5.upload(); b5.decode(); b5.sync()
     msb, _ = b5.decode_timed(10)
@@ -470,7 +511,7 @@ def main():
                   "ms_spread": round((max(per_rank_ms) - min(per_rank_ms)) / max(per_rank_ms), 4) if max(per_rank_ms) > 0 else 0.0}
 
     extra = {}
-    if rank == 0 and world == 1 and not stub and not args.strong:
+    if rank == 0 and world == 1 and not stub and not args.strong and not args.no_split:
         # the same resident batch as two halves on two streams (jsnoop_batch_set_split): beside the headline, which stays the one-stream
         # form -- the per-kernel timings of a split decode are those of launches that share the chip
         try:
@@ -520,7 +561,7 @@ def main():
                          "stages_ms": {k: round(v, 4) for k, v in stages.items()}},
         }
         if budget > 0 and n_cpu:
-            out["cpu_baseline"] = {"value": round(n_cpu * args.width * args.height / cpu_time / 1e6, 2), "unit": "Mpixels/s", "cores": 1,
+            out["cpu_baseline"] = {"value": round(n_cpu * args.width * args.height / cpu_time / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "cpu_model": cpu_model(),
                                    "kind": "port", "sample": f"{n_cpu} x {args.width}x{args.height} 4:2:0 images of this workload, oracle/oracle_imgdecode.c, "
                                                              f"1 thread, {cpu_time:.1f} s"}
             if ref_info:

@@ -216,6 +216,28 @@ public:
         nX = info[2]; nY = info[3]; dib.resize((size_t)nX * nY * 4);
         return jsnoop_batch_read_dib(m_b, nFileInd, dib.data()) == 0;
     }
+    // ---- what the per-file pass of DoBatchFileProcess leaves behind besides pixels (:805-808 DoLogSave; log body ImgDecode.cpp:3021-3745)
+    void     BatchSetOptions(bool bDecodeScanImgAc, bool bKeepPixMaps) { jsnoop_batch_set_options(m_b, bDecodeScanImgAc, bKeepPixMaps, 0); }   // before DoBatchProcess
+    bool     BatchEnableLog(bool bOn = true) { return jsnoop_batch_enable_log(m_b, bOn) == 0; }                                               // before DoBatchProcess
+    // the DecodeScanImg text of file nFileInd, one std::string per CDocLog line ("W:" / "E:" prefixed like AddLineWarn / AddLineErr colour them)
+    bool     BatchGetLog(int nFileInd, std::vector<std::string>& lines, bool bHistoEn = false, bool bStatClipEn = false, bool bQuiet = false)
+    {
+        lines.clear();
+        auto thunk = [](void* u, int lvl, const char* txt) { static_cast<std::vector<std::string>*>(u)->push_back(std::string(lvl == 2 ? "E:" : lvl == 1 ? "W:" : "") + txt); };
+        return jsnoop_batch_log(m_b, nFileInd, bHistoEn, bStatClipEn, bQuiet, thunk, &lines) == 0;
+    }
+    // DoLogSave (:807 -> source/JPEGsnoopCore.cpp:150-220) for the scan-decode part of the report: the lines above into a text file
+    bool     BatchLogSave(int nFileInd, const std::string& strLogName, bool bHistoEn = false)
+    {
+        std::vector<std::string> lines; if (!BatchGetLog(nFileInd, lines, bHistoEn)) return false;
+        FILE* f = fopen(strLogName.c_str(), "w"); if (!f) return false;
+        for (const std::string& l : lines) fprintf(f, "%s\n", l.c_str());
+        return fclose(f) == 0;
+    }
+    // m_pMcuFileMap / m_pBlkDcVal* / m_anDhtHisto / scan status / brightest pixel + average Y of file nFileInd (any pointer may be null)
+    bool     BatchGetSideOutputs(int nFileInd, uint32_t* pMcuFileMap, int16_t* pBlkDcY, int16_t* pBlkDcCb, int16_t* pBlkDcCr, uint32_t* pDhtHisto, unsigned* pStatus8, int* pBrightAvg10)
+    { return jsnoop_batch_side_outputs(m_b, nFileInd, pMcuFileMap, pBlkDcY, pBlkDcCb, pBlkDcCr, pDhtHisto, pStatus8, pBrightAvg10) == 0; }
+    bool     BatchExportTiff(int nFileInd, const std::string& strFname, int nMode = 0) { return jsnoop_batch_export_tiff(m_b, nFileInd, strFname.c_str(), nMode) == 0; }
     CimgDecodeGpu* ImgDec() { return m_pImgDec; }
     JsnoopBatch* Handle() { return m_b; }
 private:

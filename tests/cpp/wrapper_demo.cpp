@@ -35,6 +35,16 @@ int main(int argc, char** argv)
         std::vector<uint8_t> d2; unsigned bx, by;
         core.BatchGetBitmap(2, d2, bx, by);
         printf("batch count=%u size=%ux%u dib_fnv=%016llx\n", core.GetBatchFileCount(), bx, by, (unsigned long long)fnv(d2.data(), d2.size()));
+        {   // the per-file pass of the batch loop: log text and decoder side outputs of file 1, next to the single-file decoder's
+            CJPEGsnoopCoreGpu logcore;
+            logcore.BatchSetOptions(true, true); logcore.BatchEnableLog();
+            for (int i = 0; i < 2; i++) logcore.BatchAddFile(bytes.data(), bytes.size());
+            std::vector<std::string> lines; std::vector<uint32_t> mm((size_t)(x / 8) * (y / 8) + 16); unsigned st8[8] = {0}; int ba[10] = {0};
+            const bool ok = logcore.DoBatchProcess() && logcore.BatchGetLog(1, lines) && logcore.BatchGetSideOutputs(1, mm.data(), nullptr, nullptr, nullptr, nullptr, st8, ba);
+            size_t fin = 0; for (size_t i = 0; i < lines.size(); i++) if (lines[i].find("Finished Decoding SCAN Data") != std::string::npos) fin = i;
+            printf("batchlog ok=%d lines=%zu first=[%s] finished_at=%zu mcu0=%u.%u pixels=%u bright_valid=%d\n", (int)ok, lines.size(), lines.empty() ? "" : lines[0].c_str(), fin,
+                   mm[0] >> 4, mm[0] & 7, st8[3], ba[0]);
+        }
         // the core facade: AnalyzeFile-shaped entry, I_* accessors, a byte overlay (the reference's fault-injection tool) and the re-decode
         if (!core.AnalyzeFile(argv[1]) || !core.IsAnalyzed()) { printf("analyze_failed %s\n", jsnoop_last_error()); return 1; }
         unsigned cx = 0, cy = 0; core.I_GetImageSize(cx, cy);

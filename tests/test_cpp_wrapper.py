@@ -50,6 +50,11 @@ def test_wrapper_decodes_like_the_oracle(harness, oracle, tmp_path):
     mm = oracle.mcu_map()[0, 0]
     assert f"mcu0={mm >> 4}.{mm & 7}" in lines["single"]
     assert f"dib_fnv={want}" in lines["batch"] and "count=3" in lines["batch"]
+    # the per-file pass of the batch loop through the C++ facade: log text + side outputs of a batch image
+    bl = lines["batchlog"]
+    assert "ok=1" in bl and "first=[*** Decoding SCAN Data ***]" in bl and "finished_at=" in bl and " finished_at=0 " not in bl
+    mm0 = oracle.mcu_map()[0, 0]
+    assert f"mcu0={mm0 >> 4}.{mm0 & 7}" in bl and f"pixels={int(oracle.status()['num_pixels'])}" in bl and "bright_valid=1" in bl
     # the CJPEGsnoopCore facade: AnalyzeFile, I_* accessors, overlay + re-decode
     core = lines["core"]
     assert f"dib_fnv={want}" in core and "ready=1" in core and "size=336x224" in core

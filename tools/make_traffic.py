@@ -9,7 +9,7 @@ txt = open(summary).read()
 blk = re.search(r"^%s\n((?:   .*\n)+)" % re.escape(kernel), txt, re.M).group(1)
 vals = {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s+(\S+)\s+([0-9.]+) per dispatch", blk, re.M)}
 hbm = 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024
-json.dump({"kernel": {"k_idct_color": "idct_color", "k_write": "write", "k_sync": "sync"}.get(kernel, kernel), "images_per_launch": images,
+json.dump({"kernel": {"k_idct_color": "idct_color", "k_write": "write", "k_sync": "sync"}.get(kernel.split("<")[0], kernel), "images_per_launch": images,
            "hbm_bytes_per_launch": int(hbm), "fetch_size_kib": vals["FETCH_SIZE"], "write_size_kib": vals["WRITE_SIZE"],
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), 2*FETCH+WRITE, %s" % summary}, open(out, "w"), indent=1)
 print(open(out).read())

@@ -6,7 +6,7 @@ TAG=${1:-pmc}; shift || true
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS=${@:---images 256 --distinct 16 --steps 2 --warmup 1 --cpu-seconds 0 --no-extras}
+ARGS=${@:---images 256 --distinct 16 --steps 2 --warmup 1 --cpu-seconds 0 --no-extras --no-split}
 GROUPS_MAX=${PMC_GROUPS:-6}
 i=0
 for GROUP in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \

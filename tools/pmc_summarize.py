@@ -5,7 +5,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for f in sorted(glob.glob(os.path.join(root, "p*", "*counter_collection.csv"))):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            k = row["Kernel_Name"].split("(")[0]
+            k = row["Kernel_Name"].split("(")[0].replace("void ", "")      # "void k_idct_color<1>(...)" -> "k_idct_color<1>"
             agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); cnt[k][row["Counter_Name"]] += 1
 for k in sorted(agg):
     print(k)

@@ -8,7 +8,7 @@ ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT/stats
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- python $ROOT/bench.py --steps 10 --warmup 2 --cpu-seconds 0 --no-extras > $OUT/bench_line.json 2> $OUT/bench_stderr.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- python $ROOT/bench.py --steps 10 --warmup 2 --cpu-seconds 0 --no-extras --no-split > $OUT/bench_line.json 2> $OUT/bench_stderr.log
 tail -1 $OUT/bench_line.json > $OUT/bench.json
 find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 cd $ROOT && bash tools/pmc_collect.sh $TAG/pmc > /dev/null 2>&1
