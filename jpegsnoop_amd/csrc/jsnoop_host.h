@@ -76,6 +76,8 @@ struct JsnoopBatch {
     std::vector<JsImage> imgs; std::vector<JsTableSet> tables;
     struct JsImgHost { uint32_t dht_setmax[2] = { 0, 0 }; unsigned err_max = 20; bool display = true; };   // what the per-image report needs beyond the descriptor
     std::vector<JsImgHost> hinfo;
+    std::vector<uint8_t> side_mode;                               // per image: who produced its side outputs last (1 = parallel side pass, 2 = the exact-mirror reader)
+    std::vector<std::vector<uint32_t>> side_anoms;                // per image: the coefficient-index overflows of the side walk, in block order (4 words each)
     std::vector<uint8_t> side_done;                               // per image: the side-output pass has run since the last decode
     std::vector<uint32_t> host_anom;                              // per image: first block (decode order) the parallel path could not vouch for (0xFFFFFFFF: none)
     std::vector<uint32_t> host_flags, host_path, h_us_base, h_sy_base, h_sn_base, h_wg_base;

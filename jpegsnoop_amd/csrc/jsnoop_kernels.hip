@@ -48,6 +48,7 @@ struct ExactReader {
     uint32_t scan_end, scan_bad, cur_err, restart_read;
     uint32_t rst_count, rst_last, rst_expect, mcus_left, rst_interval, warn_bad, err_max;
     uint32_t used1, used2, precision, rst_handled;
+    uint32_t warn_marker;                                      // of warn_bad: the "Scan Data encountered marker" messages alone
     uint32_t* ev; uint32_t ev_cap, ev_only;                    // event log (JS_EV_*): nullptr = off; ev_only != 0: record just that kind
     uint64_t win; uint32_t win_at;                             // 8 file bytes in registers (file images are 16-byte aligned and zero padded)
     const uint32_t* fast;                                      // m_anDhtLookupfast of the six slots, [6][1 << JS_FAST_BITS] (LDS copy in k_entropy_exact)
@@ -113,7 +114,7 @@ __device__ void ex_add_byte(ExactReader& r)                                     
     }
     if (b0 == 0xFF && b1 == 0x00)      { ex_add(r, b0, r.ptr, SB_OK); r.ptr += 2; }
     else if (b0 == 0xFF && b1 == 0xFF) { ex_add(r, b0, r.ptr, SB_OK); r.ptr += 1; }
-    else if (b0 == 0xFF)               { if (r.warn_bad < r.err_max) { ex_event(r, JS_EV_MARKER, b1, r.ptr); r.warn_bad++; } ex_add(r, b0, r.ptr, SB_BADMARK); r.ptr += 1; }
+    else if (b0 == 0xFF)               { if (r.warn_bad < r.err_max) { ex_event(r, JS_EV_MARKER, b1, r.ptr); r.warn_bad++; r.warn_marker++; } ex_add(r, b0, r.ptr, SB_BADMARK); r.ptr += 1; }
     else                               { ex_add(r, b0, r.ptr, SB_OK); r.ptr += 1; }
 }
 __device__ void ex_topup(ExactReader& r)                                                // BuffTopup :1292-1323
@@ -279,7 +280,7 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
 
     ExactReader r;
     r.file = raw + im.file_off; r.flen = im.file_len; r.ts = tables + im.tableset; r.histo = s_histo; r.fast = s_fast; r.meta = s_meta; r.q = s_q; r.zz = s_zz; r.win_at = 0xFFFFFFFFu; r.win = 0;
-    r.rst_interval = im.rst_interval; r.precision = im.precision; r.err_max = im.err_max; r.warn_bad = 0;
+    r.rst_interval = im.rst_interval; r.precision = im.precision; r.err_max = im.err_max; r.warn_bad = 0; r.warn_marker = 0;
     r.rst_count = 0; r.rst_last = 0; r.rst_expect = 0; r.rst_handled = 0;
     r.ev = (im.ev_cap && events) ? events + im.ev_off : nullptr; r.ev_cap = im.ev_cap; r.ev_only = 0;       // (side-only passes log when the caller hands the event area over)
     ex_restart_scan_buf(r, im.scan_start, false);
@@ -1827,7 +1828,15 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
                 norm = false;
             } else if (active && blk < nblocks) {
                 if (cur.p + tot > seg_end) { fl |= F_OVERRUN; an = min(an, blk); }
-                if (k2 > 64u) fl |= F_COEF_OVERFLOW;
+                if (k2 > 64u) {
+                    fl |= F_COEF_OVERFLOW;
+                    // side pass: what the reference's two messages about this block quote (:1723-1735 "nNumCoeffs>64", CheckScanErrors :2605) --
+                    // the block, where the offending symbol starts, the index it ran to, where the block ends.  `flags` is the record list here.
+                    if (SIDE && flags && !captured) {
+                        const uint32_t slot = atomicAdd(&flags[0], 1u);
+                        if (slot < JS_ANOM_MAX) { uint32_t* e = flags + 4 + 4 * slot; e[0] = blk; e[1] = cur.p; e[2] = k2; e[3] = cur.p + tot; }
+                    }
+                }
             }
         }
         // value bits: EXTEND (HuffmanDc2Signed :859), precision divide (:1234-1238), dequantise (:2278)
@@ -2320,7 +2329,7 @@ __device__ uint32_t mirror_to_mcu_top(const JsImage& im, const JsTableSet* __res
     for (int i = 0; i < 6; i++) { meta12[i] = r.ts->size[i]; meta12[6 + i] = r.ts->dest_id[i]; }
     // the markers the look-ahead runs into at the end of the scan (":  Scan Data encountered marker", :1536) are logged from here
     r.ev = (events && im.ev_cap) ? events + im.ev_off : nullptr; r.ev_cap = im.ev_cap; r.ev_only = JS_EV_MARKER;
-    r.rst_interval = im.rst_interval; r.precision = im.precision; r.err_max = im.err_max; r.warn_bad = 0;
+    r.rst_interval = im.rst_interval; r.precision = im.precision; r.err_max = im.err_max; r.warn_bad = 0; r.warn_marker = 0;
     r.rst_count = 0; r.rst_last = 0; r.rst_expect = 0; r.rst_handled = 0;
     uint32_t m0 = m_top ? m_top - 1 : 0, rst_before = 0;
     for (;; m0--) {
@@ -2354,7 +2363,7 @@ __device__ uint32_t mirror_to_mcu_top(const JsImage& im, const JsTableSet* __res
 __global__ void __launch_bounds__(256) k_side_maps(const JsImage* __restrict__ imgs, uint32_t img, const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ raw,
                                                    const uint32_t* __restrict__ seg_tab, const int16_t* __restrict__ dccum, const uint8_t* __restrict__ mcu_rst,
                                                    const uint32_t* __restrict__ mcu_pos, const uint32_t* __restrict__ us_out, uint32_t us_threads,
-                                                   uint32_t* __restrict__ side, uint32_t* __restrict__ events)
+                                                   uint32_t* __restrict__ side, uint32_t* __restrict__ events, uint32_t* __restrict__ anoms)
 {
     const JsImage& im = imgs[img];
     uint32_t* sd = side + im.side_off;
@@ -2379,6 +2388,7 @@ __global__ void __launch_bounds__(256) k_side_maps(const JsImage* __restrict__ i
             else {                                                  // status words after the last MCU
                 sd[0] = r.scan_bad; sd[1] = r.scan_end; sd[2] = before + r.rst_count; sd[3] = nmcu * im.samp_h[1] * im.samp_v[1] * 64u;
                 sd[4] = r.pos0; sd[5] = r.align; sd[6] = r.warn_bad; sd[7] = im.scan_start;
+                if (anoms) anoms[1] = r.warn_marker;              // (an image with overflow records: its counter is put together on the host)
             }
         } else mcu_map[m] = (raw_of_compacted(im, raw, us_out, us_threads, ub) << 4) + a;
     }
@@ -2404,21 +2414,21 @@ __global__ void __launch_bounds__(256) k_side_maps(const JsImage* __restrict__ i
 void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* us_base, const uint32_t* sy_base, uint32_t nimg,
                          uint32_t img, uint32_t us_wg0, uint32_t us_wgs, uint32_t sy_wg0, uint32_t sy_wgs, const JsTableSet* tables, const uint8_t* raw,
                          const uint32_t* chunk_keep, const uint32_t* chunk_rst, const uint8_t* ustr, uint32_t* seg_tab, uint32_t* side, uint32_t* sub, uint64_t nsub,
-                         const int16_t* dccum, uint8_t* mcu_rst, uint32_t* mcu_pos, uint32_t* us_out, uint32_t* events)
+                         const int16_t* dccum, uint8_t* mcu_rst, uint32_t* mcu_pos, uint32_t* us_out, uint32_t* events, uint32_t* anoms)
 {
     if (!us_wgs || !sy_wgs) return;
     hipLaunchKernelGGL(k_unstuff_write, dim3(us_wgs), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, (uint8_t*)nullptr, seg_tab, us_wg0, us_out);
     if (wl == 4) hipLaunchKernelGGL((k_write<4, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
-                       sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos);
+                       sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, anoms, tab_rows, tab_lut2, sy_wg0, mcu_pos);
     else if (wl == 6) hipLaunchKernelGGL((k_write<6, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
-                       sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos);
+                       sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, anoms, tab_rows, tab_lut2, sy_wg0, mcu_pos);
     else if (wl == 8) hipLaunchKernelGGL((k_write<8, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
-                       sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos);
+                       sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, anoms, tab_rows, tab_lut2, sy_wg0, mcu_pos);
     else if (wl == 7) hipLaunchKernelGGL((k_write<7, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
-                       sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos);
+                       sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, anoms, tab_rows, tab_lut2, sy_wg0, mcu_pos);
     else hipLaunchKernelGGL((k_write<5, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
-                       sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos);
-    hipLaunchKernelGGL(k_side_maps, dim3(64), dim3(256), 0, st, imgs, img, tables, raw, seg_tab, dccum, mcu_rst, mcu_pos, us_out, us_wgs * US_THREADS, side, events);
+                       sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, anoms, tab_rows, tab_lut2, sy_wg0, mcu_pos);
+    hipLaunchKernelGGL(k_side_maps, dim3(64), dim3(256), 0, st, imgs, img, tables, raw, seg_tab, dccum, mcu_rst, mcu_pos, us_out, us_wgs * US_THREADS, side, events, anoms);
 }
 // Tail take-over for image `img` of a decoded batch (see ExactTail): the inverse byte map and the MCU bit positions through the first two
 // kernels of the side pass, then the mirror reader from the MCU that holds the first block the parallel path could not vouch for.

@@ -452,7 +452,7 @@ static int js_side_scratch(JsnoopBatch* b, uint32_t i, uint32_t** mcu_pos, uint3
 {
     const JsImage& im = b->imgs[i];
     const size_t nmcu = (size_t)im.mcu_xmax * im.mcu_ymax, usn = b->h_us_base[i + 1] - b->h_us_base[i];
-    const size_t need = (nmcu + 1 + usn * 256 + 64) * 4;
+    const size_t need = (nmcu + 1 + usn * 256 + 64 + 16 + 4 + 4 * (size_t)JS_ANOM_MAX) * 4;     // ... and the overflow records of the side walk behind it
     if (need > b->side_tmp_cap) {
         if (b->d_side_tmp) hipFree(b->d_side_tmp);
         b->d_side_tmp = nullptr; b->side_tmp_cap = 0;
@@ -470,17 +470,69 @@ int js_side_only(JsnoopBatch* b, uint32_t i)
     const size_t words = js_side_words(nmcu, im.blk_xmax * im.blk_ymax);
     HIP_TRY(hipMemsetAsync(b->dev.side + im.side_off, 0, 8 * 4, b->stream));
     HIP_TRY(hipMemsetAsync(b->dev.side + im.side_off + JS_SIDE_HISTO, 0, (words - JS_SIDE_HISTO) * 4, b->stream));
-    const bool parallel = i < b->host_path.size() && b->host_path[i] == 1 && b->host_flags[i] == 0 && !getenv("JSNOOP_SIDE_EXACT");
+    // An image whose only flag is the coefficient-index overflow walks exactly as the reference does (js_parallel_fixup): its maps,
+    // histogram and final position come from the parallel side pass like a clean image's; what the overflows add -- scan_bad, the
+    // warning counter, two messages per block -- is bookkeeping worked out below from the records the side walk leaves.
+    bool parallel = i < b->host_path.size() && b->host_path[i] == 1 && (b->host_flags[i] & ~JS_FLAGS_PIXEL_EXACT) == 0 && !getenv("JSNOOP_SIDE_EXACT");
+    if (b->side_mode.size() != b->imgs.size()) { b->side_mode.assign(b->imgs.size(), 0); b->side_anoms.assign(b->imgs.size(), std::vector<uint32_t>()); }
+    b->side_anoms[i].clear();
     if (parallel) {
         const uint32_t us0 = b->h_us_base[i], usn = b->h_us_base[i + 1] - us0, sy0 = b->h_sy_base[i], syn = b->h_sy_base[i + 1] - sy0;
         uint32_t *mcu_pos = nullptr, *us_out = nullptr;
         if (js_side_scratch(b, i, &mcu_pos, &us_out)) return -1;
+        uint32_t* anoms = us_out + (((size_t)usn * 256 + 64 + 15) & ~(size_t)15);
+        HIP_TRY(hipMemsetAsync(anoms, 0, 16, b->stream));
         HIP_TRY(hipMemsetAsync(mcu_pos, 0, ((size_t)nmcu + 1) * 4, b->stream));
         if (b->event_words) HIP_TRY(hipMemsetAsync(b->dev.events + im.ev_off, 0, 4, b->stream));   // the pass logs the end-of-scan markers: a repeated pass must not log them twice
         js_launch_side_pass(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.us_base, b->dev.sy_base, (uint32_t)b->imgs.size(), i, us0, usn, sy0, syn,
                             b->dev.tables, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst, b->dev.ustr, b->dev.seg, b->dev.side, (uint32_t*)b->dev.sub, b->total_subseq,
-                            b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out, b->event_words ? b->dev.events : nullptr);
-    } else {
+                            b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out, b->event_words ? b->dev.events : nullptr, b->host_flags[i] ? anoms : nullptr);
+        if (b->host_flags[i]) {
+            // overflow records -> bookkeeping.  Not representable here (more records than the list holds; a block that ends on the last bit of
+            // a restart interval, where the reader's position array shows a stale slot): the mirror's side-only pass below.
+            std::vector<uint32_t> rec(4 + 4 * (size_t)JS_ANOM_MAX);
+            if (b->d2h_staged(rec.data(), anoms, rec.size() * 4)) return -1;
+            const uint32_t cnt = rec[0];
+            bool ok = cnt <= JS_ANOM_MAX;
+            std::vector<std::pair<uint32_t, uint32_t>> order;                  // (block, record)
+            for (uint32_t k = 0; ok && k < cnt; k++) order.emplace_back(rec[4 + 4 * k], k);
+            std::sort(order.begin(), order.end());
+            uint32_t sdw[16];
+            if (ok && b->d2h_staged(sdw, b->dev.side + im.side_off, sizeof sdw)) return -1;
+            if (ok && sdw[11] > 1) {                                           // restart intervals: refuse block ends that sit on an interval boundary
+                const uint32_t nseg = std::min<uint32_t>(sdw[11], im.seg_cap - 1);
+                std::vector<uint32_t> st(nseg + 1);
+                if (b->d2h_staged(st.data(), b->dev.seg + im.seg_off, st.size() * 4)) return -1;
+                for (auto& o : order) { const uint32_t pe = rec[4 + 4 * o.second + 3]; if (!(pe & 7u) && std::binary_search(st.begin(), st.end(), pe >> 3)) ok = false; }
+            }
+            if (ok) {
+                std::vector<uint32_t>& out = b->side_anoms[i];
+                for (auto& o : order) for (int q = 0; q < 4; q++) out.push_back(rec[4 + 4 * o.second + q]);
+                // status words: scan_bad, and the warning counter the messages share (each overflow: up to two counted messages, then the
+                // markers the look-ahead meets at the end of the scan, which the side pass counted from zero)
+                const uint32_t emax = im.err_max, w = std::min<uint32_t>(emax, std::min<uint32_t>(2 * cnt, emax) + rec[1]);   // rec[1]: the end-of-scan markers alone (k_side_maps)
+                // (scan_bad is cleared by every restart, DecodeRestartScanBuf :4038-4075: it stays set only for an overflow behind the last marker)
+                uint32_t one = sdw[0];
+                if (cnt) {
+                    uint32_t m_last = 0;
+                    if (sdw[11] > 1) {
+                        std::vector<uint8_t> rf(nmcu);
+                        if (b->d2h_staged(rf.data(), b->dev.mcu_rst + im.mcu_off, nmcu)) return -1;
+                        for (uint32_t m = 0; m < nmcu; m++) if (rf[m]) m_last = m;
+                    }
+                    if (order.back().first / im.blk_per_mcu >= m_last) one = 1u;
+                }
+                HIP_TRY(hipMemcpyAsync(b->dev.side + im.side_off + 0, &one, 4, hipMemcpyHostToDevice, b->stream));
+                HIP_TRY(hipMemcpyAsync(b->dev.side + im.side_off + 6, &w, 4, hipMemcpyHostToDevice, b->stream));
+                HIP_TRY(hipStreamSynchronize(b->stream));
+            } else parallel = false;
+        }
+    }
+    if (parallel) b->side_mode[i] = 1;
+    else {
+        b->side_mode[i] = 2;
+        HIP_TRY(hipMemsetAsync(b->dev.side + im.side_off, 0, 8 * 4, b->stream));
+        HIP_TRY(hipMemsetAsync(b->dev.side + im.side_off + JS_SIDE_HISTO, 0, (words - JS_SIDE_HISTO) * 4, b->stream));
         // (an image of the parallel path whose flags are bookkeeping only: the mirror reader's messages are part of that bookkeeping)
         const bool with_events = b->event_words && i < b->host_path.size() && b->host_path[i] == 1;
         if (with_events) HIP_TRY(hipMemsetAsync(b->dev.events + im.ev_off, 0, 4, b->stream));

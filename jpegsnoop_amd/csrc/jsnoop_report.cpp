@@ -72,7 +72,8 @@ void js_emit_decode_events(JsnoopDecoder* d)
     // clean image of the parallel path: only the end-of-scan markers come from the device (parallel side pass), the restart bookkeeping is
     // derived below; otherwise the exact-mirror reader wrote every message itself (at decode time, or in the side-only pass of an
     // image whose flags are bookkeeping only)
-    const bool derived = d->last_path == 1 && d->last_flags == 0;
+    // ... or the parallel side pass with its overflow records (js_side_only says which of the two produced the side outputs)
+    const bool derived = d->last_path == 1 && ((size_t)d->img < b->side_mode.size() && b->side_mode[d->img] ? b->side_mode[d->img] == 1 : d->last_flags == 0);
     for (uint32_t i = 0; i < n; i++) {
         Ev e; e.kind = raw[1 + i * JS_EV_WORDS]; for (int k = 0; k < 5; k++) e.a[k] = raw[2 + i * JS_EV_WORDS + k];
         e.order = ((uint64_t)(derived ? nmcu : 0) << 32) | (2u << 28) | i;
@@ -103,10 +104,44 @@ void js_emit_decode_events(JsnoopDecoder* d)
             }
             if (im.rst_en) left--;
         }
+        // Coefficient-index overflows (records of the side walk, block order): "nNumCoeffs>64" where the offending symbol starts (:1723-1735),
+        // then CheckScanErrors' two lines at the end of the block (:2605-2650).  Positions are file offsets of bytes of the un-stuffed
+        // stream: one pass over the scan bytes with the byte rules of BuffAddByte resolves them.
+        if ((size_t)d->img < b->side_anoms.size() && !b->side_anoms[d->img].empty()) {
+            const std::vector<uint32_t>& an = b->side_anoms[d->img];
+            std::vector<std::pair<uint32_t, uint32_t*>> want;             // (un-stuffed byte index, where its file offset goes)
+            std::vector<uint32_t> pos(an.size() / 2, 0);
+            for (size_t k = 0; k < an.size() / 4; k++) { want.emplace_back(an[4 * k + 1] >> 3, &pos[2 * k]); want.emplace_back(an[4 * k + 3] >> 3, &pos[2 * k + 1]); }
+            std::sort(want.begin(), want.end(), [](const std::pair<uint32_t, uint32_t*>& x, const std::pair<uint32_t, uint32_t*>& y) { return x.first < y.first; });
+            const uint8_t* f = b->pinned + im.file_off; const uint32_t end = im.scan_start + im.scan_len;
+            uint32_t o = im.scan_start, j = 0; size_t wi = 0;
+            while (wi < want.size()) {
+                if (o >= end) { *want[wi++].second = end; continue; }
+                if (f[o] == 0xFF && o + 1 < end && f[o + 1] >= 0xD0 && f[o + 1] <= 0xD7) { o += 2; continue; }      // RSTn: not part of the stream
+                while (wi < want.size() && want[wi].first == j) *want[wi++].second = o;
+                o += (f[o] == 0xFF && o + 1 < end && f[o + 1] == 0x00) ? 2 : 1; j++;
+            }
+            const uint32_t nb = im.blk_per_mcu;
+            for (size_t k = 0; k < an.size() / 4; k++) {
+                const uint32_t blk = an[4 * k], m = blk / nb, c = blk % nb;
+                Ev e1{}; e1.kind = JS_EV_NUMCOEF; e1.a[0] = pos[2 * k]; e1.a[1] = an[4 * k + 1] & 7u; e1.a[2] = an[4 * k + 2];
+                e1.order = ((uint64_t)m << 32) | (2u << 28) | (c * 2u); evs.push_back(e1);
+                Ev e2{}; e2.kind = JS_EV_BAD_SCAN_MCU; e2.a[0] = (m % im.mcu_xmax) | ((m / im.mcu_xmax) << 16);
+                e2.a[1] = (uint32_t)im.blk_comp[c] | ((uint32_t)im.blk_ch[c] << 8) | ((uint32_t)im.blk_cv[c] << 16); e2.a[2] = pos[2 * k + 1]; e2.a[3] = an[4 * k + 3] & 7u;
+                e2.order = ((uint64_t)m << 32) | (2u << 28) | (c * 2u + 1u); evs.push_back(e2);
+            }
+        }
         std::stable_sort(evs.begin(), evs.end(), [](const Ev& x, const Ev& y) { return x.order < y.order; });
     }
     unsigned count = 0;
-    for (const Ev& e : evs) emit_event(d, im, e, count);
+    for (const Ev& e : evs) {
+        // the messages that share the reference's warning counter stop once it has reached nErrMaxDecodeScan (the mirror applies that itself;
+        // a merged list -- overflow records, then the markers at the end of the scan, each counted from zero -- gets it here)
+        const bool counted = e.kind == JS_EV_OVERREAD_BEFORE || e.kind == JS_EV_CANT_FIND || e.kind == JS_EV_MARKER || e.kind == JS_EV_BAD_MARKER ||
+                             e.kind == JS_EV_BAD_HUFF || e.kind == JS_EV_NUMCOEF || e.kind == JS_EV_BAD_SCAN_MCU;
+        if (derived && counted && count >= d->opt_err_max) continue;
+        emit_event(d, im, e, count);
+    }
     if (raw[0] > JS_EV_MAX) d->log(1, "  (decoder log truncated: %u further messages)", raw[0] - JS_EV_MAX);
 }
 

@@ -89,6 +89,7 @@ struct JsImage {
 };
 
 // Event records (6 u32 each, preceded by one count word per image): what the reference logs during the scan decode.
+#define JS_ANOM_MAX 1024           // coefficient-index overflows the side pass records per image (beyond that: the mirror's side-only pass)
 #define JS_EV_WORDS 6
 #define JS_EV_MAX   1024
 enum { JS_EV_OVERREAD_BEFORE = 1, JS_EV_OVERREAD_CODE, JS_EV_OVERREAD_BITS, JS_EV_CANT_FIND, JS_EV_RST_INDEX, JS_EV_MARKER,

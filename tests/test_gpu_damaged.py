@@ -87,3 +87,49 @@ def test_damaged_images_inside_a_batch(harness, oracle):
         assert {k: int(v) for k, v in so["status"].items()} == {("rst_count" if k == "restart_read" else k): int(v) for k, v in oracle.status().items()}, i
     assert b.info(0)["flags"] == 0 and all(b.info(i)["path"] == 1 for i in range(len(files)))
     b.close()
+
+
+def test_overflow_only_files_get_their_bookkeeping_from_the_parallel_side_pass(harness, oracle, gpu):
+    """85 % of the damaged files that leave a trace leave only coefficient-index overflows (tools/damage_survey.py).  Their pixels are the
+    parallel path's; their status words, maps, histogram and the log text (two messages per overflow, sharing the reference's warning
+    budget with the end-of-scan markers) come from the parallel side pass + the overflow records -- compared here with the compiled
+    reference itself (its log) where its library travelled, with the oracle otherwise."""
+    from fuzz_util import differs
+    ref = harness.ref_backend() if harness.have_ref() else None
+    rng = np.random.default_rng(77)
+    bases = [harness.synth_jpeg(width=320, height=240, seed=41), harness.synth_jpeg(width=333, height=217, hs=2, vs=1, restart_interval=7, seed=42),
+             harness.synth_jpeg(width=256, height=192, gray=1, seed=43), harness.synth_jpeg(width=200, height=152, hs=1, vs=1, quality=95, seed=44)]
+    found = 0
+    try:
+        for trial in range(400):
+            base = bases[trial % len(bases)]
+            p = harness.parse_jpeg(base)
+            d = bytearray(base)
+            for _ in range(int(rng.integers(1, 4))):
+                d[int(rng.integers(p.scan_start, p.scan_end - 2))] ^= 1 << int(rng.integers(8))
+            d = bytes(d)
+            em = int(rng.choice([20, 20, 3, 2, 1]))
+            gpu.set_options(decode_ac=1, err_max=em)
+            try:
+                q = harness.parse_jpeg(d)
+            except Exception:
+                continue
+            harness.drive(gpu, d, q, quiet=0)
+            if gpu.lib.jsnoop_last_flags(gpu.h) != 0x0004 or gpu.lib.jsnoop_last_path(gpu.h) != 1:
+                continue
+            found += 1
+            got_log = gpu.log_lines()
+            oracle.set_options(decode_ac=1, err_max=em)
+            harness.drive(oracle, d, q)
+            assert differs(oracle, gpu) is None, (trial, em)
+            if ref is not None:
+                ref.set_options(decode_ac=1, err_max=em)
+                harness.drive(ref, d, q, quiet=0)
+                assert got_log == ref.log_lines(), (trial, em, next((i, a, b) for i, (a, b) in enumerate(zip(got_log + [None], ref.log_lines() + [None])) if a != b))
+            if found >= 25:
+                break
+        assert found >= 10, found
+    finally:
+        gpu.set_options(); oracle.set_options()
+        if ref is not None:
+            ref.set_options(); ref.close()
