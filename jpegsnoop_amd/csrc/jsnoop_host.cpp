@@ -200,7 +200,7 @@ JsnoopBatch::~JsnoopBatch()
     for (void** p : { (void**)&dev.raw, (void**)&dev.ustr, (void**)&dev.coef, (void**)&dev.dccum, (void**)&dev.dib, (void**)&dev.planes,
                       (void**)&dev.side, (void**)&dev.imgs, (void**)&dev.tables, (void**)&dev.wg_base, (void**)&dev.sel, (void**)&dev.sums,
                       (void**)&dev.sub, (void**)&dev.probe, (void**)&dev.seg, (void**)&dev.chunk_keep, (void**)&dev.chunk_rst, (void**)&dev.us_base,
-                      (void**)&dev.sy_base, (void**)&dev.mcu_rst, (void**)&dev.dc_parts, (void**)&dev.flags, (void**)&dev.ustr_lin, (void**)&dev.events }) if (*p) hipFree(*p);
+                      (void**)&dev.sy_base, (void**)&dev.mcu_rst, (void**)&dev.dc_parts, (void**)&dev.flags, (void**)&dev.ustr_lin, (void**)&dev.events, (void**)&dev.cand, (void**)&dev.cand_req }) if (*p) hipFree(*p);
     delete helper; helper = nullptr;
     if (d_lut) hipFree(d_lut);
     if (d_side_tmp) hipFree(d_side_tmp);
@@ -379,6 +379,13 @@ int JsnoopBatch::upload()
         grow(&dev.us_base, &cap.us_base, (n + 1) * 4) || grow(&dev.sy_base, &cap.sy_base, 2 * (n + 1) * 4) ||
         grow(&dev.mcu_rst, &cap.mcu_rst, mcub + 64) || grow(&dev.dc_parts, &cap.dc_parts, JS_DC_PARTS_BYTES) || grow(&dev.ustr_lin, &cap.ustr_lin, ustr + 64) || grow(&dev.flags, &cap.flags, n * 8 + 64)) return -1;
     if (opt_want_planes && grow(&dev.planes, &cap.planes, plane * 2)) return -1;
+    {   // candidate synchronisation: when every sub-sequence can afford one walk per block of the MCU at once (the chip holds ~500 k lanes)
+        uint32_t mb = 0; for (const JsImage& im : imgs) mb = std::max(mb, im.blk_per_mcu);
+        int rounds = 2; if (const char* e = getenv("JSNOOP_CAND")) rounds = atoi(e) > 0 ? std::min(atoi(e), 8) : -1;
+        cand_blk = mb;
+        cand_rounds = (sub_wl == 4 && mb >= 1 && mb <= JS_CAND_MAX_BLK && subs * mb <= 640000ull) ? rounds : -1;
+        if (cand_rounds >= 0 && (grow(&dev.cand, &cap.cand, js_cand_bytes(subs)) || grow(&dev.cand_req, &cap.cand_req, n * JS_CAND_REQ_WORDS * 4))) return -1;
+    }
     event_words = opt_events ? (uint64_t)n * (1 + JS_EV_WORDS * JS_EV_MAX) : 0;
     if (event_words && grow(&dev.events, &cap.events, event_words * 4)) return -1;
     tab_rows = 1; tab_lut2 = 0; uint32_t tdc = 1, tac = 1;

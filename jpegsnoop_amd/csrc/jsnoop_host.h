@@ -62,10 +62,10 @@ struct JsDeviceArenas {
     uint8_t* raw; uint8_t* ustr; int16_t* coef; int16_t* dccum; uint8_t* dib; int16_t* planes; uint32_t* side;
     JsImage* imgs; JsTableSet* tables; uint32_t* wg_base; uint32_t* sel; uint64_t* sums; uint8_t* sub; uint8_t* probe;
     uint32_t* seg; uint32_t* chunk_keep; uint32_t* chunk_rst; uint32_t* us_base; uint32_t* sy_base; uint8_t* mcu_rst; uint32_t* flags; uint8_t* ustr_lin;
-    uint32_t* events; uint8_t* dc_parts;
+    uint32_t* events; uint8_t* dc_parts; uint32_t* cand; uint32_t* cand_req;
 };
 struct JsArenaCaps { size_t raw, ustr, coef, dccum, dib, planes, side, imgs, tables, wg_base, sel, sums, sub, probe,
-                            seg, chunk_keep, chunk_rst, us_base, sy_base, mcu_rst, flags, ustr_lin, events, dc_parts; };
+                            seg, chunk_keep, chunk_rst, us_base, sy_base, mcu_rst, flags, ustr_lin, events, dc_parts, cand, cand_req; };
 
 struct JsnoopBatch {
     int device; hipStream_t stream; bool own_stream;
@@ -95,6 +95,9 @@ struct JsnoopBatch {
     JsDeviceArenas dev; JsArenaCaps cap;
     bool uploaded;
     uint64_t total_blocks, dib_bytes, side_words, total_subseq, ustr_bytes, seg_words, mcu_bytes; uint32_t total_wgs, strips_per_wg, us_chunks, sy_wgs, sn_wgs, max_mcu_h, max_mcu_w;
+    // small jobs (64-byte sub-sequences, a few hundred thousand walks at most) synchronise by candidates (k_cand_*) instead of k_sync's rounds: cand_rounds
+    // = fill rounds of the chain, -1 = off (JSNOOP_CAND=0, more than JS_CAND_MAX_BLK blocks per MCU, a larger job); cand_blk = most blocks per MCU in the batch
+    int cand_rounds = -1; uint32_t cand_blk = 0;
     int sync_launches; int sub_wl;   // log2(words per sub-sequence): 4 / 5 / 7 = 64- / 128- / 512-byte sub-sequences (chosen per batch; 6 and 8 through JSNOOP_SUB_WL)
     uint32_t tab_rows, tab_lut2, tab_rows_w;     // largest decode-table footprint in the batch (sizes the kernels' LDS); _w: DC rows | AC rows << 8
     hipEvent_t ev[JSNOOP_NUM_STAGES + 1];

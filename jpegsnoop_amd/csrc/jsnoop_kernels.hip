@@ -1617,12 +1617,18 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
     // one its first sub-sequence was last walked from, the whole workgroup is already at its fixed point.
     // The left neighbour writes those slots at the end of this same launch, unordered: ONE thread reads them and the whole
     // workgroup follows its verdict (waves that disagreed would leave the others with a half-loaded table).
-    if (!first_pass) {
+    if (first_pass == 0) {
         if (t == 0) { const uint32_t lp = own0 ? A.out_p[g0 - 1] : 0u, ls = own0 ? A.out_s[g0 - 1] : 0u; s_changed = (lp == A.in_p[g0] && ls == A.in_s[g0]) ? 0 : 1; }
         __syncthreads();
         const int go = s_changed;
         __syncthreads();
         if (!go) return;
+    } else if (first_pass == 2) {
+        // Verification mode (after the candidate chain, k_cand_*): the arrays hold a chain that is a fixed point except at the
+        // sub-sequences marked with an entry state nothing equals -- every thread checks its own link.
+        bool open = false;
+        if (valid && !halo) { const size_t gq = g0 + t - 1; const uint32_t lp = i ? A.out_p[gq - 1] : 0u, ls = i ? A.out_s[gq - 1] : 0u; open = lp != A.in_p[gq] || ls != A.in_s[gq]; }
+        if (!__syncthreads_or(open ? 1 : 0)) return;
     }
     SubTabs T; load_subtabs<true>(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, t, SY_THREADS);
     if (t < T.nb) { const uint32_t rbc = t < T.n1 ? T.rb0 : (t < T.n2 ? T.rb1 : T.rb2); s_ctab[t] = make_uint2(lds_addr(T.lutp) + (rbc & 0xFFFFu), lds_addr(T.lutp) + (rbc >> 16)); }
@@ -1630,7 +1636,8 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
     const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);
     const uint32_t* st = seg_tab + im.seg_off;
     const size_t gs = g0 + t - 1;                                // this thread's slot (not for the halo thread of the first workgroup)
-    if (first_pass || !valid) { s_inp[t] = 0xFFFFFFFEu; s_ins[t] = 0; s_outp[t] = valid ? 0u : P_END; s_outs[t] = 0; s_nblk[t] = 0; }
+    const bool spec_pass = first_pass == 1;
+    if (spec_pass || !valid) { s_inp[t] = 0xFFFFFFFEu; s_ins[t] = 0; s_outp[t] = valid ? 0u : P_END; s_outs[t] = 0; s_nblk[t] = 0; }
     else if (halo) { s_inp[t] = 0xFFFFFFFEu; s_ins[t] = 0; s_outp[t] = A.out_p[gs]; s_outs[t] = A.out_s[gs]; s_nblk[t] = 0; }   // the true state left of the workgroup
     else { s_inp[t] = A.in_p[gs]; s_ins[t] = A.in_s[gs]; s_outp[t] = A.out_p[gs]; s_outs[t] = A.out_s[gs]; s_nblk[t] = A.nblk[gs]; }
     __syncthreads();
@@ -1638,9 +1645,9 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
         // ---- phase A: which sub-sequences see a new entry state?  (reads last iteration's exit states only)
         uint32_t ip = 0, is = 0;
         bool active;
-        if (!valid || (halo && !(first_pass && it == 0))) active = false;
+        if (!valid || (halo && !(spec_pass && it == 0))) active = false;
         else {
-            if (first_pass && it == 0 && i != 0) {
+            if (spec_pass && it == 0 && i != 0) {
                 // Speculative start.  This first walk only has to hand an exit state to the right neighbour (every lane walks
                 // again from its true entry state in the next round), so it covers the TAIL of the sub-sequence only: JPEG codes
                 // resynchronise within a few hundred bits, and the few lanes whose tail was too short are redone one round later.
@@ -1682,8 +1689,292 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
     if (valid && !halo) { A.out_p[gs] = s_outp[t]; A.out_s[gs] = s_outs[t]; A.in_p[gs] = s_inp[t]; A.in_s[gs] = s_ins[t]; A.nblk[gs] = s_nblk[t]; }
 }
 
+// =====================================================================================
+//  Candidate synchronisation: the small-job form of stage (2).
+//
+//  k_sync's rounds are a serial chain -- a sub-sequence learns its true entry state only after its left neighbour has walked from
+//  ITS true entry state -- and in a 4:2:0 stream the chain is long: a walk that has the bit position right but the block-in-MCU index
+//  wrong keeps disagreeing with its neighbours for thousands of bits (luma and chroma blocks share code prefixes; nothing tells a
+//  walker which block of the MCU it is in).  A batch of a thousand images hides that behind its other images; ONE image waits for
+//  it (24 rounds in a workgroup of the 3840x2160 picture of BASELINE config 2 = 0.56 of its 0.94 ms).  When the job is small enough
+//  that the chip has lanes to spare, the chain is cut by hypotheses instead (tools/mhsync_sim.c is the CPU model of what follows):
+//   k_cand_spec   one walk of every sub-sequence per block-in-MCU index h, from its first bit in state (h, DC): the exit states X[h][i]
+//                 are the CANDIDATES for the entry state of sub-sequence i + 1 -- the true one is among them for all but ~1 % of them;
+//   k_cand_walk   one walk of sub-sequence i from every distinct candidate: a memo (entry state -> exit state, blocks) of up to six
+//                 entries per sub-sequence, and per entry the slot of sub-sequence i + 1's memo that continues it (its exit state IS that
+//                 candidate) -- a map over slot numbers, eight bytes per sub-sequence (byte 7: where to go on when the entry state
+//                 is in no slot: the exit most speculative walks agree on);
+//   k_cand_chain  one workgroup per image: following the chain from the true start of the scan is now a composition of those maps --
+//                 a prefix scan (two v_perm_b32 per composition) instead of walks.  Where the chain arrives at a sub-sequence with a
+//                 state that is in no slot, the sub-sequence is queued with that state;
+//   k_cand_fill   walks the queued ones (slot 6 of their memos); the next k_cand_chain picks the chain up from there.  Two such
+//                 rounds resolve a typical image;
+//   k_cand_apply  writes the selected entry / exit states and block counts where k_block_scan and k_write2 expect them.
+//  What is still open after that (a noisy image can need a third round) is marked and left to k_sync in its verification mode,
+//  which walks exactly the marked sub-sequences and what depends on them; k_write2 verifies the whole chain in any case.
+// =====================================================================================
+#define CD_H       6                   // candidate slots = hypotheses (images with more blocks per MCU: k_sync)
+#define CD_FILL    6                   // the memo slot a queued walk fills
+#define CD_NONE    7
+#define CD_SLOTS   7
+#define CD_EMPTY   0xFFFFFFFDu         // entry position of an unused memo slot (no state has it: positions are < 2^32 - 3)
+#define CD_REQ_WGS 8                   // fill workgroups per image and round
+#define CD_REQ_CAP (CD_REQ_WGS * SY_THREADS)
+#define CD_REQ_WORDS (12 + 3 * CD_REQ_CAP)        // [0] walks queued, [4..7] / [8..11]: sub-sequences open / walks queued after chain launch 0..3 (diagnostics), then {sub-sequence, position, state}
+struct CandArrays {
+    uint32_t *xp, *xs;                 // [CD_H][n]  speculative exit states
+    uint32_t *mep, *mes, *mxp, *mxs, *mnb;   // [CD_SLOTS][n]  memo: entry state, exit state, blocks completed
+    uint2* map;                        // [n]  byte e (0..6): slot of the next sub-sequence's memo that holds the exit state of entry e (7: none); byte 7: the guess
+    uint8_t *sel;                      // [n]  slot the chain selected
+    uint32_t* req;                     // (unused here: the request areas are passed beside)
+    uint64_t n;
+};
+__device__ __forceinline__ uint32_t cd_byte(uint2 m, uint32_t e) { return ((e < 4u ? m.x : m.y) >> ((e & 3u) * 8u)) & 255u; }
+// (a then b)[e] = b[a[e]]: the bytes of a are selectors into the eight bytes of b
+__device__ __forceinline__ uint2 cd_compose(uint2 a, uint2 b) { return make_uint2(__builtin_amdgcn_perm(b.y, b.x, a.x), __builtin_amdgcn_perm(b.y, b.x, a.y)); }
+#define CD_IDENT make_uint2(0x03020100u, 0x07060504u)
+
+// common prologue of the grid kernels: image and sub-sequence of this thread (workgroups are dealt to the images by sy_base, 256 sub-sequences each)
+#define CD_PROLOGUE \
+    const uint32_t wg = blockIdx.x + sy_base[0]; \
+    const uint32_t img = find_image(sy_base, nimg, wg); \
+    const JsImage& im = imgs[img]; \
+    if (!tables[im.tableset].lut_ok) return; \
+    const uint32_t* sd = side + im.side_off; \
+    const uint32_t total_bits = sd[10] * 8, nseg = min(sd[11], im.seg_cap - 1); \
+    const uint32_t t = threadIdx.x, i = (wg - sy_base[img]) * SY_THREADS + t; \
+    const bool valid = i < im.n_subseq; \
+    const size_t g = im.subseq_off + i, n = C.n; (void)total_bits; (void)nseg; (void)valid; (void)g; (void)n;
+
+template <int WL>
+__global__ void __launch_bounds__(SY_THREADS) k_cand_spec(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sy_base, uint32_t nimg,
+                                                          const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr,
+                                                          const uint32_t* __restrict__ seg_tab, const uint32_t* __restrict__ side, CandArrays C,
+                                                          uint32_t tab_rows, uint32_t tab_lut2)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    __shared__ __attribute__((aligned(8))) uint2 s_ctab[JS_MAX_BLK_PER_MCU];
+    CD_PROLOGUE
+    const uint32_t h = blockIdx.y;
+    if (h >= im.blk_per_mcu) return;
+    SubTabs T; load_subtabs<true>(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, t, SY_THREADS);
+    if (t < T.nb) { const uint32_t rbc = t < T.n1 ? T.rb0 : (t < T.n2 ? T.rb1 : T.rb2); s_ctab[t] = make_uint2(lds_addr(T.lutp) + (rbc & 0xFFFFu), lds_addr(T.lutp) + (rbc >> 16)); }
+    __syncthreads();
+    if (!valid) return;
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);
+    const uint32_t* st = seg_tab + im.seg_off;
+    const bool in_data = i * SUB_BITS < total_bits;
+    uint32_t p = in_data ? i * SUB_BITS : P_END, s = in_data ? ST_MAKE(find_interval(st, nseg, p / 8), i ? h : 0u, 0u) : 0u, nblk = 0;
+    const uint32_t own_end = min((i + 1) * SUB_BITS, total_bits);
+    walk_sync<WL>(im, T, lds_addr(s_ctab), words, st, nseg, total_bits, own_end, p, s, nblk);
+    C.xp[h * n + g] = p; C.xs[h * n + g] = s;
+}
+
+// slot (< nb) of the first speculative exit of sub-sequence slot g that equals (p, s); CD_NONE if none does
+__device__ __forceinline__ uint32_t cd_match(const CandArrays& C, size_t g, uint32_t nb, uint32_t p, uint32_t s)
+{
+    uint32_t r = CD_NONE;
+    for (uint32_t q = nb; q-- > 0;) if (C.xp[q * C.n + g] == p && C.xs[q * C.n + g] == s) r = q;
+    return r;
+}
+
+template <int WL>
+__global__ void __launch_bounds__(SY_THREADS) k_cand_walk(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sy_base, uint32_t nimg,
+                                                          const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr,
+                                                          const uint32_t* __restrict__ seg_tab, const uint32_t* __restrict__ side, CandArrays C,
+                                                          uint32_t tab_rows, uint32_t tab_lut2)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    __shared__ __attribute__((aligned(8))) uint2 s_ctab[JS_MAX_BLK_PER_MCU];
+    CD_PROLOGUE
+    const uint32_t h = blockIdx.y, nb = im.blk_per_mcu;
+    uint8_t* mapb = reinterpret_cast<uint8_t*>(C.map);
+    if (h >= nb) { if (valid) { C.mep[h * n + g] = CD_EMPTY; mapb[g * 8 + h] = CD_NONE; } return; }
+    SubTabs T; load_subtabs<true>(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, t, SY_THREADS);
+    if (t < T.nb) { const uint32_t rbc = t < T.n1 ? T.rb0 : (t < T.n2 ? T.rb1 : T.rb2); s_ctab[t] = make_uint2(lds_addr(T.lutp) + (rbc & 0xFFFFu), lds_addr(T.lutp) + (rbc >> 16)); }
+    __syncthreads();
+    if (!valid) return;
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);
+    const uint32_t* st = seg_tab + im.seg_off;
+    // entry state: candidate h of the left neighbour (the true start of the scan for the first sub-sequence); a candidate equal to one in a lower slot is walked there
+    uint32_t p = 0, s = 0; bool use = h == 0;
+    if (i) {
+        p = C.xp[h * n + g - 1]; s = C.xs[h * n + g - 1]; use = true;
+        for (uint32_t q = 0; q < h; q++) if (C.xp[q * n + g - 1] == p && C.xs[q * n + g - 1] == s) use = false;
+    }
+    uint32_t succ = CD_NONE;
+    if (use) {
+        const uint32_t own_end = min((i + 1) * SUB_BITS, total_bits);
+        uint32_t xp = p, xs = s, nblk = 0;
+        if (!(xp != P_END && xp >= own_end)) walk_sync<WL>(im, T, lds_addr(s_ctab), words, st, nseg, total_bits, own_end, xp, xs, nblk);
+        C.mep[h * n + g] = p; C.mes[h * n + g] = s; C.mxp[h * n + g] = xp; C.mxs[h * n + g] = xs; C.mnb[h * n + g] = nblk;
+        if (i + 1 < im.n_subseq) succ = cd_match(C, g, nb, xp, xs);
+    } else C.mep[h * n + g] = CD_EMPTY;
+    mapb[g * 8 + h] = (uint8_t)succ;
+    if (h == 0) {
+        // where to go on from a sub-sequence whose entry state is in no slot: the exit state most of its speculative walks ended in
+        uint32_t best = 0, guess = CD_NONE;
+        for (uint32_t q = 0; q < nb; q++) {
+            const uint32_t qp = C.xp[q * n + g], qs = C.xs[q * n + g]; uint32_t cnt = 0;
+            for (uint32_t r = 0; r < nb; r++) cnt += (C.xp[r * n + g] == qp && C.xs[r * n + g] == qs) ? 1u : 0u;
+            if (cnt > best) { best = cnt; guess = q; }
+        }
+        if (i + 1 >= im.n_subseq) guess = CD_NONE;
+        C.mep[CD_FILL * n + g] = CD_EMPTY; mapb[g * 8 + CD_FILL] = CD_NONE; mapb[g * 8 + 7] = (uint8_t)guess;
+    }
+}
+
+// One workgroup of 16 waves per image.  `round`: 0 = first chain after k_cand_walk, > 0 = after a k_cand_fill.
+// Every wave owns a contiguous segment of the image's sub-sequences and goes through it in tiles of 256: a lane takes four consecutive maps
+// (32 contiguous bytes: the wave reads 2 KiB at a stretch), composes them, the wave scans the 64 lane products with shuffles and carries the
+// product of the tiles before along; no barrier inside a segment.  The 16 segment products meet in LDS; the second trip over the tiles
+// applies what came before the segment and writes the selections.
+#define CC_THREADS 1024
+#define CC_PER_LANE 4
+#define CC_TILE (64 * CC_PER_LANE)
+#define CC_MAX_TILES 16                // 16 waves x 16 tiles x 256 = 65536 sub-sequences per image (the host keeps larger images on k_sync)
+__device__ __forceinline__ uint2 cd_shfl_up(uint2 v, int off) { return make_uint2((uint32_t)__shfl_up((int)v.x, off), (uint32_t)__shfl_up((int)v.y, off)); }
+__device__ __forceinline__ void cd_queue(uint32_t* __restrict__ req, uint32_t* s_nreq, const CandArrays& C, size_t g0, uint32_t i, uint32_t prev)
+{
+    const uint32_t slot = atomicAdd(s_nreq, 1u);
+    if (slot < CD_REQ_CAP) { req[12 + 3 * slot] = i | (prev << 24); req[13 + 3 * slot] = C.mxp[prev * C.n + g0 + i - 1]; req[14 + 3 * slot] = C.mxs[prev * C.n + g0 + i - 1]; }
+}
+__global__ void __launch_bounds__(CC_THREADS) k_cand_chain(const JsImage* __restrict__ imgs, const JsTableSet* __restrict__ tables, CandArrays C, uint32_t* __restrict__ req_all, int round)
+{
+    __shared__ uint2 s_wtot[CC_THREADS / 64];
+    __shared__ uint8_t s_wlast[CC_THREADS / 64], s_wfirst_open[CC_THREADS / 64];
+    __shared__ uint32_t s_nreq, s_open;
+    const uint32_t img = blockIdx.x; const JsImage& im = imgs[img];
+    if (!tables[im.tableset].lut_ok) return;
+    uint32_t* req = req_all + (size_t)img * CD_REQ_WORDS;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    if (round > 0 && req[0] == 0) return;                        // nothing was queued by the chain before: its selection stands
+    const uint32_t nsub = im.n_subseq;
+    const uint32_t seg = (((nsub + CC_THREADS / 64 - 1) / (CC_THREADS / 64)) + CC_TILE - 1) / CC_TILE * CC_TILE, ntiles = seg / CC_TILE;   // per wave; a tile that starts inside the image ends inside its (256-aligned) slot range
+    const size_t g0 = im.subseq_off, n = C.n;
+    if (t == 0) { s_nreq = 0; s_open = 0; }
+    __syncthreads();
+    // ---- first trip: E[tile] = product of the maps of this wave's segment before the lane's four sub-sequences
+    uint2 E[CC_MAX_TILES]; uint2 R = CD_IDENT;
+    #pragma unroll
+    for (uint32_t tl = 0; tl < CC_MAX_TILES; tl++) {
+        E[tl] = CD_IDENT;
+        if (tl < ntiles && wave * seg + tl * CC_TILE < nsub) {
+            const uint32_t i0 = wave * seg + tl * CC_TILE + lane * CC_PER_LANE;
+            const uint4 v0 = *reinterpret_cast<const uint4*>(C.map + g0 + i0), v1 = *reinterpret_cast<const uint4*>(C.map + g0 + i0 + 2);
+            uint2 L = i0 < nsub ? make_uint2(v0.x, v0.y) : CD_IDENT;
+            if (i0 + 1 < nsub) L = cd_compose(L, make_uint2(v0.z, v0.w));
+            if (i0 + 2 < nsub) L = cd_compose(L, make_uint2(v1.x, v1.y));
+            if (i0 + 3 < nsub) L = cd_compose(L, make_uint2(v1.z, v1.w));
+            uint2 P = L;                                         // inclusive scan over the lanes
+            #pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint2 a = cd_shfl_up(P, off); if (lane >= (uint32_t)off) P = cd_compose(a, P); }
+            uint2 X = cd_shfl_up(P, 1); if (lane == 0) X = CD_IDENT;
+            E[tl] = cd_compose(R, X);
+            const uint2 T = make_uint2((uint32_t)__shfl((int)P.x, 63), (uint32_t)__shfl((int)P.y, 63));
+            R = cd_compose(R, T);
+        }
+    }
+    if (lane == 0) s_wtot[wave] = R;
+    __syncthreads();
+    uint32_t cw = 0;                                             // slot 0 of the first sub-sequence holds the true start of the scan
+    for (uint32_t w = 0; w < wave; w++) cw = cd_byte(s_wtot[w], cw);
+    // ---- second trip: the selections
+    uint32_t nopen = 0, tile_prev = CD_NONE; bool first_open = false;
+    #pragma unroll
+    for (uint32_t tl = 0; tl < CC_MAX_TILES; tl++) {
+        if (tl < ntiles && wave * seg + tl * CC_TILE < nsub) {
+            const uint32_t i0 = wave * seg + tl * CC_TILE + lane * CC_PER_LANE;
+            const uint4 v0 = *reinterpret_cast<const uint4*>(C.map + g0 + i0), v1 = *reinterpret_cast<const uint4*>(C.map + g0 + i0 + 2);
+            const uint32_t s0 = cd_byte(E[tl], cw), s1 = cd_byte(make_uint2(v0.x, v0.y), s0), s2 = cd_byte(make_uint2(v0.z, v0.w), s1), s3 = cd_byte(make_uint2(v1.x, v1.y), s2);
+            *reinterpret_cast<uint32_t*>(C.sel + g0 + i0) = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
+            // last selection of the sub-sequences this lane has: the lane before needs it as `prev`
+            const uint32_t nval = i0 >= nsub ? 0u : min(nsub - i0, (uint32_t)CC_PER_LANE);
+            const uint32_t mylast = nval == 0 ? CD_NONE : (nval == 1 ? s0 : (nval == 2 ? s1 : (nval == 3 ? s2 : s3)));
+            uint32_t prev = (uint32_t)__shfl_up((int)mylast, 1);
+            if (lane == 0) prev = tile_prev;
+            if (nval > 0 && s0 == CD_NONE) { nopen++; if (lane == 0 && tl == 0) first_open = true; else if (prev != CD_NONE && i0 > 0) cd_queue(req, &s_nreq, C, g0, i0, prev); }
+            if (nval > 1 && s1 == CD_NONE) { nopen++; if (s0 != CD_NONE) cd_queue(req, &s_nreq, C, g0, i0 + 1, s0); }
+            if (nval > 2 && s2 == CD_NONE) { nopen++; if (s1 != CD_NONE) cd_queue(req, &s_nreq, C, g0, i0 + 2, s1); }
+            if (nval > 3 && s3 == CD_NONE) { nopen++; if (s2 != CD_NONE) cd_queue(req, &s_nreq, C, g0, i0 + 3, s2); }
+            tile_prev = (uint32_t)__shfl((int)mylast, 63);
+        }
+    }
+    if (lane == 0) { s_wlast[wave] = (uint8_t)tile_prev; s_wfirst_open[wave] = first_open ? 1 : 0; }
+    if (nopen) atomicAdd(&s_open, nopen);
+    __syncthreads();
+    if (lane == 0 && wave > 0 && s_wfirst_open[wave] && s_wlast[wave - 1] != CD_NONE) cd_queue(req, &s_nreq, C, g0, wave * seg, s_wlast[wave - 1]);   // first sub-sequence of a segment: its left neighbour is the wave before's
+    __syncthreads();
+    if (t == 0) { req[0] = min(s_nreq, (uint32_t)CD_REQ_CAP); if (round < 4) { req[4 + round] = s_open; req[8 + round] = s_nreq; } }
+}
+
+template <int WL>
+__global__ void __launch_bounds__(SY_THREADS) k_cand_fill(const JsImage* __restrict__ imgs, const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr,
+                                                          const uint32_t* __restrict__ seg_tab, const uint32_t* __restrict__ side, CandArrays C,
+                                                          const uint32_t* __restrict__ req_all, uint32_t tab_rows, uint32_t tab_lut2)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    __shared__ __attribute__((aligned(8))) uint2 s_ctab[JS_MAX_BLK_PER_MCU];
+    const uint32_t img = blockIdx.y; const JsImage& im = imgs[img];
+    if (!tables[im.tableset].lut_ok) return;
+    const uint32_t* req = req_all + (size_t)img * CD_REQ_WORDS;
+    const uint32_t cnt = req[0], t = threadIdx.x, r = blockIdx.x * SY_THREADS + t;
+    if (blockIdx.x * SY_THREADS >= cnt) return;
+    const uint32_t* sd = side + im.side_off;
+    const uint32_t total_bits = sd[10] * 8, nseg = min(sd[11], im.seg_cap - 1);
+    SubTabs T; load_subtabs<true>(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, t, SY_THREADS);
+    if (t < T.nb) { const uint32_t rbc = t < T.n1 ? T.rb0 : (t < T.n2 ? T.rb1 : T.rb2); s_ctab[t] = make_uint2(lds_addr(T.lutp) + (rbc & 0xFFFFu), lds_addr(T.lutp) + (rbc >> 16)); }
+    __syncthreads();
+    if (r >= cnt) return;
+    const uint32_t i = req[12 + 3 * r] & 0xFFFFFFu, prev = req[12 + 3 * r] >> 24, p = req[13 + 3 * r], s = req[14 + 3 * r];
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);
+    const uint32_t* st = seg_tab + im.seg_off;
+    const uint32_t own_end = min((i + 1) * SUB_BITS, total_bits);
+    uint32_t xp = p, xs = s, nblk = 0;
+    if (!(xp != P_END && xp >= own_end)) walk_sync<WL>(im, T, lds_addr(s_ctab), words, st, nseg, total_bits, own_end, xp, xs, nblk);
+    const size_t g = im.subseq_off + i, n = C.n;
+    C.mep[CD_FILL * n + g] = p; C.mes[CD_FILL * n + g] = s; C.mxp[CD_FILL * n + g] = xp; C.mxs[CD_FILL * n + g] = xs; C.mnb[CD_FILL * n + g] = nblk;
+    // The maps around the new entry.  No two queued sub-sequences are neighbours (a queued one has no selection, its right neighbour got the
+    // guess), so nobody else writes these two words in this launch.
+    uint32_t sc = CD_NONE;
+    if (i + 1 < im.n_subseq) {
+        sc = cd_match(C, g, im.blk_per_mcu, xp, xs);
+        if (sc == CD_NONE && C.mep[CD_FILL * n + g + 1] == xp && C.mes[CD_FILL * n + g + 1] == xs) sc = CD_FILL;   // a walk of an earlier round next door
+    }
+    uint2 m = C.map[g]; m.y = (m.y & 0xFF00FFFFu) | (sc << 16); C.map[g] = m;
+    // left neighbour: the entry the chain came through continues here; entries that pointed at what this slot held before do so no longer
+    uint2 l = C.map[g - 1];
+    #pragma unroll
+    for (uint32_t e = 0; e < CD_SLOTS; e++) {
+        const uint32_t sh = (e & 3u) * 8u; uint32_t& w = e < 4 ? l.x : l.y;
+        if (e == prev) w = (w & ~(255u << sh)) | ((uint32_t)CD_FILL << sh);
+        else if (((w >> sh) & 255u) == CD_FILL) w = (w & ~(255u << sh)) | ((uint32_t)CD_NONE << sh);
+    }
+    C.map[g - 1] = l;
+}
+
+// The selected memo entries, where k_sync / k_block_scan / k_write2 read them.  A sub-sequence the chain reached with a state in none of its
+// slots gets an entry state no exit state equals (k_sync's verification mode walks it) and, as exit state, the guess its right neighbours were
+// selected from -- if the guess was right, the walk changes nothing further.
+__global__ void __launch_bounds__(SY_THREADS) k_cand_apply(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sy_base, uint32_t nimg,
+                                                           const JsTableSet* __restrict__ tables, const uint32_t* __restrict__ side, CandArrays C, SubArrays A)
+{
+    CD_PROLOGUE
+    if (!valid) return;
+    const uint32_t s = C.sel[g];
+    if (s < CD_NONE) { A.in_p[g] = C.mep[s * n + g]; A.in_s[g] = C.mes[s * n + g]; A.out_p[g] = C.mxp[s * n + g]; A.out_s[g] = C.mxs[s * n + g]; A.nblk[g] = C.mnb[s * n + g]; }
+    else {
+        const uint32_t gq = cd_byte(C.map[g], 7u);
+        A.in_p[g] = 0xFFFFFFFEu; A.in_s[g] = 0; A.nblk[g] = 0;
+        A.out_p[g] = gq < CD_NONE ? C.xp[gq * n + g] : P_END; A.out_s[g] = gq < CD_NONE ? C.xs[gq * n + g] : 0u;
+    }
+}
+
 // One workgroup per image: exclusive scan of blocks-per-sub-sequence.  THREADS = 256 for batches (one workgroup per image, many
-// images), 1024 for small jobs (a single large image: a quarter of the serial steps).
+// images), 1024 for small jobs.  Every wave owns a contiguous segment and goes through it in tiles of 256 (a lane: four consecutive
+// counts, one 16-byte load, the next tile's already in flight), carrying its running sum along -- no barrier inside a segment; the
+// segment sums meet in LDS once, the second trip adds what lies before the segment.  (The first form took one barrier per THREADS
+// sub-sequences: 31 of the 940 us of a single 3840x2160 image.)
 template <int WL, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_block_scan(const JsImage* __restrict__ imgs, const JsTableSet* __restrict__ tables,
                                                         SubArrays A, uint32_t* side, uint32_t* __restrict__ flags)
@@ -1692,24 +1983,43 @@ __global__ void __launch_bounds__(THREADS) k_block_scan(const JsImage* __restric
     if (!tables[im.tableset].lut_ok) { if (threadIdx.x == 0) { FLAG_OR(flags, img, 0x0020u); ANOM_MIN(flags, img, 0u); } return; }
     const uint32_t total_bits = side[im.side_off + 10] * 8;
     const uint32_t n = min(im.n_subseq, (total_bits + SUB_BITS - 1) / SUB_BITS);
-    // THREADS sub-sequences per step: inclusive scan inside each wave (shuffles), the wave totals through LDS, a running carry
     constexpr uint32_t NW = THREADS / 64;
-    __shared__ uint32_t s_w[2][NW];
+    __shared__ uint32_t s_w[NW];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t run = 0, par = 0;
-    for (uint32_t b = 0; b < n; b += THREADS, par ^= 1u) {
-        const uint32_t i = b + threadIdx.x; const uint32_t v = i < n ? A.nblk[im.subseq_off + i] : 0;
-        uint32_t inc = v;
-        #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t a = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += a; }
-        if (lane == 63) s_w[par][wave] = inc;
-        __syncthreads();                                          // (the other parity's slots are rewritten one step later: one barrier per step)
-        uint32_t pre = 0, tot = 0;
-        for (uint32_t w = 0; w < NW; w++) { const uint32_t x = s_w[par][w]; if (w < wave) pre += x; tot += x; }
-        if (i < n) A.base[im.subseq_off + i] = run + pre + inc - v;
-        run += tot;
+    const uint32_t seg = (((n + NW - 1) / NW) + 255u) & ~255u;   // per wave, whole tiles: a tile that starts below n ends inside the image's (256-aligned) slot range
+    const uint32_t* nb = A.nblk + im.subseq_off; uint32_t* base = A.base + im.subseq_off;
+    const uint32_t w0 = wave * seg, w1 = min(w0 + seg, n);
+    uint32_t run = 0;
+    if (w0 < n) {
+        uint4 nx = *reinterpret_cast<const uint4*>(nb + w0 + lane * 4);
+        for (uint32_t b = w0; b < w1; b += 256) {
+            const uint4 v = nx; const uint32_t i = b + lane * 4;
+            if (b + 256 < w1) nx = *reinterpret_cast<const uint4*>(nb + i + 256);
+            run += (i < n ? v.x : 0u) + (i + 1 < n ? v.y : 0u) + (i + 2 < n ? v.z : 0u) + (i + 3 < n ? v.w : 0u);
+        }
     }
-    if (threadIdx.x == 0) { side[im.side_off + 14] = run; if (run < im.total_blocks) { FLAG_OR(flags, img, F_SHORT); ANOM_MIN(flags, img, run); } }
+    #pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) run += __shfl_xor(run, off);
+    if (lane == 0) s_w[wave] = run;
+    __syncthreads();
+    uint32_t carry = 0, tot = 0;
+    for (uint32_t w = 0; w < NW; w++) { const uint32_t x = s_w[w]; if (w < wave) carry += x; tot += x; }
+    if (w0 < n) {
+        uint4 nx = *reinterpret_cast<const uint4*>(nb + w0 + lane * 4);
+        for (uint32_t b = w0; b < w1; b += 256) {
+            const uint4 v = nx; const uint32_t i = b + lane * 4;
+            if (b + 256 < w1) nx = *reinterpret_cast<const uint4*>(nb + i + 256);
+            const uint32_t a0 = i < n ? v.x : 0u, a1 = i + 1 < n ? v.y : 0u, a2 = i + 2 < n ? v.z : 0u, a3 = i + 3 < n ? v.w : 0u;
+            const uint32_t mine = a0 + a1 + a2 + a3;
+            uint32_t inc = mine;
+            #pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t a = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += a; }
+            const uint32_t ex = carry + inc - mine;
+            if (i < n) *reinterpret_cast<uint4*>(base + i) = make_uint4(ex, ex + a0, ex + a0 + a1, ex + a0 + a1 + a2);   // (slots past n inside the tile belong to this image: never read)
+            carry += __shfl(inc, 63);
+        }
+    }
+    if (threadIdx.x == 0) { side[im.side_off + 14] = tot; if (tot < im.total_blocks) { FLAG_OR(flags, img, F_SHORT); ANOM_MIN(flags, img, tot); } }
 }
 
 // WRITE pass.  Every 8x8 block is written by exactly one lane -- the one that decodes its DC symbol.  A lane entering
@@ -2242,6 +2552,35 @@ void js_launch_sync(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2
                        sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2);
     else hipLaunchKernelGGL(k_sync<5>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2, true), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2);
+}
+// ---- candidate synchronisation (small jobs).  cand: js_cand_bytes(nsub) bytes; req: nimg * JS_CAND_REQ_WORDS words
+static CandArrays cand_arrays(uint32_t* c, uint64_t n)
+{
+    CandArrays C; C.n = n; C.xp = c; C.xs = c + CD_H * n; uint32_t* m = c + 2 * CD_H * n;
+    C.mep = m; C.mes = m + CD_SLOTS * n; C.mxp = m + 2 * CD_SLOTS * n; C.mxs = m + 3 * CD_SLOTS * n; C.mnb = m + 4 * CD_SLOTS * n;
+    C.map = reinterpret_cast<uint2*>(m + 5 * CD_SLOTS * n); C.sel = reinterpret_cast<uint8_t*>(m + 5 * CD_SLOTS * n + 2 * n); C.req = nullptr;
+    return C;
+}
+size_t js_cand_bytes(uint64_t nsub) { return (size_t)nsub * ((2 * CD_H + 5 * CD_SLOTS + 2) * 4 + 2) + 64; }
+static_assert(CD_REQ_WORDS == JS_CAND_REQ_WORDS, "request area size");
+static_assert(CD_H == JS_CAND_MAX_BLK, "hypotheses");
+#define CAND_WL(K, GRID, BLOCK, LDS, ...) \
+    do { if (wl == 4) hipLaunchKernelGGL(K<4>, GRID, BLOCK, LDS, st, __VA_ARGS__); else if (wl == 5) hipLaunchKernelGGL(K<5>, GRID, BLOCK, LDS, st, __VA_ARGS__); \
+         else if (wl == 6) hipLaunchKernelGGL(K<6>, GRID, BLOCK, LDS, st, __VA_ARGS__); else if (wl == 7) hipLaunchKernelGGL(K<7>, GRID, BLOCK, LDS, st, __VA_ARGS__); \
+         else hipLaunchKernelGGL(K<8>, GRID, BLOCK, LDS, st, __VA_ARGS__); } while (0)
+void js_launch_cand_sync(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t sy_wgs, uint32_t max_blk,
+                         const JsTableSet* tables, const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub, uint32_t* cand, uint32_t* req, int fill_rounds)
+{
+    if (!sy_wgs || !nimg) return;
+    const size_t lds = subtabs_bytes_host(tab_rows, tab_lut2, true);
+    const CandArrays C = cand_arrays(cand, nsub);
+    CAND_WL(k_cand_spec, dim3(sy_wgs, max_blk), dim3(SY_THREADS), lds, imgs, sy_base, nimg, tables, ustr, seg_tab, side, C, tab_rows, tab_lut2);
+    CAND_WL(k_cand_walk, dim3(sy_wgs, CD_H), dim3(SY_THREADS), lds, imgs, sy_base, nimg, tables, ustr, seg_tab, side, C, tab_rows, tab_lut2);
+    for (int r = 0; r <= fill_rounds; r++) {
+        hipLaunchKernelGGL(k_cand_chain, dim3(nimg), dim3(1024), 0, st, imgs, tables, C, req, r);
+        if (r < fill_rounds) CAND_WL(k_cand_fill, dim3(CD_REQ_WGS, nimg), dim3(SY_THREADS), lds, imgs, tables, ustr, seg_tab, side, C, (const uint32_t*)req, tab_rows, tab_lut2);
+    }
+    hipLaunchKernelGGL(k_cand_apply, dim3(sy_wgs), dim3(SY_THREADS), 0, st, imgs, sy_base, nimg, tables, side, C, sub_arrays(sub, nsub));
 }
 void js_launch_block_scan(hipStream_t st, int wl, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, uint32_t* sub, uint64_t nsub, uint32_t* side, uint32_t* flags)
 {

@@ -23,6 +23,14 @@ void js_launch_unstuff(hipStream_t st, int wl, const JsImage* imgs, const uint32
                        const uint32_t* sy_base, uint32_t sy_wgs);
 void js_launch_sync(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
                     const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub, int first_pass);
+#define JS_SY_THREADS 256
+// Candidate synchronisation (the small-job form of the synchronisation stage: k_cand_spec / _walk / _chain / _fill / _apply); leaves the
+// sub-sequence arrays as js_launch_sync would, open links marked for a js_launch_sync(..., first_pass = 2) behind it.
+#define JS_CAND_MAX_BLK 6            /* images with more blocks per MCU than this synchronise the classic way */
+#define JS_CAND_REQ_WORDS (12 + 3 * 8 * JS_SY_THREADS)
+size_t js_cand_bytes(uint64_t nsub);
+void js_launch_cand_sync(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t sy_wgs, uint32_t max_blk,
+                         const JsTableSet* tables, const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub, uint32_t* cand, uint32_t* req, int fill_rounds);
 void js_launch_block_scan(hipStream_t st, int wl, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, uint32_t* sub, uint64_t nsub, uint32_t* side, uint32_t* flags);
 void js_launch_write(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
                      const uint8_t* ustr, const uint32_t* seg_tab, uint32_t* side, uint32_t* sub, uint64_t nsub,
@@ -37,7 +45,6 @@ void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab
 #define JS_DC_PARTS_BYTES (JS_DC_PARTS_IMAGES * 64 * 16)
 void js_launch_dc_scan(hipStream_t st, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, int16_t* dccum, const uint8_t* mcu_rst, void* parts_scratch /*JS_DC_PARTS_BYTES or null*/);
 #define JS_US_CHUNK 4096
-#define JS_SY_THREADS 256
 void js_launch_tail_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* us_base, const uint32_t* sy_base, uint32_t nimg,
                          uint32_t us_wg0, uint32_t us_wgs, uint32_t sy_wg0, uint32_t sy_wgs, const JsTableSet* tables, const uint8_t* raw,
                          const uint32_t* chunk_keep, const uint32_t* chunk_rst, const uint8_t* ustr, uint32_t* seg_tab, uint32_t* side, uint32_t* sub, uint64_t nsub,

@@ -263,6 +263,14 @@ int js_parallel_entropy_part(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32
     roctxRangePop();
     if (evs) HIP_TRY(hipEventRecord(evs[2], st));
     roctxRangePushA("jsnoop:sub-sequence sync");
+    if (b->cand_rounds >= 0) {
+        // small job: candidates and a chain of look-ups instead of rounds; what the chain left open is walked by k_sync in its verification mode,
+        // one more launch carries a change across workgroup boundaries
+        js_launch_cand_sync(st, b->sub_wl, b->tab_rows, b->tab_lut2, imgs, sy_base, n, sy_wgs, b->cand_blk, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
+                            b->dev.cand, b->dev.cand_req + (size_t)i0 * JS_CAND_REQ_WORDS, b->cand_rounds);
+        js_launch_sync(st, b->sub_wl, b->tab_rows, b->tab_lut2, imgs, sn_base, n, sn_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, 2);
+        js_launch_sync(st, b->sub_wl, b->tab_rows, b->tab_lut2, imgs, sn_base, n, sn_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, 0);
+    } else
     for (int l = 0; l < b->sync_launches; l++)
         js_launch_sync(st, b->sub_wl, b->tab_rows, b->tab_lut2, imgs, sn_base, n, sn_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, l == 0);
     roctxRangePop();
@@ -340,6 +348,10 @@ int js_read_flags(JsnoopBatch* b)
     if (b->d2h_staged(both.data(), b->dev.flags, 2 * n * 4)) return -1;          // (through the page-locked landing buffer)
     b->host_flags.resize(n); b->host_anom.resize(n);
     for (size_t i = 0; i < n; i++) { b->host_flags[i] = both[2 * i]; b->host_anom[i] = ~both[2 * i + 1]; }      // (the arena keeps the complement: 0 = none)
+    if (b->cand_rounds >= 0 && getenv("JSNOOP_DEBUG_CAND")) {      // candidate chain of image 0: walks queued by the last chain launch, open sub-sequences after each launch
+        uint32_t h[12]; if (b->d2h_staged(h, b->dev.cand_req, sizeof h)) return -1;
+        fprintf(stderr, "[cand] rounds %d: queued by the last chain %u; open after chain 0..: %u %u %u %u; queued: %u %u %u %u\n", b->cand_rounds, h[0], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
+    }
     return 0;
 }
 
