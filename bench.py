@@ -294,7 +294,7 @@ def extras_single_gpu(J, H, orc, np):
     # the baseline (SOF0) form of config 5 through the batch path, oracle-checked directly
     b5 = J.JpegBatch(); b5.add_jpeg(base5); b5.upload(); b5.decode(); b5.sync()
     msb, _ = b5.decode_timed(10)
-    extra["config5_baseline_form_422_rst"] = {"ms": round(msb, 4), "bit_exact": bool(int(b5.dib_checksums()[0]) == J.dib_checksum_numpy(orc.dib()))}
+    extra["config5_baseline_form_422_rst"] = {"ms": round(msb, 4), "bit_exact": bool(int(b5.dib_checksums()[0]) == want5)}     # (want5: the oracle's DIB of this file, taken above -- the oracle has decoded the damaged files since)
     b5.close()
     return extra
 

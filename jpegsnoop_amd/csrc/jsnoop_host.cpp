@@ -200,7 +200,7 @@ JsnoopBatch::~JsnoopBatch()
     for (void** p : { (void**)&dev.raw, (void**)&dev.ustr, (void**)&dev.coef, (void**)&dev.dccum, (void**)&dev.dib, (void**)&dev.planes,
                       (void**)&dev.side, (void**)&dev.imgs, (void**)&dev.tables, (void**)&dev.wg_base, (void**)&dev.sel, (void**)&dev.sums,
                       (void**)&dev.sub, (void**)&dev.probe, (void**)&dev.seg, (void**)&dev.chunk_keep, (void**)&dev.chunk_rst, (void**)&dev.us_base,
-                      (void**)&dev.sy_base, (void**)&dev.mcu_rst, (void**)&dev.dc_parts, (void**)&dev.flags, (void**)&dev.ustr_lin, (void**)&dev.events, (void**)&dev.cand, (void**)&dev.cand_req }) if (*p) hipFree(*p);
+                      (void**)&dev.sy_base, (void**)&dev.mcu_rst, (void**)&dev.dc_parts, (void**)&dev.flags, (void**)&dev.ustr_lin, (void**)&dev.events, (void**)&dev.cand, (void**)&dev.cand_req, (void**)&dev.wg_part }) if (*p) hipFree(*p);
     delete helper; helper = nullptr;
     if (d_lut) hipFree(d_lut);
     if (d_side_tmp) hipFree(d_side_tmp);
@@ -340,8 +340,10 @@ int JsnoopBatch::upload()
     std::vector<uint32_t> wg(n + 1), usb(n + 1), syb(2 * (n + 1));       // syb: write-pass bases, then sync-pass bases
     uint64_t segw = 0, mcub = 0; uint32_t usc = 0, syw = 0, snw = 0;
     strips_per_wg = 0; uint64_t total_mcus = 0; for (const JsImage& im : imgs) total_mcus += (uint64_t)im.mcu_xmax * im.mcu_ymax;
-    // back end: 8 waves per workgroup; enough MCUs per wave to amortise a workgroup's table load, enough workgroups (>= ~1500) to fill 256 CUs
-    const uint32_t mcus_per_wave = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (total_mcus + 8 * 1536 - 1) / (8 * 1536)));
+    // back end: 8 waves per workgroup; enough MCUs per wave to amortise a workgroup's table load; a small job as ONE round of workgroups over the
+    // chip's 1024 workgroup slots (one 3840x2160 image: 4 MCUs per wave, 1013 workgroups, 47 us; 3 per wave = 1350 workgroups: 51)
+    uint32_t mcus_per_wave = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (total_mcus + 8 * 1024 - 1) / (8 * 1024)));
+    if (const char* e = getenv("JSNOOP_MPW")) mcus_per_wave = (uint32_t)std::max(1, atoi(e));       // (experiments)
     // sub-sequence length: long (512 B) when the batch still yields plenty of lanes, short (128 B, 64 B) for small jobs
     uint64_t scan_total = 0; for (const JsImage& im : imgs) scan_total += im.scan_len;
     sub_wl = scan_total >= (96ull << 20) ? 7 : (scan_total < (4ull << 20) ? 4 : 5);    // (a single image / a handful: 64-byte pieces give the write pass more lanes)
@@ -379,9 +381,10 @@ int JsnoopBatch::upload()
         grow(&dev.us_base, &cap.us_base, (n + 1) * 4) || grow(&dev.sy_base, &cap.sy_base, 2 * (n + 1) * 4) ||
         grow(&dev.mcu_rst, &cap.mcu_rst, mcub + 64) || grow(&dev.dc_parts, &cap.dc_parts, JS_DC_PARTS_BYTES) || grow(&dev.ustr_lin, &cap.ustr_lin, ustr + 64) || grow(&dev.flags, &cap.flags, n * 8 + 64)) return -1;
     if (opt_want_planes && grow(&dev.planes, &cap.planes, plane * 2)) return -1;
+    { uint32_t most = 0; for (size_t i = 0; i < n; i++) most = std::max(most, wg[i + 1] - wg[i]); if (most > 64 && grow(&dev.wg_part, &cap.wg_part, (size_t)wgs * 16 + 64)) return -1; }
     {   // candidate synchronisation: when every sub-sequence can afford one walk per block of the MCU at once (the chip holds ~500 k lanes)
         uint32_t mb = 0; for (const JsImage& im : imgs) mb = std::max(mb, im.blk_per_mcu);
-        int rounds = 2; if (const char* e = getenv("JSNOOP_CAND")) rounds = atoi(e) > 0 ? std::min(atoi(e), 8) : -1;
+        int rounds = 6; if (const char* e = getenv("JSNOOP_CAND")) rounds = atoi(e) > 0 ? std::min(atoi(e), 64) : -1;
         cand_blk = mb;
         cand_rounds = (sub_wl == 4 && mb >= 1 && mb <= JS_CAND_MAX_BLK && subs * mb <= 640000ull) ? rounds : -1;
         if (cand_rounds >= 0 && (grow(&dev.cand, &cap.cand, js_cand_bytes(subs)) || grow(&dev.cand_req, &cap.cand_req, n * JS_CAND_REQ_WORDS * 4))) return -1;
@@ -419,9 +422,7 @@ int JsnoopBatch::decode(bool timed)
         HIP_TRY(hipMemsetAsync(dev.coef, 0, total_blocks * 128, stream));
         HIP_TRY(hipMemsetAsync(dev.dccum, 0, total_blocks * 2, stream));
     }
-    HIP_TRY(hipMemsetAsync(dev.side, 0, side_words * 4, stream));
-    HIP_TRY(hipMemsetAsync(dev.mcu_rst, 0, mcu_bytes, stream));
-    if (js_clear_flags(this)) return -1;
+    js_launch_clear3(stream, dev.side, side_words * 4, dev.mcu_rst, mcu_bytes, dev.flags, (size_t)n * 8);   // (one launch; all three arenas are allocated with 64 bytes of slack)
     if (event_words) HIP_TRY(hipMemsetAsync(dev.events, 0, event_words * 4, stream));
     if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
     last_timed_split = false;
@@ -465,7 +466,11 @@ int JsnoopBatch::launch_back_end_part(hipStream_t st, uint32_t i0, uint32_t nimg
     static const bool generic_only = getenv("JSNOOP_BACKEND_GENERIC") != nullptr;   // (cross-check: the all-layouts kernel for every launch)
     if (layout < 0 || generic_only) layout = 0;
     const uint32_t wgs = h_wg_base.size() > i0 + nimg ? h_wg_base[i0 + nimg] - h_wg_base[i0] : total_wgs;
-    const int rc = js_launch_idct_color(st, dev.imgs + i0, dev.wg_base + i0, nimg, wgs, tile, d_lut, dev.coef, dev.dccum, dev.dib, dev.planes, dev.side, layout);
+    // an image spread over many workgroups: per-workgroup status records and a fold, instead of every workgroup queueing on the image's two status words
+    uint32_t most = 0; for (uint32_t i = i0; i < i0 + nimg && i + 1 < h_wg_base.size(); i++) most = std::max(most, h_wg_base[i + 1] - h_wg_base[i]);
+    unsigned long long* part = nullptr;
+    if (most > 64) part = dev.wg_part;                            // (allocated by upload() when some image has that many)
+    const int rc = js_launch_idct_color(st, dev.imgs + i0, dev.wg_base + i0, nimg, wgs, tile, d_lut, dev.coef, dev.dccum, dev.dib, dev.planes, dev.side, layout, part);
     if (rc == -2) { js_set_error("back end: an MCU tile of %u bytes per wave does not fit the 160 KiB LDS", tile); return -1; }
     if (rc) { js_set_error("back end launch failed (%d): %s", rc, hipGetErrorString(hipGetLastError())); return -1; }
     return 0;

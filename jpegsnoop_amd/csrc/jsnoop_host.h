@@ -62,10 +62,10 @@ struct JsDeviceArenas {
     uint8_t* raw; uint8_t* ustr; int16_t* coef; int16_t* dccum; uint8_t* dib; int16_t* planes; uint32_t* side;
     JsImage* imgs; JsTableSet* tables; uint32_t* wg_base; uint32_t* sel; uint64_t* sums; uint8_t* sub; uint8_t* probe;
     uint32_t* seg; uint32_t* chunk_keep; uint32_t* chunk_rst; uint32_t* us_base; uint32_t* sy_base; uint8_t* mcu_rst; uint32_t* flags; uint8_t* ustr_lin;
-    uint32_t* events; uint8_t* dc_parts; uint32_t* cand; uint32_t* cand_req;
+    uint32_t* events; uint8_t* dc_parts; uint32_t* cand; uint32_t* cand_req; unsigned long long* wg_part;
 };
 struct JsArenaCaps { size_t raw, ustr, coef, dccum, dib, planes, side, imgs, tables, wg_base, sel, sums, sub, probe,
-                            seg, chunk_keep, chunk_rst, us_base, sy_base, mcu_rst, flags, ustr_lin, events, dc_parts, cand, cand_req; };
+                            seg, chunk_keep, chunk_rst, us_base, sy_base, mcu_rst, flags, ustr_lin, events, dc_parts, cand, cand_req, wg_part; };
 
 struct JsnoopBatch {
     int device; hipStream_t stream; bool own_stream;

@@ -776,7 +776,8 @@ template <int LAYOUT>
 __global__ void __launch_bounds__(BK_THREADS, JS_BK_OCC) k_idct_color(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ wg_base, uint32_t nimg,
                                                            uint32_t tile_bytes, const float* __restrict__ lut_t /*[vu][yx]*/,
                                                            const int16_t* __restrict__ coef, const int16_t* __restrict__ dccum,
-                                                           uint8_t* __restrict__ dib, int16_t* __restrict__ planes, uint32_t* __restrict__ side)
+                                                           uint8_t* __restrict__ dib, int16_t* __restrict__ planes, uint32_t* __restrict__ side,
+                                                           unsigned long long* __restrict__ wg_part)
 {
     // dynamic shared memory only: the cosine table must sit at LDS offset 0 (idct_terms addresses its rows through M0)
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
@@ -829,9 +830,31 @@ __global__ void __launch_bounds__(BK_THREADS, JS_BK_OCC) k_idct_color(const JsIm
     __syncthreads();
     if (tid == 0) {
         for (uint32_t w = 1; w < BK_WAVES; w++) { bright = s_bright[w] > bright ? s_bright[w] : bright; sum_y += s_sum[w]; }
+        // An image spread over hundreds of workgroups (a single large image: ~1000) would queue them all on these two words -- 42 ns per
+        // workgroup, 55 of the 100 us the kernel took for one 3840x2160 image: such launches leave one record per workgroup instead and
+        // k_status_reduce folds them.
+        if (wg_part) { wg_part[2 * (size_t)bx] = bright; wg_part[2 * (size_t)bx + 1] = sum_y; return; }
         uint32_t* sd = side + im.side_off;
         unsigned long long* bp = reinterpret_cast<unsigned long long*>(sd + 12);
         if ((unsigned long long)bright > __atomic_load_n(bp, __ATOMIC_RELAXED)) atomicMax(bp, (unsigned long long)bright);
+        atomicAdd(sd + 15, sum_y);
+    }
+}
+// brightest pixel / luminance sum of an image from the per-workgroup records of k_idct_color (one workgroup per image)
+__global__ void __launch_bounds__(256) k_status_reduce(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ wg_base, const unsigned long long* __restrict__ wg_part,
+                                                       uint32_t* __restrict__ side)
+{
+    __shared__ unsigned long long s_b[4]; __shared__ uint32_t s_s[4];
+    const JsImage& im = imgs[blockIdx.x];
+    unsigned long long bright = 0; uint32_t sum_y = 0;
+    for (uint32_t w = wg_base[blockIdx.x] + threadIdx.x; w < wg_base[blockIdx.x + 1]; w += 256) { const unsigned long long b = wg_part[2 * (size_t)w]; bright = b > bright ? b : bright; sum_y += (uint32_t)wg_part[2 * (size_t)w + 1]; }
+    for (int off = 32; off > 0; off >>= 1) { const unsigned long long ob = __shfl_down(bright, off); bright = ob > bright ? ob : bright; sum_y += __shfl_down(sum_y, off); }
+    if ((threadIdx.x & 63) == 0) { s_b[threadIdx.x >> 6] = bright; s_s[threadIdx.x >> 6] = sum_y; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) { bright = s_b[w] > bright ? s_b[w] : bright; sum_y += s_s[w]; }
+        uint32_t* sd = side + im.side_off;
+        atomicMax(reinterpret_cast<unsigned long long*>(sd + 12), bright);
         atomicAdd(sd + 15, sum_y);
     }
 }
@@ -1062,7 +1085,7 @@ void js_launch_entropy_exact(hipStream_t st, const JsImage* imgs, const uint32_t
     hipLaunchKernelGGL(k_entropy_exact, dim3(nsel), dim3(64), 0, st, imgs, sel, nsel, tables, raw, coef, dccum, side, side_only, events, none);
 }
 int js_launch_idct_color(hipStream_t st, const JsImage* imgs, const uint32_t* wg_base, uint32_t nimg, uint32_t total_wgs, uint32_t tile_bytes,
-                         const float* lut_t, const int16_t* coef, const int16_t* dccum, uint8_t* dib, int16_t* planes, uint32_t* side, int layout)
+                         const float* lut_t, const int16_t* coef, const int16_t* dccum, uint8_t* dib, int16_t* planes, uint32_t* side, int layout, unsigned long long* wg_part)
 {
     if (!total_wgs) return 0;
     // tile_bytes: the largest per-wave tile any image of the launch needs (js_tile_bytes).  Ordinary images leave room for four
@@ -1081,12 +1104,13 @@ int js_launch_idct_color(hipStream_t st, const JsImage* imgs, const uint32_t* wg
         }
     }
     switch (layout) {
-    case 1: hipLaunchKernelGGL(k_idct_color<1>, dim3(total_wgs), dim3(BK_THREADS), lds, st, imgs, wg_base, nimg, tile_bytes, lut_t, coef, dccum, dib, planes, side); break;
-    case 2: hipLaunchKernelGGL(k_idct_color<2>, dim3(total_wgs), dim3(BK_THREADS), lds, st, imgs, wg_base, nimg, tile_bytes, lut_t, coef, dccum, dib, planes, side); break;
-    case 3: hipLaunchKernelGGL(k_idct_color<3>, dim3(total_wgs), dim3(BK_THREADS), lds, st, imgs, wg_base, nimg, tile_bytes, lut_t, coef, dccum, dib, planes, side); break;
-    case 4: hipLaunchKernelGGL(k_idct_color<4>, dim3(total_wgs), dim3(BK_THREADS), lds, st, imgs, wg_base, nimg, tile_bytes, lut_t, coef, dccum, dib, planes, side); break;
-    default: hipLaunchKernelGGL(k_idct_color<0>, dim3(total_wgs), dim3(BK_THREADS), lds, st, imgs, wg_base, nimg, tile_bytes, lut_t, coef, dccum, dib, planes, side); break;
+    case 1: hipLaunchKernelGGL(k_idct_color<1>, dim3(total_wgs), dim3(BK_THREADS), lds, st, imgs, wg_base, nimg, tile_bytes, lut_t, coef, dccum, dib, planes, side, wg_part); break;
+    case 2: hipLaunchKernelGGL(k_idct_color<2>, dim3(total_wgs), dim3(BK_THREADS), lds, st, imgs, wg_base, nimg, tile_bytes, lut_t, coef, dccum, dib, planes, side, wg_part); break;
+    case 3: hipLaunchKernelGGL(k_idct_color<3>, dim3(total_wgs), dim3(BK_THREADS), lds, st, imgs, wg_base, nimg, tile_bytes, lut_t, coef, dccum, dib, planes, side, wg_part); break;
+    case 4: hipLaunchKernelGGL(k_idct_color<4>, dim3(total_wgs), dim3(BK_THREADS), lds, st, imgs, wg_base, nimg, tile_bytes, lut_t, coef, dccum, dib, planes, side, wg_part); break;
+    default: hipLaunchKernelGGL(k_idct_color<0>, dim3(total_wgs), dim3(BK_THREADS), lds, st, imgs, wg_base, nimg, tile_bytes, lut_t, coef, dccum, dib, planes, side, wg_part); break;
     }
+    if (wg_part) hipLaunchKernelGGL(k_status_reduce, dim3(nimg), dim3(256), 0, st, imgs, wg_base, wg_part, side);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 void js_launch_idct_probe(hipStream_t st, const float* lut_t, const int16_t* coef64, float* out64)
@@ -1101,6 +1125,21 @@ void js_launch_clip_order(hipStream_t st, const JsImage* imgs, uint32_t img, con
 { hipLaunchKernelGGL(k_clip_order, dim3(1), dim3(1024), 0, st, imgs, img, planes, budget, out6); }
 void js_launch_tiff_pack(hipStream_t st, const JsImage* imgs, uint32_t img, const uint8_t* dib, const int16_t* planes, int mode, uint8_t* out)
 { hipLaunchKernelGGL(k_tiff_pack, dim3(1024), dim3(256), 0, st, imgs, img, dib, planes, mode, out); }
+// the three arenas a decode starts from zero with (side outputs, MCU restart marks, flag words) in one launch instead of three fills
+__global__ void __launch_bounds__(256) k_clear3(uint4* __restrict__ a, size_t na, uint4* __restrict__ b, size_t nb, uint4* __restrict__ c, size_t nc)
+{
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < na + nb + nc; i += (size_t)gridDim.x * 256) {
+        if (i < na) a[i] = z; else if (i < na + nb) b[i - na] = z; else c[i - na - nb] = z;
+    }
+}
+void js_launch_clear3(hipStream_t st, void* a, size_t a_bytes, void* b, size_t b_bytes, void* c, size_t c_bytes)   // sizes rounded UP to 16 bytes: the arenas have the slack
+{
+    const size_t na = (a_bytes + 15) / 16, nb = (b_bytes + 15) / 16, nc = (c_bytes + 15) / 16, tot = na + nb + nc;
+    if (!tot) return;
+    const uint32_t wgs = (uint32_t)std::min<size_t>(2048, (tot + 1023) / 1024);
+    hipLaunchKernelGGL(k_clear3, dim3(wgs), dim3(256), 0, st, (uint4*)a, na, (uint4*)b, nb, (uint4*)c, nc);
+}
 void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, const uint8_t* dib, unsigned long long* sums)
 {
     if (!nimg) return;
@@ -1705,12 +1744,12 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
 //                 candidate) -- a map over slot numbers, eight bytes per sub-sequence (byte 7: where to go on when the entry state
 //                 is in no slot: the exit most speculative walks agree on);
 //   k_cand_chain  one workgroup per image: following the chain from the true start of the scan is now a composition of those maps --
-//                 a prefix scan (two v_perm_b32 per composition) instead of walks.  Where the chain arrives at a sub-sequence with a
-//                 state that is in no slot, the sub-sequence is queued with that state;
-//   k_cand_fill   walks the queued ones (slot 6 of their memos); the next k_cand_chain picks the chain up from there.  Two such
-//                 rounds resolve a typical image;
+//                 a prefix scan (two v_perm_b32 per composition, DPP shifts between the lanes) instead of walks.  Where the chain arrives
+//                 at a sub-sequence with a state that is in no slot, the sub-sequence is queued with that state; the same workgroup walks
+//                 the queued ones (slot 6 of their memos), patches the maps around them and follows the chain again.  Two such rounds
+//                 resolve a typical image (313 and 11 walks for the 34 533 sub-sequences of the 3840x2160 picture);
 //   k_cand_apply  writes the selected entry / exit states and block counts where k_block_scan and k_write2 expect them.
-//  What is still open after that (a noisy image can need a third round) is marked and left to k_sync in its verification mode,
+//  What is still open after the last round the host allows is marked and left to k_sync in its verification mode,
 //  which walks exactly the marked sub-sequences and what depends on them; k_write2 verifies the whole chain in any case.
 // =====================================================================================
 #define CD_H       6                   // candidate slots = hypotheses (images with more blocks per MCU: k_sync)
@@ -1718,9 +1757,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
 #define CD_NONE    7
 #define CD_SLOTS   7
 #define CD_EMPTY   0xFFFFFFFDu         // entry position of an unused memo slot (no state has it: positions are < 2^32 - 3)
-#define CD_REQ_WGS 8                   // fill workgroups per image and round
-#define CD_REQ_CAP (CD_REQ_WGS * SY_THREADS)
-#define CD_REQ_WORDS (12 + 3 * CD_REQ_CAP)        // [0] walks queued, [4..7] / [8..11]: sub-sequences open / walks queued after chain launch 0..3 (diagnostics), then {sub-sequence, position, state}
+#define CD_DIAG_WORDS 12                // per image: diagnostics of the chain (JSNOOP_DEBUG_CAND)
 struct CandArrays {
     uint32_t *xp, *xs;                 // [CD_H][n]  speculative exit states
     uint32_t *mep, *mes, *mxp, *mxs, *mnb;   // [CD_SLOTS][n]  memo: entry state, exit state, blocks completed
@@ -1824,133 +1861,190 @@ __global__ void __launch_bounds__(SY_THREADS) k_cand_walk(const JsImage* __restr
     }
 }
 
-// One workgroup of 16 waves per image.  `round`: 0 = first chain after k_cand_walk, > 0 = after a k_cand_fill.
-// Every wave owns a contiguous segment of the image's sub-sequences and goes through it in tiles of 256: a lane takes four consecutive maps
-// (32 contiguous bytes: the wave reads 2 KiB at a stretch), composes them, the wave scans the 64 lane products with shuffles and carries the
-// product of the tiles before along; no barrier inside a segment.  The 16 segment products meet in LDS; the second trip over the tiles
-// applies what came before the segment and writes the selections.
-#define CC_THREADS 1024
-#define CC_PER_LANE 4
+// One workgroup of 8 waves per image: the chain, and the walks it asks for, in rounds until it runs through (or max_rounds walk rounds
+// are spent).  Every wave owns a contiguous segment of the image's sub-sequences and goes through it in tiles of 512: a lane takes eight
+// consecutive maps (64 contiguous bytes: the wave reads 4 KiB at a stretch, the next tile's already in flight), composes them, the wave scans
+// the 64 lane products with shuffles and carries the product of the tiles before along; no barrier inside a segment.  The 8 segment
+// products meet in LDS; the second trip over the tiles applies what came before the segment and writes the selections.  A sub-sequence the
+// chain reaches with a state in none of its slots, from a left neighbour that HAS a selection, is queued; the first threads of the
+// workgroup walk the queued ones (slot 6 of their memos) and patch the two maps around each, and the chain is followed again.
+#define CC_THREADS 512                 // (eight waves: the walk inside wants more registers than sixteen waves leave)
+#define CC_PER_LANE 8
 #define CC_TILE (64 * CC_PER_LANE)
-#define CC_MAX_TILES 16                // 16 waves x 16 tiles x 256 = 65536 sub-sequences per image (the host keeps larger images on k_sync)
-__device__ __forceinline__ uint2 cd_shfl_up(uint2 v, int off) { return make_uint2((uint32_t)__shfl_up((int)v.x, off), (uint32_t)__shfl_up((int)v.y, off)); }
-__device__ __forceinline__ void cd_queue(uint32_t* __restrict__ req, uint32_t* s_nreq, const CandArrays& C, size_t g0, uint32_t i, uint32_t prev)
+#define CC_MAX_TILES 16                // 8 waves x 16 tiles x 512 = 65536 sub-sequences per image (the host keeps larger images on k_sync)
+// Inclusive scan of the lanes' maps (lane order) without the LDS crossbar: row_shr 1 / 2 / 4 / 8 inside the rows of 16, then the row totals
+// through row_bcast:15 (rows 1 and 3) and row_bcast:31 (rows 2 and 3).  A lane no source reaches reads the identity map: composing with it
+// changes nothing, so no step needs a select.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint2 cd_dpp(uint2 v)
+{
+    return make_uint2((uint32_t)__builtin_amdgcn_update_dpp((int)0x03020100, (int)v.x, CTRL, ROW_MASK, 0xF, false),
+                      (uint32_t)__builtin_amdgcn_update_dpp((int)0x07060504, (int)v.y, CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ uint2 cd_scan(uint2 P)
+{
+    P = cd_compose(cd_dpp<0x111, 0xF>(P), P);                    // row_shr:1
+    P = cd_compose(cd_dpp<0x112, 0xF>(P), P);                    // row_shr:2
+    P = cd_compose(cd_dpp<0x114, 0xF>(P), P);                    // row_shr:4
+    P = cd_compose(cd_dpp<0x118, 0xF>(P), P);                    // row_shr:8
+    P = cd_compose(cd_dpp<0x142, 0xA>(P), P);                    // row_bcast:15 into rows 1, 3
+    P = cd_compose(cd_dpp<0x143, 0xC>(P), P);                    // row_bcast:31 into rows 2, 3
+    return P;
+}
+__device__ __forceinline__ uint2 cd_lane63(uint2 P) { return make_uint2((uint32_t)__builtin_amdgcn_readlane((int)P.x, 63), (uint32_t)__builtin_amdgcn_readlane((int)P.y, 63)); }
+__device__ __forceinline__ void cd_queue(uint32_t* s_req, uint32_t* s_nreq, uint32_t i, uint32_t prev)
 {
     const uint32_t slot = atomicAdd(s_nreq, 1u);
-    if (slot < CD_REQ_CAP) { req[12 + 3 * slot] = i | (prev << 24); req[13 + 3 * slot] = C.mxp[prev * C.n + g0 + i - 1]; req[14 + 3 * slot] = C.mxs[prev * C.n + g0 + i - 1]; }
+    if (slot < CC_THREADS) s_req[slot] = i | (prev << 24);
 }
-__global__ void __launch_bounds__(CC_THREADS) k_cand_chain(const JsImage* __restrict__ imgs, const JsTableSet* __restrict__ tables, CandArrays C, uint32_t* __restrict__ req_all, int round)
-{
-    __shared__ uint2 s_wtot[CC_THREADS / 64];
-    __shared__ uint8_t s_wlast[CC_THREADS / 64], s_wfirst_open[CC_THREADS / 64];
-    __shared__ uint32_t s_nreq, s_open;
-    const uint32_t img = blockIdx.x; const JsImage& im = imgs[img];
-    if (!tables[im.tableset].lut_ok) return;
-    uint32_t* req = req_all + (size_t)img * CD_REQ_WORDS;
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    if (round > 0 && req[0] == 0) return;                        // nothing was queued by the chain before: its selection stands
-    const uint32_t nsub = im.n_subseq;
-    const uint32_t seg = (((nsub + CC_THREADS / 64 - 1) / (CC_THREADS / 64)) + CC_TILE - 1) / CC_TILE * CC_TILE, ntiles = seg / CC_TILE;   // per wave; a tile that starts inside the image ends inside its (256-aligned) slot range
-    const size_t g0 = im.subseq_off, n = C.n;
-    if (t == 0) { s_nreq = 0; s_open = 0; }
-    __syncthreads();
-    // ---- first trip: E[tile] = product of the maps of this wave's segment before the lane's four sub-sequences
-    uint2 E[CC_MAX_TILES]; uint2 R = CD_IDENT;
-    #pragma unroll
-    for (uint32_t tl = 0; tl < CC_MAX_TILES; tl++) {
-        E[tl] = CD_IDENT;
-        if (tl < ntiles && wave * seg + tl * CC_TILE < nsub) {
-            const uint32_t i0 = wave * seg + tl * CC_TILE + lane * CC_PER_LANE;
-            const uint4 v0 = *reinterpret_cast<const uint4*>(C.map + g0 + i0), v1 = *reinterpret_cast<const uint4*>(C.map + g0 + i0 + 2);
-            uint2 L = i0 < nsub ? make_uint2(v0.x, v0.y) : CD_IDENT;
-            if (i0 + 1 < nsub) L = cd_compose(L, make_uint2(v0.z, v0.w));
-            if (i0 + 2 < nsub) L = cd_compose(L, make_uint2(v1.x, v1.y));
-            if (i0 + 3 < nsub) L = cd_compose(L, make_uint2(v1.z, v1.w));
-            uint2 P = L;                                         // inclusive scan over the lanes
-            #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { const uint2 a = cd_shfl_up(P, off); if (lane >= (uint32_t)off) P = cd_compose(a, P); }
-            uint2 X = cd_shfl_up(P, 1); if (lane == 0) X = CD_IDENT;
-            E[tl] = cd_compose(R, X);
-            const uint2 T = make_uint2((uint32_t)__shfl((int)P.x, 63), (uint32_t)__shfl((int)P.y, 63));
-            R = cd_compose(R, T);
-        }
-    }
-    if (lane == 0) s_wtot[wave] = R;
-    __syncthreads();
-    uint32_t cw = 0;                                             // slot 0 of the first sub-sequence holds the true start of the scan
-    for (uint32_t w = 0; w < wave; w++) cw = cd_byte(s_wtot[w], cw);
-    // ---- second trip: the selections
-    uint32_t nopen = 0, tile_prev = CD_NONE; bool first_open = false;
-    #pragma unroll
-    for (uint32_t tl = 0; tl < CC_MAX_TILES; tl++) {
-        if (tl < ntiles && wave * seg + tl * CC_TILE < nsub) {
-            const uint32_t i0 = wave * seg + tl * CC_TILE + lane * CC_PER_LANE;
-            const uint4 v0 = *reinterpret_cast<const uint4*>(C.map + g0 + i0), v1 = *reinterpret_cast<const uint4*>(C.map + g0 + i0 + 2);
-            const uint32_t s0 = cd_byte(E[tl], cw), s1 = cd_byte(make_uint2(v0.x, v0.y), s0), s2 = cd_byte(make_uint2(v0.z, v0.w), s1), s3 = cd_byte(make_uint2(v1.x, v1.y), s2);
-            *reinterpret_cast<uint32_t*>(C.sel + g0 + i0) = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
-            // last selection of the sub-sequences this lane has: the lane before needs it as `prev`
-            const uint32_t nval = i0 >= nsub ? 0u : min(nsub - i0, (uint32_t)CC_PER_LANE);
-            const uint32_t mylast = nval == 0 ? CD_NONE : (nval == 1 ? s0 : (nval == 2 ? s1 : (nval == 3 ? s2 : s3)));
-            uint32_t prev = (uint32_t)__shfl_up((int)mylast, 1);
-            if (lane == 0) prev = tile_prev;
-            if (nval > 0 && s0 == CD_NONE) { nopen++; if (lane == 0 && tl == 0) first_open = true; else if (prev != CD_NONE && i0 > 0) cd_queue(req, &s_nreq, C, g0, i0, prev); }
-            if (nval > 1 && s1 == CD_NONE) { nopen++; if (s0 != CD_NONE) cd_queue(req, &s_nreq, C, g0, i0 + 1, s0); }
-            if (nval > 2 && s2 == CD_NONE) { nopen++; if (s1 != CD_NONE) cd_queue(req, &s_nreq, C, g0, i0 + 2, s1); }
-            if (nval > 3 && s3 == CD_NONE) { nopen++; if (s2 != CD_NONE) cd_queue(req, &s_nreq, C, g0, i0 + 3, s2); }
-            tile_prev = (uint32_t)__shfl((int)mylast, 63);
-        }
-    }
-    if (lane == 0) { s_wlast[wave] = (uint8_t)tile_prev; s_wfirst_open[wave] = first_open ? 1 : 0; }
-    if (nopen) atomicAdd(&s_open, nopen);
-    __syncthreads();
-    if (lane == 0 && wave > 0 && s_wfirst_open[wave] && s_wlast[wave - 1] != CD_NONE) cd_queue(req, &s_nreq, C, g0, wave * seg, s_wlast[wave - 1]);   // first sub-sequence of a segment: its left neighbour is the wave before's
-    __syncthreads();
-    if (t == 0) { req[0] = min(s_nreq, (uint32_t)CD_REQ_CAP); if (round < 4) { req[4 + round] = s_open; req[8 + round] = s_nreq; } }
-}
-
 template <int WL>
-__global__ void __launch_bounds__(SY_THREADS) k_cand_fill(const JsImage* __restrict__ imgs, const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr,
-                                                          const uint32_t* __restrict__ seg_tab, const uint32_t* __restrict__ side, CandArrays C,
-                                                          const uint32_t* __restrict__ req_all, uint32_t tab_rows, uint32_t tab_lut2)
+__global__ void __launch_bounds__(CC_THREADS) k_cand_chain(const JsImage* __restrict__ imgs, const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr,
+                                                           const uint32_t* __restrict__ seg_tab, const uint32_t* __restrict__ side, CandArrays C,
+                                                           uint32_t* __restrict__ diag_all, int max_rounds, uint32_t tab_rows, uint32_t tab_lut2)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     __shared__ __attribute__((aligned(8))) uint2 s_ctab[JS_MAX_BLK_PER_MCU];
-    const uint32_t img = blockIdx.y; const JsImage& im = imgs[img];
+    __shared__ uint2 s_wtot[CC_THREADS / 64];
+    __shared__ uint8_t s_wlast[CC_THREADS / 64], s_wfirst_open[CC_THREADS / 64];
+    __shared__ uint32_t s_nreq, s_open;
+    __shared__ uint32_t s_req[CC_THREADS];
+    const uint32_t img = blockIdx.x; const JsImage& im = imgs[img];
     if (!tables[im.tableset].lut_ok) return;
-    const uint32_t* req = req_all + (size_t)img * CD_REQ_WORDS;
-    const uint32_t cnt = req[0], t = threadIdx.x, r = blockIdx.x * SY_THREADS + t;
-    if (blockIdx.x * SY_THREADS >= cnt) return;
-    const uint32_t* sd = side + im.side_off;
-    const uint32_t total_bits = sd[10] * 8, nseg = min(sd[11], im.seg_cap - 1);
-    SubTabs T; load_subtabs<true>(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, t, SY_THREADS);
-    if (t < T.nb) { const uint32_t rbc = t < T.n1 ? T.rb0 : (t < T.n2 ? T.rb1 : T.rb2); s_ctab[t] = make_uint2(lds_addr(T.lutp) + (rbc & 0xFFFFu), lds_addr(T.lutp) + (rbc >> 16)); }
-    __syncthreads();
-    if (r >= cnt) return;
-    const uint32_t i = req[12 + 3 * r] & 0xFFFFFFu, prev = req[12 + 3 * r] >> 24, p = req[13 + 3 * r], s = req[14 + 3 * r];
-    const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);
-    const uint32_t* st = seg_tab + im.seg_off;
-    const uint32_t own_end = min((i + 1) * SUB_BITS, total_bits);
-    uint32_t xp = p, xs = s, nblk = 0;
-    if (!(xp != P_END && xp >= own_end)) walk_sync<WL>(im, T, lds_addr(s_ctab), words, st, nseg, total_bits, own_end, xp, xs, nblk);
-    const size_t g = im.subseq_off + i, n = C.n;
-    C.mep[CD_FILL * n + g] = p; C.mes[CD_FILL * n + g] = s; C.mxp[CD_FILL * n + g] = xp; C.mxs[CD_FILL * n + g] = xs; C.mnb[CD_FILL * n + g] = nblk;
-    // The maps around the new entry.  No two queued sub-sequences are neighbours (a queued one has no selection, its right neighbour got the
-    // guess), so nobody else writes these two words in this launch.
-    uint32_t sc = CD_NONE;
-    if (i + 1 < im.n_subseq) {
-        sc = cd_match(C, g, im.blk_per_mcu, xp, xs);
-        if (sc == CD_NONE && C.mep[CD_FILL * n + g + 1] == xp && C.mes[CD_FILL * n + g + 1] == xs) sc = CD_FILL;   // a walk of an earlier round next door
+    uint32_t* diag = diag_all + (size_t)img * CD_DIAG_WORDS;     // [0] walks still queued at the end, [4 + r] / [8 + r]: sub-sequences open / walks queued after chain r (r < 4)
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t nsub = im.n_subseq;
+    const uint32_t seg = (((nsub + CC_THREADS / 64 - 1) / (CC_THREADS / 64)) + CC_TILE - 1) / CC_TILE * CC_TILE, ntiles = seg / CC_TILE;   // per wave; a tile that starts inside the image ends inside its (256-aligned) slot range
+    const size_t g0 = im.subseq_off, n = C.n;
+    const uint2* maps = C.map + g0 + wave * seg + lane * CC_PER_LANE;            // this lane's four maps of tile 0
+    const bool has0 = ntiles > 0 && wave * seg < nsub;
+    SubTabs T = {}; bool have_tabs = false;
+    uint32_t nreq = 0;
+    for (int round = 0;; round++) {
+        if (t == 0) { s_nreq = 0; s_open = 0; }
+        __syncthreads();
+        // ---- first trip: R = product of the maps of this wave's segment
+        uint2 R = CD_IDENT;
+        uint4 nx[CC_PER_LANE / 2];
+        #pragma unroll
+        for (int q = 0; q < CC_PER_LANE / 2; q++) nx[q] = has0 ? *reinterpret_cast<const uint4*>(maps + 2 * q) : make_uint4(0, 0, 0, 0);
+        #pragma unroll 1
+        for (uint32_t tl = 0; tl < ntiles && wave * seg + tl * CC_TILE < nsub; tl++) {
+            const uint32_t i0 = wave * seg + tl * CC_TILE + lane * CC_PER_LANE;
+            uint4 v[CC_PER_LANE / 2];
+            #pragma unroll
+            for (int q = 0; q < CC_PER_LANE / 2; q++) v[q] = nx[q];
+            if (tl + 1 < ntiles && wave * seg + (tl + 1) * CC_TILE < nsub) {
+                #pragma unroll
+                for (int q = 0; q < CC_PER_LANE / 2; q++) nx[q] = *reinterpret_cast<const uint4*>(maps + (tl + 1) * CC_TILE + 2 * q);
+            }
+            uint2 L = CD_IDENT;
+            #pragma unroll
+            for (int q = 0; q < CC_PER_LANE / 2; q++) {
+                if (i0 + 2 * q < nsub) L = cd_compose(L, make_uint2(v[q].x, v[q].y));
+                if (i0 + 2 * q + 1 < nsub) L = cd_compose(L, make_uint2(v[q].z, v[q].w));
+            }
+            R = cd_compose(R, cd_lane63(cd_scan(L)));            // product over the 64 lanes, in lane order
+        }
+        if (lane == 0) s_wtot[wave] = R;
+        __syncthreads();
+        uint32_t rv = 0;                                         // slot 0 of the first sub-sequence holds the true start of the scan
+        for (uint32_t w = 0; w < wave; w++) rv = cd_byte(s_wtot[w], rv);
+        // ---- second trip: the selections (rv: the selection of the tile's first sub-sequence)
+        uint32_t nopen = 0, tile_prev = CD_NONE; bool first_open = false;
+        #pragma unroll
+        for (int q = 0; q < CC_PER_LANE / 2; q++) nx[q] = has0 ? *reinterpret_cast<const uint4*>(maps + 2 * q) : make_uint4(0, 0, 0, 0);
+        #pragma unroll 1
+        for (uint32_t tl = 0; tl < ntiles && wave * seg + tl * CC_TILE < nsub; tl++) {
+            const uint32_t i0 = wave * seg + tl * CC_TILE + lane * CC_PER_LANE;
+            uint4 v[CC_PER_LANE / 2];
+            #pragma unroll
+            for (int q = 0; q < CC_PER_LANE / 2; q++) v[q] = nx[q];
+            if (tl + 1 < ntiles && wave * seg + (tl + 1) * CC_TILE < nsub) {
+                #pragma unroll
+                for (int q = 0; q < CC_PER_LANE / 2; q++) nx[q] = *reinterpret_cast<const uint4*>(maps + (tl + 1) * CC_TILE + 2 * q);
+            }
+            uint2 L = CD_IDENT;
+            #pragma unroll
+            for (int q = 0; q < CC_PER_LANE / 2; q++) {
+                if (i0 + 2 * q < nsub) L = cd_compose(L, make_uint2(v[q].x, v[q].y));
+                if (i0 + 2 * q + 1 < nsub) L = cd_compose(L, make_uint2(v[q].z, v[q].w));
+            }
+            const uint2 P = cd_scan(L);                          // inclusive scan over the lanes
+            const uint2 X = cd_dpp<0x138, 0xF>(P);                // wave_shr:1 -- the product of the lanes before (lane 0: identity)
+            uint32_t sv[CC_PER_LANE];                            // the selections of this lane's sub-sequences
+            sv[0] = cd_byte(X, rv);
+            #pragma unroll
+            for (int q = 1; q < CC_PER_LANE; q++) sv[q] = cd_byte((q - 1) & 1 ? make_uint2(v[(q - 1) / 2].z, v[(q - 1) / 2].w) : make_uint2(v[(q - 1) / 2].x, v[(q - 1) / 2].y), sv[q - 1]);
+            rv = cd_byte(cd_lane63(P), rv);
+            uint32_t pk0 = 0, pk1 = 0;
+            #pragma unroll
+            for (int q = 0; q < 4; q++) { pk0 |= sv[q] << (8 * q); pk1 |= sv[4 + q] << (8 * q); }
+            *reinterpret_cast<uint2*>(C.sel + g0 + i0) = make_uint2(pk0, pk1);
+            // last selection of the sub-sequences this lane has: the lane after needs it as `prev`
+            const uint32_t nval = i0 >= nsub ? 0u : min(nsub - i0, (uint32_t)CC_PER_LANE);
+            uint32_t mylast = CD_NONE;
+            #pragma unroll
+            for (int q = 0; q < CC_PER_LANE; q++) if ((uint32_t)q < nval) mylast = sv[q];
+            uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)tile_prev, (int)mylast, 0x138, 0xF, 0xF, false);   // wave_shr:1; lane 0: the tile before's last
+            #pragma unroll
+            for (int q = 0; q < CC_PER_LANE; q++) {
+                if ((uint32_t)q < nval && sv[q] == CD_NONE) {
+                    nopen++;
+                    if (q == 0 && lane == 0 && tl == 0) first_open = true;
+                    else if (prev != CD_NONE && i0 + q > 0) cd_queue(s_req, &s_nreq, i0 + q, prev);
+                }
+                prev = sv[q];
+            }
+            tile_prev = (uint32_t)__builtin_amdgcn_readlane((int)mylast, 63);
+        }
+        if (lane == 0) { s_wlast[wave] = (uint8_t)tile_prev; s_wfirst_open[wave] = first_open ? 1 : 0; }
+        if (nopen) atomicAdd(&s_open, nopen);
+        __syncthreads();
+        if (lane == 0 && wave > 0 && s_wfirst_open[wave] && s_wlast[wave - 1] != CD_NONE) cd_queue(s_req, &s_nreq, wave * seg, s_wlast[wave - 1]);   // first sub-sequence of a segment: its left neighbour is the wave before's
+        __syncthreads();
+        nreq = s_nreq;
+        if (t == 0 && round < 4) { diag[4 + round] = s_open; diag[8 + round] = nreq; }
+        if (nreq == 0 || round >= max_rounds) break;
+        // ---- the queued walks (the first 1024 of them; the others are queued again by the next chain)
+        if (!have_tabs) {
+            load_subtabs<true>(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, t, CC_THREADS);
+            if (t < T.nb) { const uint32_t rbc = t < T.n1 ? T.rb0 : (t < T.n2 ? T.rb1 : T.rb2); s_ctab[t] = make_uint2(lds_addr(T.lutp) + (rbc & 0xFFFFu), lds_addr(T.lutp) + (rbc >> 16)); }
+            have_tabs = true;
+            __syncthreads();
+        }
+        if (t < min(nreq, (uint32_t)CC_THREADS)) {
+            const uint32_t* sd = side + im.side_off;
+            const uint32_t total_bits = sd[10] * 8, nseg = min(sd[11], im.seg_cap - 1);
+            const uint32_t i = s_req[t] & 0xFFFFFFu, prev = s_req[t] >> 24;
+            const size_t g = g0 + i;
+            const uint32_t p = C.mxp[prev * n + g - 1], s = C.mxs[prev * n + g - 1];
+            const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);
+            const uint32_t* st = seg_tab + im.seg_off;
+            const uint32_t own_end = min((i + 1) * SUB_BITS, total_bits);
+            uint32_t xp = p, xs = s, nblk = 0;
+            if (!(xp != P_END && xp >= own_end)) walk_sync<WL>(im, T, lds_addr(s_ctab), words, st, nseg, total_bits, own_end, xp, xs, nblk);
+            C.mep[CD_FILL * n + g] = p; C.mes[CD_FILL * n + g] = s; C.mxp[CD_FILL * n + g] = xp; C.mxs[CD_FILL * n + g] = xs; C.mnb[CD_FILL * n + g] = nblk;
+            // The maps around the new entry.  No two queued sub-sequences are neighbours (a queued one has no selection, its right neighbour
+            // got the guess), so nobody else writes these two words in this round.
+            uint32_t sc = CD_NONE;
+            if (i + 1 < nsub) {
+                sc = cd_match(C, g, im.blk_per_mcu, xp, xs);
+                if (sc == CD_NONE && C.mep[CD_FILL * n + g + 1] == xp && C.mes[CD_FILL * n + g + 1] == xs) sc = CD_FILL;   // a walk of an earlier round next door
+            }
+            uint2 m = C.map[g]; m.y = (m.y & 0xFF00FFFFu) | (sc << 16); C.map[g] = m;
+            // left neighbour: the entry the chain came through continues here; entries that pointed at what this slot held before do so no longer
+            uint2 l = C.map[g - 1];
+            #pragma unroll
+            for (uint32_t e = 0; e < CD_SLOTS; e++) {
+                const uint32_t sh = (e & 3u) * 8u; uint32_t& w = e < 4 ? l.x : l.y;
+                if (e == prev) w = (w & ~(255u << sh)) | ((uint32_t)CD_FILL << sh);
+                else if (((w >> sh) & 255u) == CD_FILL) w = (w & ~(255u << sh)) | ((uint32_t)CD_NONE << sh);
+            }
+            C.map[g - 1] = l;
+        }
+        __threadfence();                                         // the maps go to L2, this CU's L1 forgets them: the next chain reads what was patched
+        __syncthreads();
     }
-    uint2 m = C.map[g]; m.y = (m.y & 0xFF00FFFFu) | (sc << 16); C.map[g] = m;
-    // left neighbour: the entry the chain came through continues here; entries that pointed at what this slot held before do so no longer
-    uint2 l = C.map[g - 1];
-    #pragma unroll
-    for (uint32_t e = 0; e < CD_SLOTS; e++) {
-        const uint32_t sh = (e & 3u) * 8u; uint32_t& w = e < 4 ? l.x : l.y;
-        if (e == prev) w = (w & ~(255u << sh)) | ((uint32_t)CD_FILL << sh);
-        else if (((w >> sh) & 255u) == CD_FILL) w = (w & ~(255u << sh)) | ((uint32_t)CD_NONE << sh);
-    }
-    C.map[g - 1] = l;
+    if (t == 0) diag[0] = nreq;
 }
 
 // The selected memo entries, where k_sync / k_block_scan / k_write2 read them.  A sub-sequence the chain reached with a state in none of its
@@ -2562,7 +2656,7 @@ static CandArrays cand_arrays(uint32_t* c, uint64_t n)
     return C;
 }
 size_t js_cand_bytes(uint64_t nsub) { return (size_t)nsub * ((2 * CD_H + 5 * CD_SLOTS + 2) * 4 + 2) + 64; }
-static_assert(CD_REQ_WORDS == JS_CAND_REQ_WORDS, "request area size");
+static_assert(CD_DIAG_WORDS == JS_CAND_REQ_WORDS, "diagnostics area size");
 static_assert(CD_H == JS_CAND_MAX_BLK, "hypotheses");
 #define CAND_WL(K, GRID, BLOCK, LDS, ...) \
     do { if (wl == 4) hipLaunchKernelGGL(K<4>, GRID, BLOCK, LDS, st, __VA_ARGS__); else if (wl == 5) hipLaunchKernelGGL(K<5>, GRID, BLOCK, LDS, st, __VA_ARGS__); \
@@ -2576,10 +2670,7 @@ void js_launch_cand_sync(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab
     const CandArrays C = cand_arrays(cand, nsub);
     CAND_WL(k_cand_spec, dim3(sy_wgs, max_blk), dim3(SY_THREADS), lds, imgs, sy_base, nimg, tables, ustr, seg_tab, side, C, tab_rows, tab_lut2);
     CAND_WL(k_cand_walk, dim3(sy_wgs, CD_H), dim3(SY_THREADS), lds, imgs, sy_base, nimg, tables, ustr, seg_tab, side, C, tab_rows, tab_lut2);
-    for (int r = 0; r <= fill_rounds; r++) {
-        hipLaunchKernelGGL(k_cand_chain, dim3(nimg), dim3(1024), 0, st, imgs, tables, C, req, r);
-        if (r < fill_rounds) CAND_WL(k_cand_fill, dim3(CD_REQ_WGS, nimg), dim3(SY_THREADS), lds, imgs, tables, ustr, seg_tab, side, C, (const uint32_t*)req, tab_rows, tab_lut2);
-    }
+    CAND_WL(k_cand_chain, dim3(nimg), dim3(CC_THREADS), lds, imgs, tables, ustr, seg_tab, side, C, req, fill_rounds, tab_rows, tab_lut2);
     hipLaunchKernelGGL(k_cand_apply, dim3(sy_wgs), dim3(SY_THREADS), 0, st, imgs, sy_base, nimg, tables, side, C, sub_arrays(sub, nsub));
 }
 void js_launch_block_scan(hipStream_t st, int wl, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, uint32_t* sub, uint64_t nsub, uint32_t* side, uint32_t* flags)

@@ -8,8 +8,10 @@ void js_launch_entropy_exact(hipStream_t st, const JsImage* imgs, const uint32_t
                              const uint8_t* raw, int16_t* coef, int16_t* dccum, uint32_t* side, int side_only, uint32_t* events);
 int  js_launch_idct_color(hipStream_t st, const JsImage* imgs, const uint32_t* wg_base, uint32_t nimg, uint32_t total_wgs, uint32_t tile_bytes,
                           const float* lut_t, const int16_t* coef, const int16_t* dccum, uint8_t* dib, int16_t* planes, uint32_t* side,
-                          int layout /* 0 = mixed; 1..4 = every image has the fast layout with chroma expansion (2,2) / (2,1) / (1,2) / (1,1) */);
+                          int layout /* 0 = mixed; 1..4 = every image has the fast layout with chroma expansion (2,2) / (2,1) / (1,2) / (1,1) */,
+                          unsigned long long* wg_part /* null, or 2 words per workgroup (indexed like wg_base): brightest-pixel / luminance records folded by a second kernel */);
 void js_launch_idct_probe(hipStream_t st, const float* lut_t, const int16_t* coef64, float* out64);
+void js_launch_clear3(hipStream_t st, void* a, size_t a_bytes, void* b, size_t b_bytes, void* c, size_t c_bytes);   // three arenas to zero in one launch (sizes rounded up to 16 bytes)
 void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, const uint8_t* dib, unsigned long long* sums);
 void js_launch_color_probe(hipStream_t st, int y, int cb, int cr, uint32_t* out);
 #define JS_STATS_WORDS 2482          /* public layout, include/jsnoop_gpu.h JSNOOP_STATS_WORDS */
@@ -27,7 +29,7 @@ void js_launch_sync(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2
 // Candidate synchronisation (the small-job form of the synchronisation stage: k_cand_spec / _walk / _chain / _fill / _apply); leaves the
 // sub-sequence arrays as js_launch_sync would, open links marked for a js_launch_sync(..., first_pass = 2) behind it.
 #define JS_CAND_MAX_BLK 6            /* images with more blocks per MCU than this synchronise the classic way */
-#define JS_CAND_REQ_WORDS (12 + 3 * 8 * JS_SY_THREADS)
+#define JS_CAND_REQ_WORDS 12         /* per image: diagnostics of the chain */
 size_t js_cand_bytes(uint64_t nsub);
 void js_launch_cand_sync(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t sy_wgs, uint32_t max_blk,
                          const JsTableSet* tables, const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub, uint32_t* cand, uint32_t* req, int fill_rounds);

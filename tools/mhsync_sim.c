@@ -101,7 +101,7 @@ int main(int argc, char** argv)
         {
             enum { E = 16 }; St* me = malloc(sizeof(St) * nsub * E); St* mx = malloc(sizeof(St) * nsub * E); int* mn = calloc(nsub, sizeof(int));
             for (size_t i = 0; i < nsub; i++) for (int h = 0; h < nb; h++) { St e = i ? X[(i - 1) * nb + h] : (St){ 0, 0, 0 }; int dup = 0; for (int q = 0; q < mn[i]; q++) if (st_eq(me[i * E + q], e)) dup = 1; if (!dup) { me[i * E + mn[i]] = e; mx[i * E + mn[i]] = Y[i * nb + h]; mn[i]++; } }
-            long iters = 0, total_walks = 0, max_req = 0;
+            long iters = 0, total_walks = 0, max_req = 0; long* filled = calloc(nsub, sizeof(long));
             for (;; iters++) {
                 size_t* req_i = malloc(sizeof(size_t) * nsub); St* req_s = malloc(sizeof(St) * nsub); long nreq = 0;
                 St cur = { 0, 0, 0 }; int have = 1;
@@ -116,7 +116,8 @@ int main(int argc, char** argv)
                     else { int best = 0; for (int q = 0; q < mn[i]; q++) { int c2 = 0; for (int r = 0; r < mn[i]; r++) if (st_eq(mx[i * E + r], mx[i * E + q])) c2++; if (c2 > best && c2 >= 2) { best = c2; cur = mx[i * E + q]; have = 1; } } }
                 }
                 if (!nreq) { free(req_i); free(req_s); break; }
-                for (long r = 0; r < nreq; r++) { size_t i = req_i[r]; if (mn[i] < E) { me[i * E + mn[i]] = req_s[r]; mx[i * E + mn[i]] = req_s[r].p >= (i + 1) * (size_t)S ? req_s[r] : walk(req_s[r], (i + 1) * (size_t)S); mn[i]++; } }
+                if (iters >= 1 && getenv("SIM_TRACE3")) { long dbl = 0; for (long r = 0; r < nreq; r++) { size_t i = req_i[r]; if (i && mn[i - 1] > 0 && st_eq(mx[(i - 1) * E + mn[i - 1] - 1], req_s[r]) && filled[i - 1] == iters) dbl++; } printf("    round %ld: %ld requests, %ld of them right behind a sub-sequence filled in the round before\n", iters + 1, nreq, dbl); }
+                for (long r = 0; r < nreq; r++) { size_t i = req_i[r]; filled[i] = iters + 1; if (mn[i] < E) { me[i * E + mn[i]] = req_s[r]; mx[i * E + mn[i]] = req_s[r].p >= (i + 1) * (size_t)S ? req_s[r] : walk(req_s[r], (i + 1) * (size_t)S); mn[i]++; } }
                 total_walks += nreq; if (nreq > max_req) max_req = nreq; free(req_i); free(req_s);
                 if (iters > 200) break;
             }
