@@ -347,6 +347,14 @@ int JsnoopBatch::upload()
     // sub-sequence length: long (512 B) when the batch still yields plenty of lanes, short (128 B, 64 B) for small jobs
     uint64_t scan_total = 0; for (const JsImage& im : imgs) scan_total += im.scan_len;
     sub_wl = scan_total >= (96ull << 20) ? 7 : (scan_total < (4ull << 20) ? 4 : 5);    // (a single image / a handful: 64-byte pieces give the write pass more lanes)
+    // Candidate synchronisation (k_cand_*) wants 64-byte pieces and one walk per piece and block of the MCU.  It beats the rounds of k_sync far beyond
+    // what the chip holds at once (~500 k lanes): N x 1080p 4:2:0, ms per decode, candidates | rounds: 1: 0.30 | 0.80, 4: 0.37 | 0.83, 8: 0.45 | 0.95,
+    // 16: 0.64 | 1.09, 32: 1.04 | 1.31, 48: 1.44 | 1.58 (2.6 M walks); the two meet near 64 images.
+    uint32_t max_blk = 0; for (const JsImage& im : imgs) max_blk = std::max(max_blk, im.blk_per_mcu);
+    uint64_t cand_lanes = 2500000; if (const char* e = getenv("JSNOOP_CAND_LANES")) cand_lanes = strtoull(e, nullptr, 10);
+    int cand_want = 6; if (const char* e = getenv("JSNOOP_CAND")) cand_want = atoi(e) > 0 ? std::min(atoi(e), 64) : -1;
+    const bool cand_fits = cand_want >= 0 && max_blk >= 1 && max_blk <= JS_CAND_MAX_BLK && (scan_total / 64 + 64 * n) * max_blk <= cand_lanes;
+    if (cand_fits) sub_wl = 4;
     if (const char* e = getenv("JSNOOP_SUB_WL")) { const int w = atoi(e); sub_wl = (w >= 4 && w <= 8) ? w : 5; }
     const uint32_t sub_bytes = 4u << sub_wl;
     uint32_t wgs = 0; max_mcu_h = 8; max_mcu_w = 8;
@@ -382,13 +390,8 @@ int JsnoopBatch::upload()
         grow(&dev.mcu_rst, &cap.mcu_rst, mcub + 64) || grow(&dev.dc_parts, &cap.dc_parts, JS_DC_PARTS_BYTES) || grow(&dev.ustr_lin, &cap.ustr_lin, ustr + 64) || grow(&dev.flags, &cap.flags, n * 8 + 64)) return -1;
     if (opt_want_planes && grow(&dev.planes, &cap.planes, plane * 2)) return -1;
     { uint32_t most = 0; for (size_t i = 0; i < n; i++) most = std::max(most, wg[i + 1] - wg[i]); if (most > 64 && grow(&dev.wg_part, &cap.wg_part, (size_t)wgs * 16 + 64)) return -1; }
-    {   // candidate synchronisation: when every sub-sequence can afford one walk per block of the MCU at once (the chip holds ~500 k lanes)
-        uint32_t mb = 0; for (const JsImage& im : imgs) mb = std::max(mb, im.blk_per_mcu);
-        int rounds = 6; if (const char* e = getenv("JSNOOP_CAND")) rounds = atoi(e) > 0 ? std::min(atoi(e), 64) : -1;
-        cand_blk = mb;
-        cand_rounds = (sub_wl == 4 && mb >= 1 && mb <= JS_CAND_MAX_BLK && subs * mb <= 640000ull) ? rounds : -1;
-        if (cand_rounds >= 0 && (grow(&dev.cand, &cap.cand, js_cand_bytes(subs)) || grow(&dev.cand_req, &cap.cand_req, n * JS_CAND_REQ_WORDS * 4))) return -1;
-    }
+    cand_blk = max_blk; cand_rounds = (cand_fits && sub_wl == 4) ? cand_want : -1;
+    if (cand_rounds >= 0 && (grow(&dev.cand, &cap.cand, js_cand_bytes(subs)) || grow(&dev.cand_req, &cap.cand_req, n * JS_CAND_REQ_WORDS * 4))) return -1;
     event_words = opt_events ? (uint64_t)n * (1 + JS_EV_WORDS * JS_EV_MAX) : 0;
     if (event_words && grow(&dev.events, &cap.events, event_words * 4)) return -1;
     tab_rows = 1; tab_lut2 = 0; uint32_t tdc = 1, tac = 1;

@@ -1826,11 +1826,16 @@ __global__ void __launch_bounds__(SY_THREADS) k_cand_walk(const JsImage* __restr
     CD_PROLOGUE
     const uint32_t h = blockIdx.y, nb = im.blk_per_mcu;
     uint8_t* mapb = reinterpret_cast<uint8_t*>(C.map);
-    if (h >= nb) { if (valid) { C.mep[h * n + g] = CD_EMPTY; mapb[g * 8 + h] = CD_NONE; } return; }
+    // Sub-sequences behind the last one that holds data own no symbol: whatever state arrives passes through (it is P_END unless the last symbol
+    // ended on the very last bit).  The chain takes them as resolved -- every map byte points at slot 0 -- and k_cand_apply hands the exit
+    // state of the last data sub-sequence through them.
+    const uint32_t i_last = total_bits ? (total_bits - 1u) / SUB_BITS : 0u;
+    if (valid && i > i_last) { C.mep[h * n + g] = CD_EMPTY; mapb[g * 8 + h] = 0; if (h == 0) { C.mep[CD_FILL * n + g] = CD_EMPTY; mapb[g * 8 + CD_FILL] = 0; mapb[g * 8 + 7] = 0; } }
+    if (h >= nb) { if (valid && i <= i_last) { C.mep[h * n + g] = CD_EMPTY; mapb[g * 8 + h] = CD_NONE; } return; }
     SubTabs T; load_subtabs<true>(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, t, SY_THREADS);
     if (t < T.nb) { const uint32_t rbc = t < T.n1 ? T.rb0 : (t < T.n2 ? T.rb1 : T.rb2); s_ctab[t] = make_uint2(lds_addr(T.lutp) + (rbc & 0xFFFFu), lds_addr(T.lutp) + (rbc >> 16)); }
     __syncthreads();
-    if (!valid) return;
+    if (!valid || i > i_last) return;
     const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);
     const uint32_t* st = seg_tab + im.seg_off;
     // entry state: candidate h of the left neighbour (the true start of the scan for the first sub-sequence); a candidate equal to one in a lower slot is walked there
@@ -1845,7 +1850,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_cand_walk(const JsImage* __restr
         uint32_t xp = p, xs = s, nblk = 0;
         if (!(xp != P_END && xp >= own_end)) walk_sync<WL>(im, T, lds_addr(s_ctab), words, st, nseg, total_bits, own_end, xp, xs, nblk);
         C.mep[h * n + g] = p; C.mes[h * n + g] = s; C.mxp[h * n + g] = xp; C.mxs[h * n + g] = xs; C.mnb[h * n + g] = nblk;
-        if (i + 1 < im.n_subseq) succ = cd_match(C, g, nb, xp, xs);
+        if (i + 1 < im.n_subseq) succ = i == i_last ? 0u : cd_match(C, g, nb, xp, xs);
     } else C.mep[h * n + g] = CD_EMPTY;
     mapb[g * 8 + h] = (uint8_t)succ;
     if (h == 0) {
@@ -1856,7 +1861,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_cand_walk(const JsImage* __restr
             for (uint32_t r = 0; r < nb; r++) cnt += (C.xp[r * n + g] == qp && C.xs[r * n + g] == qs) ? 1u : 0u;
             if (cnt > best) { best = cnt; guess = q; }
         }
-        if (i + 1 >= im.n_subseq) guess = CD_NONE;
+        if (i + 1 >= im.n_subseq) guess = CD_NONE; else if (i == i_last) guess = 0;
         C.mep[CD_FILL * n + g] = CD_EMPTY; mapb[g * 8 + CD_FILL] = CD_NONE; mapb[g * 8 + 7] = (uint8_t)guess;
     }
 }
@@ -1872,25 +1877,31 @@ __global__ void __launch_bounds__(SY_THREADS) k_cand_walk(const JsImage* __restr
 #define CC_PER_LANE 8
 #define CC_TILE (64 * CC_PER_LANE)
 #define CC_MAX_TILES 16                // 8 waves x 16 tiles x 512 = 65536 sub-sequences per image (the host keeps larger images on k_sync)
-// Inclusive scan of the lanes' maps (lane order) without the LDS crossbar: row_shr 1 / 2 / 4 / 8 inside the rows of 16, then the row totals
-// through row_bcast:15 (rows 1 and 3) and row_bcast:31 (rows 2 and 3).  A lane no source reaches reads the identity map: composing with it
-// changes nothing, so no step needs a select.
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint2 cd_dpp(uint2 v)
+// Scan of the lanes' maps (lane order) without the LDS crossbar: row_shr 1 / 2 / 4 / 8 inside the rows of 16 (a lane no source reaches reads
+// the identity map: composing with it changes nothing, so no step needs a select), the four row totals through v_readlane and composed as
+// wave-uniform values.  (row_bcast / wave_shr, the DPP modes that cross rows, are not used: wave_shr:1 does nothing on gfx950.)
+template <int CTRL> __device__ __forceinline__ uint2 cd_dpp(uint2 v)
 {
-    return make_uint2((uint32_t)__builtin_amdgcn_update_dpp((int)0x03020100, (int)v.x, CTRL, ROW_MASK, 0xF, false),
-                      (uint32_t)__builtin_amdgcn_update_dpp((int)0x07060504, (int)v.y, CTRL, ROW_MASK, 0xF, false));
+    return make_uint2((uint32_t)__builtin_amdgcn_update_dpp((int)0x03020100, (int)v.x, CTRL, 0xF, 0xF, false),
+                      (uint32_t)__builtin_amdgcn_update_dpp((int)0x07060504, (int)v.y, CTRL, 0xF, 0xF, false));
 }
-__device__ __forceinline__ uint2 cd_scan(uint2 P)
+template <int LANE> __device__ __forceinline__ uint2 cd_lane(uint2 P) { return make_uint2((uint32_t)__builtin_amdgcn_readlane((int)P.x, LANE), (uint32_t)__builtin_amdgcn_readlane((int)P.y, LANE)); }
+struct CdScan { uint2 excl, total; };                            // product of the lanes before this one; product of all 64
+__device__ __forceinline__ CdScan cd_scan(uint2 P, uint32_t lane)
 {
-    P = cd_compose(cd_dpp<0x111, 0xF>(P), P);                    // row_shr:1
-    P = cd_compose(cd_dpp<0x112, 0xF>(P), P);                    // row_shr:2
-    P = cd_compose(cd_dpp<0x114, 0xF>(P), P);                    // row_shr:4
-    P = cd_compose(cd_dpp<0x118, 0xF>(P), P);                    // row_shr:8
-    P = cd_compose(cd_dpp<0x142, 0xA>(P), P);                    // row_bcast:15 into rows 1, 3
-    P = cd_compose(cd_dpp<0x143, 0xC>(P), P);                    // row_bcast:31 into rows 2, 3
-    return P;
+    P = cd_compose(cd_dpp<0x111>(P), P);                         // row_shr:1
+    P = cd_compose(cd_dpp<0x112>(P), P);                         // row_shr:2
+    P = cd_compose(cd_dpp<0x114>(P), P);                         // row_shr:4
+    P = cd_compose(cd_dpp<0x118>(P), P);                         // row_shr:8 -- inclusive inside each row
+    const uint2 S = cd_dpp<0x111>(P);                            // exclusive inside each row (first lane of a row: identity)
+    const uint2 t0 = cd_lane<15>(P), t1 = cd_lane<31>(P), t2 = cd_lane<47>(P), t3 = cd_lane<63>(P);
+    const uint2 q2 = cd_compose(t0, t1), q3 = cd_compose(q2, t2);
+    const uint32_t row = lane >> 4;
+    uint2 pre = CD_IDENT;
+    if (row == 1) pre = t0; else if (row == 2) pre = q2; else if (row == 3) pre = q3;
+    CdScan r; r.excl = cd_compose(pre, S); r.total = cd_compose(q3, t3);
+    return r;
 }
-__device__ __forceinline__ uint2 cd_lane63(uint2 P) { return make_uint2((uint32_t)__builtin_amdgcn_readlane((int)P.x, 63), (uint32_t)__builtin_amdgcn_readlane((int)P.y, 63)); }
 __device__ __forceinline__ void cd_queue(uint32_t* s_req, uint32_t* s_nreq, uint32_t i, uint32_t prev)
 {
     const uint32_t slot = atomicAdd(s_nreq, 1u);
@@ -1912,7 +1923,7 @@ __global__ void __launch_bounds__(CC_THREADS) k_cand_chain(const JsImage* __rest
     uint32_t* diag = diag_all + (size_t)img * CD_DIAG_WORDS;     // [0] walks still queued at the end, [4 + r] / [8 + r]: sub-sequences open / walks queued after chain r (r < 4)
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t nsub = im.n_subseq;
-    const uint32_t seg = (((nsub + CC_THREADS / 64 - 1) / (CC_THREADS / 64)) + CC_TILE - 1) / CC_TILE * CC_TILE, ntiles = seg / CC_TILE;   // per wave; a tile that starts inside the image ends inside its (256-aligned) slot range
+    const uint32_t seg = (((nsub + CC_THREADS / 64 - 1) / (CC_THREADS / 64)) + CC_TILE - 1) / CC_TILE * CC_TILE, ntiles = seg / CC_TILE;   // per wave, whole tiles
     const size_t g0 = im.subseq_off, n = C.n;
     const uint2* maps = C.map + g0 + wave * seg + lane * CC_PER_LANE;            // this lane's four maps of tile 0
     const bool has0 = ntiles > 0 && wave * seg < nsub;
@@ -1942,7 +1953,7 @@ __global__ void __launch_bounds__(CC_THREADS) k_cand_chain(const JsImage* __rest
                 if (i0 + 2 * q < nsub) L = cd_compose(L, make_uint2(v[q].x, v[q].y));
                 if (i0 + 2 * q + 1 < nsub) L = cd_compose(L, make_uint2(v[q].z, v[q].w));
             }
-            R = cd_compose(R, cd_lane63(cd_scan(L)));            // product over the 64 lanes, in lane order
+            R = cd_compose(R, cd_scan(L, lane).total);            // product over the 64 lanes, in lane order
         }
         if (lane == 0) s_wtot[wave] = R;
         __syncthreads();
@@ -1968,23 +1979,24 @@ __global__ void __launch_bounds__(CC_THREADS) k_cand_chain(const JsImage* __rest
                 if (i0 + 2 * q < nsub) L = cd_compose(L, make_uint2(v[q].x, v[q].y));
                 if (i0 + 2 * q + 1 < nsub) L = cd_compose(L, make_uint2(v[q].z, v[q].w));
             }
-            const uint2 P = cd_scan(L);                          // inclusive scan over the lanes
-            const uint2 X = cd_dpp<0x138, 0xF>(P);                // wave_shr:1 -- the product of the lanes before (lane 0: identity)
+            const CdScan sc = cd_scan(L, lane);
+            const uint2 X = sc.excl;                             // the product of the lanes before
             uint32_t sv[CC_PER_LANE];                            // the selections of this lane's sub-sequences
             sv[0] = cd_byte(X, rv);
             #pragma unroll
             for (int q = 1; q < CC_PER_LANE; q++) sv[q] = cd_byte((q - 1) & 1 ? make_uint2(v[(q - 1) / 2].z, v[(q - 1) / 2].w) : make_uint2(v[(q - 1) / 2].x, v[(q - 1) / 2].y), sv[q - 1]);
-            rv = cd_byte(cd_lane63(P), rv);
+            rv = cd_byte(sc.total, rv);
             uint32_t pk0 = 0, pk1 = 0;
             #pragma unroll
             for (int q = 0; q < 4; q++) { pk0 |= sv[q] << (8 * q); pk1 |= sv[4 + q] << (8 * q); }
-            *reinterpret_cast<uint2*>(C.sel + g0 + i0) = make_uint2(pk0, pk1);
+            if (i0 < nsub) *reinterpret_cast<uint2*>(C.sel + g0 + i0) = make_uint2(pk0, pk1);   // (a tile may reach past the image's slots -- they are 256-aligned, a tile is 512 --: a lane stores only what starts inside the image; its eight bytes then end inside the image's slots)
             // last selection of the sub-sequences this lane has: the lane after needs it as `prev`
             const uint32_t nval = i0 >= nsub ? 0u : min(nsub - i0, (uint32_t)CC_PER_LANE);
             uint32_t mylast = CD_NONE;
             #pragma unroll
             for (int q = 0; q < CC_PER_LANE; q++) if ((uint32_t)q < nval) mylast = sv[q];
-            uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)tile_prev, (int)mylast, 0x138, 0xF, 0xF, false);   // wave_shr:1; lane 0: the tile before's last
+            uint32_t prev = (uint32_t)__shfl_up((int)mylast, 1);
+            if (lane == 0) prev = tile_prev;
             #pragma unroll
             for (int q = 0; q < CC_PER_LANE; q++) {
                 if ((uint32_t)q < nval && sv[q] == CD_NONE) {
@@ -2026,7 +2038,8 @@ __global__ void __launch_bounds__(CC_THREADS) k_cand_chain(const JsImage* __rest
             // The maps around the new entry.  No two queued sub-sequences are neighbours (a queued one has no selection, its right neighbour
             // got the guess), so nobody else writes these two words in this round.
             uint32_t sc = CD_NONE;
-            if (i + 1 < nsub) {
+            if (i + 1 < nsub && (i + 1) * SUB_BITS >= total_bits) sc = 0;          // the last data sub-sequence: what follows passes any state through
+            else if (i + 1 < nsub) {
                 sc = cd_match(C, g, im.blk_per_mcu, xp, xs);
                 if (sc == CD_NONE && C.mep[CD_FILL * n + g + 1] == xp && C.mes[CD_FILL * n + g + 1] == xs) sc = CD_FILL;   // a walk of an earlier round next door
             }
@@ -2050,11 +2063,19 @@ __global__ void __launch_bounds__(CC_THREADS) k_cand_chain(const JsImage* __rest
 // The selected memo entries, where k_sync / k_block_scan / k_write2 read them.  A sub-sequence the chain reached with a state in none of its
 // slots gets an entry state no exit state equals (k_sync's verification mode walks it) and, as exit state, the guess its right neighbours were
 // selected from -- if the guess was right, the walk changes nothing further.
+template <int WL>
 __global__ void __launch_bounds__(SY_THREADS) k_cand_apply(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sy_base, uint32_t nimg,
                                                            const JsTableSet* __restrict__ tables, const uint32_t* __restrict__ side, CandArrays C, SubArrays A)
 {
     CD_PROLOGUE
     if (!valid) return;
+    const uint32_t i_last = total_bits ? (total_bits - 1u) / SUB_BITS : 0u;
+    if (i > i_last) {                                            // behind the data: the exit state of the last data sub-sequence passes through
+        const size_t gl = g - (i - i_last); const uint32_t sl = C.sel[gl];
+        const uint32_t ep = sl < CD_NONE ? C.mxp[sl * n + gl] : P_END, es = sl < CD_NONE ? C.mxs[sl * n + gl] : 0u;
+        A.in_p[g] = sl < CD_NONE ? ep : 0xFFFFFFFEu; A.in_s[g] = sl < CD_NONE ? es : 0u; A.out_p[g] = ep; A.out_s[g] = es; A.nblk[g] = 0;
+        return;
+    }
     const uint32_t s = C.sel[g];
     if (s < CD_NONE) { A.in_p[g] = C.mep[s * n + g]; A.in_s[g] = C.mes[s * n + g]; A.out_p[g] = C.mxp[s * n + g]; A.out_s[g] = C.mxs[s * n + g]; A.nblk[g] = C.mnb[s * n + g]; }
     else {
@@ -2655,7 +2676,7 @@ static CandArrays cand_arrays(uint32_t* c, uint64_t n)
     C.map = reinterpret_cast<uint2*>(m + 5 * CD_SLOTS * n); C.sel = reinterpret_cast<uint8_t*>(m + 5 * CD_SLOTS * n + 2 * n); C.req = nullptr;
     return C;
 }
-size_t js_cand_bytes(uint64_t nsub) { return (size_t)nsub * ((2 * CD_H + 5 * CD_SLOTS + 2) * 4 + 2) + 64; }
+size_t js_cand_bytes(uint64_t nsub) { return (size_t)nsub * ((2 * CD_H + 5 * CD_SLOTS + 2) * 4 + 2) + 8192; }   // (slack: the chain reads whole 512-map tiles)
 static_assert(CD_DIAG_WORDS == JS_CAND_REQ_WORDS, "diagnostics area size");
 static_assert(CD_H == JS_CAND_MAX_BLK, "hypotheses");
 #define CAND_WL(K, GRID, BLOCK, LDS, ...) \
@@ -2671,7 +2692,7 @@ void js_launch_cand_sync(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab
     CAND_WL(k_cand_spec, dim3(sy_wgs, max_blk), dim3(SY_THREADS), lds, imgs, sy_base, nimg, tables, ustr, seg_tab, side, C, tab_rows, tab_lut2);
     CAND_WL(k_cand_walk, dim3(sy_wgs, CD_H), dim3(SY_THREADS), lds, imgs, sy_base, nimg, tables, ustr, seg_tab, side, C, tab_rows, tab_lut2);
     CAND_WL(k_cand_chain, dim3(nimg), dim3(CC_THREADS), lds, imgs, tables, ustr, seg_tab, side, C, req, fill_rounds, tab_rows, tab_lut2);
-    hipLaunchKernelGGL(k_cand_apply, dim3(sy_wgs), dim3(SY_THREADS), 0, st, imgs, sy_base, nimg, tables, side, C, sub_arrays(sub, nsub));
+    CAND_WL(k_cand_apply, dim3(sy_wgs), dim3(SY_THREADS), 0, imgs, sy_base, nimg, tables, side, C, sub_arrays(sub, nsub));
 }
 void js_launch_block_scan(hipStream_t st, int wl, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, uint32_t* sub, uint64_t nsub, uint32_t* side, uint32_t* flags)
 {
