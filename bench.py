@@ -235,6 +235,23 @@ def extras_single_gpu(J, H, orc, np):
                                           "roofline_frac": round(alg1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "algorithmic_bytes": alg1,
                                           "stages_ms": {k: round(v, 4) for k, v in st1.items()}}
     one.close()
+    # small jobs between config 2 and config 3: N distinct 1920x1080 images resident in HBM, ms per decode (what a caller that cannot batch a
+    # thousand files sees; jobs this size synchronise by candidates), every DIB checked against the oracle
+    small = {}
+    fs = [H.synth_jpeg(width=1920, height=1080, hs=2, vs=2, quality=85, seed=100 + i) for i in range(16)]
+    ws = []
+    for f in fs:
+        H.drive(orc, f); ws.append(J.dib_checksum_numpy(orc.dib()))
+    for nsm in (1, 4, 16):
+        sb = J.JpegBatch()
+        for f in fs[:nsm]:
+            sb.add_jpeg(f)
+        sb.upload(); sb.decode(); sb.sync()
+        mss, sts = sb.decode_timed(10)
+        small[str(nsm)] = {"ms": round(mss, 4), "mpix_per_s": round(nsm * 1920 * 1080 / mss / 1e3, 1), "bit_exact": bool(all(int(a) == b for a, b in zip(sb.dib_checksums(), ws[:nsm]))),
+                           "sync_ms": round(sts["sync"], 4)}
+        sb.close()
+    extra["small_jobs_1080p"] = small
     # config 5: progressive multi-scan 4:2:2 with RSTn every MCU row; parity is transitive (same coefficients as the baseline encoding)
     kw5 = dict(width=1920, height=1080, hs=2, vs=1, restart_interval=120, quality=85, seed=55)
     base5, prog5 = H.synth_jpeg(progressive=0, **kw5), H.synth_jpeg(progressive=2, **kw5)
