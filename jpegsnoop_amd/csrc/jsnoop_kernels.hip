@@ -1879,7 +1879,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_cand_walk(const JsImage* __restr
 #define CC_MAX_TILES 16                // 8 waves x 16 tiles x 512 = 65536 sub-sequences per image (the host keeps larger images on k_sync)
 // Scan of the lanes' maps (lane order) without the LDS crossbar: row_shr 1 / 2 / 4 / 8 inside the rows of 16 (a lane no source reaches reads
 // the identity map: composing with it changes nothing, so no step needs a select), the four row totals through v_readlane and composed as
-// wave-uniform values.  (row_bcast / wave_shr, the DPP modes that cross rows, are not used: wave_shr:1 does nothing on gfx950.)
+// wave-uniform values.
 template <int CTRL> __device__ __forceinline__ uint2 cd_dpp(uint2 v)
 {
     return make_uint2((uint32_t)__builtin_amdgcn_update_dpp((int)0x03020100, (int)v.x, CTRL, 0xF, 0xF, false),
