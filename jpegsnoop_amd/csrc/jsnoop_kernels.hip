@@ -1876,7 +1876,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_cand_walk(const JsImage* __restr
 #define CC_THREADS 512                 // (eight waves: the walk inside wants more registers than sixteen waves leave)
 #define CC_PER_LANE 8
 #define CC_TILE (64 * CC_PER_LANE)
-#define CC_MAX_TILES 16                // 8 waves x 16 tiles x 512 = 65536 sub-sequences per image (the host keeps larger images on k_sync)
+#define CC_REQ_CAP 4096                // walks queued per round and image (a lane takes every 512th); what does not fit is queued again by the next chain
 // Scan of the lanes' maps (lane order) without the LDS crossbar: row_shr 1 / 2 / 4 / 8 inside the rows of 16 (a lane no source reaches reads
 // the identity map: composing with it changes nothing, so no step needs a select), the four row totals through v_readlane and composed as
 // wave-uniform values.
@@ -1905,7 +1905,7 @@ __device__ __forceinline__ CdScan cd_scan(uint2 P, uint32_t lane)
 __device__ __forceinline__ void cd_queue(uint32_t* s_req, uint32_t* s_nreq, uint32_t i, uint32_t prev)
 {
     const uint32_t slot = atomicAdd(s_nreq, 1u);
-    if (slot < CC_THREADS) s_req[slot] = i | (prev << 24);
+    if (slot < CC_REQ_CAP) s_req[slot] = i | (prev << 24);
 }
 template <int WL>
 __global__ void __launch_bounds__(CC_THREADS) k_cand_chain(const JsImage* __restrict__ imgs, const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr,
@@ -1917,7 +1917,7 @@ __global__ void __launch_bounds__(CC_THREADS) k_cand_chain(const JsImage* __rest
     __shared__ uint2 s_wtot[CC_THREADS / 64];
     __shared__ uint8_t s_wlast[CC_THREADS / 64], s_wfirst_open[CC_THREADS / 64];
     __shared__ uint32_t s_nreq, s_open;
-    __shared__ uint32_t s_req[CC_THREADS];
+    __shared__ uint32_t s_req[CC_REQ_CAP];
     const uint32_t img = blockIdx.x; const JsImage& im = imgs[img];
     if (!tables[im.tableset].lut_ok) return;
     uint32_t* diag = diag_all + (size_t)img * CD_DIAG_WORDS;     // [0] walks still queued at the end, [4 + r] / [8 + r]: sub-sequences open / walks queued after chain r (r < 4)
@@ -2016,17 +2016,17 @@ __global__ void __launch_bounds__(CC_THREADS) k_cand_chain(const JsImage* __rest
         nreq = s_nreq;
         if (t == 0 && round < 4) { diag[4 + round] = s_open; diag[8 + round] = nreq; }
         if (nreq == 0 || round >= max_rounds) break;
-        // ---- the queued walks (the first 1024 of them; the others are queued again by the next chain)
+        // ---- the queued walks
         if (!have_tabs) {
             load_subtabs<true>(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, t, CC_THREADS);
             if (t < T.nb) { const uint32_t rbc = t < T.n1 ? T.rb0 : (t < T.n2 ? T.rb1 : T.rb2); s_ctab[t] = make_uint2(lds_addr(T.lutp) + (rbc & 0xFFFFu), lds_addr(T.lutp) + (rbc >> 16)); }
             have_tabs = true;
             __syncthreads();
         }
-        if (t < min(nreq, (uint32_t)CC_THREADS)) {
+        for (uint32_t r = t; r < min(nreq, (uint32_t)CC_REQ_CAP); r += CC_THREADS) {
             const uint32_t* sd = side + im.side_off;
             const uint32_t total_bits = sd[10] * 8, nseg = min(sd[11], im.seg_cap - 1);
-            const uint32_t i = s_req[t] & 0xFFFFFFu, prev = s_req[t] >> 24;
+            const uint32_t i = s_req[r] & 0xFFFFFFu, prev = s_req[r] >> 24;
             const size_t g = g0 + i;
             const uint32_t p = C.mxp[prev * n + g - 1], s = C.mxs[prev * n + g - 1];
             const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);

@@ -70,7 +70,8 @@ int main(int argc, char** argv)
         St* X = malloc(sizeof(St) * nsub * nb); St* Y = malloc(sizeof(St) * nsub * nb);
         for (size_t i = 0; i < nsub; i++) for (int h = 0; h < nb; h++) {
             if (i == 0) { St s = { 0, 0, 0 }; X[h] = walk(s, S); continue; }
-            long sp = (long)i * S + (S - tail); if (sp < 0) sp = 0; St s = { (size_t)sp, h, 0 }; X[i * nb + h] = walk(s, (i + 1) * (size_t)S);
+            int hh = h; if (getenv("SIM_HYPS")) { const char* e = getenv("SIM_HYPS"); int ok = 0; for (const char* q = e; *q; q++) if (*q - '0' == h) ok = 1; if (!ok) hh = e[0] - '0'; }
+            long sp = (long)i * S + (S - tail); if (sp < 0) sp = 0; St s = { (size_t)sp, hh, 0 }; X[i * nb + h] = walk(s, (i + 1) * (size_t)S);
         }
         for (size_t i = 0; i < nsub; i++) for (int h = 0; h < nb; h++) {
             if (i == 0) { Y[h] = X[h]; continue; }
