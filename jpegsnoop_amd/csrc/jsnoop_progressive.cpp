@@ -12,6 +12,20 @@
 #include "jsnoop_launch.h"
 #include "jsnoop_progressive.h"
 
+#include <emmintrin.h>
+// first index >= q with f[index] == FF, or n
+static inline size_t js_next_ff(const uint8_t* f, size_t q, size_t n)
+{
+    const __m128i ff = _mm_set1_epi8((char)0xFF);
+    while (q + 16 <= n) {
+        const unsigned m = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(f + q)), ff));
+        if (m) return q + (unsigned)__builtin_ctz(m);
+        q += 16;
+    }
+    while (q < n && f[q] != 0xFF) q++;
+    return q;
+}
+
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
     js_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return -1; } } while (0)
 
@@ -128,6 +142,8 @@ static int prog_parse(JsnoopDecoder* d, const uint8_t* f, size_t n, ProgImage* P
             sc.seg_first = (uint32_t)segs.size(); sc.rst_interval = rst_interval;
             size_t q = end, s0 = end;
             while (q < n) {
+                q = js_next_ff(f, q, n);                                     // (sixteen bytes per step: every byte of every scan passes here)
+                if (q >= n) break;
                 if (f[q] == 0xFF && q + 1 < n && f[q + 1] != 0x00) {
                     if (f[q + 1] >= 0xD0 && f[q + 1] <= 0xD7) { segs.push_back({ (uint32_t)s0, (uint32_t)q }); q += 2; s0 = q; continue; }
                     if (f[q + 1] == 0xFF) { q++; continue; }                 // fill byte
