@@ -39,6 +39,9 @@ int         jsnoop_abi_version(void);
  * path's decode tables (two-level tables, state-only pair entries of the sync pass, value-pair entries of the write pass), every
  * first-level window checked against a plain search through the code list.  Returns the number of disagreements (0 = pass). */
 int         jsnoop_selftest_tables(unsigned seed, unsigned rounds);
+/* Host-only self test: the marker searches of the staging code (scan end, next FF: sixteen bytes per step) against byte-at-a-time loops on
+ * `rounds` random buffers dense in FF / 00 / RSTn / other markers, every alignment.  Returns the number of disagreements (0 = pass). */
+int         jsnoop_selftest_bytes(unsigned seed, unsigned rounds);
 const char* jsnoop_last_error(void);                /* thread-local text of the last failure      */
 int         jsnoop_device_count(void);              /* number of visible HIP devices (0 = none)   */
 int         jsnoop_set_device(int device);          /* device used by objects created afterwards  */

@@ -21,6 +21,7 @@ _PU, _PI = C.POINTER(C.c_uint), C.POINTER(C.c_int)
 SIGNATURES = {
     "jsnoop_abi_version": (_i, []),
     "jsnoop_selftest_tables": (_i, [C.c_uint, C.c_uint]),
+    "jsnoop_selftest_bytes": (_i, [C.c_uint, C.c_uint]),
     "jsnoop_last_error": (C.c_char_p, []),
     "jsnoop_device_count": (_i, []),
     "jsnoop_set_device": (_i, [_i]),

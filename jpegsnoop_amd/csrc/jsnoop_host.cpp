@@ -12,12 +12,12 @@
 #include <string>
 #include <vector>
 #include <chrono>
-#include <emmintrin.h>
 #include <algorithm>
 #include "../../include/jsnoop_gpu.h"
 #include "jsnoop_types.h"
 #include "jsnoop_launch.h"
 #include "jsnoop_host.h"
+#include "jsnoop_bytes.h"
 
 // ------------------------------------------------------------------------------ errors
 static thread_local std::string g_err;
@@ -237,22 +237,6 @@ int JsnoopBatch::reserve_pinned(size_t need)
     if (pinned) { memcpy(np, pinned, raw_bytes); hipHostFree(pinned); }
     pinned = np; pinned_cap = ncap;
     return 0;
-}
-// First offset q >= start with file[q] == FF, file[q + 1] neither 00 nor RSTn (and q + 1 < len), else len: where the entropy-coded data ends.
-// Sixteen bytes per step (a byte-at-a-time loop took 0.6 of the 1.9 ms a call on a 3840x2160 file cost its caller).
-static uint32_t js_scan_end(const uint8_t* f, uint32_t q, size_t len)
-{
-    const __m128i ff = _mm_set1_epi8((char)0xFF);
-    while ((size_t)q + 1 < len) {
-        if ((size_t)q + 17 <= len) {
-            unsigned m = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(f + q)), ff));
-            while (m) { const unsigned j = (unsigned)__builtin_ctz(m); m &= m - 1; const uint8_t nx = f[q + j + 1]; if (nx != 0 && !(nx >= 0xD0 && nx <= 0xD7)) return q + j; }
-            q += 16; continue;
-        }
-        if (f[q] == 0xFF && f[q + 1] != 0 && !(f[q + 1] >= 0xD0 && f[q + 1] <= 0xD7)) return q;
-        q++;
-    }
-    return (uint32_t)len;
 }
 int JsnoopBatch::add(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned scan_start, int display, int quiet)
 {
@@ -508,6 +492,27 @@ extern "C" {
 
 int jsnoop_abi_version(void) { return JSNOOP_ABI_VERSION; }
 int jsnoop_selftest_tables(unsigned seed, unsigned rounds) { return js_selftest_tables(seed, rounds); }
+int jsnoop_selftest_bytes(unsigned seed, unsigned rounds)
+{
+    // the sixteen-bytes-per-step marker searches of the staging code against byte-at-a-time loops, on buffers dense in FF / 00 / RSTn / other markers
+    int bad = 0; uint32_t x = seed * 2654435761u + 12345u;
+    auto rnd = [&x]() { x = x * 1664525u + 1013904223u; return x >> 8; };
+    for (unsigned r = 0; r < rounds; r++) {
+        const size_t n = rnd() % 300, lead = rnd() % 17;
+        std::vector<uint8_t> buf(lead + n + 1);
+        for (size_t i = 0; i < lead + n; i++) { const uint32_t k = rnd() % 16; buf[i] = k < 5 ? 0xFF : (k < 7 ? 0x00 : (k < 9 ? (uint8_t)(0xD0 + rnd() % 8) : (k == 9 ? 0xD9 : (uint8_t)rnd()))); }
+        const uint8_t* f = buf.data() + lead;                     // (every alignment of the first byte)
+        for (size_t q0 = 0; q0 <= n; q0 += 1 + rnd() % 7) {
+            size_t a = q0; while (a < n && f[a] != 0xFF) a++;
+            if (js_next_ff(f, q0, n) != a) bad++;
+            uint32_t q = (uint32_t)q0;
+            while ((size_t)q + 1 < n) { if (f[q] == 0xFF && f[q + 1] != 0 && !(f[q + 1] >= 0xD0 && f[q + 1] <= 0xD7)) break; q++; }
+            if ((size_t)q + 1 >= n) q = (uint32_t)n;
+            if (js_scan_end(f, (uint32_t)q0, n) != (q0 >= n ? (uint32_t)n : q)) bad++;
+        }
+    }
+    return bad;
+}
 const char* jsnoop_last_error(void) { return g_err.c_str(); }
 int jsnoop_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 int jsnoop_set_device(int device)

@@ -12,19 +12,7 @@
 #include "jsnoop_launch.h"
 #include "jsnoop_progressive.h"
 
-#include <emmintrin.h>
-// first index >= q with f[index] == FF, or n
-static inline size_t js_next_ff(const uint8_t* f, size_t q, size_t n)
-{
-    const __m128i ff = _mm_set1_epi8((char)0xFF);
-    while (q + 16 <= n) {
-        const unsigned m = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(f + q)), ff));
-        if (m) return q + (unsigned)__builtin_ctz(m);
-        q += 16;
-    }
-    while (q < n && f[q] != 0xFF) q++;
-    return q;
-}
+#include "jsnoop_bytes.h"
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
     js_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return -1; } } while (0)

@@ -42,6 +42,7 @@ def test_decode_table_builders_selftest(lib):
     tables, pair entries of the sync pass, value-pair entries of the write pass) against a plain search through the code list."""
     assert lib.jsnoop_selftest_tables(1, 40) == 0
     assert lib.jsnoop_selftest_tables(20260924, 40) == 0
+    assert lib.jsnoop_selftest_bytes(1, 2000) == 0 and lib.jsnoop_selftest_bytes(77, 2000) == 0      # staging's marker searches (SSE2) against byte loops
 
 
 def test_no_cpu_fallback(lib):
