@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <vector>
 #include "jsnoop_host.h"
 #include "jsnoop_launch.h"
@@ -366,8 +367,17 @@ extern "C" int jsnoop_decode_progressive(JsnoopDecoder* d, const uint8_t* f, siz
     d->preview_is_jpeg = false; d->last_path = 0; d->last_flags = 0;
     JsnoopBatch* b = d->batch;
     b->clear();
+    static const bool dbg_t = getenv("JSNOOP_DEBUG_TIMING") != nullptr;   // where a call's wall time goes (stderr, one line per call)
+    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tp[6]; int ntp = 0; if (dbg_t) tp[ntp++] = now_us();
     if (b->add_progressive(d, f, n) < 0) return -1;
-    if (b->upload() || b->decode(false) || b->sync()) return -1;
+    if (dbg_t) tp[ntp++] = now_us();
+    if (b->upload()) return -1;
+    if (dbg_t) tp[ntp++] = now_us();
+    if (b->decode(false)) return -1;
+    if (dbg_t) tp[ntp++] = now_us();
+    if (b->sync()) return -1;
+    if (dbg_t) { tp[ntp++] = now_us(); fprintf(stderr, "[timing] progressive: parse+stage %.0f upload %.0f enqueue %.0f wait %.0f us\n", tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3]); }
     const uint32_t status0 = b->host_flags[0];
     const int nscans = (int)(b->prog->first_scan[1] - b->prog->first_scan[0]);
     d->have_image = true; d->host_valid = 0; d->preview_is_jpeg = true;
