@@ -1763,7 +1763,6 @@ struct CandArrays {
     uint32_t *mep, *mes, *mxp, *mxs, *mnb;   // [CD_SLOTS][n]  memo: entry state, exit state, blocks completed
     uint2* map;                        // [n]  byte e (0..6): slot of the next sub-sequence's memo that holds the exit state of entry e (7: none); byte 7: the guess
     uint8_t *sel;                      // [n]  slot the chain selected
-    uint32_t* req;                     // (unused here: the request areas are passed beside)
     uint64_t n;
 };
 __device__ __forceinline__ uint32_t cd_byte(uint2 m, uint32_t e) { return ((e < 4u ? m.x : m.y) >> ((e & 3u) * 8u)) & 255u; }
@@ -2673,7 +2672,7 @@ static CandArrays cand_arrays(uint32_t* c, uint64_t n)
 {
     CandArrays C; C.n = n; C.xp = c; C.xs = c + CD_H * n; uint32_t* m = c + 2 * CD_H * n;
     C.mep = m; C.mes = m + CD_SLOTS * n; C.mxp = m + 2 * CD_SLOTS * n; C.mxs = m + 3 * CD_SLOTS * n; C.mnb = m + 4 * CD_SLOTS * n;
-    C.map = reinterpret_cast<uint2*>(m + 5 * CD_SLOTS * n); C.sel = reinterpret_cast<uint8_t*>(m + 5 * CD_SLOTS * n + 2 * n); C.req = nullptr;
+    C.map = reinterpret_cast<uint2*>(m + 5 * CD_SLOTS * n); C.sel = reinterpret_cast<uint8_t*>(m + 5 * CD_SLOTS * n + 2 * n);
     return C;
 }
 size_t js_cand_bytes(uint64_t nsub) { return (size_t)nsub * ((2 * CD_H + 5 * CD_SLOTS + 2) * 4 + 2) + 8192; }   // (slack: the chain reads whole 512-map tiles)
