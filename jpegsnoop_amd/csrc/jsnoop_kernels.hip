@@ -1648,6 +1648,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
     // few % of the cases, so the later launches (which carry the true states across workgroup boundaries) find next to nothing to do.
     const uint32_t own0 = (bx - sy_base[img]) * (SY_THREADS - 1);
     if (own0 * SUB_BITS >= total_bits && own0) return;          // whole workgroup lies past the end of the data
+    const uint32_t i_last = total_bits ? (total_bits - 1u) / SUB_BITS : 0u;     // the last sub-sequence that holds data
     const size_t g0 = im.subseq_off + own0;                      // slot of the first owned sub-sequence
     const bool halo = t == 0;
     const uint32_t i = own0 + t - 1u;                            // this thread's sub-sequence (thread 0 of the first workgroup: none)
@@ -1695,7 +1696,13 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
                 ip = !in_data ? P_END : (sp < total_bits ? sp : i * SUB_BITS);
                 is = in_data ? ST_MAKE(find_interval(st, nseg, ip / 8), 0u, 0u) : 0u;
             } else if (i == 0) { ip = 0; is = 0; }               // true start of the scan: interval 0, block 0, DC
-            else { ip = s_outp[t - 1]; is = s_outs[t - 1]; }
+            else {
+                // a sub-sequence behind the last one that holds data owns no symbol: the state passes through, so it takes the exit state of
+                // that last one directly (handed on one sub-sequence per round, a scan that ends on the last bit of a byte -- one image in
+                // eight -- kept its last workgroup busy for up to 63 rounds more)
+                const uint32_t tl = (i > i_last + 1u && i_last >= own0) ? i_last - own0 + 1u : t - 1u;
+                ip = s_outp[tl]; is = s_outs[tl];
+            }
             active = ip != s_inp[t] || is != s_ins[t];
         }
         if (t == 0) s_changed = 0;
