@@ -25,6 +25,9 @@ int main(int argc, char** argv)
 
     int bad = jsnoop_selftest_tables(1, 300);
     printf("selftest_tables: %d disagreements over 300 table sets\n", bad);
+    const int badb = jsnoop_selftest_bytes(5, 5000);               // the sixteen-bytes-per-step marker searches of the staging code (unaligned loads up to the last byte)
+    printf("selftest_bytes: %d disagreements over 5000 buffers\n", badb);
+    bad += badb;
 
     size_t walks = 0, accepted = 0, described = 0;
     std::vector<uint8_t> buf(1 << 20);
