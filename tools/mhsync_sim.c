@@ -48,6 +48,8 @@ int main(int argc, char** argv)
     // ---- (A) rounds of the present scheme, per workgroup of 255 owned sub-sequences (+ a speculative halo walk of the one before)
     {
         St* out = malloc(sizeof(St) * nsub); St* in = malloc(sizeof(St) * nsub); long max_it = 0, sum_it = 0, nwg = 0; long walks = 0; size_t wrong_after1 = 0;
+        St* pin = malloc(sizeof(St) * nsub); St* pout = malloc(sizeof(St) * nsub); for (size_t i = 0; i < nsub; i++) { pin[i] = (St){ (size_t)-3, 0, 0 }; pout[i] = pin[i]; }
+        const long rmax = getenv("SIM_RMAX") ? atol(getenv("SIM_RMAX")) : 1000000;
         for (size_t g0 = 0; g0 < nsub; g0 += 255, nwg++) {
             size_t g1 = g0 + 255 < nsub ? g0 + 255 : nsub;
             St halo = { 0, 0, 0 }; if (g0) { size_t i = g0 - 1; long sp = (long)i * S + (S - tail); if (sp < 0) sp = 0; St s = { (size_t)sp, 0, 0 }; halo = walk(s, (i + 1) * (size_t)S); }
@@ -56,7 +58,8 @@ int main(int argc, char** argv)
             for (;; it++) {
                 int changed = 0; St* nin = malloc(sizeof(St) * (g1 - g0));
                 for (size_t i = g0; i < g1; i++) nin[i - g0] = i == 0 ? in[0] : (i == g0 ? halo : out[i - 1]);
-                for (size_t i = g0; i < g1; i++) if (!st_eq(nin[i - g0], in[i])) { in[i] = nin[i - g0]; St o = in[i].p >= (i + 1) * (size_t)S ? in[i] : walk(in[i], (i + 1) * (size_t)S); walks++; if (!st_eq(o, out[i])) { if (getenv("SIM_TRACE2") && g0 == (size_t)atoi(getenv("SIM_TRACE2"))) printf("    round %ld sub %zu: exit (%zu,%d,%d) -> (%zu,%d,%d) truth (%zu,%d,%d)\n", it, i - g0, out[i].p, out[i].c, out[i].k, o.p, o.c, o.k, truth[i].p, truth[i].c, truth[i].k); out[i] = o; changed = 1; } }
+                if (it > rmax) { free(nin); break; }
+                for (size_t i = g0; i < g1; i++) if (!st_eq(nin[i - g0], in[i])) { pin[i] = in[i]; pout[i] = out[i]; in[i] = nin[i - g0]; St o = in[i].p >= (i + 1) * (size_t)S ? in[i] : walk(in[i], (i + 1) * (size_t)S); walks++; if (!st_eq(o, out[i])) { if (getenv("SIM_TRACE2") && g0 == (size_t)atoi(getenv("SIM_TRACE2"))) printf("    round %ld sub %zu: exit (%zu,%d,%d) -> (%zu,%d,%d) truth (%zu,%d,%d)\n", it, i - g0, out[i].p, out[i].c, out[i].k, o.p, o.c, o.k, truth[i].p, truth[i].c, truth[i].k); out[i] = o; changed = 1; } }
                 free(nin); if (!changed) break;
             }
             if (getenv("SIM_TRACE") && it >= atoi(getenv("SIM_TRACE"))) { printf("  wg at %zu: %ld rounds; final wrong:", g0, it); for (size_t i = g0; i < g1; i++) if (!st_eq(out[i], truth[i])) printf(" %zu", i - g0); printf("\n"); }
@@ -64,6 +67,29 @@ int main(int argc, char** argv)
         }
         for (size_t i = 0; i < nsub; i++) if (!st_eq(out[i], truth[i])) wrong_after1++;
         printf("(A) rounds per workgroup in the first launch: max %ld, mean %.1f over %ld workgroups; %ld walks (%.2f per sub-sequence); %zu exits still wrong after it\n", max_it, (double)sum_it / nwg, nwg, walks, (double)walks / nsub, wrong_after1);
+        if (getenv("SIM_RMAX")) {
+            // ---- (D) the rounds stopped after SIM_RMAX of them; every sub-sequence keeps its last two walks as a memo; the chain of look-ups + queued walks as in (C)
+            enum { E = 16 }; St* me = malloc(sizeof(St) * nsub * E); St* mx = malloc(sizeof(St) * nsub * E); int* mn = calloc(nsub, sizeof(int));
+            size_t open = 0; for (size_t i = 1; i < nsub; i++) if (!st_eq(in[i], out[i - 1])) open++;
+            for (size_t i = 0; i < nsub; i++) { me[i * E] = in[i]; mx[i * E] = out[i]; mn[i] = 1; if (pin[i].p != (size_t)-3 && !st_eq(pin[i], in[i])) { me[i * E + 1] = pin[i]; mx[i * E + 1] = pout[i]; mn[i] = 2; } }
+            long iters = 0, total_walks = 0, max_req = 0;
+            for (;; iters++) {
+                size_t* req_i = malloc(sizeof(size_t) * nsub); St* req_s = malloc(sizeof(St) * nsub); long nreq = 0;
+                St cur = { 0, 0, 0 }; int have = 1;
+                for (size_t i = 0; i < nsub; i++) {
+                    int f = -1; if (have) for (int q = 0; q < mn[i]; q++) if (st_eq(me[i * E + q], cur)) { f = q; break; }
+                    if (f >= 0) { cur = mx[i * E + f]; continue; }
+                    if (have) { req_i[nreq] = i; req_s[nreq] = cur; nreq++; }
+                    cur = mx[i * E]; have = 1;                    // guess: the exit of the latest walk
+                }
+                if (!nreq) { free(req_i); free(req_s); break; }
+                for (long r = 0; r < nreq; r++) { size_t i = req_i[r]; if (mn[i] < E) { me[i * E + mn[i]] = req_s[r]; mx[i * E + mn[i]] = req_s[r].p >= (i + 1) * (size_t)S ? req_s[r] : walk(req_s[r], (i + 1) * (size_t)S); mn[i]++; } }
+                total_walks += nreq; if (nreq > max_req) max_req = nreq; free(req_i); free(req_s);
+                if (iters > 200) break;
+            }
+            St cur = { 0, 0, 0 }; size_t bad = 0; for (size_t i = 0; i < nsub; i++) { int f = -1; for (int q = 0; q < mn[i]; q++) if (st_eq(me[i * E + q], cur)) { f = q; break; } if (f < 0) { bad++; break; } cur = mx[i * E + f]; if (!st_eq(cur, truth[i])) bad++; }
+            printf("(D) %ld rounds, then %zu open links; memo chain: %ld extra walk rounds, %ld walks in them (at most %ld in one), chain %s\n", rmax, open, iters, total_walks, max_req, bad ? "WRONG" : "= truth");
+        }
     }
     // ---- (B) candidates
     {
