@@ -97,7 +97,7 @@ struct JsnoopBatch {
     uint64_t total_blocks, dib_bytes, side_words, total_subseq, ustr_bytes, seg_words, mcu_bytes; uint32_t total_wgs, strips_per_wg, us_chunks, sy_wgs, sn_wgs, max_mcu_h, max_mcu_w;
     // small jobs (64-byte sub-sequences, a few hundred thousand walks at most) synchronise by candidates (k_cand_*) instead of k_sync's rounds: cand_rounds
     // = fill rounds of the chain, -1 = off (JSNOOP_CAND=0, more than JS_CAND_MAX_BLK blocks per MCU, a larger job); cand_blk = most blocks per MCU in the batch
-    int cand_rounds = -1; uint32_t cand_blk = 0;
+    int cand_rounds = -1; uint32_t cand_blk = 0; bool cand_half = false;   // cand_half: the smallest jobs (one large image, a handful) also run the write pass with two lanes per sub-sequence
     int sync_launches; int sub_wl;   // log2(words per sub-sequence): 4 / 5 / 7 = 64- / 128- / 512-byte sub-sequences (chosen per batch; 6 and 8 through JSNOOP_SUB_WL)
     uint32_t tab_rows, tab_lut2, tab_rows_w;     // largest decode-table footprint in the batch (sizes the kernels' LDS); _w: DC rows | AC rows << 8
     hipEvent_t ev[JSNOOP_NUM_STAGES + 1];

@@ -1540,12 +1540,18 @@ __device__ __forceinline__ uint2 lds_r64(uint32_t a) { const u32x2_t v = *(const
 // vote, and leaves the lane in a state in which the straight-line code of the step does nothing for it: the common step has no
 // "is this lane still going" selects.  Votes are compares written into scalar pairs and combined there; a lane reads its bit back as
 // a predicate.  a_ctab: LDS address of the per-block-of-the-MCU table {address of its DC row, address of its AC row} in lutp.
-template <int WL>
+// MID (the memo walks of the candidate form): the state at the first symbol boundary at or behind bit `mid_bits` is reported too -- {position,
+// state word, blocks completed so far} in mid3 -- so that the write pass can put a second lane on the second half of the sub-sequence; a pair
+// of symbols is not taken across that bit (the lane of the first half stops at the first boundary behind it: both must name the same one).
+template <int WL, bool MID = false>
 __device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, uint32_t a_ctab, const uint32_t* __restrict__ words, const uint32_t* __restrict__ st,
-                                          uint32_t nseg, uint32_t total_bits, uint32_t own_end, uint32_t& p_io, uint32_t& s_io, uint32_t& nblk_out)
+                                          uint32_t nseg, uint32_t total_bits, uint32_t own_end, uint32_t& p_io, uint32_t& s_io, uint32_t& nblk_out,
+                                          uint32_t mid_bits = 0, uint32_t* mid3 = nullptr)
 {
     uint32_t seg = ST_SEG(s_io), c = ST_C(s_io), k = ST_K(s_io), nblk = 0, fl = 0;
-    if (p_io == P_END || (p_io >= total_bits && seg + 1 >= nseg)) { p_io = P_END; s_io = 0; nblk_out = 0; return; }
+    if (p_io == P_END || (p_io >= total_bits && seg + 1 >= nseg)) { p_io = P_END; s_io = 0; nblk_out = 0; if (MID) { mid3[0] = P_END; mid3[1] = 0; mid3[2] = 0; } return; }
+    uint32_t mid_p = 0, mid_s = 0, mid_n = 0; uint64_t m_midc = 0ull;            // MID: lanes whose mid state is taken
+    const uint32_t mid_lim = min(mid_bits, own_end);
     uint32_t seg_end = st[seg + 1] * 8;
     Cursor cur; cur_init<WL>(cur, words, p_io);
     const uint32_t a_lp = lds_addr(T.lutp), a_l2p = lds_addr(T.lut2p);
@@ -1554,6 +1560,10 @@ __device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, ui
     uint32_t res_p = cur.p, res_s = s_io, res_n = 0;
     uint64_t m_live = WBALLOT(true);                             // lanes still inside their range
     for (;;) {
+        if (MID) {
+            const uint64_t m_m = WBALLOT(cur.p >= mid_bits) & m_live & ~m_midc;
+            if (m_m) { if (__builtin_amdgcn_inverse_ballot_w64(m_m)) { mid_p = cur.p; mid_s = cur.p == P_END ? 0u : ST_MAKE(seg, c, k); mid_n = nblk; } m_midc |= m_m; }
+        }
         // a lane that has left its range reports the state it left with; from then on it computes on whatever it holds
         const uint64_t m_act = m_live & WBALLOT(cur.p < own_end);
         if (m_act != m_live) {
@@ -1575,7 +1585,7 @@ __device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, ui
         uint32_t b1 = pe & 255u, k1 = k + ((pe >> 8) & 255u);
         const uint32_t b12 = (pe >> 16) & 255u;
         // both symbols together when the first one does not end the block and the second one starts inside this lane's own range
-        uint64_t m_two = WBALLOT(b12 != 0u) & WBALLOT(k1 < 64u) & WBALLOT(cur.p + b1 < own_end);
+        uint64_t m_two = WBALLOT(b12 != 0u) & WBALLOT(k1 < 64u) & WBALLOT(cur.p + b1 < (MID && !__builtin_amdgcn_inverse_ballot_w64(m_midc) ? mid_lim : own_end));
         const uint64_t m_slow = (WBALLOT((int32_t)pe < 0) | WBALLOT(cur.p + (__builtin_amdgcn_inverse_ballot_w64(m_two) ? b12 : b1) > seg_end)) & m_act;
         if (m_slow) {
             if (__builtin_amdgcn_inverse_ballot_w64(m_slow)) {   // no code here, or the end of the restart interval / of the data is near:
@@ -1611,6 +1621,10 @@ __device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, ui
         row = k ? ct.y : ct.x;
     }
     p_io = res_p; s_io = res_s; nblk_out = res_n;
+    if (MID) {                                                   // (a lane whose range ends before the middle: its exit state)
+        const bool got = __builtin_amdgcn_inverse_ballot_w64(m_midc);
+        mid3[0] = got ? mid_p : res_p; mid3[1] = got ? mid_s : res_s; mid3[2] = got ? mid_n : res_n;
+    }
 }
 
 // upper_bound(seg table, byte) - 1 : the interval a speculative start position lies in
@@ -1768,6 +1782,8 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
 struct CandArrays {
     uint32_t *xp, *xs;                 // [CD_H][n]  speculative exit states
     uint32_t *mep, *mes, *mxp, *mxs, *mnb;   // [CD_SLOTS][n]  memo: entry state, exit state, blocks completed
+    uint32_t *mmp, *mms, *mmn;         // [CD_SLOTS][n]  memo: state at the middle of the sub-sequence (position, state word, blocks completed before it)
+    uint32_t *hp, *hs, *hn;            // [n]  the middle state of the selected entry (k_cand_apply): where the second write lane of the sub-sequence starts
     uint2* map;                        // [n]  byte e (0..6): slot of the next sub-sequence's memo that holds the exit state of entry e (7: none); byte 7: the guess
     uint8_t *sel;                      // [n]  slot the chain selected
     uint64_t n;
@@ -1821,7 +1837,7 @@ __device__ __forceinline__ uint32_t cd_match(const CandArrays& C, size_t g, uint
     return r;
 }
 
-template <int WL>
+template <int WL, bool MID>
 __global__ void __launch_bounds__(SY_THREADS) k_cand_walk(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sy_base, uint32_t nimg,
                                                           const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr,
                                                           const uint32_t* __restrict__ seg_tab, const uint32_t* __restrict__ side, CandArrays C,
@@ -1853,9 +1869,10 @@ __global__ void __launch_bounds__(SY_THREADS) k_cand_walk(const JsImage* __restr
     uint32_t succ = CD_NONE;
     if (use) {
         const uint32_t own_end = min((i + 1) * SUB_BITS, total_bits);
-        uint32_t xp = p, xs = s, nblk = 0;
-        if (!(xp != P_END && xp >= own_end)) walk_sync<WL>(im, T, lds_addr(s_ctab), words, st, nseg, total_bits, own_end, xp, xs, nblk);
+        uint32_t xp = p, xs = s, nblk = 0, mid3[3] = { p, s, 0u };                  // (a state that passes through: the middle state is the entry state)
+        if (!(xp != P_END && xp >= own_end)) walk_sync<WL, MID>(im, T, lds_addr(s_ctab), words, st, nseg, total_bits, own_end, xp, xs, nblk, i * SUB_BITS + SUB_BITS / 2, mid3);
         C.mep[h * n + g] = p; C.mes[h * n + g] = s; C.mxp[h * n + g] = xp; C.mxs[h * n + g] = xs; C.mnb[h * n + g] = nblk;
+        if (MID) { C.mmp[h * n + g] = mid3[0]; C.mms[h * n + g] = mid3[1]; C.mmn[h * n + g] = mid3[2]; }
         if (i + 1 < im.n_subseq) succ = i == i_last ? 0u : cd_match(C, g, nb, xp, xs);
     } else C.mep[h * n + g] = CD_EMPTY;
     mapb[g * 8 + h] = (uint8_t)succ;
@@ -1913,7 +1930,7 @@ __device__ __forceinline__ void cd_queue(uint32_t* s_req, uint32_t* s_nreq, uint
     const uint32_t slot = atomicAdd(s_nreq, 1u);
     if (slot < CC_REQ_CAP) s_req[slot] = i | (prev << 24);
 }
-template <int WL>
+template <int WL, bool MID>
 __global__ void __launch_bounds__(CC_THREADS) k_cand_chain(const JsImage* __restrict__ imgs, const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr,
                                                            const uint32_t* __restrict__ seg_tab, const uint32_t* __restrict__ side, CandArrays C,
                                                            uint32_t* __restrict__ diag_all, int max_rounds, uint32_t tab_rows, uint32_t tab_lut2)
@@ -2038,9 +2055,10 @@ __global__ void __launch_bounds__(CC_THREADS) k_cand_chain(const JsImage* __rest
             const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);
             const uint32_t* st = seg_tab + im.seg_off;
             const uint32_t own_end = min((i + 1) * SUB_BITS, total_bits);
-            uint32_t xp = p, xs = s, nblk = 0;
-            if (!(xp != P_END && xp >= own_end)) walk_sync<WL>(im, T, lds_addr(s_ctab), words, st, nseg, total_bits, own_end, xp, xs, nblk);
+            uint32_t xp = p, xs = s, nblk = 0, mid3[3] = { p, s, 0u };
+            if (!(xp != P_END && xp >= own_end)) walk_sync<WL, MID>(im, T, lds_addr(s_ctab), words, st, nseg, total_bits, own_end, xp, xs, nblk, i * SUB_BITS + SUB_BITS / 2, mid3);
             C.mep[CD_FILL * n + g] = p; C.mes[CD_FILL * n + g] = s; C.mxp[CD_FILL * n + g] = xp; C.mxs[CD_FILL * n + g] = xs; C.mnb[CD_FILL * n + g] = nblk;
+            if (MID) { C.mmp[CD_FILL * n + g] = mid3[0]; C.mms[CD_FILL * n + g] = mid3[1]; C.mmn[CD_FILL * n + g] = mid3[2]; }
             // The maps around the new entry.  No two queued sub-sequences are neighbours (a queued one has no selection, its right neighbour
             // got the guess), so nobody else writes these two words in this round.
             uint32_t sc = CD_NONE;
@@ -2071,7 +2089,7 @@ __global__ void __launch_bounds__(CC_THREADS) k_cand_chain(const JsImage* __rest
 // selected from -- if the guess was right, the walk changes nothing further.
 template <int WL>
 __global__ void __launch_bounds__(SY_THREADS) k_cand_apply(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sy_base, uint32_t nimg,
-                                                           const JsTableSet* __restrict__ tables, const uint32_t* __restrict__ side, CandArrays C, SubArrays A)
+                                                           const JsTableSet* __restrict__ tables, const uint32_t* __restrict__ side, CandArrays C, SubArrays A, int mid)
 {
     CD_PROLOGUE
     if (!valid) return;
@@ -2080,11 +2098,15 @@ __global__ void __launch_bounds__(SY_THREADS) k_cand_apply(const JsImage* __rest
         const size_t gl = g - (i - i_last); const uint32_t sl = C.sel[gl];
         const uint32_t ep = sl < CD_NONE ? C.mxp[sl * n + gl] : P_END, es = sl < CD_NONE ? C.mxs[sl * n + gl] : 0u;
         A.in_p[g] = sl < CD_NONE ? ep : 0xFFFFFFFEu; A.in_s[g] = sl < CD_NONE ? es : 0u; A.out_p[g] = ep; A.out_s[g] = es; A.nblk[g] = 0;
+        if (mid) { C.hp[g] = ep; C.hs[g] = es; C.hn[g] = 0; }
         return;
     }
     const uint32_t s = C.sel[g];
-    if (s < CD_NONE) { A.in_p[g] = C.mep[s * n + g]; A.in_s[g] = C.mes[s * n + g]; A.out_p[g] = C.mxp[s * n + g]; A.out_s[g] = C.mxs[s * n + g]; A.nblk[g] = C.mnb[s * n + g]; }
-    else {
+    if (s < CD_NONE) {
+        A.in_p[g] = C.mep[s * n + g]; A.in_s[g] = C.mes[s * n + g]; A.out_p[g] = C.mxp[s * n + g]; A.out_s[g] = C.mxs[s * n + g]; A.nblk[g] = C.mnb[s * n + g];
+        if (mid) { C.hp[g] = C.mmp[s * n + g]; C.hs[g] = C.mms[s * n + g]; C.hn[g] = C.mmn[s * n + g]; }
+    } else {
+        if (mid) { C.hp[g] = 0xFFFFFFFEu; C.hs[g] = 0; C.hn[g] = 0; }   // (no lane of the write pass will agree with this: the image takes the resume path)
         const uint32_t gq = cd_byte(C.map[g], 7u);
         A.in_p[g] = 0xFFFFFFFEu; A.in_s[g] = 0; A.nblk[g] = 0;
         A.out_p[g] = gq < CD_NONE ? C.xp[gq * n + g] : P_END; A.out_s[g] = gq < CD_NONE ? C.xs[gq * n + g] : 0u;
@@ -2361,23 +2383,28 @@ __device__ __forceinline__ int32_t extend_bits(uint32_t win, uint32_t skipbits, 
     const uint32_t neglim = (0xFFFFFFFFu << size) + 1u;          // -(2^size - 1)
     return (int32_t)x < 0 ? (int32_t)vraw : (int32_t)(vraw + neglim);
 }
-template <int WL>
+// HALF (small jobs after the candidate synchronisation): two lanes per sub-sequence -- the second one enters at the state the selected memo
+// walk reported for the middle of the sub-sequence (half_*: position, state word, blocks completed before it) -- twice the lanes, half the steps of
+// the chain a wave is; the lane of the first half verifies against that middle state, the other one against the exit state as before.
+template <int WL, bool HALF = false>
 __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sy_base, uint32_t nimg,
                                                        const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr,
                                                        const uint32_t* __restrict__ seg_tab, uint32_t* __restrict__ side, SubArrays A,
                                                        int16_t* __restrict__ coef, int16_t* __restrict__ dccum, uint8_t* __restrict__ mcu_rst, uint32_t* __restrict__ flags,
-                                                       uint32_t tab_rows, uint32_t tab_lut2)
+                                                       uint32_t tab_rows, uint32_t tab_lut2, const uint32_t* __restrict__ half_p = nullptr, const uint32_t* __restrict__ half_s = nullptr,
+                                                       const uint32_t* __restrict__ half_n = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     __shared__ __attribute__((aligned(16))) int16_t s_blk[SY_THREADS][WR_STRIDE];
-    const uint32_t wg = blockIdx.x + sy_base[0];
+    const uint32_t wg = (HALF ? blockIdx.x >> 1 : blockIdx.x) + sy_base[0];
     const uint32_t img = find_image(sy_base, nimg, wg);
     const JsImage& im = imgs[img];
     if (!tables[im.tableset].lut_ok) return;
     const uint32_t* sd = side + im.side_off;
     const uint32_t total_bits = sd[10] * 8, nseg = min(sd[11], im.seg_cap - 1);
     const uint32_t lane = threadIdx.x & 63, wave0 = threadIdx.x & ~63u;
-    const uint32_t sub0 = (wg - sy_base[img]) * SY_THREADS, i = sub0 + threadIdx.x;
+    const uint32_t hi = HALF ? threadIdx.x & 1u : 0u;            // HALF: which half of the sub-sequence this lane has
+    const uint32_t sub0 = (wg - sy_base[img]) * SY_THREADS + (HALF ? (blockIdx.x & 1u) * (SY_THREADS / 2) : 0u), i = sub0 + (HALF ? threadIdx.x >> 1 : threadIdx.x);
     if (sub0 * SUB_BITS >= total_bits) return;
     // block rows are addressed with 32-bit byte offsets from the image's first row: an image of 2^25 blocks or more (2 Gpixel of
     // grayscale) is left to the exact kernel
@@ -2394,16 +2421,16 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
     char* lbuf = reinterpret_cast<char*>(s_blk[threadIdx.x]);
     const uint32_t nblocks = im.total_blocks, prec_shift = im.precision >= 8 ? ((im.precision - 8) & 31) : 0;
     const uint64_t acmask = im.decode_ac ? ~0ull : 0ull;        // DC-only mode: AC coefficients are parsed, not stored
-    const bool in_data = i * SUB_BITS < total_bits;
+    const bool in_data = i * SUB_BITS + hi * (SUB_BITS / 2) < total_bits;
     const size_t g = im.subseq_off + i;
     uint32_t fl = 0, an = 0xFFFFFFFFu, nblk = 0, seg = 0, c = 0, k = 0, seg_end = 0, blk = 0;
     uint32_t res_p = 0, res_s = 0, res_n = 0;                // what this lane reports for verification
     bool verify = false, check_n = false, active0 = false, skip0 = false;
-    const uint32_t own_end = min((i + 1) * SUB_BITS, total_bits);
+    const uint32_t own_end = min(HALF && !hi ? i * SUB_BITS + SUB_BITS / 2 : (i + 1) * SUB_BITS, total_bits);
     Cursor cur; cur.words = words; cur.widx = 0; cur.w0 = cur.w1 = cur.nxt = 0; cur.sh = 0; cur.p = 0;
     if (in_data) {
-        const uint32_t p0 = i ? A.out_p[g - 1] : 0u, s0 = i ? A.out_s[g - 1] : 0u;
-        blk = A.base[g]; seg = ST_SEG(s0); c = ST_C(s0); k = ST_K(s0);
+        const uint32_t p0 = hi ? half_p[g] : (i ? A.out_p[g - 1] : 0u), s0 = hi ? half_s[g] : (i ? A.out_s[g - 1] : 0u);
+        blk = A.base[g] + (hi ? half_n[g] : 0u); seg = ST_SEG(s0); c = ST_C(s0); k = ST_K(s0);
         verify = true;
         if (p0 != P_END && p0 >= own_end) { res_p = p0; res_s = s0; }                          // owns no symbol: passes through
         else if (p0 == P_END || (p0 >= total_bits && seg + 1 >= nseg)) { res_p = P_END; res_s = 0; check_n = true; }
@@ -2549,7 +2576,9 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
     if (verify) {
         if (check_n && !IBAL(m_cap) && res_p != P_END) { res_p = cur.p; res_s = cur.p == P_END ? 0u : ST_MAKE(seg, c, k); res_n = nblk; }
         // the chain must be at its fixed point, and the block count that fed the prefix sum must be the real one
-        if (res_p != A.out_p[g] || res_s != A.out_s[g] || (check_n && res_n != A.nblk[g])) fl |= F_NOSYNC;
+        const uint32_t want_p = HALF && !hi ? half_p[g] : A.out_p[g], want_s = HALF && !hi ? half_s[g] : A.out_s[g];
+        const uint32_t want_n = HALF ? (hi ? A.nblk[g] - half_n[g] : half_n[g]) : A.nblk[g];
+        if (res_p != want_p || res_s != want_s || (check_n && res_n != want_n)) fl |= F_NOSYNC;
     }
     if (fl) { FLAG_OR(flags, img, fl); if (an != 0xFFFFFFFFu) ANOM_MIN(flags, img, an); }
 }
@@ -2679,26 +2708,39 @@ static CandArrays cand_arrays(uint32_t* c, uint64_t n)
 {
     CandArrays C; C.n = n; C.xp = c; C.xs = c + CD_H * n; uint32_t* m = c + 2 * CD_H * n;
     C.mep = m; C.mes = m + CD_SLOTS * n; C.mxp = m + 2 * CD_SLOTS * n; C.mxs = m + 3 * CD_SLOTS * n; C.mnb = m + 4 * CD_SLOTS * n;
-    C.map = reinterpret_cast<uint2*>(m + 5 * CD_SLOTS * n); C.sel = reinterpret_cast<uint8_t*>(m + 5 * CD_SLOTS * n + 2 * n);
+    C.mmp = m + 5 * CD_SLOTS * n; C.mms = m + 6 * CD_SLOTS * n; C.mmn = m + 7 * CD_SLOTS * n;
+    uint32_t* r = m + 8 * CD_SLOTS * n;
+    C.map = reinterpret_cast<uint2*>(r); C.hp = r + 2 * n; C.hs = r + 3 * n; C.hn = r + 4 * n; C.sel = reinterpret_cast<uint8_t*>(r + 5 * n);
     return C;
 }
-size_t js_cand_bytes(uint64_t nsub) { return (size_t)nsub * ((2 * CD_H + 5 * CD_SLOTS + 2) * 4 + 2) + 8192; }   // (slack: the chain reads whole 512-map tiles)
+size_t js_cand_bytes(uint64_t nsub) { return (size_t)nsub * ((2 * CD_H + 8 * CD_SLOTS + 5) * 4 + 2) + 8192; }   // (slack: the chain reads whole 512-map tiles)
 static_assert(CD_DIAG_WORDS == JS_CAND_REQ_WORDS, "diagnostics area size");
 static_assert(CD_H == JS_CAND_MAX_BLK, "hypotheses");
 #define CAND_WL(K, GRID, BLOCK, LDS, ...) \
     do { if (wl == 4) hipLaunchKernelGGL(K<4>, GRID, BLOCK, LDS, st, __VA_ARGS__); else if (wl == 5) hipLaunchKernelGGL(K<5>, GRID, BLOCK, LDS, st, __VA_ARGS__); \
          else if (wl == 6) hipLaunchKernelGGL(K<6>, GRID, BLOCK, LDS, st, __VA_ARGS__); else if (wl == 7) hipLaunchKernelGGL(K<7>, GRID, BLOCK, LDS, st, __VA_ARGS__); \
          else hipLaunchKernelGGL(K<8>, GRID, BLOCK, LDS, st, __VA_ARGS__); } while (0)
+#define CAND_WL2(K, GRID, BLOCK, LDS, ...) \
+    do { if (wl == 4) hipLaunchKernelGGL((K<4, false>), GRID, BLOCK, LDS, st, __VA_ARGS__); else if (wl == 5) hipLaunchKernelGGL((K<5, false>), GRID, BLOCK, LDS, st, __VA_ARGS__); \
+         else if (wl == 6) hipLaunchKernelGGL((K<6, false>), GRID, BLOCK, LDS, st, __VA_ARGS__); else if (wl == 7) hipLaunchKernelGGL((K<7, false>), GRID, BLOCK, LDS, st, __VA_ARGS__); \
+         else hipLaunchKernelGGL((K<8, false>), GRID, BLOCK, LDS, st, __VA_ARGS__); } while (0)
 void js_launch_cand_sync(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t sy_wgs, uint32_t max_blk,
-                         const JsTableSet* tables, const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub, uint32_t* cand, uint32_t* req, int fill_rounds)
+                         const JsTableSet* tables, const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub, uint32_t* cand, uint32_t* req, int fill_rounds,
+                         int mid /* the memo walks report the state at the middle of every sub-sequence too (64-byte pieces only): the write pass will run two lanes per sub-sequence */)
 {
     if (!sy_wgs || !nimg) return;
     const size_t lds = subtabs_bytes_host(tab_rows, tab_lut2, true);
     const CandArrays C = cand_arrays(cand, nsub);
     CAND_WL(k_cand_spec, dim3(sy_wgs, max_blk), dim3(SY_THREADS), lds, imgs, sy_base, nimg, tables, ustr, seg_tab, side, C, tab_rows, tab_lut2);
-    CAND_WL(k_cand_walk, dim3(sy_wgs, CD_H), dim3(SY_THREADS), lds, imgs, sy_base, nimg, tables, ustr, seg_tab, side, C, tab_rows, tab_lut2);
-    CAND_WL(k_cand_chain, dim3(nimg), dim3(CC_THREADS), lds, imgs, tables, ustr, seg_tab, side, C, req, fill_rounds, tab_rows, tab_lut2);
-    CAND_WL(k_cand_apply, dim3(sy_wgs), dim3(SY_THREADS), 0, imgs, sy_base, nimg, tables, side, C, sub_arrays(sub, nsub));
+    if (mid && wl == 4) {
+        hipLaunchKernelGGL((k_cand_walk<4, true>), dim3(sy_wgs, CD_H), dim3(SY_THREADS), lds, st, imgs, sy_base, nimg, tables, ustr, seg_tab, side, C, tab_rows, tab_lut2);
+        hipLaunchKernelGGL((k_cand_chain<4, true>), dim3(nimg), dim3(CC_THREADS), lds, st, imgs, tables, ustr, seg_tab, side, C, req, fill_rounds, tab_rows, tab_lut2);
+    } else {
+        mid = 0;
+        CAND_WL2(k_cand_walk, dim3(sy_wgs, CD_H), dim3(SY_THREADS), lds, imgs, sy_base, nimg, tables, ustr, seg_tab, side, C, tab_rows, tab_lut2);
+        CAND_WL2(k_cand_chain, dim3(nimg), dim3(CC_THREADS), lds, imgs, tables, ustr, seg_tab, side, C, req, fill_rounds, tab_rows, tab_lut2);
+    }
+    CAND_WL(k_cand_apply, dim3(sy_wgs), dim3(SY_THREADS), 0, imgs, sy_base, nimg, tables, side, C, sub_arrays(sub, nsub), mid);
 }
 void js_launch_block_scan(hipStream_t st, int wl, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, uint32_t* sub, uint64_t nsub, uint32_t* side, uint32_t* flags)
 {
@@ -2717,10 +2759,16 @@ void js_launch_block_scan(hipStream_t st, int wl, const JsImage* imgs, uint32_t 
 }
 void js_launch_write(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
                      const uint8_t* ustr, const uint32_t* seg_tab, uint32_t* side, uint32_t* sub, uint64_t nsub,
-                     int16_t* coef, int16_t* dccum, uint8_t* mcu_rst, uint32_t* flags)
+                     int16_t* coef, int16_t* dccum, uint8_t* mcu_rst, uint32_t* flags, uint32_t* cand_half)
 {
     if (!total_wgs) return;
     static const bool v1 = getenv("JSNOOP_WRITE_V1") != nullptr;     // the first form of the kernel, kept as a cross-check
+    if (!v1 && cand_half && wl == 4) {                               // two lanes per sub-sequence, the second from the middle state of the selected memo walk
+        const CandArrays C = cand_arrays(cand_half, nsub);
+        hipLaunchKernelGGL((k_write2<4, true>), dim3(2 * total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                           sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2, (const uint32_t*)C.hp, (const uint32_t*)C.hs, (const uint32_t*)C.hn);
+        return;
+    }
     if (!v1) {
         if (wl == 4) hipLaunchKernelGGL((k_write2<4>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                            sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2);

@@ -267,7 +267,7 @@ int js_parallel_entropy_part(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32
         // small job: candidates and a chain of look-ups instead of rounds; what the chain left open is walked by k_sync in its verification mode,
         // one more launch carries a change across workgroup boundaries
         js_launch_cand_sync(st, b->sub_wl, b->tab_rows, b->tab_lut2, imgs, sy_base, n, sy_wgs, b->cand_blk, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
-                            b->dev.cand, b->dev.cand_req + (size_t)i0 * JS_CAND_REQ_WORDS, b->cand_rounds);
+                            b->dev.cand, b->dev.cand_req + (size_t)i0 * JS_CAND_REQ_WORDS, b->cand_rounds, b->cand_half ? 1 : 0);
         if (const char* e = getenv("JSNOOP_DEBUG_CAND")) if (atoi(e) >= 2) {      // links the chain left open, per image (diagnostics: stops the stream)
             if (hipStreamSynchronize(st) == hipSuccess) {
                 const uint64_t ns = b->total_subseq; std::vector<uint32_t> h(6 * ns);
@@ -281,14 +281,14 @@ int js_parallel_entropy_part(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32
                         fprintf(stderr, "[cand] image %u: %u sub-sequences, %u open links, first at %u", k, im.n_subseq, open, first);
                         if (first != 0xFFFFFFFFu) { const uint64_t g = im.subseq_off + first; fprintf(stderr, " (left exit %08x/%08x, entry %08x/%08x, exit %08x/%08x)", first ? h[g - 1] : 0u, first ? h[ns + g - 1] : 0u, h[2 * ns + g], h[3 * ns + g], h[g], h[ns + g]); }
                         fprintf(stderr, "\n");
-                        if (first != 0xFFFFFFFFu && first > 0) {      // the memos and maps around it (layout of cand_arrays: X 2 x 6 n, memo 5 x 7 n, maps 2 n words, selections)
+                        if (first != 0xFFFFFFFFu && first > 0) {      // the memos and maps around it (layout of cand_arrays: X 2 x 6 n, memo 8 x 7 n, maps 2 n, middle states 3 n words, selections)
                             std::vector<uint32_t> c(js_cand_bytes(ns) / 4);
                             std::vector<uint32_t> dg(JS_CAND_REQ_WORDS);
                             if (hipMemcpy(c.data(), b->dev.cand, c.size() * 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(dg.data(), b->dev.cand_req + (size_t)k * JS_CAND_REQ_WORDS, JS_CAND_REQ_WORDS * 4, hipMemcpyDeviceToHost) == hipSuccess) {
-                                const uint32_t* m = c.data() + 12 * ns; const uint8_t* sel = reinterpret_cast<const uint8_t*>(m + 35 * ns + 2 * ns);
+                                const uint32_t* m = c.data() + 12 * ns; const uint32_t* r = m + 56 * ns; const uint8_t* sel = reinterpret_cast<const uint8_t*>(r + 5 * ns);
                                 fprintf(stderr, "       chain diag: left %u; open %u %u %u %u; queued %u %u %u %u\n", dg[0], dg[4], dg[5], dg[6], dg[7], dg[8], dg[9], dg[10], dg[11]);
                                 for (uint64_t g = im.subseq_off + first - 1; g <= im.subseq_off + first; g++) {
-                                    fprintf(stderr, "       sub-sequence %u: selection %u, map %08x %08x\n", (unsigned)(g - im.subseq_off), sel[g], m[35 * ns + 2 * g], m[35 * ns + 2 * g + 1]);
+                                    fprintf(stderr, "       sub-sequence %u: selection %u, map %08x %08x\n", (unsigned)(g - im.subseq_off), sel[g], r[2 * g], r[2 * g + 1]);
                                     for (uint32_t e = 0; e < 7; e++) fprintf(stderr, "         slot %u: entry %08x/%08x exit %08x/%08x blocks %u%s\n", e, m[e * ns + g], m[7 * ns + e * ns + g], m[14 * ns + e * ns + g], m[21 * ns + e * ns + g], m[28 * ns + e * ns + g],
                                                                           e < 6 ? "" : " (filled)");
                                     fprintf(stderr, "         speculative exits:"); for (uint32_t e = 0; e < 6; e++) fprintf(stderr, " %08x/%08x", c[e * ns + g], c[6 * ns + e * ns + g]); fprintf(stderr, "\n");
@@ -309,7 +309,7 @@ int js_parallel_entropy_part(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32
     js_launch_block_scan(st, b->sub_wl, imgs, n, b->dev.tables, sub, b->total_subseq, b->dev.side, flags);
     if (evs) HIP_TRY(hipEventRecord(evs[4], st));
     js_launch_write(st, b->sub_wl, b->tab_rows_w, b->tab_lut2, imgs, sy_base, n, sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
-                    b->dev.coef, b->dev.dccum, b->dev.mcu_rst, flags);
+                    b->dev.coef, b->dev.dccum, b->dev.mcu_rst, flags, b->cand_half ? b->dev.cand : nullptr);
     if (evs) HIP_TRY(hipEventRecord(evs[5], st));
     js_launch_dc_scan(st, imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst, n == N ? b->dev.dc_parts : nullptr);   // (one scratch area: whole-batch launches only)
     roctxRangePop();
@@ -359,7 +359,7 @@ static int js_parallel_resume(JsnoopBatch* b, int extra_launches)
         js_launch_sync(b->stream, b->sub_wl, b->tab_rows, b->tab_lut2, b->dev.imgs, b->dev.sy_base + (n + 1), n, b->sn_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, 0);
     js_launch_block_scan(b->stream, b->sub_wl, b->dev.imgs, n, b->dev.tables, sub, b->total_subseq, b->dev.side, b->dev.flags);
     js_launch_write(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
-                    b->dev.coef, b->dev.dccum, b->dev.mcu_rst, b->dev.flags);
+                    b->dev.coef, b->dev.dccum, b->dev.mcu_rst, b->dev.flags, nullptr);      // (the middle states are the candidate chain's: one lane per sub-sequence here)
     js_launch_dc_scan(b->stream, b->dev.imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst, b->dev.dc_parts);
     if (b->launch_back_end(n)) return -1;
     return js_read_flags(b);

@@ -4,7 +4,10 @@ Small jobs synchronise by candidates (k_cand_spec / _walk / _chain / _apply: one
 of slot maps), larger ones by k_sync's rounds; both must leave the chain at the fixed point that IS the sequential decode of
 CimgDecode::DecodeScanImg (source/ImgDecode.cpp:3021-3645: ReadScanVal / DecodeScanComp in scan order).  The library reads its switches at
 upload: JSNOOP_CAND=0 (rounds only), JSNOOP_CAND=1 (one walk round of the chain: what stays open goes through k_sync's verification mode),
-JSNOOP_CAND_LANES=1 (job "too large": rounds), default (up to six walk rounds)."""
+JSNOOP_CAND_LANES=1 (job "too large": rounds), default (up to six walk rounds).  The smallest jobs also run the write pass with two lanes per
+sub-sequence, the second one entering at the middle state the selected memo walk reported (JSNOOP_NO_HALF=1: one lane); with one walk round
+only, the middle states of what k_sync repairs afterwards are stale and the write pass must notice (its verification fails, the decode resumes
+with one lane per sub-sequence) -- the result is the oracle's in every case."""
 import os
 
 import pytest
@@ -12,7 +15,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 MODES = [("default", {}), ("rounds_only", {"JSNOOP_CAND": "0"}), ("one_walk_round", {"JSNOOP_CAND": "1"}), ("too_large", {"JSNOOP_CAND_LANES": "1"}),
-         ("128_byte_pieces", {"JSNOOP_SUB_WL": "5"})]
+         ("128_byte_pieces", {"JSNOOP_SUB_WL": "5"}), ("one_write_lane_per_piece", {"JSNOOP_NO_HALF": "1"})]
 
 
 def _job(harness):
@@ -38,7 +41,7 @@ def job(harness, oracle):
 def test_synchronisation_forms_agree_with_the_oracle(job, mode, env):
     import jpegsnoop_amd as J
     files, want = job
-    saved = {k: os.environ.get(k) for k in ("JSNOOP_CAND", "JSNOOP_CAND_LANES", "JSNOOP_SUB_WL")}
+    saved = {k: os.environ.get(k) for k in ("JSNOOP_CAND", "JSNOOP_CAND_LANES", "JSNOOP_SUB_WL", "JSNOOP_NO_HALF")}
     try:
         for k in saved:
             os.environ.pop(k, None)
