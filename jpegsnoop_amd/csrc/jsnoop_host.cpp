@@ -352,7 +352,7 @@ int JsnoopBatch::upload()
     // 16: 0.64 | 1.09, 32: 1.04 | 1.31, 48: 1.44 | 1.58 (2.6 M walks); the two meet near 64 images.
     uint32_t max_blk = 0; for (const JsImage& im : imgs) max_blk = std::max(max_blk, im.blk_per_mcu);
     uint64_t cand_lanes = 2500000; if (const char* e = getenv("JSNOOP_CAND_LANES")) cand_lanes = strtoull(e, nullptr, 10);
-    int cand_want = 6; if (const char* e = getenv("JSNOOP_CAND")) cand_want = atoi(e) > 0 ? std::min(atoi(e), 64) : -1;
+    int cand_want = 16; if (const char* e = getenv("JSNOOP_CAND")) cand_want = atoi(e) > 0 ? std::min(atoi(e), 64) : -1;
     const bool cand_fits = cand_want >= 0 && max_blk >= 1 && max_blk <= JS_CAND_MAX_BLK && (scan_total / 64 + 64 * n) * max_blk <= cand_lanes;
     if (cand_fits) sub_wl = 4;
     if (const char* e = getenv("JSNOOP_SUB_WL")) { const int w = atoi(e); sub_wl = (w >= 4 && w <= 8) ? w : 5; }

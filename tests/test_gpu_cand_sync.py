@@ -3,8 +3,8 @@
 Small jobs synchronise by candidates (k_cand_spec / _walk / _chain / _apply: one speculative walk per block-in-MCU index, memo walks, a chain
 of slot maps), larger ones by k_sync's rounds; both must leave the chain at the fixed point that IS the sequential decode of
 CimgDecode::DecodeScanImg (source/ImgDecode.cpp:3021-3645: ReadScanVal / DecodeScanComp in scan order).  The library reads its switches at
-upload: JSNOOP_CAND=0 (rounds only), JSNOOP_CAND=1 (one walk round of the chain: what stays open goes through k_sync's verification mode),
-JSNOOP_CAND_LANES=1 (job "too large": rounds), default (up to six walk rounds).  The smallest jobs also run the write pass with two lanes per
+upload: JSNOOP_CAND=0 (rounds only), JSNOOP_CAND=1 (one walk round of the chain: what stays open trips the write pass's verification and goes through k_sync's verification mode),
+JSNOOP_CAND_LANES=1 (job "too large": rounds), default (up to sixteen walk rounds).  The smallest jobs also run the write pass with two lanes per
 sub-sequence, the second one entering at the middle state the selected memo walk reported (JSNOOP_NO_HALF=1: one lane); with one walk round
 only, the middle states of what k_sync repairs afterwards are stale and the write pass must notice (its verification fails, the decode resumes
 with one lane per sub-sequence) -- the result is the oracle's in every case."""
