@@ -1191,7 +1191,8 @@ void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, 
 // stored word-interleaved -- word w of sub-sequence l sits at 32-bit index (group*32 + w)*64 + l -- so that
 // the 64 lanes of a wave, each walking its own sub-sequence at roughly the same pace, read one coalesced
 // 256-byte row per refill instead of 64 different cache lines.
-template <int WL> __device__ __forceinline__ uint32_t phys_word(uint32_t W) { return (W & ~((64u << WL) - 1u)) | ((W & ((1u << WL) - 1u)) << 6) | ((W >> WL) & 63u); }
+// 64-byte pieces (WL = 4: small jobs, where nothing is bandwidth-bound and every launch is 1-2 % of the decode) read the linear stream as it is: no transpose pass.
+template <int WL> __device__ __forceinline__ uint32_t phys_word(uint32_t W) { return WL == 4 ? W : (W & ~((64u << WL) - 1u)) | ((W & ((1u << WL) - 1u)) << 6) | ((W >> WL) & 63u); }
 template <int WL> __device__ __forceinline__ uint32_t phys_byte(uint32_t B) { return (phys_word<WL>(B >> 2) << 2) | (B & 3u); }
 
 struct UsBytes { uint32_t keep_mask, rst_mask; };
@@ -2678,9 +2679,9 @@ void js_launch_unstuff(hipStream_t st, int wl, const JsImage* imgs, const uint32
     if (!total_chunks) return;
     hipLaunchKernelGGL(k_unstuff_count, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst);
     hipLaunchKernelGGL(k_unstuff_scan, dim3(nimg), dim3(256), 0, st, imgs, us_base, chunk_keep, chunk_rst, seg_tab, side, flags);
-    hipLaunchKernelGGL(k_unstuff_write, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, ustr_lin, seg_tab, 0u, (uint32_t*)nullptr);
-    if (wl == 4) hipLaunchKernelGGL(k_interleave<4>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
-    else if (wl == 6) hipLaunchKernelGGL(k_interleave<6>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
+    hipLaunchKernelGGL(k_unstuff_write, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, wl == 4 ? ustr : ustr_lin, seg_tab, 0u, (uint32_t*)nullptr);
+    if (wl == 4) return;                                         // (phys_word<4> is the identity)
+    if (wl == 6) hipLaunchKernelGGL(k_interleave<6>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
     else if (wl == 8) hipLaunchKernelGGL(k_interleave<8>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
     else if (wl == 7) hipLaunchKernelGGL(k_interleave<7>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
     else hipLaunchKernelGGL(k_interleave<5>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
