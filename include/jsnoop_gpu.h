@@ -212,10 +212,43 @@ int          jsnoop_batch_add_progressive(JsnoopBatch*, const uint8_t* file, siz
 /* Tiles already-added images so the batch holds `total` images (image i reuses the
  * bytes of image i % n): the bench's "N distinct seeds tiled to 1024".               */
 int          jsnoop_batch_tile(JsnoopBatch*, int total);
-/* Beyond the reference: parts = 2 makes the following decodes run the two halves of the batch on two streams side by side (same
-   arenas, same results; the kernels of one half fill the thinly populated phases of the other: about 4 % more throughput on
-   1024 x 1080p).  Off by default -- with it the per-kernel timings are those of launches that share the chip.  0 / -1. */
+/* Beyond the reference: the decodes of a batch may run its two halves on two streams side by side (same arenas, same results; the
+   kernels of one half fill the thinly populated phases of the other: about 4 % more throughput on 1024 x 1080p).  parts = 0: the
+   library decides (two streams from 96 MB of scan data in the batch -- the default), 1: one stream (profiling: per-kernel timings
+   are then those of whole-batch launches), 2: two streams whenever the batch has two images.  0 / -1.                            */
 int          jsnoop_batch_set_split(JsnoopBatch*, int parts);
+int          jsnoop_batch_split_parts(const JsnoopBatch*);              /* what the setting comes to for the images the batch holds now: 1 or 2 */
+/* ---- tuning: how the library decodes, never what it produces.  Every field has an automatic setting (0); the environment variables
+ *      of tools/README.md are read ONCE per process and only supply the defaults jsnoop_tuning_defaults returns -- nothing on the
+ *      decode path reads the environment.  A batch takes a copy at jsnoop_batch_set_tuning (call before upload; -1 + last_error on a
+ *      value out of range); jsnoop_set_tuning does the same for the private batch behind a single-image decoder.                      */
+typedef struct JsnoopTuning {
+    uint32_t struct_size;     /* sizeof(JsnoopTuning) of the caller (forward compatibility)                                          */
+    int32_t  sub_wl;          /* log2(32-bit words) of a sub-sequence: 4..8 = 64 B .. 1 KiB; 0 = by job size (4 / 5 / 7)              */
+    int32_t  cand_rounds;     /* synchronisation form: -1 = rounds of k_sync only, n > 0 = candidates with at most n walk rounds (<= 64),
+                                 0 = automatic (candidates with 16 rounds while the job is small enough, see cand_max_walks)          */
+    uint64_t cand_max_walks;  /* largest job (64-byte pieces x blocks per MCU) that synchronises by candidates; 0 = 2 500 000         */
+    int32_t  sync_launches;   /* launches of k_sync in the classic form; 0 = 2                                                        */
+    int32_t  write_lanes;     /* lanes per sub-sequence in the write pass of the smallest jobs: 1, 2; 0 = automatic (2 up to 40 960 pieces) */
+    int32_t  split;           /* as jsnoop_batch_set_split: 0 automatic, 1 one stream, 2 two streams                                  */
+    int32_t  mcus_per_wave;   /* MCUs per back-end wave; 0 = one round of workgroups over the chip, at most 64                        */
+    int32_t  pg_lanes;        /* progressive: restart intervals per wave 1, 2, 4, 8, 16 or 64 (lane-per-interval kernel); 0 = by batch size */
+    uint32_t cross_checks;    /* JSNOOP_XC_* bits: alternative code paths kept for cross-checking, same results                       */
+    uint32_t debug;           /* JSNOOP_DBG_* bits: diagnostics on stderr                                                             */
+} JsnoopTuning;
+#define JSNOOP_XC_BACKEND_GENERIC 0x01u  /* the all-layouts back-end kernel for every launch                                          */
+#define JSNOOP_XC_WRITE_V1        0x02u  /* the first form of the write pass                                                          */
+#define JSNOOP_XC_NO_TAIL         0x04u  /* damaged files: no tail take-over / second attempt, the whole image through the mirror     */
+#define JSNOOP_XC_SIDE_EXACT      0x08u  /* side outputs always from the exact-mirror reader                                          */
+#define JSNOOP_XC_CAND_VERIFY     0x10u  /* k_sync's verification mode behind every candidate chain                                   */
+#define JSNOOP_DBG_CAND           0x01u  /* candidate chain: rounds, queued walks                                                     */
+#define JSNOOP_DBG_CAND_LINKS     0x02u  /* ... and the links left open per image (stops the stream)                                  */
+#define JSNOOP_DBG_TAIL           0x04u  /* damaged files: tail take-over decisions                                                   */
+#define JSNOOP_DBG_TIMING         0x08u  /* single-image calls: where the wall time goes                                              */
+void         jsnoop_tuning_defaults(JsnoopTuning* out);                 /* struct_size set, everything else the process defaults    */
+int          jsnoop_batch_set_tuning(JsnoopBatch*, const JsnoopTuning*);
+void         jsnoop_batch_get_tuning(const JsnoopBatch*, JsnoopTuning* out);
+int          jsnoop_set_tuning(JsnoopDecoder*, const JsnoopTuning*);
 int          jsnoop_batch_count(const JsnoopBatch*);
 int          jsnoop_batch_upload(JsnoopBatch*);      /* pinned host -> HBM (async), builds device descriptors */
 int          jsnoop_batch_decode(JsnoopBatch*);      /* HBM -> HBM, asynchronous on the batch stream          */

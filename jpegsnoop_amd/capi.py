@@ -14,6 +14,16 @@ LIB_PATH = os.path.join(_HERE, "libjsnoop_gpu.so")
 NUM_STAGES = 8
 LOG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_char_p)
 
+class Tuning(C.Structure):
+    """JsnoopTuning of include/jsnoop_gpu.h: how the library decodes (0 = automatic everywhere), never what it produces."""
+    _fields_ = [("struct_size", C.c_uint32), ("sub_wl", C.c_int32), ("cand_rounds", C.c_int32), ("cand_max_walks", C.c_uint64),
+                ("sync_launches", C.c_int32), ("write_lanes", C.c_int32), ("split", C.c_int32), ("mcus_per_wave", C.c_int32),
+                ("pg_lanes", C.c_int32), ("cross_checks", C.c_uint32), ("debug", C.c_uint32)]
+
+
+XC_BACKEND_GENERIC, XC_WRITE_V1, XC_NO_TAIL, XC_SIDE_EXACT, XC_CAND_VERIFY = 1, 2, 4, 8, 16
+DBG_CAND, DBG_CAND_LINKS, DBG_TAIL, DBG_TIMING = 1, 2, 4, 8
+
 _u, _i, _p, _sz = C.c_uint, C.c_int, C.c_void_p, C.c_size_t
 _PU, _PI = C.POINTER(C.c_uint), C.POINTER(C.c_int)
 
@@ -87,6 +97,11 @@ SIGNATURES = {
     "jsnoop_batch_add_jpeg": (_i, [_p, _p, _sz]),
     "jsnoop_batch_tile": (_i, [_p, _i]),
     "jsnoop_batch_set_split": (_i, [_p, _i]),
+    "jsnoop_batch_split_parts": (_i, [_p]),
+    "jsnoop_tuning_defaults": (None, [C.POINTER(Tuning)]),
+    "jsnoop_batch_set_tuning": (_i, [_p, C.POINTER(Tuning)]),
+    "jsnoop_batch_get_tuning": (None, [_p, C.POINTER(Tuning)]),
+    "jsnoop_set_tuning": (_i, [_p, C.POINTER(Tuning)]),
     "jsnoop_batch_count": (_i, [_p]),
     "jsnoop_batch_upload": (_i, [_p]),
     "jsnoop_batch_decode": (_i, [_p]),

@@ -152,6 +152,44 @@ bool js_describe_image(JsnoopDecoder* d, JsImage* im, JsTableSet* ts, uint32_t f
     return true;
 }
 
+// ------------------------------------------------------------------------------ tuning
+// The environment supplies DEFAULTS, once per process (the variables of tools/README.md); batches copy them at creation and
+// jsnoop_batch_set_tuning replaces the copy.  Nothing below this function reads the environment.
+const JsnoopTuning& js_env_tuning()
+{
+    static const JsnoopTuning env = [] {
+        JsnoopTuning t; memset(&t, 0, sizeof t); t.struct_size = (uint32_t)sizeof t;
+        auto num = [](const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; };
+        auto on = [](const char* name) { return getenv(name) != nullptr; };
+        { const long long w = num("JSNOOP_SUB_WL", 0); t.sub_wl = (w >= 4 && w <= 8) ? (int32_t)w : 0; }
+        if (on("JSNOOP_CAND")) { const long long c = num("JSNOOP_CAND", 0); t.cand_rounds = c > 0 ? (int32_t)std::min<long long>(c, 64) : -1; }
+        t.cand_max_walks = (uint64_t)std::max<long long>(0, num("JSNOOP_CAND_LANES", 0));
+        t.sync_launches = (int32_t)std::max<long long>(0, num("JSNOOP_SYNC_LAUNCHES", 0));
+        t.write_lanes = on("JSNOOP_NO_HALF") ? 1 : 0;
+        { const long long sp = num("JSNOOP_SPLIT", 0); t.split = (sp == 1 || sp == 2) ? (int32_t)sp : 0; }
+        t.mcus_per_wave = (int32_t)std::max<long long>(0, num("JSNOOP_MPW", 0));
+        { const long long v = num("JSNOOP_PG_LANES", 0); t.pg_lanes = (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 64) ? (int32_t)v : 0; }
+        t.cross_checks = (on("JSNOOP_BACKEND_GENERIC") ? JSNOOP_XC_BACKEND_GENERIC : 0u) | (on("JSNOOP_WRITE_V1") ? JSNOOP_XC_WRITE_V1 : 0u) | (on("JSNOOP_NO_TAIL") ? JSNOOP_XC_NO_TAIL : 0u) |
+                         (on("JSNOOP_SIDE_EXACT") ? JSNOOP_XC_SIDE_EXACT : 0u) | (on("JSNOOP_CAND_VERIFY") ? JSNOOP_XC_CAND_VERIFY : 0u);
+        const long long dc = num("JSNOOP_DEBUG_CAND", 0);
+        t.debug = (dc >= 1 ? JSNOOP_DBG_CAND : 0u) | (dc >= 2 ? JSNOOP_DBG_CAND_LINKS : 0u) | (on("JSNOOP_DEBUG_TAIL") ? JSNOOP_DBG_TAIL : 0u) | (on("JSNOOP_DEBUG_TIMING") ? JSNOOP_DBG_TIMING : 0u);
+        return t;
+    }();
+    return env;
+}
+int js_check_tuning(const JsnoopTuning& t)
+{
+    if (t.struct_size != sizeof(JsnoopTuning)) { js_set_error("tuning: struct_size %u, this library has %zu", t.struct_size, sizeof(JsnoopTuning)); return -1; }
+    if (t.sub_wl != 0 && (t.sub_wl < 4 || t.sub_wl > 8)) { js_set_error("tuning: sub_wl must be 0 or 4..8"); return -1; }
+    if (t.cand_rounds < -1 || t.cand_rounds > 64) { js_set_error("tuning: cand_rounds must be -1, 0 or 1..64"); return -1; }
+    if (t.sync_launches < 0 || t.sync_launches > 64) { js_set_error("tuning: sync_launches must be 0..64"); return -1; }
+    if (t.write_lanes < 0 || t.write_lanes > 2) { js_set_error("tuning: write_lanes must be 0, 1 or 2"); return -1; }
+    if (t.split < 0 || t.split > 2) { js_set_error("tuning: split must be 0, 1 or 2"); return -1; }
+    if (t.mcus_per_wave < 0 || t.mcus_per_wave > 4096) { js_set_error("tuning: mcus_per_wave must be 0..4096"); return -1; }
+    if (!(t.pg_lanes == 0 || t.pg_lanes == 1 || t.pg_lanes == 2 || t.pg_lanes == 4 || t.pg_lanes == 8 || t.pg_lanes == 16 || t.pg_lanes == 64)) { js_set_error("tuning: pg_lanes must be 0, 1, 2, 4, 8, 16 or 64"); return -1; }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------ batch
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
@@ -161,8 +199,7 @@ JsnoopBatch::JsnoopBatch(void* user_stream)
     opt_decode_ac = 1; opt_want_planes = 0; opt_force_exact = 0;
     memset(&dev, 0, sizeof dev); memset(&cap, 0, sizeof cap);
     pinned = nullptr; pinned_cap = 0; raw_bytes = 0; uploaded = false; sync_launches = 2;
-    if (const char* e = getenv("JSNOOP_SYNC_LAUNCHES")) sync_launches = std::max(1, atoi(e));
-    if (const char* e = getenv("JSNOOP_SPLIT")) opt_split = atoi(e) == 2 ? 2 : 1;      // the default only: jsnoop_batch_set_split takes precedence afterwards
+    tune = js_env_tuning();
     for (auto& e : ev) e = nullptr;
     for (auto& e : ev2) e = nullptr;
     d_lut = nullptr;
@@ -225,7 +262,7 @@ int JsnoopBatch::ensure_aux()
 }
 void JsnoopBatch::clear()
 {
-    imgs.clear(); hinfo.clear(); tables.clear(); raw_bytes = 0; uploaded = false; host_flags.clear();
+    imgs.clear(); hinfo.clear(); tables.clear(); raw_bytes = 0; uploaded = false; host_flags.clear(); side_done.clear(); side_mode.clear(); side_anoms.clear();
     js_prog_clear(this);
 }
 int JsnoopBatch::reserve_pinned(size_t need)
@@ -343,7 +380,7 @@ int JsnoopBatch::upload()
     // back end: 8 waves per workgroup; enough MCUs per wave to amortise a workgroup's table load; a small job as ONE round of workgroups over the
     // chip's 1024 workgroup slots (one 3840x2160 image: 4 MCUs per wave, 1013 workgroups, 47 us; 3 per wave = 1350 workgroups: 51)
     uint32_t mcus_per_wave = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (total_mcus + 8 * 1024 - 1) / (8 * 1024)));
-    if (const char* e = getenv("JSNOOP_MPW")) mcus_per_wave = (uint32_t)std::max(1, atoi(e));       // (experiments)
+    if (tune.mcus_per_wave > 0) mcus_per_wave = (uint32_t)tune.mcus_per_wave;
     // sub-sequence length: long (512 B) when the batch still yields plenty of lanes, short (128 B, 64 B) for small jobs
     uint64_t scan_total = 0; for (const JsImage& im : imgs) scan_total += im.scan_len;
     sub_wl = scan_total >= (96ull << 20) ? 7 : (scan_total < (4ull << 20) ? 4 : 5);    // (a single image / a handful: 64-byte pieces give the write pass more lanes)
@@ -351,11 +388,12 @@ int JsnoopBatch::upload()
     // what the chip holds at once (~500 k lanes): N x 1080p 4:2:0, ms per decode, candidates | rounds: 1: 0.30 | 0.80, 4: 0.37 | 0.83, 8: 0.45 | 0.95,
     // 16: 0.64 | 1.09, 32: 1.04 | 1.31, 48: 1.44 | 1.58 (2.6 M walks); the two meet near 64 images.
     uint32_t max_blk = 0; for (const JsImage& im : imgs) max_blk = std::max(max_blk, im.blk_per_mcu);
-    uint64_t cand_lanes = 2500000; if (const char* e = getenv("JSNOOP_CAND_LANES")) cand_lanes = strtoull(e, nullptr, 10);
-    int cand_want = 16; if (const char* e = getenv("JSNOOP_CAND")) cand_want = atoi(e) > 0 ? std::min(atoi(e), 64) : -1;
+    const uint64_t cand_lanes = tune.cand_max_walks ? tune.cand_max_walks : 2500000;
+    const int cand_want = tune.cand_rounds == 0 ? 16 : tune.cand_rounds;
     const bool cand_fits = cand_want >= 0 && max_blk >= 1 && max_blk <= JS_CAND_MAX_BLK && (scan_total / 64 + 64 * n) * max_blk <= cand_lanes;
     if (cand_fits) sub_wl = 4;
-    if (const char* e = getenv("JSNOOP_SUB_WL")) { const int w = atoi(e); sub_wl = (w >= 4 && w <= 8) ? w : 5; }
+    if (tune.sub_wl) sub_wl = tune.sub_wl;
+    sync_launches = tune.sync_launches > 0 ? tune.sync_launches : 2;
     const uint32_t sub_bytes = 4u << sub_wl;
     uint32_t wgs = 0; max_mcu_h = 8; max_mcu_w = 8;
     for (size_t i = 0; i < n; i++) {
@@ -392,7 +430,7 @@ int JsnoopBatch::upload()
     { uint32_t most = 0; for (size_t i = 0; i < n; i++) most = std::max(most, wg[i + 1] - wg[i]); if (most > 64 && grow(&dev.wg_part, &cap.wg_part, (size_t)wgs * 16 + 64)) return -1; }
     cand_blk = max_blk; cand_rounds = (cand_fits && sub_wl == 4) ? cand_want : -1;
     // two write lanes per sub-sequence while the job leaves SIMDs idle anyway (one 3840x2160 image: write pass 88 -> 66 us; sixteen 1080p images: 111 -> 123)
-    cand_half = cand_rounds >= 0 && subs <= 40960 && !getenv("JSNOOP_NO_HALF");
+    cand_half = cand_rounds >= 0 && tune.write_lanes != 1 && (subs <= 40960 || tune.write_lanes == 2);
     if (cand_rounds >= 0 && (grow(&dev.cand, &cap.cand, js_cand_bytes(subs)) || grow(&dev.cand_req, &cap.cand_req, n * JS_CAND_REQ_WORDS * 4))) return -1;
     event_words = opt_events ? (uint64_t)n * (1 + JS_EV_WORDS * JS_EV_MAX) : 0;
     if (event_words && grow(&dev.events, &cap.events, event_words * 4)) return -1;
@@ -407,7 +445,8 @@ int JsnoopBatch::upload()
     HIP_TRY(hipMemcpyAsync(dev.sy_base, syb.data(), 2 * (n + 1) * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));          // host vectors above may go out of scope
     h_us_base = usb; h_sy_base.assign(syb.begin(), syb.begin() + n + 1); h_sn_base.assign(syb.begin() + n + 1, syb.end()); h_wg_base = wg;
-    split_parts = (opt_split == 2 && n >= 2) ? 2 : 1;
+    // two halves on two streams: by default from the batch size at which the long sub-sequences are chosen (96 MB of scan data)
+    split_parts = (n >= 2 && (tune.split == 2 || (tune.split == 0 && scan_total >= (96ull << 20)))) ? 2 : 1;
     uploaded = true;
     return 0;
 }
@@ -418,7 +457,7 @@ int JsnoopBatch::decode(bool timed)
     HIP_TRY(hipSetDevice(device));
     if (!uploaded && upload()) return -1;
     const uint32_t n = (uint32_t)imgs.size();
-    side_done.assign(n, 0);
+    side_done.assign(n, 0); side_mode.assign(n, 0); side_anoms.assign(n, std::vector<uint32_t>());   // (nothing of an earlier decode's side pass survives)
     JsRange r_("jsnoop:decode (enqueue)");
     if (js_prog_count(this)) return decode_progressive(timed);     // SOF2 files: every scan of every image, one launch per dependency level
     if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
@@ -468,8 +507,7 @@ int JsnoopBatch::launch_back_end_part(hipStream_t st, uint32_t i0, uint32_t nimg
         const int l = !js_fast_layout(im) ? 0 : (im.expand_h[2] == 2 ? (im.expand_v[2] == 2 ? 1 : 2) : (im.expand_v[2] == 2 ? 3 : 4));
         layout = layout < 0 ? l : (layout == l ? l : 0);
     }
-    static const bool generic_only = getenv("JSNOOP_BACKEND_GENERIC") != nullptr;   // (cross-check: the all-layouts kernel for every launch)
-    if (layout < 0 || generic_only) layout = 0;
+    if (layout < 0 || (tune.cross_checks & JSNOOP_XC_BACKEND_GENERIC)) layout = 0;   // (cross-check: the all-layouts kernel for every launch)
     const uint32_t wgs = h_wg_base.size() > i0 + nimg ? h_wg_base[i0 + nimg] - h_wg_base[i0] : total_wgs;
     // an image spread over many workgroups: per-workgroup status records and a fold, instead of every workgroup queueing on the image's two status words
     uint32_t most = 0; for (uint32_t i = i0; i < i0 + nimg && i + 1 < h_wg_base.size(); i++) most = std::max(most, h_wg_base[i + 1] - h_wg_base[i]);
@@ -625,7 +663,7 @@ void jsnoop_decode_scan_img(JsnoopDecoder* d, const uint8_t* file, size_t len, u
     b->clear();
     b->opt_decode_ac = d->opt_decode_ac;
     d->last_path = 0; d->last_flags = 0;
-    static const bool dbg_t = getenv("JSNOOP_DEBUG_TIMING") != nullptr;   // where a call's wall time goes (stderr, one line per call)
+    const bool dbg_t = (b->tune.debug & JSNOOP_DBG_TIMING) != 0;   // where a call's wall time goes (stderr, one line per call)
     auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tp[10]; int ntp = 0; if (dbg_t) tp[ntp++] = now_us();
     if (b->add(d, file, len, start, display, quiet) < 0) return;   // early returns of DecodeScanImg: no preview
@@ -810,11 +848,34 @@ int jsnoop_batch_add_jpeg(JsnoopBatch* b, const uint8_t* file, size_t len)
     return b->add(&tmp, file, len, scan_start, 1);
 }
 int jsnoop_batch_tile(JsnoopBatch* b, int total) { return b->tile(total); }
+static void js_resolve_split(JsnoopBatch* b)
+{
+    uint64_t scan_total = 0; for (const JsImage& im : b->imgs) scan_total += im.scan_len;
+    b->split_parts = (b->imgs.size() >= 2 && (b->tune.split == 2 || (b->tune.split == 0 && scan_total >= (96ull << 20)))) ? 2 : 1;
+}
 int jsnoop_batch_set_split(JsnoopBatch* b, int parts)
 {
-    if (!b || (parts != 1 && parts != 2)) { js_set_error("jsnoop_batch_set_split: parts must be 1 or 2"); return -1; }
-    b->opt_split = parts; b->split_parts = (parts == 2 && b->imgs.size() >= 2) ? 2 : 1;
+    if (!b || parts < 0 || parts > 2) { js_set_error("jsnoop_batch_set_split: parts must be 0 (automatic), 1 or 2"); return -1; }
+    b->tune.split = parts; js_resolve_split(b);
     return 0;
+}
+int jsnoop_batch_split_parts(const JsnoopBatch* b) { return b ? b->split_parts : 1; }
+void jsnoop_tuning_defaults(JsnoopTuning* out) { if (out) *out = js_env_tuning(); }
+int jsnoop_batch_set_tuning(JsnoopBatch* b, const JsnoopTuning* t)
+{
+    if (!b || !t) { js_set_error("jsnoop_batch_set_tuning: null argument"); return -1; }
+    if (js_check_tuning(*t)) return -1;
+    b->tune = *t; b->uploaded = false;                           // sub-sequence length, synchronisation form and work split are fixed by upload()
+    if (b->helper) b->helper->tune = *t;
+    js_prog_dirty(b);
+    js_resolve_split(b);
+    return 0;
+}
+void jsnoop_batch_get_tuning(const JsnoopBatch* b, JsnoopTuning* out) { if (b && out) *out = b->tune; }
+int jsnoop_set_tuning(JsnoopDecoder* d, const JsnoopTuning* t)
+{
+    if (!d || !d->batch) { js_set_error("jsnoop_set_tuning: no decoder"); return -1; }
+    return jsnoop_batch_set_tuning(d->batch, t);
 }
 int jsnoop_batch_count(const JsnoopBatch* b) { return (int)b->imgs.size(); }
 int jsnoop_batch_upload(JsnoopBatch* b) { return b->upload(); }

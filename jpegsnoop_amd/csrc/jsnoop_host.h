@@ -84,7 +84,8 @@ struct JsnoopBatch {
     // A large batch decodes as two halves on two streams (stream, aux[0]): the kernels of one half fill the tails and the thinly
     // populated phases (second synchronisation launch, DC scan) of the other -- 14.2 -> 13.7 ms per 1024 images.  Both halves live in
     // the same arenas; a launch over a half passes pointers to its first image and its first prefix entry.
-    int opt_split = 1, split_parts = 1;                           // opt-in (jsnoop_batch_set_split / JSNOOP_SPLIT=2): the per-kernel timings of a split decode are those of launches that share the chip
+    int split_parts = 1;                                          // what tune.split came to for the uploaded batch
+    JsnoopTuning tune;                                            // how this batch decodes (jsnoop_batch_set_tuning; process defaults: js_env_tuning)
     hipEvent_t ev2[JSNOOP_NUM_STAGES + 1];                        // stage events of the second half (timed decodes)
     bool last_timed_split = false;
     bool last_used_parallel = false;                              // false: no table set of the batch fits the parallel path, the exact-mirror kernel decoded everything
@@ -98,7 +99,7 @@ struct JsnoopBatch {
     // small jobs (64-byte sub-sequences, a few hundred thousand walks at most) synchronise by candidates (k_cand_*) instead of k_sync's rounds: cand_rounds
     // = fill rounds of the chain, -1 = off (JSNOOP_CAND=0, more than JS_CAND_MAX_BLK blocks per MCU, a larger job); cand_blk = most blocks per MCU in the batch
     int cand_rounds = -1; uint32_t cand_blk = 0; bool cand_half = false;   // cand_half: the smallest jobs (one large image, a handful) also run the write pass with two lanes per sub-sequence
-    int sync_launches; int sub_wl;   // log2(words per sub-sequence): 4 / 5 / 7 = 64- / 128- / 512-byte sub-sequences (chosen per batch; 6 and 8 through JSNOOP_SUB_WL)
+    int sync_launches; int sub_wl;   // log2(words per sub-sequence): 4 / 5 / 7 = 64- / 128- / 512-byte sub-sequences (chosen per batch; 6 and 8 through the tuning struct)
     uint32_t tab_rows, tab_lut2, tab_rows_w;     // largest decode-table footprint in the batch (sizes the kernels' LDS); _w: DC rows | AC rows << 8
     hipEvent_t ev[JSNOOP_NUM_STAGES + 1];
     // helper streams for work that forks inside one decode (independent scans of a progressive file), created on first use
@@ -137,6 +138,9 @@ struct JsnoopBatch {
 int  js_clear_flags(JsnoopBatch* b);                              // flag arena: two words per image (flags, complement of the first anomalous block)
 int  js_read_flags(JsnoopBatch* b);                               // -> host_flags, host_anom
 void js_set_error(const char* fmt, ...);
+const JsnoopTuning& js_env_tuning();                             // the process defaults: environment variables, read once
+int  js_check_tuning(const JsnoopTuning& t);                      // 0 / -1 + error text
+void js_debug_cand_links(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32_t n);   // JSNOOP_DBG_CAND_LINKS (jsnoop_parallel.cpp)
 // roctx ranges around the host-side stages (rocprofv3 --marker-trace makes a timeline self-describing: upload / clear / entropy
 // stages / back end / read-back).  One push and pop per stage and call: nothing per image.
 #include <rocprofiler-sdk-roctx/roctx.h>
@@ -154,6 +158,7 @@ int  js_side_only(JsnoopBatch* b, uint32_t i);
 int  js_jfif_walk(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned* scan_start);   // jfif_front.cpp
 size_t js_prog_count(const JsnoopBatch* b);                            // jsnoop_progressive.cpp: progressive images in the batch
 void js_prog_clear(JsnoopBatch* b);
+void js_prog_dirty(JsnoopBatch* b);
 void js_prog_free(JsnoopBatch* b);
 void js_prog_dup(JsnoopBatch* b, uint32_t src, uint32_t dst);
 bool js_is_progressive(const uint8_t* file, size_t len);               // first SOF marker of the stream is SOF2

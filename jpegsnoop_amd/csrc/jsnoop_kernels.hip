@@ -402,9 +402,12 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
 // Plain fp32 multiplies and adds issue at full rate on gfx950; their packed forms do not (profiles/r02_instr_rates.txt), so
 // the pixels are converted one at a time.  crm = RN(Cr * (2 - 2*0.299f)) and cbm = RN(Cb * (2 - 2*0.114f)) depend on the
 // chroma sample only: subsampled images form them once per chroma sample, not per pixel.
+#define RB_BIAS (127.5f + 0.000244140625f)                        // see pack_bgr
 struct Rgbf { float r, g, b; };                                  // the three channels after "+= 128", before the range cap
 __device__ __forceinline__ float chroma_r(float fcr) { const float kr = 0.299f; return __fmul_rn(fcr, 2 - 2 * kr); }   // folded in fp32 exactly as the reference's expression
 __device__ __forceinline__ float chroma_b(float fcb) { const float kb = 0.114f; return __fmul_rn(fcb, 2 - 2 * kb); }
+// PACK: the result goes to pack_bgr (R and B carry pack_bgr's bias instead of the reference's + 128; G is the reference's)
+template <bool PACK>
 __device__ __forceinline__ Rgbf ycc_core(float fy, float crm, float cbm)
 {
     const float kr = 0.299f, kg = 0.587f, kb = 0.114f, rkg = 1.0f / kg;
@@ -413,16 +416,19 @@ __device__ __forceinline__ Rgbf ycc_core(float fy, float crm, float cbm)
     const float x = __fsub_rn(__fsub_rn(fy, __fmul_rn(kb, b)), __fmul_rn(kr, r));
     const float q0 = __fmul_rn(x, rkg);
     const float g = __builtin_fmaf(__builtin_fmaf(-kg, q0, x), rkg, q0);          // == x / kg, see above
-    o.r = __fadd_rn(r, 128.0f); o.g = __fadd_rn(g, 128.0f); o.b = __fadd_rn(b, 128.0f);
+    o.r = __fadd_rn(r, PACK ? RB_BIAS : 128.0f); o.g = __fadd_rn(g, 128.0f); o.b = __fadd_rn(b, PACK ? RB_BIAS : 128.0f);
     return o;
 }
 // <0 -> 0, >255 -> 255, else truncate (:4128-4136); bytes B,G,R,0 (:4786-4789).  floor() equals the truncation wherever the value
-// is not capped to 0 anyway, and v_cvt_pk_u8_f32 saturates an integral float to [0, 255] into the byte it is told to fill.
+// is not capped to 0 anyway, and v_cvt_pk_u8_f32 (round to nearest) saturates to [0, 255] into the byte it is told to fill.  R and B
+// are RN(chroma term + Y): for every (Y, Cb) / (Y, Cr) pair (2 x 65536 cases) the conversion of RN(v + (127.5 + 2^-12)) equals
+// floor(RN(v + 128)) under either tie rule -- no floor instruction for them (rb_bias below; tests/test_gpu_parity.py::test_color_sweep is
+// the gate, all 2^24 triples against the oracle).  G has arbitrary fractions: it keeps the floor.
 __device__ __forceinline__ uint32_t pack_bgr(const Rgbf& c)
 {
-    uint32_t o = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(c.b), 0, 0u);
+    uint32_t o = __builtin_amdgcn_cvt_pk_u8_f32(c.b, 0, 0u);
     o = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(c.g), 1, o);
-    return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(c.r), 2, o);
+    return __builtin_amdgcn_cvt_pk_u8_f32(c.r, 2, o);
 }
 // ... then ChannelExtract :4832-4872 on the capped values (the preview modes other than RGB)
 __device__ __forceinline__ uint32_t channel_extract(const Rgbf& c, int y, int cb, int cr, uint32_t mode)
@@ -448,11 +454,19 @@ template <bool RGB_ONLY>
 __device__ __forceinline__ uint32_t ycc_to_bgra(int py, int pcb, int pcr, uint32_t mode)
 {
     const int y = clamp_s8(py >> 3), cb = clamp_s8(pcb >> 3), cr = clamp_s8(pcr >> 3);
-    const Rgbf c = ycc_core((float)y, chroma_r((float)cr), chroma_b((float)cb));
+    const Rgbf c = ycc_core<RGB_ONLY>((float)y, chroma_r((float)cr), chroma_b((float)cb));
     return RGB_ONLY ? pack_bgr(c) : channel_extract(c, y, cb, cr, mode);
 }
 __device__ __forceinline__ int s16_lo(uint32_t w) { return (int)(int16_t)w; }
 __device__ __forceinline__ int s16_hi(uint32_t w) { return (int)w >> 16; }
+
+// LDS through its own 32-bit addresses: an address kept in a register goes into the ds instruction as it is (no base added per access)
+typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_u8_t*)p; }
+__device__ __forceinline__ uint32_t lds_r32(uint32_t a) { return *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)a; }
+__device__ __forceinline__ uint2 lds_r64(uint32_t a) { const u32x2_t v = *(const __attribute__((address_space(3))) u32x2_t*)(uintptr_t)a; return make_uint2(v.x, v.y); }
+__device__ __forceinline__ void lds_w64(uint32_t a, uint32_t x, uint32_t y) { u32x2_t v; v.x = x; v.y = y; *(__attribute__((address_space(3))) u32x2_t*)(uintptr_t)a = v; }
 
 // ---- IDCT term loop ------------------------------------------------------------------------------------------------------
 // What an instruction costs on gfx950 (tools/probes/pk_f32_rate.hip, profiles/r02_instr_rates.txt): plain fp32 / integer VOP2
@@ -463,28 +477,62 @@ __device__ __forceinline__ int s16_hi(uint32_t w) { return (int)w >> 16; }
 // the scalar unit from row offsets that sit two to a dword (one v_readlane per two terms, one scalar instruction per term).  The cosine table therefore has
 // to start at LDS offset 0 (the kernels use dynamic shared memory only and check it).
 //
-// List of a block (this wave's LDS): coefficients as fp32 at slot = rank among the non-zero AC coefficients (ascending natural
-// order, the reference's summation order), padded with up to three 0.0f (their products are exact +-0 and leave the sum
-// unchanged) -- all written by ONE store instruction: zero lanes fill the padding; row offsets (natural index * 256) as 16-bit words.
-struct WaveList { float* coef; uint16_t* rowh; };           // 68 floats; 68 x 16 bit: row * 256 = the row's LDS offset, two to a dword
-#define LIST_BYTES (68 * 4 + 144)
+// List of a block (this wave's LDS): the coefficients as fp32 and the LDS offsets of their table rows (16 bits each), both written by
+// EVERY lane -- the non-zero AC coefficients at slot = rank (ascending natural order, the reference's summation order), the zero lanes
+// behind them (slot 63 - number of zero lanes below: a full permutation of the 64 slots, no predicate, no bank conflict), each with its
+// own row: their products are exact +-0 and leave the sum unchanged, so the list is padded to any multiple of four for free and never
+// holds a stale entry.  A wave has TWO such lists: the list of block j + 1 is written, and its first reads are issued, before the terms
+// of block j run (idct_prep / idct_run) -- the LDS round trips of the list build are off the critical path of the wave.
+// Held per lane: the slot offset of a zero lane (63 - lane), the row word it contributes, and the addresses it reads back from: the pair
+// of row words (lane q < 32: terms 2q, 2q+1) and the coefficient of term (lane & 15) of a round; the wave's base is wave-uniform.
+struct WaveList { uint32_t base /*SGPR*/, z_off, row_w, a_rows, a_ey; };
+#define LIST_BUF_BYTES (64 * 4 + 64 * 2)
+#define LIST_BYTES (2 * LIST_BUF_BYTES)
+__device__ __forceinline__ WaveList wave_list(const void* mem, uint32_t lane)
+{
+    WaveList L; L.base = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(mem));
+    L.z_off = 63u - lane; L.row_w = lane << 8; L.a_rows = L.base + 256u + (lane & 31u) * 4u; L.a_ey = L.base + (lane & 15u) * 4u;
+    return L;
+}
+__device__ __forceinline__ void lds_w32(uint32_t a, uint32_t x) { *(__attribute__((address_space(3))) uint32_t*)(uintptr_t)a = x; }
+__device__ __forceinline__ void lds_w16(uint32_t a, uint32_t x) { *(__attribute__((address_space(3))) uint16_t*)(uintptr_t)a = (uint16_t)x; }
 
 #define DPP_BC(I) " row_newbcast:" #I " row_mask:0xf bank_mask:0xf\n\t"
+// (ablation builds of tools/build_variant.sh: results wrong, timing valid -- which part of a term the kernel waits for)
+#ifdef JS_EXP_T_NOREAD
+#define T_RD(X) ""
+#else
+#define T_RD(X) "ds_read_addtid_b32 %[" #X "]\n\t"
+#endif
+#ifdef JS_EXP_T_NOMATH
+#define T_MUL(X, I) ""
+#define T_ADD(X) ""
+#else
+#define T_MUL(X, I) "v_mul_f32_dpp %[" #X "], %[ey], %[" #X "]" DPP_BC(I)
+#define T_ADD(X) "v_add_f32 %[acc], %[acc], %[" #X "]\n\t"
+#endif
+#ifdef JS_EXP_T_NOM0
+#define T_RL(S, Q) ""
+#define T_M0(OP) ""
+#else
+#define T_RL(S, Q) "v_readlane_b32 %[" #S "], %[rows], " #Q "\n\t"
+#define T_M0(OP) OP
+#endif
 // first group of a round: four table reads in flight (M0 needs one wait state before the read that uses it)
 #define T_ISSUE(L0, L1, L2, L3, QA, QB)                                                                                          \
-    "v_readlane_b32 %[sp0], %[rows], " #QA "\n\t" "s_and_b32 m0, %[sp0], 0xffff\n\t" "v_readlane_b32 %[sp1], %[rows], " #QB "\n\t"  \
-    "ds_read_addtid_b32 %[" #L0 "]\n\t" "s_lshr_b32 m0, %[sp0], 16\n\t" "s_nop 0\n\t" "ds_read_addtid_b32 %[" #L1 "]\n\t"            \
-    "s_and_b32 m0, %[sp1], 0xffff\n\t" "s_nop 0\n\t" "ds_read_addtid_b32 %[" #L2 "]\n\t"                                             \
-    "s_lshr_b32 m0, %[sp1], 16\n\t" "s_nop 0\n\t" "ds_read_addtid_b32 %[" #L3 "]\n\t"
+    T_RL(sp0, QA) T_M0("s_and_b32 m0, %[sp0], 0xffff\n\t") T_RL(sp1, QB)                                                            \
+    T_RD(L0) T_M0("s_lshr_b32 m0, %[sp0], 16\n\t") "s_nop 0\n\t" T_RD(L1)                                                          \
+    T_M0("s_and_b32 m0, %[sp1], 0xffff\n\t") "s_nop 0\n\t" T_RD(L2)                                                               \
+    T_M0("s_lshr_b32 m0, %[sp1], 16\n\t") "s_nop 0\n\t" T_RD(L3)
 // one term of the group in flight retires (multiply with the coefficient as DPP operand, add) while the read of a term of the next
 // group is issued: per term one scalar instruction (M0), one LDS read, two vector instructions
 #define T_STEP1(X, Y, I, M0OP)                                                                                                   \
-    M0OP "s_waitcnt lgkmcnt(3)\n\t" "v_mul_f32_dpp %[" #X "], %[ey], %[" #X "]" DPP_BC(I) "ds_read_addtid_b32 %[" #Y "]\n\t" "v_add_f32 %[acc], %[acc], %[" #X "]\n\t"
+    T_M0(M0OP) "s_waitcnt lgkmcnt(3)\n\t" T_MUL(X, I) T_RD(Y) T_ADD(X)
 #define T_STEP(X0, X1, X2, X3, Y0, Y1, Y2, Y3, I0, I1, I2, I3, QA, QB)                                                           \
-    "v_readlane_b32 %[sp0], %[rows], " #QA "\n\t" "v_readlane_b32 %[sp1], %[rows], " #QB "\n\t"                                      \
+    T_RL(sp0, QA) T_RL(sp1, QB)                                                                                                  \
     T_STEP1(X0, Y0, I0, "s_and_b32 m0, %[sp0], 0xffff\n\t") T_STEP1(X1, Y1, I1, "s_lshr_b32 m0, %[sp0], 16\n\t")                     \
     T_STEP1(X2, Y2, I2, "s_and_b32 m0, %[sp1], 0xffff\n\t") T_STEP1(X3, Y3, I3, "s_lshr_b32 m0, %[sp1], 16\n\t")
-#define T_DRAIN1(X, I, CNT) "s_waitcnt lgkmcnt(" #CNT ")\n\t" "v_mul_f32_dpp %[" #X "], %[ey], %[" #X "]" DPP_BC(I) "v_add_f32 %[acc], %[acc], %[" #X "]\n\t"
+#define T_DRAIN1(X, I, CNT) "s_waitcnt lgkmcnt(" #CNT ")\n\t" T_MUL(X, I) T_ADD(X)
 #define T_DRAIN(X0, X1, X2, X3, I0, I1, I2, I3) T_DRAIN1(X0, I0, 3) T_DRAIN1(X1, I1, 2) T_DRAIN1(X2, I2, 1) T_DRAIN1(X3, I3, 0)
 #define T_EXIT_IF_LE(K, LABEL) "s_cmp_le_u32 %[nl], " #K "\n\t" "s_cbranch_scc1 " LABEL "%=\n\t"
 // sixteen terms (one round): rows of the round in dwords Q0 .. Q0+7 of `rows`, coefficients in lanes 0 .. 15 of every row of `ey`,
@@ -509,36 +557,54 @@ struct WaveList { float* coef; uint16_t* rowh; };           // 68 floats; 68 x 1
 
 // DecodeIdctCalcFloat(64) :2372-2392 on one block held one coefficient per lane (lane = natural index; the caller has zeroed
 // lane 0: DC is excluded from the sum, :2381).  Only non-zero coefficients are visited, in ascending natural order, separate
-// multiply and add.  Returns the sum BEFORE the reference's final * 0.25.
-__device__ __forceinline__ float idct_terms(int cv16, const WaveList L, uint32_t lane)
+// multiply and add.  The table in LDS holds 2 x the reference's entries (an exact scaling of every product and every partial sum):
+// idct_run returns 2 x the reference's sum before its final * 0.25, which is the f * 8 SetFullRes forms (to_sample).
+// cvu: the coefficient as the 16 bits the arena holds, zero-extended (the sign extension rides on the conversion: a loop-carried
+// int16 that is sign-extended separately costs an instruction per block and row).
+// idct_prep builds the list in buffer `buf` (0 / 1) and issues the reads of its row words and of its first sixteen coefficients;
+// idct_run, any time later, runs the terms (nothing else may have written that buffer in between).
+struct IdctPrep { uint32_t n, rows2; float ey; };
+__device__ __forceinline__ IdctPrep idct_prep(uint32_t cvu, const WaveList L, uint32_t buf)
 {
-    const bool nz = cv16 != 0;
+    IdctPrep P; P.rows2 = 0; P.ey = 0.0f;
+    const bool nz = cvu != 0;
     const uint64_t mask = WBALLOT(nz);
-    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_popcountll(mask));   // wave-uniform: the exit tests are scalar compares
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    const uint32_t zrank = lane - rank;                          // zero lanes: how many zero lanes lie below
-    float acc = 0.0f;
-    const uint32_t li = lane & 15u;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(P.n) : "s"(mask) : "scc");      // wave-uniform, 32 bits, in an SGPR: the exit tests are scalar compares
 #ifndef JS_EXP_NOTERMS
-    if (n) {                                                     // (a block without AC coefficients: no list, no terms)
-        if (nz || zrank < 3u) L.coef[nz ? rank : n + zrank] = (float)cv16;          // zero lanes write the 0.0f padding
-        if (nz) L.rowh[rank] = (uint16_t)(lane << 8);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        const uint32_t rows2 = reinterpret_cast<const uint32_t*>(L.rowh)[lane & 31u];  // lane q (< 32): rows of terms 2q, 2q+1
+    // (no branch around this for a block without AC coefficients: straight-line code lets the waits ahead of idct_run count exactly the
+    //  LDS operations issued behind the ones they wait for -- a join of two paths makes them wait for everything)
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    uint32_t cf;                                                 // (float)(int16_t)cvu
+    asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(cf) : "v"(cvu));
+    const uint32_t slot = nz ? rank : rank + L.z_off;            // zero lanes: slot 63 - (zero lanes below)
+    const uint32_t bo = buf * LIST_BUF_BYTES;
+    lds_w32(L.base + (slot << 2) + bo, cf);
+    lds_w16(L.base + (slot << 1) + (bo + 256u), L.row_w);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    P.rows2 = lds_r32(L.a_rows + bo);
+    P.ey = __uint_as_float(lds_r32(L.a_ey + bo));
+#endif
+    return P;
+}
+__device__ __forceinline__ float idct_run(const IdctPrep& P, const WaveList L, uint32_t buf, uint32_t lane)
+{
+    float acc = 0.0f;
+#ifndef JS_EXP_NOTERMS
+    const uint32_t n = P.n, rows2 = P.rows2;
+    if (n) {
+        const uint32_t a_ey = L.a_ey + buf * LIST_BUF_BYTES;
         float a0, a1, a2, a3, b0, b1, b2, b3; uint32_t sp0, sp1;
-        { const float ey = L.coef[li]; const uint32_t nl = n; IDCT_ROUND(0, 1, 2, 3, 4, 5, 6, 7); }
-        if (n > 16) { const float ey = L.coef[16 + li]; const uint32_t nl = n - 16; IDCT_ROUND(8, 9, 10, 11, 12, 13, 14, 15); }
-        if (n > 32) { const float ey = L.coef[32 + li]; const uint32_t nl = n - 32; IDCT_ROUND(16, 17, 18, 19, 20, 21, 22, 23); }
-        if (n > 48) { const float ey = L.coef[48 + li]; const uint32_t nl = n - 48; IDCT_ROUND(24, 25, 26, 27, 28, 29, 30, 31); }
+        { const float ey = P.ey; const uint32_t nl = n; IDCT_ROUND(0, 1, 2, 3, 4, 5, 6, 7); }
+        if (n > 16) { const float ey = __uint_as_float(lds_r32(a_ey + 64u)); const uint32_t nl = n - 16; IDCT_ROUND(8, 9, 10, 11, 12, 13, 14, 15); }
+        if (n > 32) { const float ey = __uint_as_float(lds_r32(a_ey + 128u)); const uint32_t nl = n - 32; IDCT_ROUND(16, 17, 18, 19, 20, 21, 22, 23); }
+        if (n > 48) { const float ey = __uint_as_float(lds_r32(a_ey + 192u)); const uint32_t nl = n - 48; IDCT_ROUND(24, 25, 26, 27, 28, 29, 30, 31); }
     }
 #else
-    acc = (float)(n + li);
+    acc = (float)(P.n + (lane & 15u));
 #endif
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     return acc;
 }
-__device__ __forceinline__ void list_init(const WaveList L, uint32_t lane)    // row entries must always name a table row: stale entries are read as padding
-{ if (lane < 36) reinterpret_cast<uint32_t*>(L.rowh)[lane] = 0u; }
 
 // SetFullRes :2468-2561 into the wave's LDS MCU tile (replicated eH x eV times).
 // meta = comp-1 | eh<<4 | ev<<8 | (blk_ch*8)<<12 | (blk_cv*8)<<20 of the block's slot in the MCU.
@@ -549,8 +615,9 @@ __device__ __forceinline__ uint32_t tile_offset(uint32_t meta, uint32_t plane_el
     return comp0 * plane_elems + y0 * rs + x0;
 }
 // fp32 sum of the terms -> sample: the reference forms f = sum * 0.25 (:2389) and (short)((short)(f * 8) + dc) (:2517-2519); both
-// scalings are exact powers of two (no term sum is small enough to go denormal), so f * 8 is sum * 2 bit for bit.
-__device__ __forceinline__ int16_t to_sample(float sum, int16_t dc) { return (int16_t)((int16_t)(int)__fmul_rn(sum, 2.0f) + dc); }
+// scalings are exact powers of two (no term sum is small enough to go denormal), so f * 8 is sum * 2 bit for bit -- and that factor
+// sits in the LDS copy of the table (idct_terms): sum2 is 2 x the reference's sum already.
+__device__ __forceinline__ int16_t to_sample(float sum2, int16_t dc) { return (int16_t)((int16_t)(int)sum2 + dc); }
 __device__ __forceinline__ void sample_to_lds(uint32_t meta /*wave-uniform*/, int16_t smp, int16_t* pl, uint32_t rs)
 {
     const uint32_t eh = (meta >> 4) & 15u, ev = (meta >> 8) & 15u;
@@ -624,12 +691,11 @@ __device__ __forceinline__ void mcu_to_dib(const JsImage& im, const int16_t* til
 // blocks UN-replicated (one LDS store per block instead of up to four); a lane's four pixels share EH-fold chroma samples, whose
 // clamp, int -> float conversion and multiplication by (2 - 2*0.299f) / (2 - 2*0.114f) are done once per sample.
 template <uint32_t EH, uint32_t EV>
-__device__ __forceinline__ void mcu_to_dib_fast(const JsImage& im, const int16_t* tile, uint32_t plane_elems, uint32_t rs, uint32_t quads, uint32_t total,
+__device__ __forceinline__ void mcu_to_dib_fast(const JsImage& im, uint32_t img_x, uint32_t img_y, const int16_t* tile, uint32_t plane_elems, uint32_t rs, uint32_t quads, uint32_t total,
                                                 uint32_t lane, uint32_t ly0, uint32_t lq0, uint32_t my, uint32_t mx, uint32_t mw, uint32_t mh,
                                                 uint8_t* __restrict__ dibp, int16_t* __restrict__ planes, uint32_t pw, bool want_planes,
                                                 uint64_t& bright, int& best_y, uint32_t& sum_y)
-{
-    const uint32_t img_x = im.img_x, img_y = im.img_y;
+{   // (img_x, img_y by value: read once per wave -- through `im` they are re-read from memory after every MCU's stores)
     const uint32_t dq = 64u % quads, dy = 64u / quads;
     uint32_t y = ly0, q = lq0;
     uint8_t* mcu_low = dibp + ((size_t)(img_y - (my + 1u) * mh) * img_x + (size_t)mx * mw) * 4;
@@ -655,8 +721,8 @@ __device__ __forceinline__ void mcu_to_dib_fast(const JsImage& im, const int16_t
         bright4(qy, py * img_x + px, bright, best_y);
         const int cy[4] = { clamp_s8(s16_lo(qy.x) >> 3), clamp_s8(s16_hi(qy.x) >> 3), clamp_s8(s16_lo(qy.y) >> 3), clamp_s8(s16_hi(qy.y) >> 3) };
         uint4 v;
-        v.x = pack_bgr(ycc_core((float)cy[0], crm[0], cbm[0])); v.y = pack_bgr(ycc_core((float)cy[1], crm[1], cbm[1]));
-        v.z = pack_bgr(ycc_core((float)cy[2], crm[2], cbm[2])); v.w = pack_bgr(ycc_core((float)cy[3], crm[3], cbm[3]));
+        v.x = pack_bgr(ycc_core<true>((float)cy[0], crm[0], cbm[0])); v.y = pack_bgr(ycc_core<true>((float)cy[1], crm[1], cbm[1]));
+        v.z = pack_bgr(ycc_core<true>((float)cy[2], crm[2], cbm[2])); v.w = pack_bgr(ycc_core<true>((float)cy[3], crm[3], cbm[3]));
         sum_y += (uint32_t)(cy[0] + cy[1] + cy[2] + cy[3] + 512);                          // nSumY += nFinalY (:4751)
         *reinterpret_cast<uint4*>(mcu_low + ((mh - 1u - y) * img_x + x) * 4u) = v;
         if (want_planes) {
@@ -686,7 +752,8 @@ __device__ __forceinline__ void back_end_mcus(const BackEndCtx& C, uint64_t& bri
     const WaveList L = C.L; int16_t* tile = C.tile;
     const uint32_t nb = FAST ? EH * EV + 2u : im.blk_per_mcu, nmcu = im.mcu_xmax * im.mcu_ymax, pw = im.blk_xmax * 8;   // FAST: known at compile time
     const uint32_t mw = FAST ? 8u * EH : im.mcu_w, mh = FAST ? 8u * EV : im.mcu_h, rs = mw + 8, plane_elems = mh * rs, ncomp = im.ncomp;
-    const uint32_t mcus_across = im.img_x / mw, shift_ind = im.shift_mcu_y * mcus_across + im.shift_mcu_x;
+    const uint32_t img_x = im.img_x, img_y = im.img_y;
+    const uint32_t mcus_across = img_x / mw, shift_ind = im.shift_mcu_y * mcus_across + im.shift_mcu_x;
     const bool want_planes = im.want_planes != 0, rgb_only = im.preview_mode == 1, any_shift = (im.shift_y | im.shift_cb | im.shift_cr) != 0;
     const uint32_t quads = mw / 4, total = quads * mh, ly0 = lane / quads, lq0 = lane % quads;
     int best_y = -0x7FFFFFFF;
@@ -700,25 +767,43 @@ __device__ __forceinline__ void back_end_mcus(const BackEndCtx& C, uint64_t& bri
         const bool full_v = (im.samp_v[cc] * 8 == mh && im.expand_v[cc] == 1) || (im.samp_v[cc] == 1 && im.expand_v[cc] * 8 == mh);
         partial = partial || !full_h || !full_v;
     }
-    int cv[BK_CHUNK]; int16_t dcv[BK_CHUNK];
+    uint32_t cv[BK_CHUNK]; int16_t dcv[BK_CHUNK];
     // DC-only mode: the reference does not run the IDCT at all (:1827), whatever sits at the AC positions -- a DC symbol with a run
     // nibble stores its value there (DecodeIdctSet with ind = zrl, :1713)
     const bool with_ac = im.decode_ac != 0;
-    const int ac_mask = (lane != 0 && with_ac) ? -1 : 0;         // lane 0 holds the DC difference: not part of the sum (:2381)
+    uint32_t ac_mask = (lane != 0 && with_ac) ? 0xFFFFu : 0u;    // lane 0 holds the DC difference: not part of the sum (:2381)
+    asm volatile("" : "+v"(ac_mask));                         // (kept a mask in a VGPR: v_and_b32 issues at full rate, the v_cndmask the compiler prefers does not)
     uint32_t meta[BK_CHUNK], toff[BK_CHUNK];                     // placement word (wave-uniform) and this lane's tile offset per block slot
-    // m is wave-uniform (kept in SGPRs): the row addresses are a scalar base plus the lane, the DC words a scalar address
-    auto load_chunk = [&](uint32_t m, uint32_t base) {
-        const int16_t* p = C.cbase + ((size_t)m * nb + base) * 64 + lane;
-        // the DC words of the chunk: wave-uniform, so they come as aligned dwords through the scalar cache into SGPRs
-        const size_t d0 = im.coef_off + (size_t)m * nb + base;
+    // m is wave-uniform (kept in SGPRs): the row addresses are a scalar base plus the lane, the DC words a scalar address.
+    // A chunk is FETCHED (loads issued, nothing waits) and later TAKEN (first use of what came back): the next MCU's fetch is issued before
+    // the colour phase of the current one and taken at the top of the next iteration, so the loads fly during the colour phase -- a mask or a
+    // shift applied at fetch time would make the wave wait for its loads on the spot.
+    const size_t coef_off = im.coef_off;                         // (a local: the image record is not re-read after the DIB stores)
+    uint32_t raw[BK_CHUNK]; uint32_t dw0 = 0, dw1 = 0, dw2 = 0, dw3 = 0, dodd = 0;
+    // (a lane fetches the DWORD that holds its coefficient -- lanes 2q and 2q+1 the same one -- and shifts its half down when the row is
+    // taken: a 16-bit value carried around the loop is widened by the compiler at the loop's end, which is where the wave would wait)
+    const uint32_t half_sh = (lane & 1u) * 16u;
+    auto fetch_rows = [&](uint32_t m, uint32_t base) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(C.cbase + ((size_t)m * nb + base) * 64) + (lane >> 1);
+        #pragma unroll
+        for (int j = 0; j < BK_CHUNK; j++) raw[j] = base + j < nb ? p[j * 32] : 0u;
+    };
+    // the DC words of the chunk: wave-uniform, so they come as aligned dwords through the scalar cache into SGPRs.  (Scalar loads share
+    // their counter with the LDS: issued before the colour phase, its first LDS wait would wait for them too -- they are issued behind it.)
+    auto fetch_dc = [&](uint32_t m, uint32_t base) {
+        const size_t d0 = coef_off + (size_t)m * nb + base;
         const uint32_t* q32 = reinterpret_cast<const uint32_t*>(C.dccum) + (d0 >> 1);
-        const uint32_t odd = (uint32_t)d0 & 1u;
-        const uint32_t w0 = q32[0], w1 = q32[1], w2 = q32[2], w3 = q32[3];       // 8 int16 from an even index cover BK_CHUNK = 6 from d0 (the arena has slack)
+        dodd = (uint32_t)d0 & 1u;
+        dw0 = q32[0]; dw1 = q32[1]; dw2 = q32[2]; dw3 = q32[3];                 // 8 int16 from an even index cover BK_CHUNK = 6 from d0 (the arena has slack)
+    };
+    auto take_chunk = [&](uint32_t base) {
+        // (the scalar loads are waited for HERE: while one is pending, every LDS wait of the block loop would have to wait for everything)
+        asm volatile("" : : "s"(dw0), "s"(dw1), "s"(dw2), "s"(dw3));
         #pragma unroll
         for (int j = 0; j < BK_CHUNK; j++) {
             const uint32_t c = base + j;
-            cv[j] = c < nb ? ((int)p[j * 64] & ac_mask) : 0;
-            const uint32_t h = (uint32_t)j + odd, w = (h >> 1) == 0 ? w0 : ((h >> 1) == 1 ? w1 : ((h >> 1) == 2 ? w2 : w3));
+            cv[j] = (raw[j] >> half_sh) & ac_mask;
+            const uint32_t h = (uint32_t)j + dodd, w = (h >> 1) == 0 ? dw0 : ((h >> 1) == 1 ? dw1 : ((h >> 1) == 2 ? dw2 : dw3));
             dcv[j] = c < nb ? (int16_t)(w >> ((h & 1u) * 16u)) : (int16_t)0;
         }
     };
@@ -737,25 +822,37 @@ __device__ __forceinline__ void back_end_mcus(const BackEndCtx& C, uint64_t& bri
     uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(C.wg_in_img * BK_WAVES + C.wave));
     const uint32_t xmax = im.mcu_xmax, step_x = wstride % xmax, step_y = wstride / xmax;
     uint32_t mx = m % xmax, my = m / xmax;                       // MCU coordinates, stepped along with m (no division in the loop)
-    if (m < nmcu) load_chunk(m, 0);
+    if (m < nmcu) { fetch_rows(m, 0); fetch_dc(m, 0); }
+    #pragma nounroll
     for (; m < nmcu; m += wstride, mx += step_x, my += step_y) {
         if (mx >= xmax) { mx -= xmax; my++; }
+        take_chunk(0);
         if (partial) { for (uint32_t i = lane; i < ncomp * plane_elems; i += 64) tile[i] = 0; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); }
         // ---- IDCT of the MCU's blocks, decode order ---------------------------------------------------
         for (uint32_t base = 0; base < nb; base += BK_CHUNK) {
-            if (base) load_chunk(m, base);
+            if (base) { fetch_rows(m, base); fetch_dc(m, base); take_chunk(base); }
             if (nb > BK_CHUNK) place_chunk(base);
+            IdctPrep P = idct_prep(cv[0], L, 0);                 // (every chunk holds at least one block)
             #pragma unroll
             for (int j = 0; j < BK_CHUNK; j++)
                 if (base + j < nb) {
-                    const int16_t smp = to_sample(idct_terms(cv[j], L, lane), dcv[j]);
+                    IdctPrep Pn = P;
+#ifndef JS_EXP_NOPIPE
+                    if (j + 1 < BK_CHUNK && base + j + 1 < nb) Pn = idct_prep(cv[j + 1], L, (uint32_t)(j + 1) & 1u);   // the next block's list, while this block's terms run
+#endif
+                    const int16_t smp = to_sample(idct_run(P, L, (uint32_t)j & 1u, lane), dcv[j]);
                     if (FAST) tile[toff[j]] = smp; else sample_to_lds(meta[j], smp, tile + toff[j], rs);
+#ifdef JS_EXP_NOPIPE
+                    if (j + 1 < BK_CHUNK && base + j + 1 < nb) Pn = idct_prep(cv[j + 1], L, (uint32_t)(j + 1) & 1u);
+#endif
+                    P = Pn;
                 }
         }
-        if (m + wstride < nmcu) load_chunk(m + wstride, 0);           // next MCU's rows fly during the colour phase
+        const uint32_t m_next = m + wstride < nmcu ? m + wstride : m;   // (the last round fetches its own MCU again: no branch around the fetches)
+        fetch_rows(m_next, 0);                                        // next MCU's rows fly during the colour phase
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #ifndef JS_EXP_NOCOLOR
-        if (FAST) mcu_to_dib_fast<EH, EV>(im, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, C.dibp, C.planes, pw, want_planes, bright, best_y, sum_y);
+        if (FAST) mcu_to_dib_fast<EH, EV>(im, img_x, img_y, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, C.dibp, C.planes, pw, want_planes, bright, best_y, sum_y);
         else {
             const bool shifted = any_shift && my * mcus_across + mx >= shift_ind;
             if (rgb_only) mcu_to_dib<true>(im, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, shifted, C.dibp, C.planes, pw, want_planes, bright, best_y, sum_y);
@@ -763,6 +860,7 @@ __device__ __forceinline__ void back_end_mcus(const BackEndCtx& C, uint64_t& bri
         }
 #endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        fetch_dc(m_next, 0);
     }
 }
 
@@ -773,7 +871,7 @@ __device__ __forceinline__ void back_end_mcus(const BackEndCtx& C, uint64_t& bri
 // fast layout with chroma expansion (2,2) / (2,1) / (1,2) / (1,1) -- the host checks -- and the kernel holds that one path only: a
 // quarter of the code (the four-layout kernel is 20 k instructions, its 4:2:0 loop alone 4.5 k) and registers allocated for it alone.
 template <int LAYOUT>
-__global__ void __launch_bounds__(BK_THREADS, JS_BK_OCC) k_idct_color(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ wg_base, uint32_t nimg,
+__global__ void __launch_bounds__(BK_THREADS, LAYOUT ? JS_BK_OCC : JS_BK_OCC - 2) k_idct_color(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ wg_base, uint32_t nimg,
                                                            uint32_t tile_bytes, const float* __restrict__ lut_t /*[vu][yx]*/,
                                                            const int16_t* __restrict__ coef, const int16_t* __restrict__ dccum,
                                                            uint8_t* __restrict__ dib, int16_t* __restrict__ planes, uint32_t* __restrict__ side,
@@ -794,14 +892,13 @@ __global__ void __launch_bounds__(BK_THREADS, JS_BK_OCC) k_idct_color(const JsIm
     while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (wg_base[mid] <= bx) lo = mid; else hi = mid; }
     const JsImage& im = imgs[lo];
 
-    for (uint32_t i = tid; i < 64 * 64; i += BK_THREADS) s_lut[i] = lut_t[i];
+    for (uint32_t i = tid; i < 64 * 64; i += BK_THREADS) s_lut[i] = __fmul_rn(lut_t[i], 2.0f);          // 2 x the table: see idct_terms
     if (tid < im.blk_per_mcu) { const uint32_t comp = im.blk_comp[tid];
         s_meta[tid] = (comp - 1) | (im.expand_h[comp] << 4) | (im.expand_v[comp] << 8) | ((uint32_t)im.blk_ch[tid] * 8u << 12) | ((uint32_t)im.blk_cv[tid] * 8u << 20); }
     BackEndCtx C;
     C.im = &im; C.cbase = coef + im.coef_off * 64; C.dccum = dccum; C.dibp = dib + im.dib_off; C.planes = planes;
-    C.L.coef = reinterpret_cast<float*>(wave_mem); C.L.rowh = reinterpret_cast<uint16_t*>(wave_mem + 68 * 4); C.tile = reinterpret_cast<int16_t*>(wave_mem + LIST_BYTES);
+    C.L = wave_list(wave_mem, lane); C.tile = reinterpret_cast<int16_t*>(wave_mem + LIST_BYTES);
     C.s_meta = s_meta; C.lane = lane; C.wave = wave; C.wg_in_img = bx - wg_base[lo]; C.wgs_in_img = wg_base[lo + 1] - wg_base[lo];
-    list_init(C.L, lane);
     __syncthreads();
 
     uint64_t bright = 0; uint32_t sum_y = 0;
@@ -864,13 +961,13 @@ __global__ void __launch_bounds__(64) k_idct_probe(const float* __restrict__ lut
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     float* s_lut = reinterpret_cast<float*>(s_dyn);
-    WaveList L; L.coef = reinterpret_cast<float*>(s_dyn + 64 * 64 * sizeof(float)); L.rowh = reinterpret_cast<uint16_t*>(s_dyn + 64 * 64 * sizeof(float) + 68 * 4);
+    const WaveList L = wave_list(s_dyn + 64 * 64 * sizeof(float), threadIdx.x);
     if ((uint32_t)(size_t)s_dyn != 0u) __builtin_trap();
     const uint32_t lane = threadIdx.x;
-    for (uint32_t i = lane; i < 64 * 64; i += 64) s_lut[i] = lut_t[i];
-    list_init(L, lane);
+    for (uint32_t i = lane; i < 64 * 64; i += 64) s_lut[i] = __fmul_rn(lut_t[i], 2.0f);
     __syncthreads();
-    out64[lane] = __fmul_rn(idct_terms(lane ? (int)coef64[lane] : 0, L, lane), 0.25f);
+    const IdctPrep P = idct_prep(lane ? (uint32_t)(uint16_t)coef64[lane] : 0u, L, 0);
+    out64[lane] = __fmul_rn(idct_run(P, L, 0, lane), 0.125f);
 }
 
 // ConvertYCCtoRGBFastFloat on one triple (the RGB of the brightest pixel, :4805-4811).
@@ -1528,12 +1625,6 @@ __device__ __forceinline__ bool walk_slow(const JsImage& im, const uint32_t* __r
     return false;
 }
 
-// LDS through its own 32-bit addresses: an address kept in a register goes into the ds instruction as it is (no base added per access)
-typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_u8_t*)p; }
-__device__ __forceinline__ uint32_t lds_r32(uint32_t a) { return *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)a; }
-__device__ __forceinline__ uint2 lds_r64(uint32_t a) { const u32x2_t v = *(const __attribute__((address_space(3))) u32x2_t*)(uintptr_t)a; return make_uint2(v.x, v.y); }
 
 // SYNC flavour: state only.  Walks the symbols that start inside [entry position, own_end).
 // The lanes of a wave step together (one table entry per lane and step); everything a lane rarely needs -- a code longer than
@@ -2443,15 +2534,16 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
     const char* qzb = reinterpret_cast<const char*>(W.qz);
     uint32_t comp = comp_of(T, c), wb = comp == 0 ? wb0 : (comp == 1 ? wb1 : wb2);
     uint64_t m_act = WBALLOT(active0), m_skip = WBALLOT(skip0), m_cap = 0ull;
-    // DC differences of finished blocks wait in registers (eight per lane, newest in the low half of dcq0) and leave together when some
-    // lane holds eight: a store instruction per step for a handful of 2-byte values costs the vector memory pipe as much as a full one
-    // (-0.45 ms per 1024 images with the stores simply removed).
+    // DC differences of finished blocks wait in registers -- eight per lane, in memory order: the oldest in the low half of dcq0 (a lane's
+    // finished blocks have consecutive numbers) -- and leave as ONE 16-byte store of the lanes that hold eight: what the vector memory pipe
+    // is charged for is the store instruction, not its bytes (a 2-byte store per block: +0.45 ms per 1024 images; eight 2-byte stores per
+    // lane and eight blocks: +0.4).  The address is only 2-byte aligned: global memory takes unaligned 16-byte accesses.
     uint32_t dcq0 = 0, dcq1 = 0, dcq2 = 0, dcq3 = 0, dccnt = 0, dclast = 0, dq0 = 0;
-    auto dc_store_all = [&]() {
+    auto dc_store_rest = [&]() {                                 // what is left at the end: the newest dccnt values sit in the top halves
         #pragma unroll
-        for (uint32_t j = 0; j < 8; j++) {
-            const uint32_t q = j < 2 ? dcq0 : (j < 4 ? dcq1 : (j < 6 ? dcq2 : dcq3));
-            if (j < dccnt) dbase[dclast - j] = (int16_t)((j & 1u) ? q >> 16 : q);
+        for (uint32_t h = 0; h < 8; h++) {
+            const uint32_t q = h < 2 ? dcq0 : (h < 4 ? dcq1 : (h < 6 ? dcq2 : dcq3));
+            if (h + dccnt >= 8u) dbase[dclast - 7u + h] = (int16_t)((h & 1u) ? q >> 16 : q);
         }
         dccnt = 0;
     };
@@ -2566,14 +2658,21 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
                     }
                 }
                 if (flush) {
-                    dcq3 = __builtin_amdgcn_alignbit(dcq3, dcq2, 16u); dcq2 = __builtin_amdgcn_alignbit(dcq2, dcq1, 16u); dcq1 = __builtin_amdgcn_alignbit(dcq1, dcq0, 16u);
-                    dcq0 = (dcq0 << 16) | (dq0 & 0xFFFFu); dccnt++; dclast = fblk;
+                    dcq0 = __builtin_amdgcn_alignbit(dcq1, dcq0, 16u); dcq1 = __builtin_amdgcn_alignbit(dcq2, dcq1, 16u); dcq2 = __builtin_amdgcn_alignbit(dcq3, dcq2, 16u);
+                    dcq3 = (dcq3 >> 16) | (dq0 << 16); dccnt++; dclast = fblk;
                 }
-                if (WBALLOT(dccnt >= 8u)) dc_store_all();
+                if (WBALLOT(dccnt >= 8u)) {
+                    if (dccnt >= 8u) {
+                        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                        u32x4_t t; t.x = dcq0; t.y = dcq1; t.z = dcq2; t.w = dcq3;
+                        *reinterpret_cast<u32x4_t*>(dbase + (dclast - 7u)) = t;
+                        dccnt = 0;
+                    }
+                }
             }
         }
     }
-    dc_store_all();
+    dc_store_rest();
     if (verify) {
         if (check_n && !IBAL(m_cap) && res_p != P_END) { res_p = cur.p; res_s = cur.p == P_END ? 0u : ST_MAKE(seg, c, k); res_n = nblk; }
         // the chain must be at its fixed point, and the block count that fed the prefix sum must be the real one
@@ -2760,10 +2859,9 @@ void js_launch_block_scan(hipStream_t st, int wl, const JsImage* imgs, uint32_t 
 }
 void js_launch_write(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
                      const uint8_t* ustr, const uint32_t* seg_tab, uint32_t* side, uint32_t* sub, uint64_t nsub,
-                     int16_t* coef, int16_t* dccum, uint8_t* mcu_rst, uint32_t* flags, uint32_t* cand_half)
+                     int16_t* coef, int16_t* dccum, uint8_t* mcu_rst, uint32_t* flags, uint32_t* cand_half, bool v1 /* the first form of the kernel, kept as a cross-check */)
 {
     if (!total_wgs) return;
-    static const bool v1 = getenv("JSNOOP_WRITE_V1") != nullptr;     // the first form of the kernel, kept as a cross-check
     if (!v1 && cand_half && wl == 4) {                               // two lanes per sub-sequence, the second from the middle state of the selected memo walk
         const CandArrays C = cand_arrays(cand_half, nsub);
         hipLaunchKernelGGL((k_write2<4, true>), dim3(2 * total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,

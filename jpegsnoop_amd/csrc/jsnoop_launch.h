@@ -38,7 +38,7 @@ void js_launch_block_scan(hipStream_t st, int wl, const JsImage* imgs, uint32_t 
 void js_launch_write(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
                      const uint8_t* ustr, const uint32_t* seg_tab, uint32_t* side, uint32_t* sub, uint64_t nsub,
                      int16_t* coef, int16_t* dccum, uint8_t* mcu_rst, uint32_t* flags,
-                     uint32_t* cand_half /* null, or the candidate arena of a job that was synchronised by candidates: two lanes per sub-sequence (64-byte pieces only) */);
+                     uint32_t* cand_half /* null, or the candidate arena of a job that was synchronised by candidates: two lanes per sub-sequence (64-byte pieces only) */, bool v1);
 // side-output pass over one image the parallel path decoded (MCU file map, block-DC maps, code-length histogram, status words)
 void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* us_base, const uint32_t* sy_base, uint32_t nimg,
                          uint32_t img, uint32_t us_wg0, uint32_t us_wgs, uint32_t sy_wg0, uint32_t sy_wgs, const JsTableSet* tables, const uint8_t* raw,

@@ -246,6 +246,40 @@ int js_selftest_tables(unsigned seed, unsigned rounds)
     return usable ? bad : -1;
 }
 
+// JSNOOP_DBG_CAND_LINKS: the links the candidate chain left open, per image, with the memos and maps around the first one (stops the stream).
+void js_debug_cand_links(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32_t n)
+{
+    uint32_t* sub = (uint32_t*)b->dev.sub;
+    if (hipStreamSynchronize(st) == hipSuccess) {
+        const uint64_t ns = b->total_subseq; std::vector<uint32_t> h(6 * ns);
+        if (hipMemcpy(h.data(), sub, 6 * ns * 4, hipMemcpyDeviceToHost) == hipSuccess)
+            for (uint32_t k = i0; k < i0 + n; k++) {
+                const JsImage& im = b->imgs[k]; uint32_t open = 0, first = 0xFFFFFFFFu;
+                for (uint32_t i = 0; i < im.n_subseq; i++) {
+                    const uint64_t g = im.subseq_off + i; const uint32_t lp = i ? h[g - 1] : 0u, ls = i ? h[ns + g - 1] : 0u;
+                    if (lp != h[2 * ns + g] || ls != h[3 * ns + g]) { open++; if (first == 0xFFFFFFFFu) first = i; }
+                }
+                fprintf(stderr, "[cand] image %u: %u sub-sequences, %u open links, first at %u", k, im.n_subseq, open, first);
+                if (first != 0xFFFFFFFFu) { const uint64_t g = im.subseq_off + first; fprintf(stderr, " (left exit %08x/%08x, entry %08x/%08x, exit %08x/%08x)", first ? h[g - 1] : 0u, first ? h[ns + g - 1] : 0u, h[2 * ns + g], h[3 * ns + g], h[g], h[ns + g]); }
+                fprintf(stderr, "\n");
+                if (first != 0xFFFFFFFFu && first > 0) {      // the memos and maps around it (layout of cand_arrays: X 2 x 6 n, memo 8 x 7 n, maps 2 n, middle states 3 n words, selections)
+                    std::vector<uint32_t> c(js_cand_bytes(ns) / 4);
+                    std::vector<uint32_t> dg(JS_CAND_REQ_WORDS);
+                    if (hipMemcpy(c.data(), b->dev.cand, c.size() * 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(dg.data(), b->dev.cand_req + (size_t)k * JS_CAND_REQ_WORDS, JS_CAND_REQ_WORDS * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+                        const uint32_t* m = c.data() + 12 * ns; const uint32_t* r = m + 56 * ns; const uint8_t* sel = reinterpret_cast<const uint8_t*>(r + 5 * ns);
+                        fprintf(stderr, "       chain diag: left %u; open %u %u %u %u; queued %u %u %u %u\n", dg[0], dg[4], dg[5], dg[6], dg[7], dg[8], dg[9], dg[10], dg[11]);
+                        for (uint64_t g = im.subseq_off + first - 1; g <= im.subseq_off + first; g++) {
+                            fprintf(stderr, "       sub-sequence %u: selection %u, map %08x %08x\n", (unsigned)(g - im.subseq_off), sel[g], r[2 * g], r[2 * g + 1]);
+                            for (uint32_t e = 0; e < 7; e++) fprintf(stderr, "         slot %u: entry %08x/%08x exit %08x/%08x blocks %u%s\n", e, m[e * ns + g], m[7 * ns + e * ns + g], m[14 * ns + e * ns + g], m[21 * ns + e * ns + g], m[28 * ns + e * ns + g],
+                                                                  e < 6 ? "" : " (filled)");
+                            fprintf(stderr, "         speculative exits:"); for (uint32_t e = 0; e < 6; e++) fprintf(stderr, " %08x/%08x", c[e * ns + g], c[6 * ns + e * ns + g]); fprintf(stderr, "\n");
+                        }
+                    }
+                }
+            }
+    }
+}
+
 // Launches stages 1..5 (unstuff, sync, block scan, write, DC scan) for images [i0, i0 + n) of the batch on stream st.  The arenas and
 // the prefix tables are the batch's: a part passes pointers to its first image / first prefix entry (the kernels add the first
 // entry to their block index) and the number of workgroups its images own.
@@ -268,41 +302,11 @@ int js_parallel_entropy_part(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32
         // one more launch carries a change across workgroup boundaries
         js_launch_cand_sync(st, b->sub_wl, b->tab_rows, b->tab_lut2, imgs, sy_base, n, sy_wgs, b->cand_blk, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
                             b->dev.cand, b->dev.cand_req + (size_t)i0 * JS_CAND_REQ_WORDS, b->cand_rounds, b->cand_half ? 1 : 0);
-        if (const char* e = getenv("JSNOOP_DEBUG_CAND")) if (atoi(e) >= 2) {      // links the chain left open, per image (diagnostics: stops the stream)
-            if (hipStreamSynchronize(st) == hipSuccess) {
-                const uint64_t ns = b->total_subseq; std::vector<uint32_t> h(6 * ns);
-                if (hipMemcpy(h.data(), sub, 6 * ns * 4, hipMemcpyDeviceToHost) == hipSuccess)
-                    for (uint32_t k = i0; k < i0 + n; k++) {
-                        const JsImage& im = b->imgs[k]; uint32_t open = 0, first = 0xFFFFFFFFu;
-                        for (uint32_t i = 0; i < im.n_subseq; i++) {
-                            const uint64_t g = im.subseq_off + i; const uint32_t lp = i ? h[g - 1] : 0u, ls = i ? h[ns + g - 1] : 0u;
-                            if (lp != h[2 * ns + g] || ls != h[3 * ns + g]) { open++; if (first == 0xFFFFFFFFu) first = i; }
-                        }
-                        fprintf(stderr, "[cand] image %u: %u sub-sequences, %u open links, first at %u", k, im.n_subseq, open, first);
-                        if (first != 0xFFFFFFFFu) { const uint64_t g = im.subseq_off + first; fprintf(stderr, " (left exit %08x/%08x, entry %08x/%08x, exit %08x/%08x)", first ? h[g - 1] : 0u, first ? h[ns + g - 1] : 0u, h[2 * ns + g], h[3 * ns + g], h[g], h[ns + g]); }
-                        fprintf(stderr, "\n");
-                        if (first != 0xFFFFFFFFu && first > 0) {      // the memos and maps around it (layout of cand_arrays: X 2 x 6 n, memo 8 x 7 n, maps 2 n, middle states 3 n words, selections)
-                            std::vector<uint32_t> c(js_cand_bytes(ns) / 4);
-                            std::vector<uint32_t> dg(JS_CAND_REQ_WORDS);
-                            if (hipMemcpy(c.data(), b->dev.cand, c.size() * 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(dg.data(), b->dev.cand_req + (size_t)k * JS_CAND_REQ_WORDS, JS_CAND_REQ_WORDS * 4, hipMemcpyDeviceToHost) == hipSuccess) {
-                                const uint32_t* m = c.data() + 12 * ns; const uint32_t* r = m + 56 * ns; const uint8_t* sel = reinterpret_cast<const uint8_t*>(r + 5 * ns);
-                                fprintf(stderr, "       chain diag: left %u; open %u %u %u %u; queued %u %u %u %u\n", dg[0], dg[4], dg[5], dg[6], dg[7], dg[8], dg[9], dg[10], dg[11]);
-                                for (uint64_t g = im.subseq_off + first - 1; g <= im.subseq_off + first; g++) {
-                                    fprintf(stderr, "       sub-sequence %u: selection %u, map %08x %08x\n", (unsigned)(g - im.subseq_off), sel[g], r[2 * g], r[2 * g + 1]);
-                                    for (uint32_t e = 0; e < 7; e++) fprintf(stderr, "         slot %u: entry %08x/%08x exit %08x/%08x blocks %u%s\n", e, m[e * ns + g], m[7 * ns + e * ns + g], m[14 * ns + e * ns + g], m[21 * ns + e * ns + g], m[28 * ns + e * ns + g],
-                                                                          e < 6 ? "" : " (filled)");
-                                    fprintf(stderr, "         speculative exits:"); for (uint32_t e = 0; e < 6; e++) fprintf(stderr, " %08x/%08x", c[e * ns + g], c[6 * ns + e * ns + g]); fprintf(stderr, "\n");
-                                }
-                            }
-                        }
-                    }
-            }
-        }
+        if (b->tune.debug & JSNOOP_DBG_CAND_LINKS) js_debug_cand_links(b, st, i0, n);
         // A chain that ran through needs nothing more; one that did not (the walk rounds were used up: rare) leaves links marked open, the write
         // pass's verification trips over them and js_parallel_resume repairs them with k_sync's verification mode.  (JSNOOP_CAND_VERIFY=1: run that
         // mode here, on every decode -- two launches that return at once in the normal case, 12 us of a 390 us decode.)
-        static const bool verify_here = getenv("JSNOOP_CAND_VERIFY") != nullptr;
-        if (verify_here) {
+        if (b->tune.cross_checks & JSNOOP_XC_CAND_VERIFY) {
             js_launch_sync(st, b->sub_wl, b->tab_rows, b->tab_lut2, imgs, sn_base, n, sn_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, 2);
             js_launch_sync(st, b->sub_wl, b->tab_rows, b->tab_lut2, imgs, sn_base, n, sn_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, 0);
         }
@@ -315,7 +319,7 @@ int js_parallel_entropy_part(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32
     js_launch_block_scan(st, b->sub_wl, imgs, n, b->dev.tables, sub, b->total_subseq, b->dev.side, flags);
     if (evs) HIP_TRY(hipEventRecord(evs[4], st));
     js_launch_write(st, b->sub_wl, b->tab_rows_w, b->tab_lut2, imgs, sy_base, n, sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
-                    b->dev.coef, b->dev.dccum, b->dev.mcu_rst, flags, b->cand_half ? b->dev.cand : nullptr);
+                    b->dev.coef, b->dev.dccum, b->dev.mcu_rst, flags, b->cand_half ? b->dev.cand : nullptr, (b->tune.cross_checks & JSNOOP_XC_WRITE_V1) != 0);
     if (evs) HIP_TRY(hipEventRecord(evs[5], st));
     js_launch_dc_scan(st, imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst, n == N ? b->dev.dc_parts : nullptr);   // (one scratch area: whole-batch launches only)
     roctxRangePop();
@@ -365,7 +369,7 @@ static int js_parallel_resume(JsnoopBatch* b, int extra_launches)
         js_launch_sync(b->stream, b->sub_wl, b->tab_rows, b->tab_lut2, b->dev.imgs, b->dev.sy_base + (n + 1), n, b->sn_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, l == 0 ? 2 : 0);
     js_launch_block_scan(b->stream, b->sub_wl, b->dev.imgs, n, b->dev.tables, sub, b->total_subseq, b->dev.side, b->dev.flags);
     js_launch_write(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.sy_base, n, b->sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
-                    b->dev.coef, b->dev.dccum, b->dev.mcu_rst, b->dev.flags, nullptr);      // (the middle states are the candidate chain's: one lane per sub-sequence here)
+                    b->dev.coef, b->dev.dccum, b->dev.mcu_rst, b->dev.flags, nullptr, (b->tune.cross_checks & JSNOOP_XC_WRITE_V1) != 0);      // (the middle states are the candidate chain's: one lane per sub-sequence here)
     js_launch_dc_scan(b->stream, b->dev.imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst, b->dev.dc_parts);
     if (b->launch_back_end(n)) return -1;
     return js_read_flags(b);
@@ -384,7 +388,7 @@ int js_read_flags(JsnoopBatch* b)
     if (b->d2h_staged(both.data(), b->dev.flags, 2 * n * 4)) return -1;          // (through the page-locked landing buffer)
     b->host_flags.resize(n); b->host_anom.resize(n);
     for (size_t i = 0; i < n; i++) { b->host_flags[i] = both[2 * i]; b->host_anom[i] = ~both[2 * i + 1]; }      // (the arena keeps the complement: 0 = none)
-    if (b->cand_rounds >= 0 && getenv("JSNOOP_DEBUG_CAND")) {      // candidate chain of image 0: walks queued by the last chain launch, open sub-sequences after each launch
+    if (b->cand_rounds >= 0 && (b->tune.debug & JSNOOP_DBG_CAND)) {      // candidate chain of image 0: walks queued by the last chain launch, open sub-sequences after each launch
         uint32_t h[12]; if (b->d2h_staged(h, b->dev.cand_req, sizeof h)) return -1;
         fprintf(stderr, "[cand] rounds %d: queued by the last chain %u; open after chain 0..: %u %u %u %u; queued: %u %u %u %u\n", b->cand_rounds, h[0], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
     }
@@ -417,7 +421,8 @@ int js_parallel_fixup(JsnoopBatch* b)
     // at the top of the MCU that holds it and decodes from there to the end (k_entropy_exact in tail mode) -- a damaged byte near the end of a
     // file, a scan that ends a few blocks early or late: milliseconds instead of a sequential decode of the whole file.  An anomaly in the
     // first MCU (or none recorded), tables outside the LUT form: the whole image through the mirror, as before.
-    static const bool no_tail = getenv("JSNOOP_NO_TAIL") != nullptr;     // (cross-check: every flagged image through the whole mirror)
+    const bool no_tail = (b->tune.cross_checks & JSNOOP_XC_NO_TAIL) != 0;     // (cross-check: every flagged image through the whole mirror)
+    const bool dbg_tail = (b->tune.debug & JSNOOP_DBG_TAIL) != 0;
     // Second attempt first, for an image whose entropy data "ended" before its MCUs did although the file goes on: the scan was cut at a
     // marker that is no RSTn (or at an FF FF pair) -- which the reference does not stop at: it keeps the FF as data, reports it and reads on
     // (BuffAddByte :1486-1561).  A private one-image batch decodes the same file with the scan running to the end of the file and those
@@ -428,15 +433,21 @@ int js_parallel_fixup(JsnoopBatch* b)
         const JsImage& im = b->imgs[i];
         if (!(b->host_flags[i] & JSNOOP_FLAG_SHORT) || (b->host_flags[i] & (JSNOOP_FLAG_TABLES | JSNOOP_FLAG_NOSYNC | JSNOOP_FLAG_FORCED))) continue;
         if ((uint64_t)im.scan_start + im.scan_len + 2 > im.file_len || !b->tables[im.tableset].lut_ok) continue;      // the data really ends with the file
-        if (!b->helper) { b->helper = new JsnoopBatch(nullptr); b->helper->device = b->device; b->helper->is_helper = true; if (b->helper->init()) return -1; }
+        // (a helper that cannot be set up, or whose decode fails, costs the image its short cut, not the batch its result: the image keeps
+        //  its flags and goes through the mirror below)
+        if (!b->helper) {
+            b->helper = new JsnoopBatch(nullptr); b->helper->device = b->device; b->helper->is_helper = true; b->helper->tune = b->tune;
+            if (b->helper->init()) { delete b->helper; b->helper = nullptr; break; }
+        }
         JsnoopBatch* h = b->helper;
         h->clear(); h->opt_decode_ac = (int)im.decode_ac; h->opt_want_planes = 0; h->opt_force_exact = 0;
-        if (h->add_clone(b, i, true) < 0 || h->upload() || h->decode(false) || h->sync()) return -1;
+        if (h->add_clone(b, i, true) < 0 || h->upload() || h->decode(false) || h->sync()) continue;
         const JsImage& hm = h->imgs[0];
-        if (hm.total_blocks != im.total_blocks) { js_set_error("second attempt: geometry mismatch"); return -1; }
+        if (hm.total_blocks != im.total_blocks) continue;
         HIP_TRY(hipMemcpyAsync(b->dev.coef + im.coef_off * 64, h->dev.coef + hm.coef_off * 64, (size_t)im.total_blocks * 128, hipMemcpyDeviceToDevice, b->stream));
         HIP_TRY(hipMemcpyAsync(b->dev.dccum + im.coef_off, h->dev.dccum + hm.coef_off, (size_t)im.total_blocks * 2, hipMemcpyDeviceToDevice, b->stream));
-        if (getenv("JSNOOP_DEBUG_TAIL")) fprintf(stderr, "[tail] image %u flags 0x%04x: decoded through the markers of its scan (second attempt: path %u, flags 0x%04x)\n", i, b->host_flags[i], h->host_path[0], h->host_flags[0]);
+        HIP_TRY(hipStreamSynchronize(b->stream));                  // the helper's arenas are reused by the next flagged image (its own stream): the copies must have left them
+        if (dbg_tail) fprintf(stderr, "[tail] image %u flags 0x%04x: decoded through the markers of its scan (second attempt: path %u, flags 0x%04x)\n", i, b->host_flags[i], h->host_path[0], h->host_flags[0]);
         b->host_flags[i] = (b->host_flags[i] & JS_FLAGS_PIXEL_EXACT) | JSNOOP_FLAG_MARKER | (h->host_flags[0] & ~(uint32_t)JSNOOP_FLAG_FORCED);
         b->host_anom[i] = 0xFFFFFFFFu;                              // nothing left for the tail pass below: the second attempt had its own
         patched = true;
@@ -448,7 +459,7 @@ int js_parallel_fixup(JsnoopBatch* b)
         if ((b->host_flags[i] & JSNOOP_FLAG_MARKER) && b->host_anom[i] == 0xFFFFFFFFu) continue;    // resolved by the second attempt
         const bool tail_ok = !no_tail && !(b->host_flags[i] & (JSNOOP_FLAG_TABLES | JSNOOP_FLAG_NOSYNC | JSNOOP_FLAG_FORCED)) && b->tables[im.tableset].lut_ok &&
                              b->host_anom[i] != 0xFFFFFFFFu && b->host_anom[i] / im.blk_per_mcu >= 1u && b->host_anom[i] < im.total_blocks;
-        if (getenv("JSNOOP_DEBUG_TAIL")) fprintf(stderr, "[tail] image %u flags 0x%04x first anomalous block %u (MCU %u of %u) -> %s\n", i, b->host_flags[i], b->host_anom[i],
+        if (dbg_tail) fprintf(stderr, "[tail] image %u flags 0x%04x first anomalous block %u (MCU %u of %u) -> %s\n", i, b->host_flags[i], b->host_anom[i],
                                                  b->host_anom[i] / im.blk_per_mcu, im.mcu_xmax * im.mcu_ymax, tail_ok ? "tail take-over" : "whole mirror");
         if (tail_ok) tails.push_back(i); else { bad.push_back(i); b->host_path[i] = 2; }
     }
@@ -465,7 +476,7 @@ int js_parallel_fixup(JsnoopBatch* b)
                                 b->dev.chunk_keep, b->dev.chunk_rst, b->dev.ustr, b->dev.seg, b->dev.side, (uint32_t*)b->dev.sub, b->total_subseq,
                                 b->dev.coef, b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out, b->dev.flags, b->dev.sel);
             HIP_TRY(hipStreamSynchronize(b->stream));              // (dev.sel and the scratch area are reused by the next image)
-            if (getenv("JSNOOP_DEBUG_TAIL")) {
+            if (dbg_tail) {
                 const uint32_t ma = b->host_anom[i] / im.blk_per_mcu; uint32_t pos[3] = { 0, 0, 0 };
                 hipMemcpy(pos, mcu_pos + (ma ? ma - 1 : 0), 12, hipMemcpyDeviceToHost);
                 fprintf(stderr, "[tail] image %u: bit positions of MCU tops %u..%u: %u %u %u\n", i, ma ? ma - 1 : 0, (ma ? ma - 1 : 0) + 2, pos[0], pos[1], pos[2]);
@@ -521,7 +532,7 @@ int js_side_only(JsnoopBatch* b, uint32_t i)
     // An image whose only flag is the coefficient-index overflow walks exactly as the reference does (js_parallel_fixup): its maps,
     // histogram and final position come from the parallel side pass like a clean image's; what the overflows add -- scan_bad, the
     // warning counter, two messages per block -- is bookkeeping worked out below from the records the side walk leaves.
-    bool parallel = i < b->host_path.size() && b->host_path[i] == 1 && (b->host_flags[i] & ~JS_FLAGS_PIXEL_EXACT) == 0 && !getenv("JSNOOP_SIDE_EXACT");
+    bool parallel = i < b->host_path.size() && b->host_path[i] == 1 && (b->host_flags[i] & ~JS_FLAGS_PIXEL_EXACT) == 0 && !(b->tune.cross_checks & JSNOOP_XC_SIDE_EXACT);
     if (b->side_mode.size() != b->imgs.size()) { b->side_mode.assign(b->imgs.size(), 0); b->side_anoms.assign(b->imgs.size(), std::vector<uint32_t>()); }
     b->side_anoms[i].clear();
     if (parallel) {

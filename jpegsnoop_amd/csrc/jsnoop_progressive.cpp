@@ -232,6 +232,7 @@ struct JsProgBatch {
     uint32_t pg_lanes = 1;                                         // intervals per wave of the sequential scan kinds (batch-wide choice)
 };
 size_t js_prog_count(const JsnoopBatch* b) { return b->prog ? b->prog->frames.size() : 0; }
+void js_prog_dirty(JsnoopBatch* b) { if (b->prog) b->prog->dirty = true; }   // a tuning change: the work lists are rebuilt at the next decode
 void js_prog_clear(JsnoopBatch* b) { if (b->prog) { JsProgBatch* g = b->prog; g->frames.clear(); g->scans.clear(); g->tabs.clear(); g->segs.clear(); g->level.clear(); g->first_scan.clear(); g->nlev = 0; g->dirty = true; } }
 void js_prog_free(JsnoopBatch* b) { if (b->prog) { if (b->prog->d_buf) hipFree(b->prog->d_buf); delete b->prog; b->prog = nullptr; } }
 // image `src` once more as image `dst` (tile): same scans, tables and intervals (file-relative), its own frame entry
@@ -298,7 +299,7 @@ static int js_prog_upload(JsnoopBatch* b)
     // (a lane-per-interval wave is a latency chain of its own: below ~64 x 1080p files with a marker per MCU row the chip is not full of
     //  them and the wave-per-interval kernel is as fast; 128 files: 20 against 12 Gpixel/s, 1024 files: 35 against 13)
     g->pg_lanes = (nsc && total_iv / nsc >= 16 && total_iv >= 98304) ? 64u : (total_iv > 32768 ? 8u : 1u);
-    if (const char* e = getenv("JSNOOP_PG_LANES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 64) g->pg_lanes = (uint32_t)v; }
+    if (b->tune.pg_lanes) g->pg_lanes = (uint32_t)b->tune.pg_lanes;
     std::vector<uint32_t> ls, lw; g->lvl_first.clear(); g->lvl_count.clear(); g->lvl_wgs.clear();
     for (int lv = 0; lv < g->nlev; lv++) {
         g->lvl_first.push_back((uint32_t)ls.size()); uint32_t acc = 0; const size_t w0 = lw.size();
@@ -367,7 +368,7 @@ extern "C" int jsnoop_decode_progressive(JsnoopDecoder* d, const uint8_t* f, siz
     d->preview_is_jpeg = false; d->last_path = 0; d->last_flags = 0;
     JsnoopBatch* b = d->batch;
     b->clear();
-    static const bool dbg_t = getenv("JSNOOP_DEBUG_TIMING") != nullptr;   // where a call's wall time goes (stderr, one line per call)
+    const bool dbg_t = (d->batch->tune.debug & JSNOOP_DBG_TIMING) != 0;   // where a call's wall time goes (stderr, one line per call)
     auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tp[6]; int ntp = 0; if (dbg_t) tp[ntp++] = now_us();
     if (b->add_progressive(d, f, n) < 0) return -1;

@@ -175,8 +175,18 @@ class JpegBatch:
 
     def tile(self, total: int) -> int: return self._chk(self._lib.jsnoop_batch_tile(self._h, total), "batch_tile")
     def set_split(self, parts: int) -> None:
-        """parts = 2: later decodes run the two halves of the batch on two streams side by side (same results); 1: one stream."""
+        """parts = 2: later decodes run the two halves of the batch on two streams side by side (same results); 1: one stream; 0: the library decides."""
         self._chk(self._lib.jsnoop_batch_set_split(self._h, parts), "batch_set_split")
+    def split_parts(self) -> int: return int(self._lib.jsnoop_batch_split_parts(self._h))
+    def tuning(self) -> "capi.Tuning":
+        t = capi.Tuning(); self._lib.jsnoop_batch_get_tuning(self._h, C.byref(t)); return t
+    def set_tuning(self, **fields) -> None:
+        """Replaces fields of the batch's JsnoopTuning (e.g. sub_wl=5, cand_rounds=-1); call before upload()."""
+        t = self.tuning()
+        for k, v in fields.items():
+            if not hasattr(t, k): raise AttributeError("JsnoopTuning has no field " + k)
+            setattr(t, k, v)
+        self._chk(self._lib.jsnoop_batch_set_tuning(self._h, C.byref(t)), "batch_set_tuning")
     def clear(self): self._lib.jsnoop_batch_clear(self._h)
     def __len__(self): return self._lib.jsnoop_batch_count(self._h)
     def upload(self): self._chk(self._lib.jsnoop_batch_upload(self._h), "batch_upload")

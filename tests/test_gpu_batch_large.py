@@ -14,9 +14,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_batch_above_the_long_subsequence_threshold(harness, oracle, monkeypatch):
+def test_batch_above_the_long_subsequence_threshold(harness, oracle):
     import jpegsnoop_amd as J
-    monkeypatch.delenv("JSNOOP_SUB_WL", raising=False)
     files = [harness.synth_jpeg(width=1920, height=1080, hs=2, vs=2, quality=85, seed=500 + i) for i in range(8)]
     n = 192
     assert n * min(len(f) for f in files) >= 96 << 20, "batch too small to cross the threshold"
@@ -25,6 +24,7 @@ def test_batch_above_the_long_subsequence_threshold(harness, oracle, monkeypatch
         b.add_jpeg(f)
     b.tile(n)
     b.upload(); b.decode(); b.sync()
+    assert b.split_parts() == 2                                     # the library's default for a batch this size: two halves on two streams
     sums = b.dib_checksums()
     assert all(b.info(i)["path"] == 1 and b.info(i)["flags"] == 0 for i in range(n))
     for j, f in enumerate(files):

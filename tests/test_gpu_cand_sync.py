@@ -2,20 +2,19 @@
 
 Small jobs synchronise by candidates (k_cand_spec / _walk / _chain / _apply: one speculative walk per block-in-MCU index, memo walks, a chain
 of slot maps), larger ones by k_sync's rounds; both must leave the chain at the fixed point that IS the sequential decode of
-CimgDecode::DecodeScanImg (source/ImgDecode.cpp:3021-3645: ReadScanVal / DecodeScanComp in scan order).  The library reads its switches at
-upload: JSNOOP_CAND=0 (rounds only), JSNOOP_CAND=1 (one walk round of the chain: what stays open trips the write pass's verification and goes through k_sync's verification mode),
-JSNOOP_CAND_LANES=1 (job "too large": rounds), default (up to sixteen walk rounds).  The smallest jobs also run the write pass with two lanes per
-sub-sequence, the second one entering at the middle state the selected memo walk reported (JSNOOP_NO_HALF=1: one lane); with one walk round
+CimgDecode::DecodeScanImg (source/ImgDecode.cpp:3021-3645: ReadScanVal / DecodeScanComp in scan order).  The forms are chosen through the batch's
+JsnoopTuning (jsnoop_batch_set_tuning, applied at upload): cand_rounds = -1 (rounds only), cand_rounds = 1 (one walk round of the chain: what stays open trips
+the write pass's verification and goes through k_sync's verification mode), cand_max_walks = 1 (job "too large": rounds), default (up to sixteen walk
+rounds).  The smallest jobs also run the write pass with two lanes per sub-sequence, the second one entering at the middle state the selected memo walk
+reported (write_lanes = 1: one lane); a job between the two forms takes the hybrid (bounded rounds + memo) when the library has one; with one walk round
 only, the middle states of what k_sync repairs afterwards are stale and the write pass must notice (its verification fails, the decode resumes
 with one lane per sub-sequence) -- the result is the oracle's in every case."""
-import os
-
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-MODES = [("default", {}), ("rounds_only", {"JSNOOP_CAND": "0"}), ("one_walk_round", {"JSNOOP_CAND": "1"}), ("too_large", {"JSNOOP_CAND_LANES": "1"}),
-         ("128_byte_pieces", {"JSNOOP_SUB_WL": "5"}), ("one_write_lane_per_piece", {"JSNOOP_NO_HALF": "1"})]
+MODES = [("default", {}), ("rounds_only", {"cand_rounds": -1}), ("one_walk_round", {"cand_rounds": 1}), ("too_large", {"cand_max_walks": 1}),
+         ("128_byte_pieces", {"sub_wl": 5}), ("one_write_lane_per_piece", {"write_lanes": 1})]
 
 
 def _job(harness):
@@ -37,32 +36,43 @@ def job(harness, oracle):
     return files, want
 
 
-@pytest.mark.parametrize("mode,env", MODES, ids=[m for m, _ in MODES])
-def test_synchronisation_forms_agree_with_the_oracle(job, mode, env):
+@pytest.mark.parametrize("mode,tuning", MODES, ids=[m for m, _ in MODES])
+def test_synchronisation_forms_agree_with_the_oracle(job, mode, tuning):
     import jpegsnoop_amd as J
     files, want = job
-    saved = {k: os.environ.get(k) for k in ("JSNOOP_CAND", "JSNOOP_CAND_LANES", "JSNOOP_SUB_WL", "JSNOOP_NO_HALF")}
-    try:
-        for k in saved:
-            os.environ.pop(k, None)
-        os.environ.update(env)
-        for group in (files, files[:1], files[5:6], files[2:9]):      # the whole job, single images (one of them noisy), a mixed handful
-            b = J.JpegBatch()
-            for f in group:
-                b.add_jpeg(f)
-            b.upload(); b.decode(); b.sync()
-            sums = b.dib_checksums()
-            base = files.index(group[0])
-            for i in range(len(group)):
-                inf = b.info(i)
-                assert inf["path"] == 1 and inf["flags"] == 0, (mode, base + i, inf)
-                assert int(sums[i]) == want[base + i], (mode, base + i)
-            b.decode(); b.sync()                                       # a second decode of the resident batch: same arenas, same answer
-            assert [int(s) for s in b.dib_checksums()] == [int(s) for s in sums], mode
-            b.close()
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    for group in (files, files[:1], files[5:6], files[2:9]):      # the whole job, single images (one of them noisy), a mixed handful
+        b = J.JpegBatch()
+        b.set_tuning(**tuning)
+        for f in group:
+            b.add_jpeg(f)
+        b.upload(); b.decode(); b.sync()
+        sums = b.dib_checksums()
+        base = files.index(group[0])
+        for i in range(len(group)):
+            inf = b.info(i)
+            assert inf["path"] == 1 and inf["flags"] == 0, (mode, base + i, inf)
+            assert int(sums[i]) == want[base + i], (mode, base + i)
+        b.decode(); b.sync()                                       # a second decode of the resident batch: same arenas, same answer
+        assert [int(s) for s in b.dib_checksums()] == [int(s) for s in sums], mode
+        b.close()
+
+
+def test_tuning_struct_round_trip_and_range_checks():
+    """jsnoop_batch_set_tuning / _get_tuning: what was set comes back; a value out of range is refused with an error text and changes nothing;
+    the environment only supplies the defaults jsnoop_tuning_defaults returns."""
+    import ctypes as C
+    import jpegsnoop_amd as J
+    from jpegsnoop_amd import capi
+    lib = capi.load()
+    d = capi.Tuning(); lib.jsnoop_tuning_defaults(C.byref(d))
+    assert d.struct_size == C.sizeof(capi.Tuning)
+    b = J.JpegBatch()
+    b.set_tuning(sub_wl=6, cand_rounds=3, split=2, write_lanes=1, cross_checks=capi.XC_BACKEND_GENERIC)
+    t = b.tuning()
+    assert (t.sub_wl, t.cand_rounds, t.split, t.write_lanes, t.cross_checks) == (6, 3, 2, 1, capi.XC_BACKEND_GENERIC)
+    for bad in (dict(sub_wl=3), dict(sub_wl=9), dict(cand_rounds=65), dict(split=3), dict(write_lanes=3), dict(pg_lanes=5), dict(struct_size=8)):
+        with pytest.raises(RuntimeError):
+            b.set_tuning(**bad)
+        assert "tuning" in capi.last_error()
+        assert b.tuning().sub_wl == 6                             # unchanged
+    b.close()

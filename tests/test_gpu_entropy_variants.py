@@ -1,16 +1,11 @@
 """GPU: the tunable forms of the parallel entropy path give the answer of the default one.
 
-* every sub-sequence length the kernels are instantiated for (JSNOOP_SUB_WL = 4 ... 8: 64 B ... 1 KiB per lane; the library
-  picks 5 or 7 by batch size on its own) -- same DIBs, same side outputs, parallel path taken;
-* the first form of the write pass (k_write<., false>, JSNOOP_WRITE_V1=1: read once per process, hence the subprocess) against the
+* every sub-sequence length the kernels are instantiated for (JsnoopTuning.sub_wl = 4 ... 8: 64 B ... 1 KiB per lane; the library
+  picks 4, 5 or 7 by batch size on its own) -- same DIBs, same side outputs, parallel path taken;
+* the first form of the write pass (k_write<., false>, cross_checks = JSNOOP_XC_WRITE_V1) against the
   second (k_write2, the one the main path launches): the checksums of a mixed batch, RSTn streams and 4:4:4 / 4:2:2 / 4:2:0 / gray
   layouts included, must be identical and equal to the oracle's.
 """
-import json
-import os
-import subprocess
-import sys
-
 import numpy as np
 import pytest
 
@@ -26,11 +21,11 @@ def _files(harness):
 
 
 @pytest.mark.parametrize("wl", [4, 5, 6, 7, 8])
-def test_every_subsequence_length(harness, oracle, monkeypatch, wl):
+def test_every_subsequence_length(harness, oracle, wl):
     import jpegsnoop_amd as J
-    monkeypatch.setenv("JSNOOP_SUB_WL", str(wl))
     files = _files(harness)
     b = J.JpegBatch()
+    b.set_tuning(sub_wl=wl)
     for f in files:
         b.add_jpeg(f)
     b.tile(3 * len(files))
@@ -42,34 +37,24 @@ def test_every_subsequence_length(harness, oracle, monkeypatch, wl):
     b.close()
 
 
-_CHILD = r"""
-import json, sys
-sys.path.insert(0, sys.argv[1])
-import jpegsnoop_amd as J
-from oracle import harness as H
-kws = json.loads(sys.argv[2])
-b = J.JpegBatch()
-for i, kw in enumerate(kws):
-    b.add_jpeg(H.synth_jpeg(seed=900 + i, **kw))
-b.tile(4 * len(kws))
-b.upload(); b.decode(); b.sync()
-print(json.dumps({"sums": [int(x) for x in b.dib_checksums()], "paths": [b.info(i)["path"] for i in range(4 * len(kws))],
-                  "flags": [b.info(i)["flags"] for i in range(4 * len(kws))]}))
-"""
-
-
-def _run_child(extra_env):
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ); env.pop("JSNOOP_WRITE_V1", None); env.pop("JSNOOP_SUB_WL", None); env.update(extra_env)
-    out = subprocess.run([sys.executable, "-c", _CHILD, root, json.dumps(KWS)], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    return json.loads(out.stdout.strip().splitlines()[-1])
+def _decode_all(J, harness, **tuning):
+    b = J.JpegBatch()
+    b.set_tuning(**tuning)
+    for f in _files(harness):
+        b.add_jpeg(f)
+    n = 4 * len(KWS)
+    b.tile(n)
+    b.upload(); b.decode(); b.sync()
+    out = {"sums": [int(x) for x in b.dib_checksums()], "paths": [b.info(i)["path"] for i in range(n)], "flags": [b.info(i)["flags"] for i in range(n)]}
+    b.close()
+    return out
 
 
 def test_write_pass_first_and_second_form_agree(harness, oracle):
     import jpegsnoop_amd as J
-    v2 = _run_child({})
-    v1 = _run_child({"JSNOOP_WRITE_V1": "1"})
+    from jpegsnoop_amd import capi
+    v2 = _decode_all(J, harness)
+    v1 = _decode_all(J, harness, cross_checks=capi.XC_WRITE_V1)
     assert v1["sums"] == v2["sums"]
     assert set(v1["paths"]) == {1} and set(v2["paths"]) == {1} and not any(v1["flags"]) and not any(v2["flags"])
     for j, f in enumerate(_files(harness)):
@@ -80,7 +65,7 @@ def test_write_pass_first_and_second_form_agree(harness, oracle):
 
 def test_two_stream_split_gives_the_same_batch(harness, oracle):
     """jsnoop_batch_set_split(2): the two halves of a batch on two streams, same arenas -- every DIB as with one stream, flags clean,
-    a stream with restart markers and a grayscale image among them; then back to one stream."""
+    a stream with restart markers and a grayscale image among them; then back to one stream.  (0 = automatic: one stream for a batch this small.)"""
     import jpegsnoop_amd as J
     files = _files(harness)
     n = 5 * len(files) + 3                                          # an odd count: halves of different size
@@ -88,9 +73,12 @@ def test_two_stream_split_gives_the_same_batch(harness, oracle):
     for f in files:
         b.add_jpeg(f)
     b.tile(n)
+    b.set_split(1)
     b.upload(); b.decode(); b.sync()
     one = b.dib_checksums().copy()
-    b.set_split(2)
+    assert b.split_parts() == 1
+    b.set_split(0); assert b.split_parts() == 1                    # automatic: far below 96 MB of scan data
+    b.set_split(2); assert b.split_parts() == 2
     for _ in range(3):
         b.decode()
     b.sync()

@@ -106,13 +106,13 @@ def test_corrupt_streams_exact_path(harness, oracle, gpu):
 
 
 @pytest.mark.parametrize("force_exact,sub_wl", [(False, 5), (False, 7), (True, 5)])
-def test_batch_api(harness, oracle, force_exact, sub_wl, monkeypatch):
+def test_batch_api(harness, oracle, force_exact, sub_wl):
     import jpegsnoop_amd as J
-    monkeypatch.setenv("JSNOOP_SUB_WL", str(sub_wl))        # 128-byte or 512-byte sub-sequences
     kws = [dict(width=320, height=240), dict(width=333, height=217, hs=1, vs=1), dict(width=160, height=120, gray=1),
            dict(width=640, height=360, hs=2, vs=1, restart_interval=40), dict(width=1280, height=720, quality=92)]
     files = [harness.synth_jpeg(seed=20 + i, **kw) for i, kw in enumerate(kws)]
     b = J.JpegBatch(want_planes=True, force_exact=force_exact)
+    b.set_tuning(sub_wl=sub_wl)                              # 128-byte or 512-byte sub-sequences
     for f in files:
         b.add_jpeg(f)
     b.tile(10)
