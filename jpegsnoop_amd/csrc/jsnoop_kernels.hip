@@ -487,7 +487,7 @@ __device__ __forceinline__ void lds_w64(uint32_t a, uint32_t x, uint32_t y) { u3
 // of row words (lane q < 32: terms 2q, 2q+1) and the coefficient of term (lane & 15) of a round; the wave's base is wave-uniform.
 struct WaveList { uint32_t base /*SGPR*/, z_off, row_w, a_rows, a_ey; };
 #define LIST_BUF_BYTES (64 * 4 + 64 * 2)
-#define LIST_BYTES (2 * LIST_BUF_BYTES)
+#define LIST_BYTES 1024                                       // per wave: two one-block lists (general path) or the two halves' lists of the pair form
 __device__ __forceinline__ WaveList wave_list(const void* mem, uint32_t lane)
 {
     WaveList L; L.base = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(mem));
@@ -501,6 +501,16 @@ __device__ __forceinline__ void lds_w16(uint32_t a, uint32_t x) { *(__attribute_
 // (ablation builds of tools/build_variant.sh: results wrong, timing valid -- which part of a term the kernel waits for)
 #ifdef JS_EXP_T_NOREAD
 #define T_RD(X) ""
+#elif defined(JS_EXP_T_HALFREAD)
+#define T_RD(X) T_RD_##X
+#define T_RD_a0 "ds_read_addtid_b32 %[a0]\n\t"
+#define T_RD_a1 ""
+#define T_RD_a2 "ds_read_addtid_b32 %[a2]\n\t"
+#define T_RD_a3 ""
+#define T_RD_b0 "ds_read_addtid_b32 %[b0]\n\t"
+#define T_RD_b1 ""
+#define T_RD_b2 "ds_read_addtid_b32 %[b2]\n\t"
+#define T_RD_b3 ""
 #else
 #define T_RD(X) "ds_read_addtid_b32 %[" #X "]\n\t"
 #endif
@@ -604,6 +614,109 @@ __device__ __forceinline__ float idct_run(const IdctPrep& P, const WaveList L, u
 #endif
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     return acc;
+}
+
+// ---- two blocks per wave -------------------------------------------------------------------------------------------------
+// The fast layouts run the same sum on TWO blocks at a time: lanes 0..31 hold block A, lanes 32..63 block B, a lane owns the output
+// samples 2l and 2l+1 of its block (l = lane & 31) and the coefficients 2l and 2l+1 (one dword of the block's row).  A term of both blocks
+// is then ONE table read -- ds_read_b64 at row offset + l * 8: the two table entries of the lane's samples sit side by side in the row,
+// and an 8-byte read costs the LDS pipe what a 4-byte one does (profiles/r02_instr_rates.txt) -- where the one-block form needs two: the
+// LDS pipe, which the term loop loads as heavily as the vector unit, does half the work (with every second table read simply left out
+// the kernel runs 6.91 -> 6.33 ms, profiles/r04_backend_experiments.txt).  The price: the two lists advance in lock step (the shorter one
+// runs on its zero padding), and the row address is a vector add (v_add_u32_dpp with the row word of term k broadcast in its half) in
+// place of the scalar M0 write -- which also retires the v_readlane per two terms.
+// Lists, per half: 64 coefficients as fp32, 64 row words (natural index * 256) as dwords; slots as in the one-block form.
+struct PairList { uint32_t a_half, z0, a_ey, a_rw, l8, row0; };
+#define PAIR_LIST_BYTES (2 * 512)
+__device__ __forceinline__ PairList pair_list(const void* mem, uint32_t lane)
+{
+    PairList L; const uint32_t l = lane & 31u;
+    L.a_half = lds_addr(mem) + (lane >> 5) * 512u; L.z0 = 63u - 2u * l; L.a_ey = L.a_half + (lane & 15u) * 4u; L.a_rw = L.a_half + 256u + (lane & 15u) * 4u;
+    L.l8 = l * 8u; L.row0 = (2u * l) << 8;
+    return L;
+}
+// (the table pairs live in FIXED registers v48..v63: inline asm cannot name the halves of a 64-bit operand, and the multiplies work on them)
+#define P_AD(K) "v_add_u32_dpp %[ad], %[rw], %[l8] row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
+#define P_S(x) #x
+#define P_XS(x) P_S(x)
+#define P_LO_RA0 48
+#define P_HI_RA0 49
+#define P_LO_RA1 50
+#define P_HI_RA1 51
+#define P_LO_RA2 52
+#define P_HI_RA2 53
+#define P_LO_RA3 54
+#define P_HI_RA3 55
+#define P_LO_RB0 56
+#define P_HI_RB0 57
+#define P_LO_RB1 58
+#define P_HI_RB1 59
+#define P_LO_RB2 60
+#define P_HI_RB2 61
+#define P_LO_RB3 62
+#define P_HI_RB3 63
+#define P_VLO(X) "v" P_XS(P_LO_##X)
+#define P_VHI(X) "v" P_XS(P_HI_##X)
+#define P_RD_(X) "ds_read_b64 v[" P_XS(P_LO_##X) ":" P_XS(P_HI_##X) "], %[ad]\n\t"
+#define P_MUL_(X, K) "v_mul_f32_dpp " P_VLO(X) ", %[ey], " P_VLO(X) DPP_BC(K) "v_mul_f32_dpp " P_VHI(X) ", %[ey], " P_VHI(X) DPP_BC(K)
+#define P_ADD_(X) "v_add_f32 %[acc0], %[acc0], " P_VLO(X) "\n\t" "v_add_f32 %[acc1], %[acc1], " P_VHI(X) "\n\t"
+// One step = term K of both lists: leave when the longer list has no term K (the scalar unit is nearly idle in this form: two scalar
+// instructions per step are free, a padded step is 17 vector cycles); the table pair of term K + 4 is fetched meanwhile (what is fetched
+// past the end of the lists is dropped behind the last step).
+#define P_EXIT(K) "s_cmp_le_u32 %[nl], " #K "\n\t" "s_cbranch_scc1 .Lpe%=\n\t"
+#define P_STEPF(X, Y, K, KN) P_EXIT(K) "s_waitcnt lgkmcnt(3)\n\t" P_MUL_(X, K) P_AD(KN) P_RD_(Y) P_ADD_(X)
+#define P_STEPL(X, K, CNT) P_EXIT(K) "s_waitcnt lgkmcnt(" #CNT ")\n\t" P_MUL_(X, K) P_ADD_(X)
+// sixteen terms of both blocks: row words and coefficients of the round in lanes 0..15 of every row of rw / ey (per half),
+// nl = terms left including this round's (> 0): the length of the longer list (the shorter one runs on its zero entries)
+#define PAIR_ROUND()                                                                                                             \
+    asm volatile(                                                                                                                \
+        P_AD(0) P_RD_(RA0) P_AD(1) P_RD_(RA1) P_AD(2) P_RD_(RA2) P_AD(3) P_RD_(RA3)                                              \
+        "s_waitcnt lgkmcnt(3)\n\t" P_MUL_(RA0, 0) P_AD(4) P_RD_(RB0) P_ADD_(RA0)                                                 \
+        P_STEPF(RA1, RB1, 1, 5) P_STEPF(RA2, RB2, 2, 6) P_STEPF(RA3, RB3, 3, 7)                                                  \
+        P_STEPF(RB0, RA0, 4, 8) P_STEPF(RB1, RA1, 5, 9) P_STEPF(RB2, RA2, 6, 10) P_STEPF(RB3, RA3, 7, 11)                        \
+        P_STEPF(RA0, RB0, 8, 12) P_STEPF(RA1, RB1, 9, 13) P_STEPF(RA2, RB2, 10, 14) P_STEPF(RA3, RB3, 11, 15)                    \
+        P_STEPL(RB0, 12, 3) P_STEPL(RB1, 13, 2) P_STEPL(RB2, 14, 1) P_STEPL(RB3, 15, 0)                                          \
+        ".Lpe%=:\n\t" "s_waitcnt lgkmcnt(0)"                                                                                     \
+        : [acc0] "+v"(acc0), [acc1] "+v"(acc1), [ad] "=&v"(ad),                                                                  \
+          "={v[48:49]}"(a0), "={v[50:51]}"(a1), "={v[52:53]}"(a2), "={v[54:55]}"(a3), "={v[56:57]}"(b0), "={v[58:59]}"(b1), "={v[60:61]}"(b2), "={v[62:63]}"(b3) \
+        : [rw] "v"(rw), [ey] "v"(ey), [l8] "v"(L.l8), [nl] "s"(nl) : "scc")
+
+// d: the lane's two coefficients, c[2l] | c[2l+1] << 16 (DC and, in DC-only mode, everything already masked out).
+// Returns in acc0 / acc1 the sums (x 2, see idct_run) of the lane's samples 2l and 2l+1 of its block.
+__device__ __forceinline__ void idct_pair(uint32_t d, const PairList L, uint32_t lane, float& acc0, float& acc1)
+{
+    acc0 = 0.0f; acc1 = 0.0f;
+    const bool nz0 = (d & 0xFFFFu) != 0u, nz1 = (d >> 16) != 0u;
+    const uint64_t m0 = WBALLOT(nz0), m1 = WBALLOT(nz1);
+    const uint32_t na = (uint32_t)__builtin_popcount((uint32_t)m0) + (uint32_t)__builtin_popcount((uint32_t)m1);
+    const uint32_t nb = (uint32_t)__builtin_popcount((uint32_t)(m0 >> 32)) + (uint32_t)__builtin_popcount((uint32_t)(m1 >> 32));
+    uint32_t n = na > nb ? na : nb;
+    asm("" : "+s"(n));                                           // wave-uniform, in an SGPR: the exit tests are scalar compares
+#ifndef JS_EXP_NOTERMS
+    if (n) {
+        // coefficients of the half below this one in natural order: c[2l'] and c[2l'+1] of the lanes l' < l of the same half
+        uint32_t r0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+        r0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, r0));
+        r0 -= lane >= 32u ? na : 0u;
+        const uint32_t r1 = r0 + (nz0 ? 1u : 0u);
+        const uint32_t s0 = nz0 ? r0 : r0 + L.z0, s1 = nz1 ? r1 : r1 + (L.z0 - 1u);      // zero entries: slot 63 - (zero entries below)
+        uint32_t cf0, cf1;
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(cf0) : "v"(d));
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(cf1) : "v"(d));
+        const uint32_t w0 = L.a_half + (s0 << 2), w1 = L.a_half + (s1 << 2);
+        lds_w32(w0, cf0); lds_w32(w1, cf1); lds_w32(w0 + 256u, L.row0); lds_w32(w1 + 256u, L.row0 + 256u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        f32x2_t a0, a1, a2, a3, b0, b1, b2, b3; uint32_t ad;
+        { const float ey = __uint_as_float(lds_r32(L.a_ey)); const uint32_t rw = lds_r32(L.a_rw), nl = n; PAIR_ROUND(); }
+        if (n > 16) { const float ey = __uint_as_float(lds_r32(L.a_ey + 64u)); const uint32_t rw = lds_r32(L.a_rw + 64u), nl = n - 16; PAIR_ROUND(); }
+        if (n > 32) { const float ey = __uint_as_float(lds_r32(L.a_ey + 128u)); const uint32_t rw = lds_r32(L.a_rw + 128u), nl = n - 32; PAIR_ROUND(); }
+        if (n > 48) { const float ey = __uint_as_float(lds_r32(L.a_ey + 192u)); const uint32_t rw = lds_r32(L.a_rw + 192u), nl = n - 48; PAIR_ROUND(); }
+    }
+#else
+    acc0 = (float)(n + (lane & 15u)); acc1 = acc0;
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // SetFullRes :2468-2561 into the wave's LDS MCU tile (replicated eH x eV times).
@@ -741,7 +854,7 @@ __device__ __forceinline__ void mcu_to_dib_fast(const JsImage& im, uint32_t img_
 // the current MCU is converted.
 struct BackEndCtx {
     const JsImage* im; const int16_t* cbase; const int16_t* dccum; uint8_t* dibp; int16_t* planes;
-    WaveList L; int16_t* tile; const uint32_t* s_meta; uint32_t lane, wg_in_img, wgs_in_img, wave;
+    WaveList L; const void* listmem; int16_t* tile; const uint32_t* s_meta; uint32_t lane, wg_in_img, wgs_in_img, wave;
 };
 // FAST: the layouts of mcu_to_dib_fast (EH, EV = chroma expansion); otherwise the general path.
 template <bool FAST, uint32_t EH, uint32_t EV>
@@ -864,6 +977,68 @@ __device__ __forceinline__ void back_end_mcus(const BackEndCtx& C, uint64_t& bri
     }
 }
 
+// The fast layouts (three components, Y un-expanded, Cb and Cr one block each expanded EH x EV): blocks two at a time (idct_pair), decode order
+// kept -- (Y0, Y1), (Y2, Y3), (Cb, Cr) for 4:2:0; a layout with an odd block count leaves half B of its last pair idle.
+template <uint32_t EH, uint32_t EV>
+__device__ __forceinline__ void back_end_pairs(const BackEndCtx& C, uint64_t& bright, uint32_t& sum_y)
+{
+    const JsImage& im = *C.im;
+    const uint32_t lane = C.lane, l = lane & 31u, hi = lane >> 5;
+    const PairList L = pair_list(C.listmem, lane); int16_t* tile = C.tile;
+    constexpr uint32_t nb = EH * EV + 2u, np = (nb + 1u) / 2u, mw = 8u * EH, mh = 8u * EV, rs = mw + 8u, plane_elems = mh * rs;
+    const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax, pw = im.blk_xmax * 8, img_x = im.img_x, img_y = im.img_y;
+    const bool want_planes = im.want_planes != 0;
+    constexpr uint32_t quads = mw / 4, total = quads * mh;
+    const uint32_t ly0 = lane / quads, lq0 = lane % quads;
+    int best_y = -0x7FFFFFFF;
+    // per pair: does this half hold a block, where do the lane's two samples (2l, 2l+1: row l / 4, columns 2 (l % 4) and the next) go in the tile
+    bool live[np]; uint32_t toff2[np], cmask[np];
+    // DC-only mode: the reference does not run the IDCT at all (:1827); the DC difference (coefficient 0: low half of lane l == 0) is not part of the sum (:2381)
+    const uint32_t ac = im.decode_ac != 0 ? (l == 0u ? 0xFFFF0000u : 0xFFFFFFFFu) : 0u;
+    #pragma unroll
+    for (uint32_t p = 0; p < np; p++) {
+        const uint32_t slot = 2u * p + hi; live[p] = slot < nb;
+        const uint32_t meta = C.s_meta[live[p] ? slot : nb - 1u], comp0 = meta & 15u;
+        toff2[p] = comp0 == 0 ? (((meta >> 20) & 255u) + (l >> 2)) * rs + ((meta >> 12) & 255u) + (l & 3u) * 2u : plane_elems + (comp0 - 1u) * 64u + 2u * l;
+        cmask[p] = live[p] ? ac : 0u;
+        asm volatile("" : "+v"(cmask[p]));                       // (a mask in a VGPR: v_and_b32 issues at full rate, the v_cndmask the compiler prefers does not)
+    }
+    const size_t coef_off = im.coef_off;
+    uint32_t raw[np]; int dcl[np];
+    // A lane fetches the dword that holds its two coefficients (an idle half re-reads block A: nothing is read past the arena) and the
+    // cumulative DC of its block; the next MCU's fetch is issued before the colour phase of the current one and first used after it.
+    auto fetch = [&](uint32_t m) {
+        const uint32_t* p32 = reinterpret_cast<const uint32_t*>(C.cbase + (size_t)m * nb * 64);
+        const int16_t* d16 = C.dccum + coef_off + (size_t)m * nb;
+        #pragma unroll
+        for (uint32_t p = 0; p < np; p++) { raw[p] = p32[p * 64u + (live[p] ? lane : l)]; dcl[p] = (int)d16[2u * p + (live[p] ? hi : 0u)]; }
+    };
+    const uint32_t wstride = C.wgs_in_img * BK_WAVES;
+    uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(C.wg_in_img * BK_WAVES + C.wave));
+    const uint32_t xmax = im.mcu_xmax, step_x = wstride % xmax, step_y = wstride / xmax;
+    uint32_t mx = m % xmax, my = m / xmax;                       // MCU coordinates, stepped along with m (no division in the loop)
+    if (m < nmcu) fetch(m);
+    #pragma nounroll
+    for (; m < nmcu; m += wstride, mx += step_x, my += step_y) {
+        if (mx >= xmax) { mx -= xmax; my++; }
+        #pragma unroll
+        for (uint32_t p = 0; p < np; p++) {
+            float acc0, acc1;
+            idct_pair(raw[p] & cmask[p], L, lane, acc0, acc1);
+            // fp32 sums (x 2: the table holds 2 x the reference's entries) -> samples, to_sample on both; the int16 wrap of the sum is the low half
+            const uint32_t x0 = (uint32_t)((int)acc0 + dcl[p]), x1 = (uint32_t)((int)acc1 + dcl[p]);
+            if (live[p]) *reinterpret_cast<uint32_t*>(tile + toff2[p]) = __builtin_amdgcn_perm(x1, x0, 0x05040100u);
+        }
+        const uint32_t m_next = m + wstride < nmcu ? m + wstride : m;   // (the last round fetches its own MCU again: no branch around the fetch)
+        fetch(m_next);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#ifndef JS_EXP_NOCOLOR
+        mcu_to_dib_fast<EH, EV>(im, img_x, img_y, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, C.dibp, C.planes, pw, want_planes, bright, best_y, sum_y);
+#endif
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 #ifndef JS_BK_OCC
 #define JS_BK_OCC 8     // 64 VGPRs: with the small tiles of the common layouts four workgroups (32 waves) fit a CU
 #endif
@@ -897,23 +1072,23 @@ __global__ void __launch_bounds__(BK_THREADS, LAYOUT ? JS_BK_OCC : JS_BK_OCC - 2
         s_meta[tid] = (comp - 1) | (im.expand_h[comp] << 4) | (im.expand_v[comp] << 8) | ((uint32_t)im.blk_ch[tid] * 8u << 12) | ((uint32_t)im.blk_cv[tid] * 8u << 20); }
     BackEndCtx C;
     C.im = &im; C.cbase = coef + im.coef_off * 64; C.dccum = dccum; C.dibp = dib + im.dib_off; C.planes = planes;
-    C.L = wave_list(wave_mem, lane); C.tile = reinterpret_cast<int16_t*>(wave_mem + LIST_BYTES);
+    C.L = wave_list(wave_mem, lane); C.listmem = wave_mem; C.tile = reinterpret_cast<int16_t*>(wave_mem + LIST_BYTES);
     C.s_meta = s_meta; C.lane = lane; C.wave = wave; C.wg_in_img = bx - wg_base[lo]; C.wgs_in_img = wg_base[lo + 1] - wg_base[lo];
     __syncthreads();
 
     uint64_t bright = 0; uint32_t sum_y = 0;
     // the common layouts take the short colour path: Y un-expanded, Cb and Cr one block each, both expanded EH x EV with EH, EV in {1, 2}
-    if (LAYOUT == 1) back_end_mcus<true, 2, 2>(C, bright, sum_y);
-    else if (LAYOUT == 2) back_end_mcus<true, 2, 1>(C, bright, sum_y);
-    else if (LAYOUT == 3) back_end_mcus<true, 1, 2>(C, bright, sum_y);
-    else if (LAYOUT == 4) back_end_mcus<true, 1, 1>(C, bright, sum_y);
+    if (LAYOUT == 1) back_end_pairs<2, 2>(C, bright, sum_y);
+    else if (LAYOUT == 2) back_end_pairs<2, 1>(C, bright, sum_y);
+    else if (LAYOUT == 3) back_end_pairs<1, 2>(C, bright, sum_y);
+    else if (LAYOUT == 4) back_end_pairs<1, 1>(C, bright, sum_y);
     else {
         const uint32_t eh = im.expand_h[2], ev = im.expand_v[2];
         const bool fast = js_fast_layout(im);
-        if (fast && eh == 2 && ev == 2) back_end_mcus<true, 2, 2>(C, bright, sum_y);
-        else if (fast && eh == 2) back_end_mcus<true, 2, 1>(C, bright, sum_y);
-        else if (fast && ev == 2) back_end_mcus<true, 1, 2>(C, bright, sum_y);
-        else if (fast) back_end_mcus<true, 1, 1>(C, bright, sum_y);
+        if (fast && eh == 2 && ev == 2) back_end_pairs<2, 2>(C, bright, sum_y);
+        else if (fast && eh == 2) back_end_pairs<2, 1>(C, bright, sum_y);
+        else if (fast && ev == 2) back_end_pairs<1, 2>(C, bright, sum_y);
+        else if (fast) back_end_pairs<1, 1>(C, bright, sum_y);
         else back_end_mcus<false, 1, 1>(C, bright, sum_y);
     }
 
@@ -962,12 +1137,25 @@ __global__ void __launch_bounds__(64) k_idct_probe(const float* __restrict__ lut
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     float* s_lut = reinterpret_cast<float*>(s_dyn);
     const WaveList L = wave_list(s_dyn + 64 * 64 * sizeof(float), threadIdx.x);
+    const PairList LP = pair_list(s_dyn + 64 * 64 * sizeof(float), threadIdx.x);
     if ((uint32_t)(size_t)s_dyn != 0u) __builtin_trap();
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x, l = lane & 31u;
     for (uint32_t i = lane; i < 64 * 64; i += 64) s_lut[i] = __fmul_rn(lut_t[i], 2.0f);
     __syncthreads();
+    // both production forms of the term loop: the block alone (general layouts), and as both halves of a pair (the fast layouts) --
+    // a sample on which any of the three results differs comes back as NaN
     const IdctPrep P = idct_prep(lane ? (uint32_t)(uint16_t)coef64[lane] : 0u, L, 0);
-    out64[lane] = __fmul_rn(idct_run(P, L, 0, lane), 0.125f);
+    const float one = __fmul_rn(idct_run(P, L, 0, lane), 0.125f);
+    __syncthreads();
+    const uint32_t d = reinterpret_cast<const uint32_t*>(coef64)[l] & (l == 0u ? 0xFFFF0000u : 0xFFFFFFFFu);
+    float acc0, acc1;
+    idct_pair(d, LP, lane, acc0, acc1);
+    float* s_chk = reinterpret_cast<float*>(s_dyn);                // (the table is no longer needed)
+    __syncthreads();
+    s_chk[(lane >> 5) * 64u + 2u * l] = __fmul_rn(acc0, 0.125f); s_chk[(lane >> 5) * 64u + 2u * l + 1u] = __fmul_rn(acc1, 0.125f);
+    __syncthreads();
+    const bool same = __float_as_uint(s_chk[lane]) == __float_as_uint(one) && __float_as_uint(s_chk[64u + lane]) == __float_as_uint(one);
+    out64[lane] = same ? one : __uint_as_float(0x7FC00000u);
 }
 
 // ConvertYCCtoRGBFastFloat on one triple (the RGB of the brightest pixel, :4805-4811).
