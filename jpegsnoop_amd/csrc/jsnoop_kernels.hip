@@ -1471,6 +1471,7 @@ void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, 
 #define F_RST_MISALIGN  0x0008u
 #define F_SHORT         0x0010u
 #define F_NOSYNC        0x0080u
+#define F_BAD_EDGE      0x0100u          // a code that matches nothing within 64 bits of an interval end: what the reference does there depends on its look-ahead
 
 // Physical layout of the compacted stream: 64 consecutive sub-sequences (64 x 128 B = 8 KiB, or 64 x 512 B = 32 KiB) form a group
 // stored word-interleaved -- word w of sub-sequence l sits at 32-bit index (group*32 + w)*64 + l -- so that
@@ -1784,19 +1785,28 @@ __device__ __forceinline__ uint32_t sym_lookup(const SubTabs& T, uint32_t win, u
 }
 
 // What the reference sees as RSV_RST_TERM (:1167-1176) -- no code fits in what is left of the interval --
-// or a code that matches nothing.  Returns false when the walk is over (end of the entropy data).
+// or a code that matches nothing.  Returns WS_OVER when the walk is over (end of the entropy data), WS_BAD_CODE when a code that matches
+// nothing ended the block the reference's way, else WS_GO_ON.
+// A code that matches nothing, far from any marker (the reader's 32-bit register holds no restart marker's shadow: 64 bits of margin):
+// ReadScanVal consumes ONE bit and reports RSV_UNDERFLOW (:1178-1186, :1270-1282), DecodeScanComp gives the block up there and then
+// without running the IDCT (:1737-1757, m_afIdctBlock still holds DecodeIdctClear's zeros :2243) -- the block keeps its DC difference
+// if it had decoded one, its AC part counts as zero, and the next block starts at the next bit.  The walks do exactly that (the write
+// pass empties the block's AC part before it leaves); what the flag then stands for is bookkeeping (scan_bad, messages, the histogram
+// slot of "one bit"), which the mirror's side-only pass produces on request.  Closer to an interval end the outcome depends on what the
+// reader's look-ahead has already seen: F_BAD_EDGE, the mirror takes over as before.
+enum { WS_OVER = 0, WS_GO_ON = 1, WS_BAD_CODE = 2 };
 template <bool WRITE, int WL>
-__device__ __forceinline__ bool walk_slow(const JsImage& im, const uint32_t* __restrict__ words, const uint32_t* __restrict__ st, uint32_t nseg,
+__device__ __forceinline__ int walk_slow(const JsImage& im, const uint32_t* __restrict__ words, const uint32_t* __restrict__ st, uint32_t nseg,
                                        Cursor& cur, uint32_t len, uint32_t& seg, uint32_t& seg_end, uint32_t& c, uint32_t& k,
                                        uint32_t blk, bool mark, uint8_t* __restrict__ mcu_rst, uint32_t& flags, uint32_t& anom)
 {
     const uint32_t remain = seg_end > cur.p ? seg_end - cur.p : 0u;
     if (len == 0 && remain >= 16) {
-        // No code matches although a whole code could still fit: a corrupt stream (the reference skips one bit
-        // and reports it, :1178-1186) -- or simply a speculative walk that is not synchronised yet.
-        if (WRITE && blk < im.total_blocks) { flags |= F_BAD_CODE; anom = min(anom, blk); }
+        // No code matches although a whole code could still fit: a corrupt stream -- or simply a speculative walk that is not synchronised yet.
+        const bool native = remain >= 64;
+        if (WRITE && blk < im.total_blocks) { flags |= native ? F_BAD_CODE : (F_BAD_CODE | F_BAD_EDGE); if (!native) anom = min(anom, blk); }
         cur_skip<WL>(cur, 1);
-        return true;
+        return native ? WS_BAD_CODE : WS_GO_ON;
     }
     if (seg + 1 < nseg) {
         if (WRITE) {
@@ -1806,11 +1816,11 @@ __device__ __forceinline__ bool walk_slow(const JsImage& im, const uint32_t* __r
         seg++; const uint32_t np = seg_end; seg_end = st[seg + 1] * 8; c = 0; k = 0;
         if (WRITE && seg_end == np && seg + 1 < nseg) { flags |= F_RST_MISALIGN; anom = min(anom, blk); }       // back-to-back RSTn
         cur_init<WL>(cur, words, np);
-        return true;
+        return WS_GO_ON;
     }
     if (WRITE && blk < im.total_blocks) { flags |= F_SHORT; anom = min(anom, blk); }
     cur.p = P_END; c = 0; k = 0; seg = 0;
-    return false;
+    return WS_OVER;
 }
 
 
@@ -1873,7 +1883,8 @@ __device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, ui
                 const uint32_t e = sym_lookup(T, win, lrow, 0u);
                 const uint32_t len = (e >> 8) & 31u, run = (e >> 4) & 15u, size = e & 15u;
                 if (len == 0 || cur.p + len > seg_end) {
-                    walk_slow<false, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, 0, false, nullptr, fl, fl);   // end of the data: p = P_END
+                    const int ws = walk_slow<false, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, 0, false, nullptr, fl, fl);   // end of the data: p = P_END
+                    if (ws == WS_BAD_CODE) { k = 0u; c = c + 1 == T.nb ? 0u : c + 1; nblk++; }                                        // the block ends with the bad code
                 } else {
                     cur_skip<WL>(cur, len + size);
                     const uint32_t kn = k == 0 ? 1u : k + run + 1u;
@@ -2552,11 +2563,12 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         bool two = !SIDE && active && ((e >> 24) & 1u) && (run | size) != 0u && k2 < 64u && k3 <= 64u && cur.p + tot < own_end && cur.p + tot + tot2 <= seg_end;
         // ---- anything out of the ordinary sits behind one vote: no code, the end of the interval inside the code or its value
         //      bits, a run past the 64th coefficient
-        bool norm = active;
+        bool norm = active, bad = false;                         // bad: a code that matches nothing ended the block (walk_slow)
         if (WBALLOT(len == 0 || cur.p + tot > seg_end || k2 > 64u) & amask) {
             if (active && (len == 0 || cur.p + len > seg_end)) {  // interval / stream end, or a code that matches nothing
-                const bool more = walk_slow<true, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, blk, !captured, rstf, fl, an);
-                if (!more) { if (!captured) { captured = true; res_p = P_END; res_s = 0; res_n = nblk; } active = false; }
+                const int ws = walk_slow<true, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, blk, !captured, rstf, fl, an);
+                if (ws == WS_OVER) { if (!captured) { captured = true; res_p = P_END; res_s = 0; res_n = nblk; } active = false; }
+                bad = ws == WS_BAD_CODE;
                 comp = comp_of(T, c); wb = comp == 0 ? wb0 : (comp == 1 ? wb1 : wb2);
                 norm = false;
             } else if (active && blk < nblocks) {
@@ -2583,6 +2595,13 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         if (!SIDE && norm && !skip && (isdc || (decode_ac && size)) && ind < 64) lbuf[qz >> 16] = dq;
         if (SIDE && norm && !captured && blk < nblocks) atomicAdd(&s_histo[((isdc ? 0u : 4u) + tset.dest_id[comp * 2 + (isdc ? 0u : 1u)]) * 17u + len], 1u);
         dq0 = (norm && isdc) ? dq : dq0;
+        if (WBALLOT(bad) & amask) {
+            if (bad) {                                           // the block keeps its DC difference (none decoded yet: 0) and nothing else
+                if (isdc) dq0 = 0;
+                if (!SIDE && !skip) { uint32_t* z = reinterpret_cast<uint32_t*>(lbuf); for (int j = 0; j < WR_STRIDE / 2; j++) z[j] = 0u; lbuf[0] = dq0; }
+                if (SIDE && !captured && blk < nblocks) atomicAdd(&s_histo[((isdc ? 0u : 4u) + tset.dest_id[comp * 2 + (isdc ? 0u : 1u)]) * 17u + 1u], 1u);   // (one bit "used": m_anDhtHisto[..][1])
+            }
+        }
         two = two && norm;
         if (!SIDE) {                                             // second symbol: bits [tot, tot + tot2) of the same window (tot + tot2 <= 24)
             const uint32_t vraw2 = __builtin_amdgcn_ubfe(win, 32u - tot - tot2, size2);
@@ -2594,8 +2613,8 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         }
         cur_skip<WL>(cur, norm ? (two ? tot + tot2 : tot) : 0u);
         const uint32_t kn = two ? k3 : k2;
-        const bool done = norm && !isdc && (two ? ((run2 | size2) == 0u || k3 >= 64u) : ((run | size) == 0u || k2 >= 64u));
-        k = norm ? (done ? 0u : kn) : k;
+        const bool done = bad || (norm && !isdc && (two ? ((run2 | size2) == 0u || k3 >= 64u) : ((run | size) == 0u || k2 >= 64u)));
+        k = norm ? (done ? 0u : kn) : (bad ? 0u : k);
         const bool flush = done && !skip && blk < nblocks;
         const uint32_t fblk = blk;
         if (done) {
@@ -2771,22 +2790,23 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
         uint64_t m_two = WBALLOT(tot2 != 0u) & WBALLOT(k3 <= 64u) & WBALLOT(p1 < own_end) & WBALLOT(p2 <= seg_end) & m_act;
         // ---- anything out of the ordinary sits behind one vote: no code, the end of the interval inside the code or its value
         //      bits, a run past the 64th coefficient
-        uint64_t m_norm = m_act, m_nost = 0ull;
+        uint64_t m_norm = m_act, m_nost = 0ull, m_bad = 0ull;      // m_bad: a code that matches nothing ended the lane's block (walk_slow)
         const uint64_t m_abn = (WBALLOT(len == 0u) | WBALLOT(p1 > seg_end) | WBALLOT(k2 > 64u)) & m_act;
         if (m_abn) {
             const uint64_t m_slow = (WBALLOT(len == 0u) | WBALLOT(cur.p + len > seg_end)) & m_act;
-            bool over = false;                                   // (lane masks change in wave-uniform code only)
+            bool over = false, bad = false;                      // (lane masks change in wave-uniform code only)
             if (IBAL(m_slow)) {                                  // interval / stream end, or a code that matches nothing
                 const bool notcap = !IBAL(m_cap);
-                const bool more = walk_slow<true, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, blk, notcap, rstf, fl, an);
-                if (!more && notcap) { res_p = P_END; res_s = 0; res_n = nblk; }
-                over = !more;
+                const int ws = walk_slow<true, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, blk, notcap, rstf, fl, an);
+                if (ws == WS_OVER && notcap) { res_p = P_END; res_s = 0; res_n = nblk; }
+                over = ws == WS_OVER; bad = ws == WS_BAD_CODE;
                 comp = comp_of(T, c); wb = comp == 0 ? wb0 : (comp == 1 ? wb1 : wb2);
                 tot = 0; size = 0; k2 = k;                       // the step below does nothing for this lane
             } else if (IBAL(m_act)) {
                 if (blk < nblocks) { if (p1 > seg_end) { fl |= F_OVERRUN; an = min(an, blk); } if (k2 > 64u) fl |= F_COEF_OVERFLOW; }
             }
             const uint64_t m_over = WBALLOT(over);
+            m_bad = WBALLOT(bad) & m_act;
             m_cap |= m_over; m_act &= ~m_over;
             m_norm &= ~m_slow; m_two &= ~m_slow;
             m_nost = WBALLOT(k2 > 64u);
@@ -2801,6 +2821,12 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
         const uint32_t dq = (uint32_t)((int32_t)(int16_t)val * (int32_t)(qz & 0xFFFFu));
         if (IBAL(m_st)) *reinterpret_cast<int16_t*>(lbuf + ((qz >> 16) << 1)) = (int16_t)dq;
         dq0 = IBAL(m_dc & m_norm) ? dq : dq0;                    // the block's DC difference
+        if (m_bad) {
+            if (IBAL(m_bad)) {                                   // the block keeps its DC difference (none decoded yet: 0) and nothing else
+                if (IBAL(m_dc)) dq0 = 0u;
+                if (!IBAL(m_skip)) { uint32_t* z = reinterpret_cast<uint32_t*>(lbuf); for (int j = 0; j < WR_STRIDE / 2; j++) z[j] = 0u; *reinterpret_cast<int16_t*>(lbuf) = (int16_t)dq0; }
+            }
+        }
         if (IBAL(m_two & ~m_skip & acmask)) *reinterpret_cast<int16_t*>(lbuf + ((qz2 >> 16) << 1)) = (int16_t)((int32_t)(int16_t)val2 * (int32_t)(qz2 & 0xFFFFu));
         // ---- advance
         const bool two = IBAL(m_two);
@@ -2811,7 +2837,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
         }
         const uint32_t kn = two ? k3 : k2;
         const uint64_t m_eob = (m_two & WBALLOT((run2 | size2) == 0u)) | (~m_two & WBALLOT((run | size) == 0u));
-        const uint64_t m_done = m_norm & ~m_dc & (m_eob | WBALLOT(kn >= 64u));
+        const uint64_t m_done = (m_norm & ~m_dc & (m_eob | WBALLOT(kn >= 64u))) | m_bad;
         k = IBAL(m_done) ? 0u : kn;
         if (m_done) {
             const uint64_t m_flush = m_done & ~m_skip & WBALLOT(blk < nblocks);

@@ -532,7 +532,7 @@ int js_side_only(JsnoopBatch* b, uint32_t i)
     // An image whose only flag is the coefficient-index overflow walks exactly as the reference does (js_parallel_fixup): its maps,
     // histogram and final position come from the parallel side pass like a clean image's; what the overflows add -- scan_bad, the
     // warning counter, two messages per block -- is bookkeeping worked out below from the records the side walk leaves.
-    bool parallel = i < b->host_path.size() && b->host_path[i] == 1 && (b->host_flags[i] & ~JS_FLAGS_PIXEL_EXACT) == 0 && !(b->tune.cross_checks & JSNOOP_XC_SIDE_EXACT);
+    bool parallel = i < b->host_path.size() && b->host_path[i] == 1 && (b->host_flags[i] & ~JS_FLAGS_SIDE_PARALLEL) == 0 && !(b->tune.cross_checks & JSNOOP_XC_SIDE_EXACT);
     if (b->side_mode.size() != b->imgs.size()) { b->side_mode.assign(b->imgs.size(), 0); b->side_anoms.assign(b->imgs.size(), std::vector<uint32_t>()); }
     b->side_anoms[i].clear();
     if (parallel) {

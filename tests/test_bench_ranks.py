@@ -97,4 +97,20 @@ def test_world_size_mismatch_fails_loudly():
 
 def test_more_gpus_than_devices_fails_loudly():
     p = run_bench("--gpus", "64", "--steps", "1")          # no box has 64 devices: the launcher must refuse before spawning
-    assert p.returncode != 0 and b"HIP device" in p.stderr
+    assert p.returncode != 0
+    import re
+    m = re.search(rb"bench\.py: --gpus 64 requested but only (\d+) HIP device\(s\) are visible", p.stderr)
+    assert m and int(m.group(1)) < 64, p.stderr[-500:]
+    assert b"torch.distributed" not in p.stderr                # refused before a single rank was spawned
+
+
+def test_strong_job_at_world_size_2_is_refused_the_same_way_without_devices():
+    """`bench.py --gpus 2 --strong` (no --stub) on a box with fewer than two devices: the same refusal, the same text."""
+    sys.path.insert(0, ROOT)
+    import jpegsnoop_amd as J
+    have = int(J.load(require_device=False).jsnoop_device_count())
+    if have >= 2:
+        import pytest
+        pytest.skip("two devices are visible here: the launcher would run the job")
+    p = run_bench("--gpus", "2", "--strong", "--steps", "1")
+    assert p.returncode != 0 and (b"bench.py: --gpus 2 requested but only %d HIP device(s) are visible" % have) in p.stderr

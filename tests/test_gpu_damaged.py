@@ -67,6 +67,38 @@ def test_truncated_1080p_decodes_in_milliseconds(harness, oracle):
     b.close()
 
 
+@pytest.mark.parametrize("kind", ["ones16", "garbage"])
+def test_codes_that_match_nothing_are_decoded_by_the_parallel_path(harness, oracle, gpu, kind):
+    """A code that matches nothing far from any marker (ReadScanVal: one bit consumed, RSV_UNDERFLOW, :1178-1186 / :1270-1282; DecodeScanComp
+    gives the block up without an IDCT, :1737-1757): the walks of the parallel path do the same -- the block keeps its DC difference, its AC
+    part is emptied, the next block starts one bit on -- so a 1080p file with sixteen one-bits, or 256 random bytes (FF among them: the scan
+    is then decoded a second time through its stray markers), at 30 % of its scan decodes in well under 50 ms instead of the seconds the
+    sequential mirror takes for the remaining 70 %; DIB and planes are the oracle's, and so are the side outputs (the mirror's side-only
+    pass, on request)."""
+    import jpegsnoop_amd as J
+    from fuzz_util import differs
+    base = harness.synth_jpeg(width=1920, height=1080, seed=31)
+    p = harness.parse_jpeg(base)
+    d = bytearray(base); i = p.scan_start + int((p.scan_end - p.scan_start) * 0.3)
+    if kind == "ones16":
+        d[i:i + 4] = b"\xff\x00\xff\x00"
+    else:
+        d[i:i + 256] = np.random.RandomState(5).randint(0, 256, 256).astype(np.uint8).tobytes()
+    data = bytes(d)
+    b = J.JpegBatch(want_planes=True); b.add_jpeg(data); b.upload(); b.decode(); b.sync()
+    t = time.perf_counter(); b.decode(); b.sync(); ms = (time.perf_counter() - t) * 1e3
+    harness.drive(oracle, data)
+    inf = b.info(0)
+    assert inf["path"] == 1 and (inf["flags"] & 0x0001) and not (inf["flags"] & 0x0100), inf      # BAD_CODE, not BAD_EDGE
+    assert np.array_equal(b.dib(0), oracle.dib())
+    for pa, pb in zip(oracle.planes(), b.planes(0)):
+        assert np.array_equal(pa, pb)
+    assert ms < 50.0, f"{ms:.1f} ms"
+    b.close()
+    harness.drive(gpu, data)                                          # the single-image API: side outputs and status words too
+    assert differs(oracle, gpu) is None
+
+
 def test_damaged_images_inside_a_batch(harness, oracle):
     import jpegsnoop_amd as J
     base = harness.synth_jpeg(width=640, height=480, seed=29)
