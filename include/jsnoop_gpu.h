@@ -182,12 +182,12 @@ uint32_t        jsnoop_last_flags(JsnoopDecoder*);                     /* JSNOOP
 #define JSNOOP_FLAG_BAD_CODE      0x0001u  /* no Huffman code matches (alone: decoded the reference's way by the parallel path) */
 #define JSNOOP_FLAG_OVERRUN       0x0002u  /* code or extra bits run past the interval / scan end       */
 #define JSNOOP_FLAG_COEF_OVERFLOW 0x0004u  /* coefficient index > 63                                    */
-#define JSNOOP_FLAG_RST_MISALIGN  0x0008u  /* RSTn not on an MCU boundary                               */
+#define JSNOOP_FLAG_RST_MISALIGN  0x0008u  /* RSTn not on an MCU boundary (alone: followed the reference's way) */
 #define JSNOOP_FLAG_SHORT         0x0010u  /* entropy data ends before all MCUs are decoded             */
 #define JSNOOP_FLAG_TABLES        0x0020u  /* tables not expressible in the parallel path's LUT form    */
 #define JSNOOP_FLAG_MARKER        0x0040u  /* non-RST marker or FFFF inside the scan                    */
 #define JSNOOP_FLAG_NOSYNC        0x0080u  /* sub-sequence chain failed to converge                     */
-#define JSNOOP_FLAG_BAD_EDGE      0x0100u  /* no code matches within 64 bits of an interval end (with BAD_CODE) */
+#define JSNOOP_FLAG_BAD_EDGE      0x0100u  /* an anomaly whose outcome depends on the reader's look-ahead: mirror */
 #define JSNOOP_FLAG_FORCED        0x8000u  /* caller forced the exact path                              */
 
 /* ---- batch submit: N files -> N DIBs, all resident in HBM --------------------------

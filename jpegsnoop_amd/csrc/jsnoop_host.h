@@ -134,7 +134,7 @@ struct JsnoopBatch {
 };
 
 // flags that leave coefficients, planes and DIB of the parallel path reference-exact (bookkeeping differs: status words, warning counter, log)
-#define JS_FLAGS_PIXEL_EXACT (JSNOOP_FLAG_COEF_OVERFLOW | JSNOOP_FLAG_BAD_CODE)
+#define JS_FLAGS_PIXEL_EXACT (JSNOOP_FLAG_COEF_OVERFLOW | JSNOOP_FLAG_BAD_CODE | JSNOOP_FLAG_RST_MISALIGN)
 // ... of which the parallel side pass can also produce the bookkeeping (the others get theirs from the mirror's side-only pass)
 #define JS_FLAGS_SIDE_PARALLEL (JSNOOP_FLAG_COEF_OVERFLOW)
 int  js_clear_flags(JsnoopBatch* b);                              // flag arena: two words per image (flags, complement of the first anomalous block)

@@ -1784,6 +1784,23 @@ __device__ __forceinline__ uint32_t sym_lookup(const SubTabs& T, uint32_t win, u
     return e;
 }
 
+// The restart mark of MCU m: 0 = none, j + 1 = the DC predictors are cleared in front of block j of the MCU.  One byte per MCU, set by
+// compare-and-swap on its word (lanes of different sub-sequences may meet markers in neighbouring MCUs); false when the MCU already carries
+// a different mark (two markers inside one MCU: hostile, left to the mirror).
+__device__ __forceinline__ bool mark_reset(uint8_t* __restrict__ mcu_rst, uint32_t m, uint32_t v)
+{
+    uint32_t* w = reinterpret_cast<uint32_t*>(mcu_rst + (m & ~3u)); const uint32_t sh = (m & 3u) * 8u;      // (the arena is 16-byte aligned per image)
+    uint32_t old = *reinterpret_cast<volatile uint32_t*>(w);
+    for (;;) {
+        const uint32_t cur = (old >> sh) & 255u;
+        if (cur == v) return true;
+        if (cur != 0u) return false;
+        const uint32_t seen = atomicCAS(w, old, old | (v << sh));
+        if (seen == old) return true;
+        old = seen;
+    }
+}
+
 // What the reference sees as RSV_RST_TERM (:1167-1176) -- no code fits in what is left of the interval --
 // or a code that matches nothing.  Returns WS_OVER when the walk is over (end of the entropy data), WS_BAD_CODE when a code that matches
 // nothing ended the block the reference's way, else WS_GO_ON.
@@ -1798,7 +1815,7 @@ enum { WS_OVER = 0, WS_GO_ON = 1, WS_BAD_CODE = 2 };
 template <bool WRITE, int WL>
 __device__ __forceinline__ int walk_slow(const JsImage& im, const uint32_t* __restrict__ words, const uint32_t* __restrict__ st, uint32_t nseg,
                                        Cursor& cur, uint32_t len, uint32_t& seg, uint32_t& seg_end, uint32_t& c, uint32_t& k,
-                                       uint32_t blk, bool mark, uint8_t* __restrict__ mcu_rst, uint32_t& flags, uint32_t& anom)
+                                       uint32_t blk, bool mark, uint8_t* __restrict__ mcu_rst, uint32_t& flags, uint32_t& anom, bool spec = false)
 {
     const uint32_t remain = seg_end > cur.p ? seg_end - cur.p : 0u;
     if (len == 0 && remain >= 16) {
@@ -1809,12 +1826,19 @@ __device__ __forceinline__ int walk_slow(const JsImage& im, const uint32_t* __re
         return native ? WS_BAD_CODE : WS_GO_ON;
     }
     if (seg + 1 < nseg) {
+        // The reference's restart is marker-driven and happens INSIDE DecodeScanComp (:1644-1680): whatever is left of the interval is dropped,
+        // the three DC predictors are cleared, and the block in progress simply goes on with the new interval's bits -- coefficient index and
+        // position in the MCU are kept.  On an MCU boundary that is the well-formed case; anywhere else (a damaged interval that lost or gained
+        // blocks) the walks follow all the same: the reset is recorded for the block in progress (block-in-MCU index + 1 in the MCU's mark; the
+        // DC scan clears its sums in front of that block), and F_RST_MISALIGN then only stands for bookkeeping (messages).  Two resets inside one
+        // MCU, or two markers back to back (the reference meets the second one inside its retry and files the DC value under index 1): F_BAD_EDGE.
         if (WRITE) {
-            if (k != 0 || c != 0 || remain >= 8) { flags |= F_RST_MISALIGN; anom = min(anom, blk); }   // well-formed: < 8 pad bits, on an MCU boundary
-            if (mark && blk < im.total_blocks) mcu_rst[blk / im.blk_per_mcu] = 1;
+            if (k != 0 || c != 0 || remain >= 8) flags |= F_RST_MISALIGN;                       // well-formed: < 8 pad bits, on an MCU boundary
+            if (mark && blk < im.total_blocks && !mark_reset(mcu_rst, blk / im.blk_per_mcu, c + 1u)) { flags |= F_BAD_EDGE; anom = min(anom, blk); }
         }
-        seg++; const uint32_t np = seg_end; seg_end = st[seg + 1] * 8; c = 0; k = 0;
-        if (WRITE && seg_end == np && seg + 1 < nseg) { flags |= F_RST_MISALIGN; anom = min(anom, blk); }       // back-to-back RSTn
+        seg++; const uint32_t np = seg_end; seg_end = st[seg + 1] * 8;
+        if (spec) { c = 0; k = 0; }                              // a speculative walk (its exit state is only a guess): in a well-formed stream an MCU starts here
+        if (WRITE && seg_end == np && seg + 1 < nseg) { flags |= F_RST_MISALIGN | F_BAD_EDGE; anom = min(anom, blk); }       // back-to-back RSTn
         cur_init<WL>(cur, words, np);
         return WS_GO_ON;
     }
@@ -1836,7 +1860,7 @@ __device__ __forceinline__ int walk_slow(const JsImage& im, const uint32_t* __re
 template <int WL, bool MID = false>
 __device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, uint32_t a_ctab, const uint32_t* __restrict__ words, const uint32_t* __restrict__ st,
                                           uint32_t nseg, uint32_t total_bits, uint32_t own_end, uint32_t& p_io, uint32_t& s_io, uint32_t& nblk_out,
-                                          uint32_t mid_bits = 0, uint32_t* mid3 = nullptr)
+                                          uint32_t mid_bits = 0, uint32_t* mid3 = nullptr, bool spec = false)
 {
     uint32_t seg = ST_SEG(s_io), c = ST_C(s_io), k = ST_K(s_io), nblk = 0, fl = 0;
     if (p_io == P_END || (p_io >= total_bits && seg + 1 >= nseg)) { p_io = P_END; s_io = 0; nblk_out = 0; if (MID) { mid3[0] = P_END; mid3[1] = 0; mid3[2] = 0; } return; }
@@ -1883,7 +1907,7 @@ __device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, ui
                 const uint32_t e = sym_lookup(T, win, lrow, 0u);
                 const uint32_t len = (e >> 8) & 31u, run = (e >> 4) & 15u, size = e & 15u;
                 if (len == 0 || cur.p + len > seg_end) {
-                    const int ws = walk_slow<false, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, 0, false, nullptr, fl, fl);   // end of the data: p = P_END
+                    const int ws = walk_slow<false, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, 0, false, nullptr, fl, fl, spec);   // end of the data: p = P_END
                     if (ws == WS_BAD_CODE) { k = 0u; c = c + 1 == T.nb ? 0u : c + 1; nblk++; }                                        // the block ends with the bad code
                 } else {
                     cur_skip<WL>(cur, len + size);
@@ -2029,7 +2053,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
             uint32_t p = s_inp[u], s = s_ins[u], nblk = 0;
             const uint32_t own_end = min((iu + 1) * SUB_BITS, total_bits);
             if (!(p != P_END && p >= own_end))                   // else: owns no symbol, the state passes through
-                walk_sync<WL>(im, T, a_ctab, words, st, nseg, total_bits, own_end, p, s, nblk);
+                walk_sync<WL>(im, T, a_ctab, words, st, nseg, total_bits, own_end, p, s, nblk, 0u, nullptr, spec_pass && it == 0);
             if (p != s_outp[u] || s != s_outs[u]) { s_outp[u] = p; s_outs[u] = s; s_changed = 1; }
             s_nblk[u] = nblk;
         }
@@ -2116,7 +2140,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_cand_spec(const JsImage* __restr
     const bool in_data = i * SUB_BITS < total_bits;
     uint32_t p = in_data ? i * SUB_BITS : P_END, s = in_data ? ST_MAKE(find_interval(st, nseg, p / 8), i ? h : 0u, 0u) : 0u, nblk = 0;
     const uint32_t own_end = min((i + 1) * SUB_BITS, total_bits);
-    walk_sync<WL>(im, T, lds_addr(s_ctab), words, st, nseg, total_bits, own_end, p, s, nblk);
+    walk_sync<WL>(im, T, lds_addr(s_ctab), words, st, nseg, total_bits, own_end, p, s, nblk, 0u, nullptr, true);      // (speculative: the exit states are candidates)
     C.xp[h * n + g] = p; C.xs[h * n + g] = s;
 }
 
@@ -2917,12 +2941,16 @@ __device__ __forceinline__ void dc_scan_range(const JsImage& im, int16_t* __rest
     int any_reset = 0;
     for (uint32_t base = m_begin; base < m_end; base += DC_THREADS) {
         const uint32_t m = base + t; const bool valid = m < m_end;
+        // the MCU's restart mark: 0 = none, j + 1 = the predictors are cleared in front of its block j (a marker on the MCU boundary: 1;
+        // a marker the reference met inside the MCU -- a damaged interval -- : the block that was in progress, walk_slow)
+        const uint32_t rj = valid ? rf[m] : 0u;
         int v[NBMAX];
-        DcSeg own = { 0, 0, 0, valid && rf[m] ? 1 : 0 };
+        DcSeg own = { 0, 0, 0, rj ? 1 : 0 };                     // the MCU as a scan element: sums since its reset if it has one, else of all its blocks
         #pragma unroll
         for (uint32_t c = 0; c < NBMAX; c++) {
             v[c] = (valid && c < nb) ? (int)d[(size_t)m * nb + c] : 0;
-            if (c < n1) own.s0 += v[c]; else if (c < n2) own.s1 += v[c]; else own.s2 += v[c];
+            const int a = (rj && c + 1u < rj) ? 0 : v[c];        // in front of the reset: not part of what the MCU hands on
+            if (c < n1) own.s0 += a; else if (c < n2) own.s1 += a; else own.s2 += a;
         }
         DcSeg inc = own;                                         // inclusive scan over the lanes of the wave
         #pragma unroll
@@ -2934,12 +2962,15 @@ __device__ __forceinline__ void dc_scan_range(const JsImage& im, int16_t* __rest
         __syncthreads();
         DcSeg pre = carry, tot = carry;                          // what enters this wave / leaves the step
         for (uint32_t w = 0; w < DC_THREADS / 64; w++) { const DcSeg x = s_w[w]; if (w < wave) pre = dc_combine(pre, x); tot = dc_combine(tot, x); }
-        inc = dc_combine(pre, inc);
-        // sums entering this MCU: nothing after a reset, else the inclusive result minus the MCU's own contribution
-        int c0 = own.r ? 0 : inc.s0 - own.s0, c1 = own.r ? 0 : inc.s1 - own.s1, c2 = own.r ? 0 : inc.s2 - own.s2;
+        // sums entering this MCU: everything in front of it -- the wave's exclusive prefix behind what enters the wave
+        DcSeg exc; exc.s0 = __shfl_up(inc.s0, 1); exc.s1 = __shfl_up(inc.s1, 1); exc.s2 = __shfl_up(inc.s2, 1); exc.r = __shfl_up(inc.r, 1);
+        if (lane == 0) { exc.s0 = exc.s1 = exc.s2 = 0; exc.r = 0; }
+        const DcSeg in = dc_combine(pre, exc);
+        int c0 = in.s0, c1 = in.s1, c2 = in.s2;
         if (WRITE && valid) {
             #pragma unroll
             for (uint32_t c = 0; c < NBMAX; c++) if (c < nb) {
+                if (c + 1u == rj) { c0 = 0; c1 = 0; c2 = 0; }
                 int16_t o;
                 if (c < n1) { c0 += v[c]; o = (int16_t)c0; } else if (c < n2) { c1 += v[c]; o = (int16_t)c1; } else { c2 += v[c]; o = (int16_t)c2; }
                 d[(size_t)m * nb + c] = o;
@@ -3153,7 +3184,7 @@ __device__ uint32_t mirror_to_mcu_top(const JsImage& im, const JsTableSet* __res
     for (;; m0--) {
         if (m0 == 0) { ex_restart_scan_buf(r, im.scan_start, false); ex_topup(r); break; }
         const uint32_t p = mcu_pos[m0];
-        if (mcu_rst[im.mcu_off + m0]) {                             // first MCU of an interval: the RSTn in front of it has been handled (:1644-1680)
+        if (mcu_rst[im.mcu_off + m0] == 1u) {                       // first MCU of an interval: the RSTn in front of it has been handled (:1644-1680); (a mark > 1: the marker lies INSIDE the MCU, the reader meets it itself)
             const uint32_t u1 = (p + 7) >> 3;                       //   fewer than 8 pad bits, else the parallel path had flagged the image
             rst_before = find_interval(st, nseg, min(u1, total_bytes ? total_bytes - 1 : 0));
             ex_restart_scan_buf(r, raw_of_compacted(im, raw, us_out, us_threads, u1), true); ex_topup(r);
