@@ -336,21 +336,23 @@ __device__ __forceinline__ int lr_huff(LReader& r, const JsProgTable& t, bool ta
 __device__ constexpr uint8_t kZzNat[64] = {
      0, 1, 8,16, 9, 2, 3,10, 17,24,32,25,18,11, 4, 5, 12,19,26,33,40,48,41,34, 27,20,13, 6, 7,14,21,28,
     35,42,49,56,57,50,43,36, 29,22,15,23,30,37,44,51, 58,59,52,45,38,31,39,46, 53,60,61,54,47,55,62,63 };
-// History of a block for a refinement scan, one bit per zig-zag position: coefficient non-zero / negative.
-__device__ __forceinline__ void history_masks(const int16_t* __restrict__ gblk, uint64_t& nz, uint64_t& neg)
+// History of a block for a refinement scan, one bit per zig-zag position: coefficient non-zero / negative / bit `al` already set (a
+// correction bit leaves such a coefficient alone: libjpeg's guard "(*thiscoef & p1) == 0", jdphuff.c decode_mcu_AC_refine -- a
+// well-formed stream never sets the bit, a hostile one may, and the add would otherwise carry into the neighbouring coefficient).
+__device__ __forceinline__ void history_masks(const int16_t* __restrict__ gblk, uint32_t al, uint64_t& nz, uint64_t& neg, uint64_t& set)
 {
     uint32_t w[32];
     #pragma unroll
     for (int q = 0; q < 8; q++) { const uint4 x = reinterpret_cast<const uint4*>(gblk)[q]; w[4 * q] = x.x; w[4 * q + 1] = x.y; w[4 * q + 2] = x.z; w[4 * q + 3] = x.w; }
-    uint32_t nzl = 0, nzh = 0, ngl = 0, ngh = 0;
+    uint32_t nzl = 0, nzh = 0, ngl = 0, ngh = 0, stl = 0, sth = 0;
     #pragma unroll
     for (int k = 0; k < 64; k++) {
         const int nat = kZzNat[k];
         const uint32_t c = (nat & 1) ? w[nat >> 1] >> 16 : w[nat >> 1] & 0xFFFFu;
-        const uint32_t one = min(c, 1u), sg = c >> 15;
-        if (k < 32) { nzl |= one << k; ngl |= sg << k; } else { nzh |= one << (k - 32); ngh |= sg << (k - 32); }
+        const uint32_t one = min(c, 1u), sg = c >> 15, pb = (c >> al) & 1u;
+        if (k < 32) { nzl |= one << k; ngl |= sg << k; stl |= pb << k; } else { nzh |= one << (k - 32); ngh |= sg << (k - 32); sth |= pb << (k - 32); }
     }
-    nz = ((uint64_t)nzh << 32) | nzl; neg = ((uint64_t)ngh << 32) | ngl;
+    nz = ((uint64_t)nzh << 32) | nzl; neg = ((uint64_t)ngh << 32) | ngl; set = ((uint64_t)sth << 32) | stl;
 }
 
 __global__ void __launch_bounds__(PL_THREADS) k_prog_scan_lanes(const JsImage* __restrict__ imgs, const JsProgFrame* __restrict__ frames, const JsProgScan* __restrict__ scans,
@@ -457,8 +459,8 @@ __global__ void __launch_bounds__(PL_THREADS) k_prog_scan_lanes(const JsImage* _
             const bool inb = j < nu;
             const uint32_t u = u0 + (inb ? j : 0u);
             int16_t* gblk = cbase + block_row(im, fr, comp, u % NBX, u / NBX) * 64;
-            uint64_t nz = 0, neg = 0;
-            if (__any(inb)) { if (inb) history_masks(gblk, nz, neg); }
+            uint64_t nz = 0, neg = 0, p1set = 0;
+            if (__any(inb)) { if (inb) history_masks(gblk, (uint32_t)al, nz, neg, p1set); }
             uint32_t* gw = reinterpret_cast<uint32_t*>(gblk);
             bool adv = false, has_new = false; int newv = 0; uint32_t run = 0;
             for (uint32_t k = SS; k <= SE; k++) {                // k is wave-uniform
@@ -482,7 +484,7 @@ __global__ void __launch_bounds__(PL_THREADS) k_prog_scan_lanes(const JsImage* _
                     const bool hist = (nz >> k) & 1ull;
                     int delta = 0; bool was_zero = false;
                     if (hist) {                                  // a coefficient with history: one correction bit
-                        if (lr_bits(r, 1)) delta = ((neg >> k) & 1ull) ? m1 : p1;
+                        if (lr_bits(r, 1) && !((p1set >> k) & 1ull)) delta = ((neg >> k) & 1ull) ? m1 : p1;
                     } else if (!eobrun && adv) {                 // a zero: counts towards the run, or takes the new value
                         if (run == 0) { if (has_new) { delta = newv; was_zero = true; } adv = false; }
                         else run--;

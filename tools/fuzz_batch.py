@@ -13,13 +13,13 @@ orc = H.oracle_backend()
 B = F.bases(H)
 bad = 0; total = 0
 for rnd in range(12):
-    os.environ["JSNOOP_SUB_WL"] = "7" if rnd % 2 else "5"
     files = []
     while len(files) < 24:
         data, q, mode = F.mutate(H, rng, B[int(rng.integers(len(B)))])
         if mode <= 5: files.append(data)                      # byte-level damage only: add_jpeg parses the header itself
         elif rng.integers(3) == 0: files.append(B[int(rng.integers(len(B)))])
     batch = J.JpegBatch(want_planes=True); idx = []
+    batch.set_tuning(sub_wl=7 if rnd % 2 else 5)
     for f in files:
         try: idx.append(batch.add_jpeg(f))
         except Exception: idx.append(None)                        # header no longer walkable
