@@ -243,13 +243,16 @@ def extras_single_gpu(J, H, orc, np):
     ws = []
     for f in fs:
         H.drive(orc, f); ws.append(J.dib_checksum_numpy(orc.dib()))
-    for nsm in (1, 4, 16):
+    for nsm in (1, 4, 16, 64, 128):                               # (64 and 128: the sixteen pictures four / eight times over, every one with its own bytes)
         sb = J.JpegBatch()
-        for f in fs[:nsm]:
+        for f in fs[:min(nsm, 16)]:
             sb.add_jpeg(f)
+        if nsm > 16:
+            sb.tile(nsm)
         sb.upload(); sb.decode(); sb.sync()
         mss, sts = sb.decode_timed(10)
-        small[str(nsm)] = {"ms": round(mss, 4), "mpix_per_s": round(nsm * 1920 * 1080 / mss / 1e3, 1), "bit_exact": bool(all(int(a) == b for a, b in zip(sb.dib_checksums(), ws[:nsm]))),
+        tn = sb.tuning()
+        small[str(nsm)] = {"ms": round(mss, 4), "mpix_per_s": round(nsm * 1920 * 1080 / mss / 1e3, 1), "bit_exact": bool(all(int(a) == ws[i % 16] for i, a in enumerate(sb.dib_checksums()))),
                            "sync_ms": round(sts["sync"], 4)}
         sb.close()
     extra["small_jobs_1080p"] = small

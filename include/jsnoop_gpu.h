@@ -225,10 +225,10 @@ int          jsnoop_batch_split_parts(const JsnoopBatch*);              /* what 
  *      value out of range); jsnoop_set_tuning does the same for the private batch behind a single-image decoder.                      */
 typedef struct JsnoopTuning {
     uint32_t struct_size;     /* sizeof(JsnoopTuning) of the caller (forward compatibility)                                          */
-    int32_t  sub_wl;          /* log2(32-bit words) of a sub-sequence: 4..8 = 64 B .. 1 KiB; 0 = by job size (4 / 5 / 7)              */
+    int32_t  sub_wl;          /* log2(32-bit words) of a sub-sequence: 4..8 = 64 B .. 1 KiB; 0 = by job size (4 / 6 / 7)              */
     int32_t  cand_rounds;     /* synchronisation form: -1 = rounds of k_sync only, n > 0 = candidates with at most n walk rounds (<= 64),
                                  0 = automatic (candidates with 16 rounds while the job is small enough, see cand_max_walks)          */
-    uint64_t cand_max_walks;  /* largest job (64-byte pieces x blocks per MCU) that synchronises by candidates; 0 = 2 500 000         */
+    uint64_t cand_max_walks;  /* largest job (64-byte pieces x blocks per MCU) that synchronises by candidates; 0 = 4 500 000         */
     int32_t  sync_launches;   /* launches of k_sync in the classic form; 0 = 2                                                        */
     int32_t  write_lanes;     /* lanes per sub-sequence in the write pass of the smallest jobs: 1, 2; 0 = automatic (2 up to 40 960 pieces) */
     int32_t  split;           /* as jsnoop_batch_set_split: 0 automatic, 1 one stream, 2 two streams                                  */

@@ -383,12 +383,12 @@ int JsnoopBatch::upload()
     if (tune.mcus_per_wave > 0) mcus_per_wave = (uint32_t)tune.mcus_per_wave;
     // sub-sequence length: long (512 B) when the batch still yields plenty of lanes, short (128 B, 64 B) for small jobs
     uint64_t scan_total = 0; for (const JsImage& im : imgs) scan_total += im.scan_len;
-    sub_wl = scan_total >= (96ull << 20) ? 7 : (scan_total < (4ull << 20) ? 4 : 5);    // (a single image / a handful: 64-byte pieces give the write pass more lanes)
+    sub_wl = scan_total >= (96ull << 20) ? 7 : (scan_total < (4ull << 20) ? 4 : 6);    // (a single image / a handful: 64-byte pieces give the write pass more lanes; 256-byte pieces between the candidate form and the large batches: 128 x 1080p 2.45 against 2.70 ms with 128-byte pieces)
     // Candidate synchronisation (k_cand_*) wants 64-byte pieces and one walk per piece and block of the MCU.  It beats the rounds of k_sync far beyond
     // what the chip holds at once (~500 k lanes): N x 1080p 4:2:0, ms per decode, candidates | rounds: 1: 0.30 | 0.80, 4: 0.37 | 0.83, 8: 0.45 | 0.95,
     // 16: 0.64 | 1.09, 32: 1.04 | 1.31, 48: 1.44 | 1.58 (2.6 M walks); the two meet near 64 images.
     uint32_t max_blk = 0; for (const JsImage& im : imgs) max_blk = std::max(max_blk, im.blk_per_mcu);
-    const uint64_t cand_lanes = tune.cand_max_walks ? tune.cand_max_walks : 2500000;
+    const uint64_t cand_lanes = tune.cand_max_walks ? tune.cand_max_walks : 4500000;     // (64 x 1080p = 3.6 M walks: 1.59 ms by candidates, 1.77 by rounds; 96 images: 2.21 against 2.12)
     const int cand_want = tune.cand_rounds == 0 ? 16 : tune.cand_rounds;
     const bool cand_fits = cand_want >= 0 && max_blk >= 1 && max_blk <= JS_CAND_MAX_BLK && (scan_total / 64 + 64 * n) * max_blk <= cand_lanes;
     if (cand_fits) sub_wl = 4;
