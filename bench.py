@@ -251,7 +251,6 @@ def extras_single_gpu(J, H, orc, np):
             sb.tile(nsm)
         sb.upload(); sb.decode(); sb.sync()
         mss, sts = sb.decode_timed(10)
-        tn = sb.tuning()
         small[str(nsm)] = {"ms": round(mss, 4), "mpix_per_s": round(nsm * 1920 * 1080 / mss / 1e3, 1), "bit_exact": bool(all(int(a) == ws[i % 16] for i, a in enumerate(sb.dib_checksums()))),
                            "sync_ms": round(sts["sync"], 4)}
         sb.close()
@@ -282,6 +281,21 @@ def extras_single_gpu(J, H, orc, np):
                                                       "bit_exact_vs_baseline_encoding": ok5b, "speedup_vs_single_call": round(ms5 / (ms5b / nb5), 1),
                                                       "stages_ms": {"scans": round(st5b["write"], 3), "finalize": round(st5b["dcscan"], 3), "idct_color": round(st5b["idct_color"], 3)}}
         p5.close()
+    # ... and as most progressive files in the wild come: no restart markers at all (libjpeg-turbo's file, tests/golden/pillow/: the baseline
+    # encoding of the same picture is the oracle's input).  Every scan is ONE interval: the scan kinds decode on one lane / one wave each.
+    try:
+        pdir = os.path.join(ROOT, "tests", "golden", "pillow")
+        pprog = open(os.path.join(pdir, "p422_nodri_1920x1080_prog.jpg"), "rb").read(); pbase = open(os.path.join(pdir, "p422_nodri_1920x1080_base.jpg"), "rb").read()
+        H.drive(orc, pbase)
+        decn = J.CimgDecode()
+        nscn = decn.DecodeProgressive(pprog)
+        okn = bool(np.array_equal(decn.GetBitmapPtr()[-1080:, :1920], orc.dib()[-1080:, :1920]))
+        tn0 = time.perf_counter(); decn.DecodeProgressive(pprog); msn = (time.perf_counter() - tn0) * 1e3
+        extra["config5_progressive_no_rst"] = {"scans": nscn, "ms_end_to_end": round(msn, 2), "mpix_per_s": round(1920 * 1080 / msn / 1e3, 2), "bit_exact_vs_libjpeg_baseline_encoding": okn,
+                                               "note": "libjpeg-turbo progressive 1920x1080 4:2:2 without DRI: restart intervals are the parallel grain of the progressive path, a scan without markers is one interval"}
+        decn.close()
+    except Exception as e:
+        extra["config5_progressive_no_rst"] = {"error": repr(e)}
     # damaged files (JPEGsnoop's daily input): one 1080p file each, decode + sync of a resident batch of one, DIB checked against the oracle.
     # "flip": the scan bit flips of tools/corrupt_timing.py that leave a trace (coefficient-index overflow); "cut": truncated at half its
     # scan (the rest decodes as the zero bytes CwindowBuf::Buf returns past the end); "marker": two bytes overwritten by a stray marker

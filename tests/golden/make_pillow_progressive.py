@@ -27,6 +27,7 @@ CASES = [
     dict(name="p422_rstblk_112x64", w=112, h=64, sub="4:2:2", q=50, restart_blocks=3),
     dict(name="p420_q100_64x48", w=64, h=48, sub="4:2:0", q=100),
     dict(name="p422_rst_1920x1080", w=1920, h=1080, sub="4:2:2", q=80, restart_rows=1, noise=6),   # BASELINE config 5's shape, written by libjpeg-turbo
+    dict(name="p422_nodri_1920x1080", w=1920, h=1080, sub="4:2:2", q=80, noise=6),                  # ... and as most progressive files in the wild come: no restart markers
 ]
 
 
