@@ -157,6 +157,9 @@ RATE_KERNEL32(k_term_dpp,     R4("v_add_u32_dpp %4, %9, %11" DPPB "\n\tds_read_b
 RATE_KERNEL64(k_pk_add_f32,   BODY8SELF("v_pk_add_f32", "%8, ", ""))
 RATE_KERNEL64(k_pk_mul_f32,   BODY8SELF("v_pk_mul_f32", "%8, ", ""))
 RATE_KERNEL64(k_pk_fma_f32,   BODY8SELF("v_pk_fma_f32", "%8, %9, ", ""))
+// 64-bit DPP move (gfx90a+: row_newbcast only): does it broadcast two dwords for the price of one v_mov_b32_dpp?  And ds_read_b128.
+RATE_KERNEL64(k_mov_b64_dpp,  BODY8("v_mov_b64_dpp", "%8" DPPB))
+RATE_KERNEL64(k_pk_mul_opsel, BODY8SELF("v_pk_mul_f32", "%8, ", " op_sel_hi:[1,0]"))
 
 // ---- VGPR-index mode: 64 registers v[64:127] hold a table, the row comes from an SGPR through M0 -------------------
 // (a) function: acc = sum over a pseudo-random row sequence of c * T[row], against the same sum formed from LDS
@@ -221,7 +224,7 @@ int main()
         { "v_add_f32", k_add_f32, 32, "" }, { "v_mul_f32", k_mul_f32, 32, "" }, { "v_fma_f32", k_fma_f32, 32, "" }, { "v_fma_f32 x,1.0,acc", k_fma_one, 32, "" },
         { "v_mul_f32 sgpr src", k_mul_sgpr, 32, "" }, { "v_mul_f32 inline const", k_mul_inl, 32, "" }, { "v_mul_f32 literal", k_mul_lit, 32, "" },
         { "v_min_f32", k_min_f32, 32, "" }, { "v_max_f32", k_max_f32, 32, "" }, { "v_floor_f32", k_floor_f32, 32, "" }, { "v_trunc_f32", k_trunc_f32, 32, "" },
-        { "v_pk_add_f32", k_pk_add_f32, 32, "2 flops/lane" }, { "v_pk_mul_f32", k_pk_mul_f32, 32, "2 flops/lane" }, { "v_pk_fma_f32", k_pk_fma_f32, 32, "4 flops/lane" },
+        { "v_mov_b64_dpp row_newbcast", k_mov_b64_dpp, 32, "two dwords per lane" }, { "v_pk_mul_f32 op_sel_hi:[1,0]", k_pk_mul_opsel, 32, "both products with src1.lo" }, { "v_pk_add_f32", k_pk_add_f32, 32, "2 flops/lane" }, { "v_pk_mul_f32", k_pk_mul_f32, 32, "2 flops/lane" }, { "v_pk_fma_f32", k_pk_fma_f32, 32, "4 flops/lane" },
         { "v_mul_f32_dpp row_newbcast", k_mul_dpp, 32, "" }, { "v_add_u32_dpp row_newbcast", k_addu_dpp, 32, "" }, { "v_mov_b32_dpp row_newbcast", k_mov_dpp, 32, "" },
         { "v_mov_b32_dpp row_shr:1", k_mov_dpp_shr, 32, "" }, { "v_add_u32_sdwa", k_sdwa, 32, "" },
         { "v_mov_b32", k_mov_b32, 32, "" }, { "v_add_u32", k_add_u32, 32, "" }, { "v_add_u32 inline const", k_add_inl, 32, "" }, { "v_add_u32 literal", k_add_lit, 32, "" }, { "v_sub_u32", k_sub_u32, 32, "" },
