@@ -447,6 +447,9 @@ def main():
     pixels = batch.pixels()
     alg_bytes = batch.algorithmic_bytes()
 
+    # The decode form is the library's default (jsnoop_batch_set_split(0): two halves of a batch this size on two streams) unless --no-split.
+    if not stub:
+        batch.set_split(1 if args.no_split else 0)
     # ---- parity gate + cpu_baseline sample (the oracle is only the checker / the baseline here) ----
     batch.decode(); batch.sync()
     sums = batch.dib_checksums()
@@ -502,9 +505,6 @@ def main():
             ref.close()
 
     # ---- timed region -----------------------------------------------------------------------
-    # The decode form is the library's default (jsnoop_batch_set_split(0): two halves of a batch this size on two streams) unless --no-split.
-    if not stub:
-        batch.set_split(1 if args.no_split else 0)
     for _ in range(args.warmup):
         batch.decode()
     batch.sync()

@@ -208,7 +208,8 @@ public:
     int      BatchAddFile(const uint8_t* pFile, size_t nLen) { return jsnoop_batch_add_jpeg(m_b, pFile, nLen); }
     unsigned GetBatchFileCount() const { return (unsigned)jsnoop_batch_count(m_b); }                                                             // :680
     bool     DoBatchProcess() { return jsnoop_batch_upload(m_b) == 0 && jsnoop_batch_decode(m_b) == 0 && jsnoop_batch_sync(m_b) == 0; }
-    bool     BatchSetSplit(int nParts) { return jsnoop_batch_set_split(m_b, nParts) == 0; }   // 2: the halves of the batch on two streams side by side (same results)
+    bool     BatchSetSplit(int nParts) { return jsnoop_batch_set_split(m_b, nParts) == 0; }   // 0: the library decides (default), 1: one stream, 2: the halves of the batch on two streams side by side (same results)
+    bool     BatchSetTuning(const JsnoopTuning& t) { return jsnoop_batch_set_tuning(m_b, &t) == 0; }   // how the batch decodes, never what it produces (jsnoop_tuning_defaults fills a struct)
     const void* BatchBitmapDevicePtr(int nFileInd) const { return jsnoop_batch_dib_dev(m_b, nFileInd); }
     bool     BatchGetBitmap(int nFileInd, std::vector<uint8_t>& dib, unsigned& nX, unsigned& nY)
     {

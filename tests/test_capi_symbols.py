@@ -69,3 +69,31 @@ def test_product_does_not_link_the_oracle(lib):
             if f.endswith((".py", ".cpp", ".h", ".hip")):
                 txt = open(os.path.join(root, f), errors="replace").read()
                 assert "oracle_imgdecode" not in txt and "liboracle" not in txt and "from oracle" not in txt, f
+
+
+def test_tuning_defaults_come_from_the_environment_once_and_nothing_on_the_decode_path_reads_it(lib):
+    """JsnoopTuning (include/jsnoop_gpu.h): the environment variables of tools/README.md only preset the struct jsnoop_tuning_defaults
+    returns -- per process, read once; the sources of the library hold no getenv outside that one function."""
+    import ctypes as C
+    import subprocess
+    import sys
+    from jpegsnoop_amd import capi
+    t = capi.Tuning(); lib.jsnoop_tuning_defaults(C.byref(t))
+    assert t.struct_size == C.sizeof(capi.Tuning)
+    child = ("import sys, ctypes as C; sys.path.insert(0, %r); from jpegsnoop_amd import capi; lib = capi.load(require_device=False); "
+             "t = capi.Tuning(); lib.jsnoop_tuning_defaults(C.byref(t)); "
+             "print(t.sub_wl, t.cand_rounds, t.cand_max_walks, t.sync_launches, t.write_lanes, t.split, t.mcus_per_wave, t.pg_lanes, t.cross_checks, t.debug)") % ROOT
+    env = {k: v for k, v in os.environ.items() if not k.startswith("JSNOOP_")}
+    out = subprocess.check_output([sys.executable, "-c", child], env=env).decode().split()
+    assert [int(x) for x in out] == [0] * 10                                        # no variable set: every field automatic
+    env.update(JSNOOP_SUB_WL="6", JSNOOP_CAND="0", JSNOOP_CAND_LANES="123", JSNOOP_SYNC_LAUNCHES="3", JSNOOP_NO_HALF="1", JSNOOP_SPLIT="2", JSNOOP_MPW="16",
+               JSNOOP_PG_LANES="64", JSNOOP_WRITE_V1="1", JSNOOP_SIDE_EXACT="1", JSNOOP_DEBUG_CAND="2", JSNOOP_DEBUG_TIMING="1")
+    out = subprocess.check_output([sys.executable, "-c", child], env=env).decode().split()
+    assert [int(x) for x in out] == [6, -1, 123, 3, 1, 2, 16, 64, capi.XC_WRITE_V1 | capi.XC_SIDE_EXACT, capi.DBG_CAND | capi.DBG_CAND_LINKS | capi.DBG_TIMING]
+    hits = []
+    for f in os.listdir(os.path.join(ROOT, "jpegsnoop_amd", "csrc")):
+        if f.endswith((".cpp", ".hip", ".h")):
+            for n, line in enumerate(open(os.path.join(ROOT, "jpegsnoop_amd", "csrc", f), errors="replace"), 1):
+                if "getenv(" in line:
+                    hits.append((f, n))
+    assert hits and all(f == "jsnoop_host.cpp" for f, _ in hits) and len(hits) == 2, hits       # the two lambdas of js_env_tuning

@@ -1,0 +1,18 @@
+#!/bin/bash
+# usage (on the GPU box): tools/final_round.sh <tag>  -- the evidence of a round in one call: kernel stats + PMC passes (one-stream launches),
+# the default bench line, damaged-file timing, small jobs, call latency; everything under gpurun_out/<tag>/
+TAG=${1:-rXX_final}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+bash tools/profile_round.sh $TAG > $OUT/profile_round.log 2>&1
+python bench.py 2> $OUT/bench_default.err | tail -1 > $OUT/bench_default.json
+timeout 400 python tools/fuzz_1080p_timing.py 1000 17 > $OUT/fuzz_1080p_timing.log 2>&1; cp gpurun_out/fuzz_1080p_timing.json $OUT/ 2>/dev/null
+python tools/small_jobs.py 1 2 4 8 16 32 48 64 96 128 256 2>/dev/null | tail -1 > $OUT/small_jobs.json
+python tools/call_latency.py 2>/dev/null | tail -1 > $OUT/call_latency.json
+python - <<PY
+import json
+d = json.load(open("$OUT/bench_default.json"))
+print("default line:", d["value"], d["unit"], d["ms_per_step"], "ms/step", d["bit_exact"], d["config"]["decode_form"], d["roofline"]["frac"], d["roofline"]["stages_ms"])
+PY
+tail -12 $OUT/fuzz_1080p_timing.log
+head -12 $OUT/kernel_stats.csv | cut -c1-200
