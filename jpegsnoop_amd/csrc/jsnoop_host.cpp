@@ -466,7 +466,9 @@ int JsnoopBatch::decode(bool timed)
         HIP_TRY(hipMemsetAsync(dev.coef, 0, total_blocks * 128, stream));
         HIP_TRY(hipMemsetAsync(dev.dccum, 0, total_blocks * 2, stream));
     }
-    js_launch_clear3(stream, dev.side, side_words * 4, dev.mcu_rst, mcu_bytes, dev.flags, (size_t)n * 8);   // (one launch; all three arenas are allocated with 64 bytes of slack)
+    // (one launch; all three arenas are allocated with 64 bytes of slack.  The parallel path's decode touches the status words of the side blocks only:
+    //  histogram and maps are the side pass's, which clears them itself -- 0.33 MB per 1080p image that need not be written per decode)
+    js_launch_clear3(stream, dev.side, side_words * 4, dev.mcu_rst, mcu_bytes, dev.flags, (size_t)n * 8, parallel_ok ? dev.imgs : nullptr, n);
     if (event_words) HIP_TRY(hipMemsetAsync(dev.events, 0, event_words * 4, stream));
     if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
     last_timed_split = false;

@@ -1411,19 +1411,25 @@ void js_launch_clip_order(hipStream_t st, const JsImage* imgs, uint32_t img, con
 void js_launch_tiff_pack(hipStream_t st, const JsImage* imgs, uint32_t img, const uint8_t* dib, const int16_t* planes, int mode, uint8_t* out)
 { hipLaunchKernelGGL(k_tiff_pack, dim3(1024), dim3(256), 0, st, imgs, img, dib, planes, mode, out); }
 // the three arenas a decode starts from zero with (side outputs, MCU restart marks, flag words) in one launch instead of three fills
-__global__ void __launch_bounds__(256) k_clear3(uint4* __restrict__ a, size_t na, uint4* __restrict__ b, size_t nb, uint4* __restrict__ c, size_t nc)
+__global__ void __launch_bounds__(256) k_clear3(uint4* __restrict__ a, size_t na, uint4* __restrict__ b, size_t nb, uint4* __restrict__ c, size_t nc,
+                                                const JsImage* __restrict__ imgs, uint32_t nimg, uint32_t* __restrict__ side)
 {
     const uint4 z = make_uint4(0, 0, 0, 0);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < na + nb + nc; i += (size_t)gridDim.x * 256) {
-        if (i < na) a[i] = z; else if (i < na + nb) b[i - na] = z; else c[i - na - nb] = z;
+    // imgs: only the sixteen status words of every image's side block (what the decode itself reads or accumulates into: scan length, interval count,
+    // brightest pixel, luminance sum) -- histogram and maps belong to the side pass, which clears them itself; na == 0 then
+    const size_t ns = imgs ? (size_t)nimg * (JS_SIDE_HISTO / 4) : 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < ns + na + nb + nc; i += (size_t)gridDim.x * 256) {
+        if (i < ns) reinterpret_cast<uint4*>(side + imgs[i / (JS_SIDE_HISTO / 4)].side_off)[i % (JS_SIDE_HISTO / 4)] = z;
+        else if (i < ns + na) a[i - ns] = z; else if (i < ns + na + nb) b[i - ns - na] = z; else c[i - ns - na - nb] = z;
     }
 }
-void js_launch_clear3(hipStream_t st, void* a, size_t a_bytes, void* b, size_t b_bytes, void* c, size_t c_bytes)   // sizes rounded UP to 16 bytes: the arenas have the slack
+void js_launch_clear3(hipStream_t st, void* a, size_t a_bytes, void* b, size_t b_bytes, void* c, size_t c_bytes, const JsImage* imgs, uint32_t nimg)   // sizes rounded UP to 16 bytes: the arenas have the slack
 {
-    const size_t na = (a_bytes + 15) / 16, nb = (b_bytes + 15) / 16, nc = (c_bytes + 15) / 16, tot = na + nb + nc;
+    // imgs != nullptr: of the side arena `a` only every image's status words are cleared (a decode of the parallel path); else all of it
+    const size_t na = imgs ? 0 : (a_bytes + 15) / 16, nb = (b_bytes + 15) / 16, nc = (c_bytes + 15) / 16, tot = na + nb + nc + (imgs ? (size_t)nimg * (JS_SIDE_HISTO / 4) : 0);
     if (!tot) return;
     const uint32_t wgs = (uint32_t)std::min<size_t>(2048, (tot + 1023) / 1024);
-    hipLaunchKernelGGL(k_clear3, dim3(wgs), dim3(256), 0, st, (uint4*)a, na, (uint4*)b, nb, (uint4*)c, nc);
+    hipLaunchKernelGGL(k_clear3, dim3(wgs), dim3(256), 0, st, (uint4*)a, na, (uint4*)b, nb, (uint4*)c, nc, imgs, nimg, (uint32_t*)a);
 }
 void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, const uint8_t* dib, unsigned long long* sums)
 {

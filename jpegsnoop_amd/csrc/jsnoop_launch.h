@@ -11,7 +11,7 @@ int  js_launch_idct_color(hipStream_t st, const JsImage* imgs, const uint32_t* w
                           int layout /* 0 = mixed; 1..4 = every image has the fast layout with chroma expansion (2,2) / (2,1) / (1,2) / (1,1) */,
                           unsigned long long* wg_part /* null, or 2 words per workgroup (indexed like wg_base): brightest-pixel / luminance records folded by a second kernel */);
 void js_launch_idct_probe(hipStream_t st, const float* lut_t, const int16_t* coef64, float* out64);
-void js_launch_clear3(hipStream_t st, void* a, size_t a_bytes, void* b, size_t b_bytes, void* c, size_t c_bytes);   // three arenas to zero in one launch (sizes rounded up to 16 bytes)
+void js_launch_clear3(hipStream_t st, void* a, size_t a_bytes, void* b, size_t b_bytes, void* c, size_t c_bytes, const JsImage* imgs = nullptr, uint32_t nimg = 0);   // three arenas to zero in one launch (sizes rounded up to 16 bytes)
 void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, const uint8_t* dib, unsigned long long* sums);
 void js_launch_color_probe(hipStream_t st, int y, int cb, int cr, uint32_t* out);
 #define JS_STATS_WORDS 2482          /* public layout, include/jsnoop_gpu.h JSNOOP_STATS_WORDS */
