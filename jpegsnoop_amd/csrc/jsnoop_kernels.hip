@@ -1464,7 +1464,10 @@ void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, 
 // sub-sequence length is a per-batch choice: WL = log2(32-bit words per sub-sequence) = 4 (64 B, a handful of images), 5 (128 B) or 7 (512 B, large batches);
 // 6 and 8 are instantiated for experiments (JSNOOP_SUB_WL)
 #define SUB_BITS   (32u << WL)
-#define SYNC_SPEC_TAIL (WL >= 7 ? 2048u : 1024u)   // bits at the end of a sub-sequence the first (speculative) walk covers
+#ifndef JS_SPEC_TAIL7
+#define JS_SPEC_TAIL7 1536u
+#endif
+#define SYNC_SPEC_TAIL (WL >= 7 ? JS_SPEC_TAIL7 : 1024u)   // bits at the end of a sub-sequence the first (speculative) walk covers
 
 // flag arena: two words per image -- [2 * img] the F_* bits, [2 * img + 1] the first block (decode order) at which something other than a
 // coefficient-index overflow was seen (stored complemented; 0 = none): everything before it is what the reference decodes, and the exact-mirror
