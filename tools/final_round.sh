@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box): tools/final_round.sh <tag>  -- the evidence of a round in one call: kernel stats + PMC passes (one-stream launches),
-# the default bench line, damaged-file timing, small jobs, call latency; everything under gpurun_out/<tag>/
+# the default bench line, damaged-file timing, small jobs, call latency, a 5000-case parity fuzz, PMC passes of a progressive batch; everything under gpurun_out/<tag>/
 TAG=${1:-rXX_final}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
@@ -9,6 +9,8 @@ python bench.py 2> $OUT/bench_default.err | tail -1 > $OUT/bench_default.json
 timeout 400 python tools/fuzz_1080p_timing.py 1000 17 > $OUT/fuzz_1080p_timing.log 2>&1; cp gpurun_out/fuzz_1080p_timing.json $OUT/ 2>/dev/null
 python tools/small_jobs.py 1 2 4 8 16 32 48 64 96 128 256 2>/dev/null | tail -1 > $OUT/small_jobs.json
 python tools/call_latency.py 2>/dev/null | tail -1 > $OUT/call_latency.json
+timeout 420 python tools/fuzz_gpu.py ${FUZZ_CASES:-5000} 4242 > $OUT/fuzz_gpu.log 2>&1; tail -2 $OUT/fuzz_gpu.log
+bash tools/pmc_progressive.sh $TAG/prog 64 > $OUT/pmc_progressive.log 2>&1; python tools/prog_batch.py 64 3 2>/dev/null | tail -1 > $OUT/prog_batch64.json
 python - <<PY
 import json
 d = json.load(open("$OUT/bench_default.json"))
