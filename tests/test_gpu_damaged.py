@@ -191,3 +191,30 @@ def test_overflow_only_files_get_their_bookkeeping_from_the_parallel_side_pass(h
         gpu.set_options(); oracle.set_options()
         if ref is not None:
             ref.set_options(); ref.close()
+
+
+@pytest.mark.parametrize("tuning", [dict(split=2), dict(split=2, sub_wl=7, cand_rounds=-1), dict(split=1, sub_wl=7, cand_rounds=-1)])
+def test_damaged_files_inside_a_batch_on_two_streams(harness, oracle, tuning):
+    """Damaged and healthy files mixed in one batch, decoded as two halves on two streams (the default form of a large batch) and with the 512-byte
+    sub-sequences of large batches: flags are per image, the repair passes (tail take-over, second attempt, resumed chain) run behind the join of
+    the streams -- every DIB is the oracle's, the healthy neighbours of a damaged file stay on the parallel path with no flag."""
+    import jpegsnoop_amd as J
+    base = [harness.synth_jpeg(width=640, height=480, seed=31), harness.synth_jpeg(width=800, height=600, hs=2, vs=1, restart_interval=25, seed=32),
+            harness.synth_jpeg(width=512, height=384, hs=1, vs=1, seed=33)]
+    files = [base[0], _damage(harness, base[0], "cut", 0.6), base[1], _damage(harness, base[1], "rst", 0.5), _damage(harness, base[2], "marker", 0.7),
+             base[2], _damage(harness, base[0], "zeros", 0.3), _damage(harness, base[1], "delete", 0.8), base[1]]
+    healthy = {0, 2, 5, 8}
+    b = J.JpegBatch()
+    b.set_tuning(**tuning)
+    for f in files:
+        b.add_jpeg(f)
+    b.upload()
+    for _ in range(2):
+        b.decode(); b.sync()
+        assert b.split_parts() == tuning["split"]
+        for i, f in enumerate(files):
+            harness.drive(oracle, f)
+            assert np.array_equal(b.dib(i), oracle.dib()), (tuning, i)
+            if i in healthy:
+                assert b.info(i)["path"] == 1 and b.info(i)["flags"] == 0, (tuning, i, b.info(i))
+    b.close()
