@@ -242,6 +242,7 @@ typedef struct JsnoopTuning {
 #define JSNOOP_XC_NO_TAIL         0x04u  /* damaged files: no tail take-over / second attempt, the whole image through the mirror     */
 #define JSNOOP_XC_SIDE_EXACT      0x08u  /* side outputs always from the exact-mirror reader                                          */
 #define JSNOOP_XC_CAND_VERIFY     0x10u  /* k_sync's verification mode behind every candidate chain                                   */
+#define JSNOOP_XC_UNSTUFF_3PASS   0x20u  /* un-stuffing as count / scan / write passes instead of the fused look-back pass            */
 #define JSNOOP_DBG_CAND           0x01u  /* candidate chain: rounds, queued walks                                                     */
 #define JSNOOP_DBG_CAND_LINKS     0x02u  /* ... and the links left open per image (stops the stream)                                  */
 #define JSNOOP_DBG_TAIL           0x04u  /* damaged files: tail take-over decisions                                                   */

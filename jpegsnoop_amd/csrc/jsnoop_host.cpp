@@ -170,7 +170,8 @@ const JsnoopTuning& js_env_tuning()
         t.mcus_per_wave = (int32_t)std::max<long long>(0, num("JSNOOP_MPW", 0));
         { const long long v = num("JSNOOP_PG_LANES", 0); t.pg_lanes = (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 64) ? (int32_t)v : 0; }
         t.cross_checks = (on("JSNOOP_BACKEND_GENERIC") ? JSNOOP_XC_BACKEND_GENERIC : 0u) | (on("JSNOOP_WRITE_V1") ? JSNOOP_XC_WRITE_V1 : 0u) | (on("JSNOOP_NO_TAIL") ? JSNOOP_XC_NO_TAIL : 0u) |
-                         (on("JSNOOP_SIDE_EXACT") ? JSNOOP_XC_SIDE_EXACT : 0u) | (on("JSNOOP_CAND_VERIFY") ? JSNOOP_XC_CAND_VERIFY : 0u);
+                         (on("JSNOOP_SIDE_EXACT") ? JSNOOP_XC_SIDE_EXACT : 0u) | (on("JSNOOP_CAND_VERIFY") ? JSNOOP_XC_CAND_VERIFY : 0u) |
+                         (on("JSNOOP_UNSTUFF_3PASS") ? JSNOOP_XC_UNSTUFF_3PASS : 0u);
         const long long dc = num("JSNOOP_DEBUG_CAND", 0);
         t.debug = (dc >= 1 ? JSNOOP_DBG_CAND : 0u) | (dc >= 2 ? JSNOOP_DBG_CAND_LINKS : 0u) | (on("JSNOOP_DEBUG_TAIL") ? JSNOOP_DBG_TAIL : 0u) | (on("JSNOOP_DEBUG_TIMING") ? JSNOOP_DBG_TIMING : 0u);
         return t;
@@ -239,7 +240,7 @@ JsnoopBatch::~JsnoopBatch()
     for (void** p : { (void**)&dev.raw, (void**)&dev.ustr, (void**)&dev.coef, (void**)&dev.dccum, (void**)&dev.dib, (void**)&dev.planes,
                       (void**)&dev.side, (void**)&dev.imgs, (void**)&dev.tables, (void**)&dev.wg_base, (void**)&dev.sel, (void**)&dev.sums,
                       (void**)&dev.sub, (void**)&dev.probe, (void**)&dev.seg, (void**)&dev.chunk_keep, (void**)&dev.chunk_rst, (void**)&dev.us_base,
-                      (void**)&dev.sy_base, (void**)&dev.mcu_rst, (void**)&dev.dc_parts, (void**)&dev.flags, (void**)&dev.ustr_lin, (void**)&dev.events, (void**)&dev.cand, (void**)&dev.cand_req, (void**)&dev.wg_part }) if (*p) hipFree(*p);
+                      (void**)&dev.sy_base, (void**)&dev.mcu_rst, (void**)&dev.dc_parts, (void**)&dev.flags, (void**)&dev.ustr_lin, (void**)&dev.events, (void**)&dev.cand, (void**)&dev.cand_req, (void**)&dev.wg_part, (void**)&dev.us_state }) if (*p) hipFree(*p);
     delete helper; helper = nullptr;
     if (d_lut) hipFree(d_lut);
     if (d_side_tmp) hipFree(d_side_tmp);
@@ -410,7 +411,7 @@ int JsnoopBatch::upload()
         im.seg_cap = (uint32_t)std::min<uint64_t>((1u << 20) - 1, want_seg * 2 + 16); im.seg_off = segw; segw += align_up(im.seg_cap, 4);   // 20-bit interval index in the state word
         im.mcu_off = mcub; mcub += align_up(nmcu, 16);
         im.ev_cap = opt_events ? JS_EV_MAX : 0; im.ev_off = (uint64_t)i * (1 + JS_EV_WORDS * JS_EV_MAX);
-        usb[i] = usc; usc += (uint32_t)(((im.scan_start & 15) + (uint64_t)im.scan_len + JS_US_CHUNK - 1) / JS_US_CHUNK);
+        usb[i] = usc; usc += std::max(1u, (uint32_t)(((im.scan_start & 15) + (uint64_t)im.scan_len + JS_US_CHUNK - 1) / JS_US_CHUNK));   // (at least one chunk: its last chunk leaves the image's totals)
         syb[i] = syw; syw += (im.n_subseq + JS_SY_THREADS - 1) / JS_SY_THREADS;
         syb[n + 1 + i] = snw; snw += (im.n_subseq + JS_SY_THREADS - 2) / (JS_SY_THREADS - 1);   // sync pass: one thread per workgroup walks a halo
         max_mcu_h = std::max(max_mcu_h, im.mcu_h); max_mcu_w = std::max(max_mcu_w, im.mcu_w);
@@ -425,7 +426,9 @@ int JsnoopBatch::upload()
         grow(&dev.sub, &cap.sub, subs * 24 + 64) || grow(&dev.probe, &cap.probe, 1024) || grow(&dev.seg, &cap.seg, segw * 4 + 64) ||
         grow(&dev.chunk_keep, &cap.chunk_keep, (size_t)usc * 4 + 64) || grow(&dev.chunk_rst, &cap.chunk_rst, (size_t)usc * 4 + 64) ||
         grow(&dev.us_base, &cap.us_base, (n + 1) * 4) || grow(&dev.sy_base, &cap.sy_base, 2 * (n + 1) * 4) ||
-        grow(&dev.mcu_rst, &cap.mcu_rst, mcub + 64) || grow(&dev.dc_parts, &cap.dc_parts, JS_DC_PARTS_BYTES) || grow(&dev.ustr_lin, &cap.ustr_lin, ustr + 64) || grow(&dev.flags, &cap.flags, n * 8 + 64)) return -1;
+        grow(&dev.mcu_rst, &cap.mcu_rst, mcub + 64) || grow(&dev.dc_parts, &cap.dc_parts, JS_DC_PARTS_BYTES) || grow(&dev.ustr_lin, &cap.ustr_lin, ustr + 64) || grow(&dev.flags, &cap.flags, n * 8 + 64) ||
+        grow(&dev.us_state, &cap.us_state, (size_t)usc * 8 + 64)) return -1;
+    HIP_TRY(hipMemsetAsync(dev.us_state, 0, (size_t)usc * 8, stream)); us_epoch = 0;      // (no word of an earlier layout may look current)
     if (opt_want_planes && grow(&dev.planes, &cap.planes, plane * 2)) return -1;
     { uint32_t most = 0; for (size_t i = 0; i < n; i++) most = std::max(most, wg[i + 1] - wg[i]); if (most > 64 && grow(&dev.wg_part, &cap.wg_part, (size_t)wgs * 16 + 64)) return -1; }
     cand_blk = max_blk; cand_rounds = (cand_fits && sub_wl == 4) ? cand_want : -1;
@@ -461,6 +464,7 @@ int JsnoopBatch::decode(bool timed)
     JsRange r_("jsnoop:decode (enqueue)");
     if (js_prog_count(this)) return decode_progressive(timed);     // SOF2 files: every scan of every image, one launch per dependency level
     if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
+    us_epoch = us_epoch % 255u + 1u;                               // both halves of a split decode share it: their chunks are disjoint
     bool parallel_ok = !opt_force_exact; if (parallel_ok) { parallel_ok = false; for (const JsTableSet& t : tables) parallel_ok = parallel_ok || t.lut_ok; }
     if (!parallel_ok) {           // the exact-mirror kernel stores only what it decodes; the parallel path writes every block whole
         HIP_TRY(hipMemsetAsync(dev.coef, 0, total_blocks * 128, stream));

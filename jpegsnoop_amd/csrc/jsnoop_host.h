@@ -63,9 +63,10 @@ struct JsDeviceArenas {
     JsImage* imgs; JsTableSet* tables; uint32_t* wg_base; uint32_t* sel; uint64_t* sums; uint8_t* sub; uint8_t* probe;
     uint32_t* seg; uint32_t* chunk_keep; uint32_t* chunk_rst; uint32_t* us_base; uint32_t* sy_base; uint8_t* mcu_rst; uint32_t* flags; uint8_t* ustr_lin;
     uint32_t* events; uint8_t* dc_parts; uint32_t* cand; uint32_t* cand_req; unsigned long long* wg_part;
+    unsigned long long* us_state;                                 // chained-scan state of the fused un-stuffing pass, one word per chunk (k_unstuff_write<true>)
 };
 struct JsArenaCaps { size_t raw, ustr, coef, dccum, dib, planes, side, imgs, tables, wg_base, sel, sums, sub, probe,
-                            seg, chunk_keep, chunk_rst, us_base, sy_base, mcu_rst, flags, ustr_lin, events, dc_parts, cand, cand_req, wg_part; };
+                            seg, chunk_keep, chunk_rst, us_base, sy_base, mcu_rst, flags, ustr_lin, events, dc_parts, cand, cand_req, wg_part, us_state; };
 
 struct JsnoopBatch {
     int device; hipStream_t stream; bool own_stream;
@@ -80,6 +81,7 @@ struct JsnoopBatch {
     std::vector<std::vector<uint32_t>> side_anoms;                // per image: the coefficient-index overflows of the side walk, in block order (4 words each)
     std::vector<uint8_t> side_done;                               // per image: the side-output pass has run since the last decode
     std::vector<uint32_t> host_anom;                              // per image: first block (decode order) the parallel path could not vouch for (0xFFFFFFFF: none)
+    std::vector<uint8_t> host_anom_kind;                          // ... and what it was: 0 = the mirror takes over there, 1 / 2 = the reference's decode ends in that block (at its DC symbol / behind it)
     std::vector<uint32_t> host_flags, host_path, h_us_base, h_sy_base, h_sn_base, h_wg_base;
     // A large batch decodes as two halves on two streams (stream, aux[0]): the kernels of one half fill the tails and the thinly
     // populated phases (second synchronisation launch, DC scan) of the other -- 14.2 -> 13.7 ms per 1024 images.  Both halves live in
@@ -95,6 +97,7 @@ struct JsnoopBatch {
     int  d2h_staged(void* dst, const void* src, size_t bytes);
     JsDeviceArenas dev; JsArenaCaps cap;
     bool uploaded;
+    uint32_t us_epoch = 0;                                        // decode counter 1..255 the chained-scan state words are tagged with (cleared at upload)
     uint64_t total_blocks, dib_bytes, side_words, total_subseq, ustr_bytes, seg_words, mcu_bytes; uint32_t total_wgs, strips_per_wg, us_chunks, sy_wgs, sn_wgs, max_mcu_h, max_mcu_w;
     // small jobs (64-byte sub-sequences, a few hundred thousand walks at most) synchronise by candidates (k_cand_*) instead of k_sync's rounds: cand_rounds
     // = fill rounds of the chain, -1 = off (JSNOOP_CAND=0, more than JS_CAND_MAX_BLK blocks per MCU, a larger job); cand_blk = most blocks per MCU in the batch
@@ -128,7 +131,8 @@ struct JsnoopBatch {
     int  sync();
     int  read_dib(int i, uint8_t* dst);
     int  read_planes(int i, int16_t* y, int16_t* cb, int16_t* cr);
-    int  run_exact(const std::vector<uint32_t>& which);
+    int  run_exact(const std::vector<uint32_t>& which);       // (entropy only: the caller re-runs the back end)
+    int  redo_back_end(const std::vector<uint32_t>& which);   // the back end again for the listed images (their reductions cleared first); many images: the whole batch
     int  launch_back_end_part(hipStream_t st, uint32_t i0, uint32_t n);   // ... over images [i0, i0 + n) on stream st
     int  launch_back_end(uint32_t nimg);        // k_idct_color over the first nimg images (tile size from their CURRENT preview state)
 };

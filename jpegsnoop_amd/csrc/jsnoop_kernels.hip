@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
         // Tail mode: the MCU the mirror takes over at, and everything from there on emptied first -- the mirror stores what it decodes, and
         // MCUs it never reaches (the scan-stop logic after an overread, :3623-3625) must read as the cleared arrays of the reference.
         if (threadIdx.x == 0) {
-            uint32_t m0 = min(~tail.flags[2u * sel[j] + 1u] / im.blk_per_mcu, nmcu);
+            uint32_t m0 = min((~tail.flags[2u * sel[j] + 1u] >> 2) / im.blk_per_mcu, nmcu);   // (the word holds the complement of block << 2 | kind)
             while (m0 && tail.mcu_pos[m0] == 0u) m0--;             // (an MCU top the side walk did not reach: fall back to an earlier one)
             s_m0 = m0;
         }
@@ -498,36 +498,11 @@ __device__ __forceinline__ void lds_w32(uint32_t a, uint32_t x) { *(__attribute_
 __device__ __forceinline__ void lds_w16(uint32_t a, uint32_t x) { *(__attribute__((address_space(3))) uint16_t*)(uintptr_t)a = (uint16_t)x; }
 
 #define DPP_BC(I) " row_newbcast:" #I " row_mask:0xf bank_mask:0xf\n\t"
-// (ablation builds of tools/build_variant.sh: results wrong, timing valid -- which part of a term the kernel waits for)
-#ifdef JS_EXP_T_NOREAD
-#define T_RD(X) ""
-#elif defined(JS_EXP_T_HALFREAD)
-#define T_RD(X) T_RD_##X
-#define T_RD_a0 "ds_read_addtid_b32 %[a0]\n\t"
-#define T_RD_a1 ""
-#define T_RD_a2 "ds_read_addtid_b32 %[a2]\n\t"
-#define T_RD_a3 ""
-#define T_RD_b0 "ds_read_addtid_b32 %[b0]\n\t"
-#define T_RD_b1 ""
-#define T_RD_b2 "ds_read_addtid_b32 %[b2]\n\t"
-#define T_RD_b3 ""
-#else
 #define T_RD(X) "ds_read_addtid_b32 %[" #X "]\n\t"
-#endif
-#ifdef JS_EXP_T_NOMATH
-#define T_MUL(X, I) ""
-#define T_ADD(X) ""
-#else
 #define T_MUL(X, I) "v_mul_f32_dpp %[" #X "], %[ey], %[" #X "]" DPP_BC(I)
 #define T_ADD(X) "v_add_f32 %[acc], %[acc], %[" #X "]\n\t"
-#endif
-#ifdef JS_EXP_T_NOM0
-#define T_RL(S, Q) ""
-#define T_M0(OP) ""
-#else
 #define T_RL(S, Q) "v_readlane_b32 %[" #S "], %[rows], " #Q "\n\t"
 #define T_M0(OP) OP
-#endif
 // first group of a round: four table reads in flight (M0 needs one wait state before the read that uses it)
 #define T_ISSUE(L0, L1, L2, L3, QA, QB)                                                                                          \
     T_RL(sp0, QA) T_M0("s_and_b32 m0, %[sp0], 0xffff\n\t") T_RL(sp1, QB)                                                            \
@@ -580,7 +555,6 @@ __device__ __forceinline__ IdctPrep idct_prep(uint32_t cvu, const WaveList L, ui
     const bool nz = cvu != 0;
     const uint64_t mask = WBALLOT(nz);
     asm("s_bcnt1_i32_b64 %0, %1" : "=s"(P.n) : "s"(mask) : "scc");      // wave-uniform, 32 bits, in an SGPR: the exit tests are scalar compares
-#ifndef JS_EXP_NOTERMS
     // (no branch around this for a block without AC coefficients: straight-line code lets the waits ahead of idct_run count exactly the
     //  LDS operations issued behind the ones they wait for -- a join of two paths makes them wait for everything)
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -593,13 +567,11 @@ __device__ __forceinline__ IdctPrep idct_prep(uint32_t cvu, const WaveList L, ui
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     P.rows2 = lds_r32(L.a_rows + bo);
     P.ey = __uint_as_float(lds_r32(L.a_ey + bo));
-#endif
     return P;
 }
 __device__ __forceinline__ float idct_run(const IdctPrep& P, const WaveList L, uint32_t buf, uint32_t lane)
 {
     float acc = 0.0f;
-#ifndef JS_EXP_NOTERMS
     const uint32_t n = P.n, rows2 = P.rows2;
     if (n) {
         const uint32_t a_ey = L.a_ey + buf * LIST_BUF_BYTES;
@@ -609,9 +581,6 @@ __device__ __forceinline__ float idct_run(const IdctPrep& P, const WaveList L, u
         if (n > 32) { const float ey = __uint_as_float(lds_r32(a_ey + 128u)); const uint32_t nl = n - 32; IDCT_ROUND(16, 17, 18, 19, 20, 21, 22, 23); }
         if (n > 48) { const float ey = __uint_as_float(lds_r32(a_ey + 192u)); const uint32_t nl = n - 48; IDCT_ROUND(24, 25, 26, 27, 28, 29, 30, 31); }
     }
-#else
-    acc = (float)(P.n + (lane & 15u));
-#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     return acc;
 }
@@ -692,7 +661,6 @@ __device__ __forceinline__ void idct_pair(uint32_t d, const PairList L, uint32_t
     const uint32_t nb = (uint32_t)__builtin_popcount((uint32_t)(m0 >> 32)) + (uint32_t)__builtin_popcount((uint32_t)(m1 >> 32));
     uint32_t n = na > nb ? na : nb;
     asm("" : "+s"(n));                                           // wave-uniform, in an SGPR: the exit tests are scalar compares
-#ifndef JS_EXP_NOTERMS
     if (n) {
         // coefficients of the half below this one in natural order: c[2l'] and c[2l'+1] of the lanes l' < l of the same half
         uint32_t r0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
@@ -713,9 +681,6 @@ __device__ __forceinline__ void idct_pair(uint32_t d, const PairList L, uint32_t
         if (n > 32) { const float ey = __uint_as_float(lds_r32(L.a_ey + 128u)); const uint32_t rw = lds_r32(L.a_rw + 128u), nl = n - 32; PAIR_ROUND(); }
         if (n > 48) { const float ey = __uint_as_float(lds_r32(L.a_ey + 192u)); const uint32_t rw = lds_r32(L.a_rw + 192u), nl = n - 48; PAIR_ROUND(); }
     }
-#else
-    acc0 = (float)(n + (lane & 15u)); acc1 = acc0;
-#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
@@ -950,28 +915,21 @@ __device__ __forceinline__ void back_end_mcus(const BackEndCtx& C, uint64_t& bri
             for (int j = 0; j < BK_CHUNK; j++)
                 if (base + j < nb) {
                     IdctPrep Pn = P;
-#ifndef JS_EXP_NOPIPE
                     if (j + 1 < BK_CHUNK && base + j + 1 < nb) Pn = idct_prep(cv[j + 1], L, (uint32_t)(j + 1) & 1u);   // the next block's list, while this block's terms run
-#endif
                     const int16_t smp = to_sample(idct_run(P, L, (uint32_t)j & 1u, lane), dcv[j]);
                     if (FAST) tile[toff[j]] = smp; else sample_to_lds(meta[j], smp, tile + toff[j], rs);
-#ifdef JS_EXP_NOPIPE
-                    if (j + 1 < BK_CHUNK && base + j + 1 < nb) Pn = idct_prep(cv[j + 1], L, (uint32_t)(j + 1) & 1u);
-#endif
                     P = Pn;
                 }
         }
         const uint32_t m_next = m + wstride < nmcu ? m + wstride : m;   // (the last round fetches its own MCU again: no branch around the fetches)
         fetch_rows(m_next, 0);                                        // next MCU's rows fly during the colour phase
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#ifndef JS_EXP_NOCOLOR
         if (FAST) mcu_to_dib_fast<EH, EV>(im, img_x, img_y, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, C.dibp, C.planes, pw, want_planes, bright, best_y, sum_y);
         else {
             const bool shifted = any_shift && my * mcus_across + mx >= shift_ind;
             if (rgb_only) mcu_to_dib<true>(im, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, shifted, C.dibp, C.planes, pw, want_planes, bright, best_y, sum_y);
             else          mcu_to_dib<false>(im, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, shifted, C.dibp, C.planes, pw, want_planes, bright, best_y, sum_y);
         }
-#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         fetch_dc(m_next, 0);
     }
@@ -1032,9 +990,7 @@ __device__ __forceinline__ void back_end_pairs(const BackEndCtx& C, uint64_t& br
         const uint32_t m_next = m + wstride < nmcu ? m + wstride : m;   // (the last round fetches its own MCU again: no branch around the fetch)
         fetch(m_next);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#ifndef JS_EXP_NOCOLOR
         mcu_to_dib_fast<EH, EV>(im, img_x, img_y, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, C.dibp, C.planes, pw, want_planes, bright, best_y, sum_y);
-#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
@@ -1473,7 +1429,15 @@ void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, 
 // coefficient-index overflow was seen (stored complemented; 0 = none): everything before it is what the reference decodes, and the exact-mirror
 // reader can take over from the MCU that holds it (k_entropy_exact, tail mode) instead of from the first byte of the scan.
 #define FLAG_OR(flags, img, bits) atomicOr(&(flags)[2u * (img)], (bits))
-#define ANOM_MIN(flags, img, blk) atomicMax(&(flags)[2u * (img) + 1u], ~(uint32_t)(blk))   // kept as the maximum of ~block: "none" is 0, one memset clears the arena
+// The anomaly word is a KEY, block << 2 | kind, so that the first anomaly of an image also says what it was: kind 0 = "the mirror takes over here",
+// AK_DEAD_DC / AK_DEAD_AC = the reference's decode ENDS in this block (value bits of a symbol ran past the end of a restart interval: its register
+// over-reads, scan_end and scan_bad are set for good, :1229-1282 and :3623-3625) -- at the block's DC symbol / behind it.  An anomaly of kind 0 in
+// the same block sorts first.
+#define AK_MIRROR  0u
+#define AK_DEAD_DC 1u
+#define AK_DEAD_AC 2u
+#define ANOM_KEY(blk, kind) (((uint32_t)(blk) << 2) | (kind))
+#define ANOM_MIN(flags, img, key) atomicMax(&(flags)[2u * (img) + 1u], ~(uint32_t)(key))   // kept as the maximum of ~key: "none" is 0, one memset clears the arena
 #define F_BAD_CODE      0x0001u
 #define F_OVERRUN       0x0002u
 #define F_COEF_OVERFLOW 0x0004u
@@ -1593,17 +1557,36 @@ __global__ void __launch_bounds__(256) k_unstuff_scan(const JsImage* __restrict_
         uint32_t* sd = side + im.side_off; uint32_t* st = seg_tab + im.seg_off;
         sd[10] = run_k; sd[11] = run_r + 1;
         st[0] = 0;
-        if (run_r + 2 <= im.seg_cap) st[run_r + 1] = run_k; else { FLAG_OR(flags, img, F_OVERRUN); ANOM_MIN(flags, img, 0u); }
+        if (run_r + 2 <= im.seg_cap) st[run_r + 1] = run_k; else { FLAG_OR(flags, img, F_OVERRUN); ANOM_MIN(flags, img, ANOM_KEY(0u, AK_MIRROR)); }
     }
 }
 
+// Chained scan state of the fused un-stuffing pass: one 64-bit word per chunk, self-contained (a reader needs nothing else, so plain relaxed
+// device-scope atomics carry it -- no fence, no cache write-back):  [63:56] epoch of the decode that wrote it (1..255; the arena is cleared
+// at upload and every decode rewrites every word, so a word of another epoch is simply "not there yet"), [55:54] 1 = the chunk's own counts,
+// 2 = the inclusive prefix over the image's chunks up to and including it, [53:32] RSTn markers (saturating: anything near 2^22 is far
+// beyond every interval table and ends in the overflow flag), [31:0] kept bytes.
+#define US_ST_AGG 1u
+#define US_ST_INC 2u
+__device__ __forceinline__ uint64_t us_pack(uint32_t epoch, uint32_t kind, uint32_t keep, uint32_t rst)
+{ return ((uint64_t)epoch << 56) | ((uint64_t)kind << 54) | ((uint64_t)min(rst, 0x3FFFFFu) << 32) | keep; }
+__device__ __forceinline__ uint32_t us_sat_add(uint32_t a, uint32_t b) { return min(a + b, 0x3FFFFFu); }
+
+// The un-stuffing pass proper: classifies the chunk's bytes, finds where its kept bytes go, writes them (and the interval table entries of its
+// RSTn markers).  FUSED (the decode): ONE pass over the file bytes -- the chunk's place in its image comes from a decoupled look-back over the
+// chunks before it (us_state; workgroups are dispatched in index order, so every chunk a workgroup waits for is running or done), the last
+// chunk of an image also leaves the totals where k_unstuff_scan used to (side block words 10 / 11, interval 0 and the end sentinel), and the
+// exclusive prefixes are kept in chunk_keep / chunk_rst for the side passes.  !FUSED: prefixes are read from chunk_keep / chunk_rst
+// (k_unstuff_count + k_unstuff_scan before it: the three-pass form, kept as a cross-check; and the side passes).
 // Side-output pass (us_out != nullptr, grid = the chunks of one image starting at workgroup wg0): instead of writing the
 // stream again, every thread records the compacted-stream index of its first kept byte -- the inverse map
 // "compacted byte -> file offset" that the MCU file map needs (k_side_maps).
+template <bool FUSED>
 __global__ void __launch_bounds__(US_THREADS) k_unstuff_write(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ us_base, uint32_t nimg,
-                                                              const uint8_t* __restrict__ raw, const uint32_t* __restrict__ chunk_keep,
-                                                              const uint32_t* __restrict__ chunk_rst, uint8_t* __restrict__ ustr, uint32_t* __restrict__ seg_tab,
-                                                              uint32_t wg0, uint32_t* __restrict__ us_out)
+                                                              const uint8_t* __restrict__ raw, uint32_t* __restrict__ chunk_keep,
+                                                              uint32_t* __restrict__ chunk_rst, uint8_t* __restrict__ ustr, uint32_t* __restrict__ seg_tab,
+                                                              uint32_t wg0, uint32_t* __restrict__ us_out,
+                                                              unsigned long long* __restrict__ us_state, uint32_t epoch, uint32_t* __restrict__ side, uint32_t* __restrict__ flags)
 {
     const uint32_t wg = blockIdx.x + wg0 + us_base[0];
     const uint32_t img = find_image(us_base, nimg, wg);
@@ -1615,9 +1598,58 @@ __global__ void __launch_bounds__(US_THREADS) k_unstuff_write(const JsImage* __r
     uint32_t pk = nk, pr = nr;                                             // inclusive wave scans
     for (int off = 1; off < 64; off <<= 1) { uint32_t a = __shfl_up(pk, off), b = __shfl_up(pr, off); if (lane >= (uint32_t)off) { pk += a; pr += b; } }
     __shared__ uint32_t wk[US_THREADS / 64], wr[US_THREADS / 64];
+    __shared__ uint32_t s_excl[2];
     if (lane == 63) { wk[wave] = pk; wr[wave] = pr; }
     __syncthreads();
-    uint32_t bk = chunk_keep[wg], br = chunk_rst[wg];
+    uint32_t bk, br;
+    if (FUSED) {
+        const uint32_t ci = wg - us_base[img], nc = us_base[img + 1] - us_base[img];
+        if (wave == 0) {
+            const uint32_t agg_k = wk[0] + wk[1] + wk[2] + wk[3], agg_r = us_sat_add(us_sat_add(wr[0], wr[1]), us_sat_add(wr[2], wr[3]));
+            uint32_t ek = 0, er = 0;
+            if (ci) {
+                if (lane == 0) __hip_atomic_store(&us_state[wg], us_pack(epoch, US_ST_AGG, agg_k, agg_r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // look-back, 64 chunks per trip: lane j reads the state of chunk wg - 1 - j (of the same image), and the wave waits until every
+                // chunk between itself and the closest inclusive prefix has published something
+                uint32_t back = 1;                                       // distance of lane 0's chunk
+                for (;;) {
+                    const bool valid = back + lane <= ci;
+                    uint64_t v = 0; bool ready = false;
+                    for (;;) {
+                        if (valid) { v = __hip_atomic_load(&us_state[wg - back - lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ready = (uint32_t)(v >> 56) == epoch && ((v >> 54) & 3u) != 0u; }
+                        const uint64_t m_inc = WBALLOT(valid && ready && ((v >> 54) & 3u) == US_ST_INC), m_wait = WBALLOT(valid && !ready);
+                        const uint64_t below = m_inc ? ((m_inc & (0 - m_inc)) - 1ull) : ~0ull;   // lanes closer than the closest inclusive prefix (all, if there is none)
+                        if (!(m_wait & (below | (m_inc & (0 - m_inc))))) {
+                            const bool take = valid && (((1ull << lane) & below) || ((1ull << lane) & m_inc & (0 - m_inc)));
+                            uint32_t tk = take ? (uint32_t)v : 0u, tr = take ? (uint32_t)(v >> 32) & 0x3FFFFFu : 0u;
+                            for (int off = 32; off > 0; off >>= 1) { tk += __shfl_xor(tk, off); tr = us_sat_add(tr, __shfl_xor(tr, off)); }
+                            ek += tk; er = us_sat_add(er, tr);
+                            if (m_inc) back = 0;                         // done
+                            else back += 64;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (back == 0 || back > ci) break;                   // (past the image's first chunk without an inclusive prefix cannot happen: chunk 0 publishes one)
+                }
+            }
+            if (lane == 0) {
+                __hip_atomic_store(&us_state[wg], us_pack(epoch, US_ST_INC, ek + agg_k, us_sat_add(er, agg_r)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_excl[0] = ek; s_excl[1] = er;
+                chunk_keep[wg] = ek; chunk_rst[wg] = er;               // (the side passes of this decode read them)
+                if (ci + 1 == nc) {                                      // the image's totals: un-stuffed length, intervals, interval 0 and the end sentinel
+                    const uint32_t run_k = ek + agg_k, run_r = us_sat_add(er, agg_r);
+                    uint32_t* sd = side + im.side_off; uint32_t* st = seg_tab + im.seg_off;
+                    sd[10] = run_k; sd[11] = run_r + 1;
+                    st[0] = 0;
+                    if (run_r + 2 <= im.seg_cap) st[run_r + 1] = run_k; else { FLAG_OR(flags, img, F_OVERRUN); ANOM_MIN(flags, img, ANOM_KEY(0u, AK_MIRROR)); }
+                }
+            }
+        }
+        __syncthreads();
+        bk = s_excl[0]; br = s_excl[1];
+    } else { bk = chunk_keep[wg]; br = chunk_rst[wg]; }
+    const uint32_t cbase_out = bk, phase = cbase_out & 3u;               // the image's stream starts 16-byte aligned
     for (uint32_t w = 0; w < wave; w++) { bk += wk[w]; br += wr[w]; }
     uint32_t out = bk + pk - nk, seg = br + pr - nr;                       // exclusive prefixes of this thread
     if (us_out) { us_out[blockIdx.x * US_THREADS + threadIdx.x] = out; return; }
@@ -1625,7 +1657,6 @@ __global__ void __launch_bounds__(US_THREADS) k_unstuff_write(const JsImage* __r
     // the chunk leaves as whole aligned 32-bit words; only the ragged first / last word goes out byte by byte.
     __shared__ __attribute__((aligned(4))) uint8_t s_out[US_CHUNK + 8];
     __shared__ uint32_t s_total;
-    const uint32_t cbase_out = chunk_keep[wg], phase = cbase_out & 3u;     // the image's stream starts 16-byte aligned
     uint32_t* st = seg_tab + im.seg_off;
     if (c.keep_mask | c.rst_mask) {
         const uint4 v = *reinterpret_cast<const uint4*>(raw + o16);
@@ -1827,10 +1858,16 @@ __device__ __forceinline__ int walk_slow(const JsImage& im, const uint32_t* __re
                                        uint32_t blk, bool mark, uint8_t* __restrict__ mcu_rst, uint32_t& flags, uint32_t& anom, bool spec = false)
 {
     const uint32_t remain = seg_end > cur.p ? seg_end - cur.p : 0u;
-    if (len == 0 && remain >= 16) {
+    // What the reference does with "no code here" depends on whether its look-ahead has met the marker behind the interval (m_bRestartRead):
+    // BuffTopup :1292-1323 runs right in front of every match and loads whole bytes while eight bits of the register are vacant, so the RSTn has
+    // been met exactly when at most 24 bits of the interval are left -- then "nothing fits" IS the end of the interval (RSV_RST_TERM :1167-1176),
+    // with 25 or more it is a code that matches nothing (one bit consumed, :1178-1186).  In the LAST interval no RSTn follows (the reference reads
+    // on through whatever marker ends the scan): there the margin of 64 bits stays, and anything closer is the mirror's.
+    const bool more = seg + 1 < nseg;
+    if (len == 0 && remain >= (more ? 25u : 16u)) {
         // No code matches although a whole code could still fit: a corrupt stream -- or simply a speculative walk that is not synchronised yet.
-        const bool native = remain >= 64;
-        if (WRITE && blk < im.total_blocks) { flags |= native ? F_BAD_CODE : (F_BAD_CODE | F_BAD_EDGE); if (!native) anom = min(anom, blk); }
+        const bool native = more || remain >= 64;
+        if (WRITE && blk < im.total_blocks) { flags |= native ? F_BAD_CODE : (F_BAD_CODE | F_BAD_EDGE); if (!native) anom = min(anom, ANOM_KEY(blk, AK_MIRROR)); }
         cur_skip<WL>(cur, 1);
         return native ? WS_BAD_CODE : WS_GO_ON;
     }
@@ -1843,15 +1880,15 @@ __device__ __forceinline__ int walk_slow(const JsImage& im, const uint32_t* __re
         // MCU, or two markers back to back (the reference meets the second one inside its retry and files the DC value under index 1): F_BAD_EDGE.
         if (WRITE) {
             if (k != 0 || c != 0 || remain >= 8) flags |= F_RST_MISALIGN;                       // well-formed: < 8 pad bits, on an MCU boundary
-            if (mark && blk < im.total_blocks && !mark_reset(mcu_rst, blk / im.blk_per_mcu, c + 1u)) { flags |= F_BAD_EDGE; anom = min(anom, blk); }
+            if (mark && blk < im.total_blocks && !mark_reset(mcu_rst, blk / im.blk_per_mcu, c + 1u)) { flags |= F_BAD_EDGE; anom = min(anom, ANOM_KEY(blk, AK_MIRROR)); }
         }
         seg++; const uint32_t np = seg_end; seg_end = st[seg + 1] * 8;
         if (spec) { c = 0; k = 0; }                              // a speculative walk (its exit state is only a guess): in a well-formed stream an MCU starts here
-        if (WRITE && seg_end == np && seg + 1 < nseg) { flags |= F_RST_MISALIGN | F_BAD_EDGE; anom = min(anom, blk); }       // back-to-back RSTn
+        if (WRITE && seg_end == np && seg + 1 < nseg) { flags |= F_RST_MISALIGN | F_BAD_EDGE; anom = min(anom, ANOM_KEY(blk, AK_MIRROR)); }       // back-to-back RSTn
         cur_init<WL>(cur, words, np);
         return WS_GO_ON;
     }
-    if (WRITE && blk < im.total_blocks) { flags |= F_SHORT; anom = min(anom, blk); }
+    if (WRITE && blk < im.total_blocks) { flags |= F_SHORT; anom = min(anom, ANOM_KEY(blk, AK_MIRROR)); }
     cur.p = P_END; c = 0; k = 0; seg = 0;
     return WS_OVER;
 }
@@ -2447,7 +2484,7 @@ __global__ void __launch_bounds__(THREADS) k_block_scan(const JsImage* __restric
                                                         SubArrays A, uint32_t* side, uint32_t* __restrict__ flags)
 {
     const uint32_t img = blockIdx.x; const JsImage& im = imgs[img];
-    if (!tables[im.tableset].lut_ok) { if (threadIdx.x == 0) { FLAG_OR(flags, img, 0x0020u); ANOM_MIN(flags, img, 0u); } return; }
+    if (!tables[im.tableset].lut_ok) { if (threadIdx.x == 0) { FLAG_OR(flags, img, 0x0020u); ANOM_MIN(flags, img, ANOM_KEY(0u, AK_MIRROR)); } return; }
     const uint32_t total_bits = side[im.side_off + 10] * 8;
     const uint32_t n = min(im.n_subseq, (total_bits + SUB_BITS - 1) / SUB_BITS);
     constexpr uint32_t NW = THREADS / 64;
@@ -2486,7 +2523,7 @@ __global__ void __launch_bounds__(THREADS) k_block_scan(const JsImage* __restric
             carry += __shfl(inc, 63);
         }
     }
-    if (threadIdx.x == 0) { side[im.side_off + 14] = tot; if (tot < im.total_blocks) { FLAG_OR(flags, img, F_SHORT); ANOM_MIN(flags, img, tot); } }
+    if (threadIdx.x == 0) { side[im.side_off + 14] = tot; if (tot < im.total_blocks) { FLAG_OR(flags, img, F_SHORT); ANOM_MIN(flags, img, ANOM_KEY(tot, AK_MIRROR)); } }
 }
 
 // WRITE pass.  Every 8x8 block is written by exactly one lane -- the one that decodes its DC symbol.  A lane entering
@@ -2605,7 +2642,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
                 comp = comp_of(T, c); wb = comp == 0 ? wb0 : (comp == 1 ? wb1 : wb2);
                 norm = false;
             } else if (active && blk < nblocks) {
-                if (cur.p + tot > seg_end) { fl |= F_OVERRUN; an = min(an, blk); }
+                if (cur.p + tot > seg_end) { fl |= F_OVERRUN; an = min(an, ANOM_KEY(blk, AK_MIRROR)); }
                 if (k2 > 64u) {
                     fl |= F_COEF_OVERFLOW;
                     // side pass: what the reference's two messages about this block quote (:1723-1735 "nNumCoeffs>64", CheckScanErrors :2605) --
@@ -2740,7 +2777,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
     if (sub0 * SUB_BITS >= total_bits) return;
     // block rows are addressed with 32-bit byte offsets from the image's first row: an image of 2^25 blocks or more (2 Gpixel of
     // grayscale) is left to the exact kernel
-    if (im.total_blocks >= (1u << 25)) { if (threadIdx.x == 0) { FLAG_OR(flags, img, F_SHORT); ANOM_MIN(flags, img, 0u); } return; }
+    if (im.total_blocks >= (1u << 25)) { if (threadIdx.x == 0) { FLAG_OR(flags, img, F_SHORT); ANOM_MIN(flags, img, ANOM_KEY(0u, AK_MIRROR)); } return; }
     const JsTableSet& tset = tables[im.tableset];
     SubTabs T; T.nb = im.blk_per_mcu; T.n1 = im.samp_h[1] * im.samp_v[1]; T.n2 = im.ncomp == 3 ? T.n1 + im.samp_h[2] * im.samp_v[2] : T.nb;
     WriteTabs W; load_wtabs(W, s_dyn, tset, tab_rows, tab_lut2, im.ncomp, threadIdx.x, SY_THREADS);
@@ -2836,7 +2873,13 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
                 comp = comp_of(T, c); wb = comp == 0 ? wb0 : (comp == 1 ? wb1 : wb2);
                 tot = 0; size = 0; k2 = k;                       // the step below does nothing for this lane
             } else if (IBAL(m_act)) {
-                if (blk < nblocks) { if (p1 > seg_end) { fl |= F_OVERRUN; an = min(an, blk); } if (k2 > 64u) fl |= F_COEF_OVERFLOW; }
+                if (blk < nblocks) {
+                    // value bits past the end of the interval.  With an RSTn behind it the reference's register over-reads -- its decode of the image ENDS
+                    // in this block (ANOM_KEY); at the end of the scan data it reads on through the marker bytes (F_SHORT / second attempt).  The walk
+                    // itself goes on as the synchronisation walks did: what it writes from here on is replaced (js_parallel_fixup).
+                    if (p1 > seg_end) { fl |= F_OVERRUN; an = min(an, ANOM_KEY(blk, seg + 1u < nseg ? (IBAL(m_dc) ? AK_DEAD_DC : AK_DEAD_AC) : AK_MIRROR)); }
+                    if (k2 > 64u) fl |= F_COEF_OVERFLOW;
+                }
             }
             const uint64_t m_over = WBALLOT(over);
             m_bad = WBALLOT(bad) & m_act;
@@ -3027,12 +3070,18 @@ __global__ void __launch_bounds__(DC_THREADS) k_dc_scan_parts(const JsImage* __r
 
 void js_launch_unstuff(hipStream_t st, int wl, const JsImage* imgs, const uint32_t* us_base, uint32_t nimg, uint32_t total_chunks, const uint8_t* raw,
                        uint32_t* chunk_keep, uint32_t* chunk_rst, uint8_t* ustr_lin, uint8_t* ustr, uint32_t* seg_tab, uint32_t* side, uint32_t* flags,
-                       const uint32_t* sy_base, uint32_t sy_wgs)
+                       const uint32_t* sy_base, uint32_t sy_wgs, unsigned long long* us_state, uint32_t epoch)
 {
     if (!total_chunks) return;
-    hipLaunchKernelGGL(k_unstuff_count, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst);
-    hipLaunchKernelGGL(k_unstuff_scan, dim3(nimg), dim3(256), 0, st, imgs, us_base, chunk_keep, chunk_rst, seg_tab, side, flags);
-    hipLaunchKernelGGL(k_unstuff_write, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, wl == 4 ? ustr : ustr_lin, seg_tab, 0u, (uint32_t*)nullptr);
+    if (us_state) {          // one pass over the file bytes: the chunks' places come from a decoupled look-back (k_unstuff_write<true>)
+        hipLaunchKernelGGL(k_unstuff_write<true>, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, wl == 4 ? ustr : ustr_lin, seg_tab, 0u,
+                           (uint32_t*)nullptr, us_state, epoch, side, flags);
+    } else {                 // the three-pass form (cross-check): count, scan per image, write
+        hipLaunchKernelGGL(k_unstuff_count, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst);
+        hipLaunchKernelGGL(k_unstuff_scan, dim3(nimg), dim3(256), 0, st, imgs, us_base, chunk_keep, chunk_rst, seg_tab, side, flags);
+        hipLaunchKernelGGL(k_unstuff_write<false>, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, wl == 4 ? ustr : ustr_lin, seg_tab, 0u,
+                           (uint32_t*)nullptr, (unsigned long long*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    }
     if (wl == 4) return;                                         // (phys_word<4> is the identity)
     if (wl == 6) hipLaunchKernelGGL(k_interleave<6>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
     else if (wl == 8) hipLaunchKernelGGL(k_interleave<8>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
@@ -3275,7 +3324,8 @@ void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab
                          const int16_t* dccum, uint8_t* mcu_rst, uint32_t* mcu_pos, uint32_t* us_out, uint32_t* events, uint32_t* anoms)
 {
     if (!us_wgs || !sy_wgs) return;
-    hipLaunchKernelGGL(k_unstuff_write, dim3(us_wgs), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, (uint8_t*)nullptr, seg_tab, us_wg0, us_out);
+    hipLaunchKernelGGL(k_unstuff_write<false>, dim3(us_wgs), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, const_cast<uint32_t*>(chunk_keep), const_cast<uint32_t*>(chunk_rst), (uint8_t*)nullptr, seg_tab, us_wg0, us_out,
+                       (unsigned long long*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr);
     if (wl == 4) hipLaunchKernelGGL((k_write<4, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, anoms, tab_rows, tab_lut2, sy_wg0, mcu_pos);
     else if (wl == 6) hipLaunchKernelGGL((k_write<6, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
@@ -3296,13 +3346,58 @@ void js_launch_tail_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab
                          int16_t* coef, int16_t* dccum, uint8_t* mcu_rst, uint32_t* mcu_pos, uint32_t* us_out, const uint32_t* flags, const uint32_t* sel1)
 {
     if (!us_wgs || !sy_wgs) return;
-    hipLaunchKernelGGL(k_unstuff_write, dim3(us_wgs), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, (uint8_t*)nullptr, seg_tab, us_wg0, us_out);
+    hipLaunchKernelGGL(k_unstuff_write<false>, dim3(us_wgs), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, const_cast<uint32_t*>(chunk_keep), const_cast<uint32_t*>(chunk_rst), (uint8_t*)nullptr, seg_tab, us_wg0, us_out,
+                       (unsigned long long*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr);
 #define JS_TAIL_WALK(W) hipLaunchKernelGGL((k_write<W, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side, \
                        sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos)
     if (wl == 4) JS_TAIL_WALK(4); else if (wl == 6) JS_TAIL_WALK(6); else if (wl == 8) JS_TAIL_WALK(8); else if (wl == 7) JS_TAIL_WALK(7); else JS_TAIL_WALK(5);
 #undef JS_TAIL_WALK
     ExactTail t; t.flags = flags; t.seg_tab = seg_tab; t.mcu_rst = mcu_rst; t.mcu_pos = mcu_pos; t.us_out = us_out; t.us_threads = us_wgs * US_THREADS;
     hipLaunchKernelGGL(k_entropy_exact, dim3(1), dim3(64), 0, st, imgs, sel1, 1u, tables, raw, coef, dccum, side, 0, (uint32_t*)nullptr, t);
+}
+// An image whose decode ENDS in block `bstar` (ANOM_KEY kinds AK_DEAD_*): the value bits of a symbol ran past the end of a restart interval, the
+// reference's register over-reads (:1229-1282), scan_end and scan_bad stay set, and from then on every block fails at its first read without
+// consuming anything: block bstar keeps its DC difference if that had been decoded (AK_DEAD_AC) and nothing else, the blocks behind it in its MCU
+// are empty with the predictors standing, the rest of that MCU row is never decoded (:3623-3625: the row loop stops, the cleared arrays stay), and
+// of every later row only the first MCU is "decoded" -- empty blocks, predictors standing.  No restart is handled any more.
+//  k_dead_fill (before the DC scan is repeated for the image): rows from bstar on emptied, DC differences of all blocks back in the dccum
+//  array (they survive in slot 0 of the rows), restart marks behind bstar removed;  k_dead_rows (after it): cumulative DC of the MCUs the
+//  reference never reaches back to the cleared arrays' zero.
+__global__ void __launch_bounds__(256) k_dead_fill(const JsImage* __restrict__ imgs, uint32_t img, uint32_t bstar, uint32_t kind,
+                                                   int16_t* __restrict__ coef, int16_t* __restrict__ dccum, uint8_t* __restrict__ mcu_rst)
+{
+    const JsImage& im = imgs[img];
+    const uint32_t nb = im.blk_per_mcu, total = im.total_blocks, nmcu = im.mcu_xmax * im.mcu_ymax, mstar = bstar / nb;
+    int16_t* cb = coef + im.coef_off * 64; int16_t* d = dccum + im.coef_off; uint8_t* rf = mcu_rst + im.mcu_off;
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
+    const bool keep_dc = kind == AK_DEAD_AC;
+    for (uint32_t b = gid; b < total; b += gsz) d[b] = (b < bstar || (b == bstar && keep_dc)) ? cb[(size_t)b * 64] : (int16_t)0;
+    uint4* rows = reinterpret_cast<uint4*>(cb + (size_t)bstar * 64);
+    for (size_t q = gid; q < (size_t)(total - bstar) * 8; q += gsz) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (q == 0 && keep_dc) v.x = rows[0].x & 0xFFFFu;        // (slot 0 of row bstar: its DC difference)
+        rows[q] = v;
+    }
+    for (uint32_t m = mstar + gid; m < nmcu; m += gsz) {
+        const uint32_t mark = rf[m];
+        if (mark && (m > mstar || mstar * nb + mark - 1u > bstar)) rf[m] = 0;
+    }
+}
+__global__ void __launch_bounds__(256) k_dead_rows(const JsImage* __restrict__ imgs, uint32_t img, uint32_t bstar, int16_t* __restrict__ dccum)
+{
+    const JsImage& im = imgs[img];
+    const uint32_t nb = im.blk_per_mcu, nmcu = im.mcu_xmax * im.mcu_ymax, mstar = bstar / nb, xmax = im.mcu_xmax;
+    int16_t* d = dccum + im.coef_off;
+    for (uint32_t q = (mstar + 1) * nb + blockIdx.x * 256 + threadIdx.x; q < nmcu * nb; q += gridDim.x * 256) {
+        const uint32_t m = q / nb;
+        if (m / xmax == mstar / xmax || m % xmax != 0) d[q] = 0;
+    }
+}
+void js_launch_dead_fill(hipStream_t st, const JsImage* imgs, uint32_t img, uint32_t bstar, uint32_t kind, const JsTableSet* tables, int16_t* coef, int16_t* dccum, uint8_t* mcu_rst)
+{
+    hipLaunchKernelGGL(k_dead_fill, dim3(256), dim3(256), 0, st, imgs, img, bstar, kind, coef, dccum, mcu_rst);
+    hipLaunchKernelGGL(k_dc_scan, dim3(1), dim3(DC_THREADS), 0, st, imgs + img, tables, dccum, (const uint8_t*)mcu_rst);
+    hipLaunchKernelGGL(k_dead_rows, dim3(64), dim3(256), 0, st, imgs, img, bstar, dccum);
 }
 void js_launch_dc_scan(hipStream_t st, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, int16_t* dccum, const uint8_t* mcu_rst, void* parts_scratch)
 {

@@ -22,7 +22,7 @@ void js_launch_tiff_pack(hipStream_t st, const JsImage* imgs, uint32_t img, cons
 void js_launch_color_sweep(hipStream_t st, uint32_t* out /*2^24 words*/);
 void js_launch_unstuff(hipStream_t st, int wl, const JsImage* imgs, const uint32_t* us_base, uint32_t nimg, uint32_t total_chunks, const uint8_t* raw,
                        uint32_t* chunk_keep, uint32_t* chunk_rst, uint8_t* ustr_lin, uint8_t* ustr, uint32_t* seg_tab, uint32_t* side, uint32_t* flags,
-                       const uint32_t* sy_base, uint32_t sy_wgs);
+                       const uint32_t* sy_base, uint32_t sy_wgs, unsigned long long* us_state /*nullptr: the three-pass form*/, uint32_t epoch);
 void js_launch_sync(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
                     const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub, int first_pass);
 #define JS_SY_THREADS 256
@@ -47,6 +47,8 @@ void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab
                          uint32_t* anoms /* [0] count, 4 words per record from [4]: block, bit position of the symbol, index it ran to, bit position behind the block; or null */);
 #define JS_DC_PARTS_IMAGES 8         /* batches of up to this many images take the two-level DC scan */
 #define JS_DC_PARTS_BYTES (JS_DC_PARTS_IMAGES * 64 * 16)
+void js_launch_dead_fill(hipStream_t st, const JsImage* imgs, uint32_t img, uint32_t bstar, uint32_t kind /*1: the decode ends at the block's DC symbol, 2: behind it*/,
+                         const JsTableSet* tables, int16_t* coef, int16_t* dccum, uint8_t* mcu_rst);
 void js_launch_dc_scan(hipStream_t st, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, int16_t* dccum, const uint8_t* mcu_rst, void* parts_scratch /*JS_DC_PARTS_BYTES or null*/);
 #define JS_US_CHUNK 4096
 void js_launch_tail_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* us_base, const uint32_t* sy_base, uint32_t nimg,

@@ -293,7 +293,8 @@ int js_parallel_entropy_part(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32
     const uint32_t us_chunks = b->h_us_base[i0 + n] - b->h_us_base[i0], sy_wgs = b->h_sy_base[i0 + n] - b->h_sy_base[i0], sn_wgs = b->h_sn_base[i0 + n] - b->h_sn_base[i0];
     roctxRangePushA("jsnoop:unstuff");
     js_launch_unstuff(st, b->sub_wl, imgs, us_base, n, us_chunks, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst,
-                      b->dev.ustr_lin, b->dev.ustr, b->dev.seg, b->dev.side, flags, sy_base, sy_wgs);
+                      b->dev.ustr_lin, b->dev.ustr, b->dev.seg, b->dev.side, flags, sy_base, sy_wgs,
+                      (b->tune.cross_checks & JSNOOP_XC_UNSTUFF_3PASS) ? nullptr : b->dev.us_state, b->us_epoch);
     roctxRangePop();
     if (evs) HIP_TRY(hipEventRecord(evs[2], st));
     roctxRangePushA("jsnoop:sub-sequence sync");
@@ -348,7 +349,24 @@ int JsnoopBatch::run_exact(const std::vector<uint32_t>& which)
     }
     HIP_TRY(hipMemcpyAsync(dev.sel, which.data(), which.size() * 4, hipMemcpyHostToDevice, stream));
     js_launch_entropy_exact(stream, dev.imgs, dev.sel, (uint32_t)which.size(), dev.tables, dev.raw, dev.coef, dev.dccum, dev.side, 0, event_words ? dev.events : nullptr);
-    if (launch_back_end((uint32_t)imgs.size())) return -1;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+// The back end ran on the flagged images' first (partial) coefficients; their reductions in the side block (brightest pixel, sum of Y) are cleared
+// and recomputed with their pixels.  A handful of images: one launch each over the image's own workgroups -- the batch's other images are not
+// touched (one hostile file must not cost a batch its whole back end again); many: the whole batch in one launch.
+int JsnoopBatch::redo_back_end(const std::vector<uint32_t>& which)
+{
+    if (which.empty()) return 0;
+    HIP_TRY(hipSetDevice(device));
+    const uint32_t n = (uint32_t)imgs.size();
+    if (which.size() * 8 >= n && which.size() > 1) {
+        for (uint32_t i = 0; i < n; i++) HIP_TRY(hipMemsetAsync(dev.side + imgs[i].side_off + 12, 0, 16, stream));
+        if (launch_back_end(n)) return -1;
+    } else for (uint32_t i : which) {
+        HIP_TRY(hipMemsetAsync(dev.side + imgs[i].side_off + 12, 0, 16, stream));
+        if (launch_back_end_part(stream, i, 1)) return -1;
+    }
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -386,8 +404,11 @@ int js_read_flags(JsnoopBatch* b)
     const size_t n = b->imgs.size();
     std::vector<uint32_t> both(2 * n);
     if (b->d2h_staged(both.data(), b->dev.flags, 2 * n * 4)) return -1;          // (through the page-locked landing buffer)
-    b->host_flags.resize(n); b->host_anom.resize(n);
-    for (size_t i = 0; i < n; i++) { b->host_flags[i] = both[2 * i]; b->host_anom[i] = ~both[2 * i + 1]; }      // (the arena keeps the complement: 0 = none)
+    b->host_flags.resize(n); b->host_anom.resize(n); b->host_anom_kind.resize(n);
+    for (size_t i = 0; i < n; i++) {                              // (the arena keeps the complement of block << 2 | kind: 0 = none)
+        const uint32_t key = ~both[2 * i + 1];
+        b->host_flags[i] = both[2 * i]; b->host_anom[i] = key == 0xFFFFFFFFu ? 0xFFFFFFFFu : key >> 2; b->host_anom_kind[i] = key == 0xFFFFFFFFu ? 0 : (uint8_t)(key & 3u);
+    }
     if (b->cand_rounds >= 0 && (b->tune.debug & JSNOOP_DBG_CAND)) {      // candidate chain of image 0: walks queued by the last chain launch, open sub-sequences after each launch
         uint32_t h[12]; if (b->d2h_staged(h, b->dev.cand_req, sizeof h)) return -1;
         fprintf(stderr, "[cand] rounds %d: queued by the last chain %u; open after chain 0..: %u %u %u %u; queued: %u %u %u %u\n", b->cand_rounds, h[0], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
@@ -428,9 +449,24 @@ int js_parallel_fixup(JsnoopBatch* b)
     // (BuffAddByte :1486-1561).  A private one-image batch decodes the same file with the scan running to the end of the file and those
     // bytes left in the stream (us_classify); its coefficients and cumulative DC replace the image's.  What such bytes change besides
     // the data is bookkeeping (scan_bad, messages): the side-only pass of the mirror, on request, like for every flagged image.
+    std::vector<uint32_t> redo;                                     // images whose coefficients change below: their pixels are made again
+    // First of all the images whose FIRST anomaly is the end of the reference's own decode (value bits of a symbol past the end of a restart interval:
+    // its register over-reads, :1229-1282, and no block decodes any more): everything up to that block is the parallel path's, everything behind it is
+    // determined -- empty blocks, predictors standing, only the first MCU of every later row reached (:3623-3625) -- and is filled in on the device.
+    // Whatever the walks met behind that block (they went on decoding bits the reference never reads) is of no consequence.
+    std::vector<uint8_t> dead(n, 0);
+    if (!no_tail) for (uint32_t i = 0; i < n; i++) {
+        const JsImage& im = b->imgs[i];
+        if (!b->host_anom_kind[i] || (b->host_flags[i] & (JSNOOP_FLAG_TABLES | JSNOOP_FLAG_NOSYNC | JSNOOP_FLAG_FORCED)) || b->host_anom[i] >= im.total_blocks) continue;
+        js_launch_dead_fill(b->stream, b->dev.imgs, i, b->host_anom[i], b->host_anom_kind[i], b->dev.tables, b->dev.coef, b->dev.dccum, b->dev.mcu_rst);
+        if (dbg_tail) fprintf(stderr, "[tail] image %u flags 0x%04x: the reference's decode ends in block %u (MCU %u of %u, kind %u): filled in\n", i, b->host_flags[i], b->host_anom[i],
+                              b->host_anom[i] / im.blk_per_mcu, im.mcu_xmax * im.mcu_ymax, b->host_anom_kind[i]);
+        dead[i] = 1; redo.push_back(i);
+    }
     bool patched = false;
     if (!b->is_helper && !no_tail) for (uint32_t i = 0; i < n; i++) {
         const JsImage& im = b->imgs[i];
+        if (dead[i]) continue;
         if (!(b->host_flags[i] & JSNOOP_FLAG_SHORT) || (b->host_flags[i] & (JSNOOP_FLAG_TABLES | JSNOOP_FLAG_NOSYNC | JSNOOP_FLAG_FORCED))) continue;
         if ((uint64_t)im.scan_start + im.scan_len + 2 > im.file_len || !b->tables[im.tableset].lut_ok) continue;      // the data really ends with the file
         // (a helper that cannot be set up, or whose decode fails, costs the image its short cut, not the batch its result: the image keeps
@@ -450,11 +486,11 @@ int js_parallel_fixup(JsnoopBatch* b)
         if (dbg_tail) fprintf(stderr, "[tail] image %u flags 0x%04x: decoded through the markers of its scan (second attempt: path %u, flags 0x%04x)\n", i, b->host_flags[i], h->host_path[0], h->host_flags[0]);
         b->host_flags[i] = (b->host_flags[i] & JS_FLAGS_PIXEL_EXACT) | JSNOOP_FLAG_MARKER | (h->host_flags[0] & ~(uint32_t)JSNOOP_FLAG_FORCED);
         b->host_anom[i] = 0xFFFFFFFFu;                              // nothing left for the tail pass below: the second attempt had its own
-        patched = true;
+        patched = true; redo.push_back(i);
     }
     std::vector<uint32_t> bad, tails;
     for (uint32_t i = 0; i < n; i++) {
-        if (!(b->host_flags[i] & ~JS_FLAGS_PIXEL_EXACT)) continue;
+        if (dead[i] || !(b->host_flags[i] & ~JS_FLAGS_PIXEL_EXACT)) continue;
         const JsImage& im = b->imgs[i];
         if ((b->host_flags[i] & JSNOOP_FLAG_MARKER) && b->host_anom[i] == 0xFFFFFFFFu) continue;    // resolved by the second attempt
         // (restarts the walks followed off an MCU boundary, or over leftover bytes, leave marks and MCU tops the take-over's seeding does not read: whole mirror)
@@ -477,6 +513,7 @@ int js_parallel_fixup(JsnoopBatch* b)
                                 b->dev.chunk_keep, b->dev.chunk_rst, b->dev.ustr, b->dev.seg, b->dev.side, (uint32_t*)b->dev.sub, b->total_subseq,
                                 b->dev.coef, b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out, b->dev.flags, b->dev.sel);
             HIP_TRY(hipStreamSynchronize(b->stream));              // (dev.sel and the scratch area are reused by the next image)
+            redo.push_back(i);
             if (dbg_tail) {
                 const uint32_t ma = b->host_anom[i] / im.blk_per_mcu; uint32_t pos[3] = { 0, 0, 0 };
                 hipMemcpy(pos, mcu_pos + (ma ? ma - 1 : 0), 12, hipMemcpyDeviceToHost);
@@ -485,22 +522,12 @@ int js_parallel_fixup(JsnoopBatch* b)
         }
         patched = true;
     }
-    if (patched) {
-        if (bad.empty()) {                                          // pixels of the patched images (and the reductions of all: see below)
-            for (uint32_t i = 0; i < n; i++) { HIP_TRY(hipMemsetAsync(b->dev.side + b->imgs[i].side_off + 12, 0, 16, b->stream)); }
-            if (b->launch_back_end(n)) return -1;
-            HIP_TRY(hipStreamSynchronize(b->stream));
-            HIP_TRY(hipGetLastError());
-            return 0;
-        }
-    }
-    if (bad.empty()) return 0;
-    // The back end already ran on the flagged images' (partial) coefficients; their sums in the side block
-    // (brightest pixel, sum of Y) are cleared together with the side block in run_exact and recomputed.
-    // Unflagged images must not accumulate twice: clear every image's reduction words, the back end
-    // below recomputes them for the whole batch.
-    for (uint32_t i = 0; i < n; i++) { HIP_TRY(hipMemsetAsync(b->dev.side + b->imgs[i].side_off + 12, 0, 16, b->stream)); }
-    return b->run_exact(bad);
+    (void)patched;
+    // whole images through the mirror (entropy), then the pixels of everything that changed since the batch's back end ran
+    if (b->run_exact(bad)) return -1;
+    for (uint32_t i : bad) redo.push_back(i);
+    std::sort(redo.begin(), redo.end()); redo.erase(std::unique(redo.begin(), redo.end()), redo.end());
+    return b->redo_back_end(redo);
 }
 
 // Side outputs (MCU file map, block-DC maps, Huffman code-length histogram, status words) of image i, produced on

@@ -218,3 +218,84 @@ def test_damaged_files_inside_a_batch_on_two_streams(harness, oracle, tuning):
             if i in healthy:
                 assert b.info(i)["path"] == 1 and b.info(i)["flags"] == 0, (tuning, i, b.info(i))
     b.close()
+
+
+def _overrun_file(harness, J, seed=35):
+    """A 1080p file with restart markers in which, behind a marker met INSIDE a block (two bytes lost in front of the second RSTn: every later
+    marker then falls off an MCU boundary), the value bits of some symbol run past the end of a restart interval -- the reference's register
+    over-reads there (ReadScanVal :1229-1282), scan_end / scan_bad stay set, and its decode of the image is over (:3623-3625).  Found by cutting
+    the tail off the interval in front of a later marker until the parallel path reports the overrun."""
+    base = harness.synth_jpeg(width=1920, height=1080, restart_interval=120, seed=seed)
+    p = harness.parse_jpeg(base)
+    d = bytearray(base); j = bytes(d).index(b"\xff\xd1", p.scan_start); del d[j - 2:j]
+    marks = [k for k in range(p.scan_start, len(d) - 1) if d[k] == 0xFF and 0xD0 <= d[k + 1] <= 0xD7]
+    b = J.JpegBatch()
+    try:
+        for which in (len(marks) // 3, len(marks) // 2, 2 * len(marks) // 3):
+            for cut in range(1, 7):
+                e = bytearray(d); k = marks[which]
+                if 0xFF in e[k - cut - 1:k]:
+                    continue
+                del e[k - cut:k]
+                b.clear(); b.add_jpeg(bytes(e)); b.upload(); b.decode(); b.sync()
+                if b.info(0)["flags"] & 0x0002:
+                    return bytes(e)
+    finally:
+        b.close()
+    pytest.skip("no cut produced a value-bit overrun on this picture")
+
+
+def test_value_bits_past_an_interval_end_end_the_decode_on_the_device(harness, oracle, gpu):
+    """The slow class round 4 left (every one of the hostile 1080p files above 50 ms carried JSNOOP_FLAG_OVERRUN beside a misplaced marker: whole
+    mirror, 0.7-2.4 s): the decode of such a file ENDS at the overrun -- the block in progress keeps its DC difference, every later block fails
+    at its first read, the MCU row stops and of each later row only the first MCU is reached.  The parallel path keeps everything up to that
+    block and fills the rest in on the device (k_dead_fill, DC scan, k_dead_rows)."""
+    import jpegsnoop_amd as J
+    from fuzz_util import differs
+    data = _overrun_file(harness, J)
+    b = J.JpegBatch(want_planes=True); b.add_jpeg(data); b.upload(); b.decode(); b.sync()
+    t = time.perf_counter(); b.decode(); b.sync(); ms = (time.perf_counter() - t) * 1e3
+    harness.drive(oracle, data)
+    inf = b.info(0)
+    assert inf["path"] == 1 and (inf["flags"] & 0x0002) and (inf["flags"] & 0x0008), inf                 # OVERRUN beside RST_MISALIGN: round 4's whole-mirror class
+    assert np.array_equal(b.dib(0), oracle.dib())
+    for pa, pb in zip(oracle.planes(), b.planes(0)):
+        assert np.array_equal(pa, pb)
+    assert ms < 50.0, f"{ms:.1f} ms"
+    b.close()
+    harness.drive(gpu, data)                                          # single-image API: side outputs and status words (the mirror's side-only pass) too
+    assert differs(oracle, gpu) is None
+
+
+def test_one_hostile_file_does_not_cost_the_batch_its_time(harness, oracle):
+    """A batch of 192 x 1080p (the production form: 512-byte pieces, two streams) with ONE hostile file in it -- the overrun file above, the worst class of
+    tools/fuzz_1080p_timing.py -- takes at most twice the time of the clean batch: the repair touches that image alone (its fill-in, its DC scan, its own
+    workgroups of the back end), not the batch's back end."""
+    import jpegsnoop_amd as J
+    hostile = _overrun_file(harness, J)
+    files = [harness.synth_jpeg(width=1920, height=1080, seed=700 + i) for i in range(8)]
+    def run(extra):
+        b = J.JpegBatch()
+        for f in files:
+            b.add_jpeg(f)
+        b.tile(191)
+        b.add_jpeg(extra)
+        b.upload(); b.decode(); b.sync()
+        best = 1e9
+        for _ in range(3):
+            t = time.perf_counter(); b.decode(); b.sync(); best = min(best, (time.perf_counter() - t) * 1e3)
+        return b, best
+    bc, clean = run(files[0])
+    assert all(bc.info(i)["flags"] == 0 for i in range(192))
+    bc.close()
+    bh, dirty = run(hostile)
+    harness.drive(oracle, hostile)
+    assert bh.info(191)["path"] == 1 and bh.info(191)["flags"] & 0x0002
+    assert np.array_equal(bh.dib(191), oracle.dib())
+    sums = bh.dib_checksums()
+    for j, f in enumerate(files):
+        harness.drive(oracle, f)
+        want = J.dib_checksum_numpy(oracle.dib())
+        assert all(int(s) == want for s in sums[j:191:8]), j
+    bh.close()
+    assert dirty <= 2.0 * clean, f"clean {clean:.2f} ms, with one hostile file {dirty:.2f} ms"
