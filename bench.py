@@ -56,6 +56,8 @@ def parse_args(argv=None):
     ap.add_argument("--job-images", type=int, default=8192, help="--strong: files in the whole job (BASELINE config 4 names 8192)")
     ap.add_argument("--stub", action="store_true", help="CPU dry run of the rank logic: stand-in batch, gloo backend (tests)")
     ap.add_argument("--stub-ms", type=float, default=2.0, help="--stub: pretended decode time per step")
+    ap.add_argument("--share-device", action="store_true", help="TEST ONLY: all ranks decode on device 0 (gloo instead of RCCL: RCCL wants one device per rank) -- runs the real "
+                    "N-rank path on a one-GPU box; its value is meaningless as a scaling figure and the line says so")
     return ap.parse_args(argv)
 
 
@@ -68,7 +70,7 @@ def spawn_ranks(args, argv):
     """`bench.py --gpus N` outside torch.distributed.run: become the launcher of N ranks (one per GPU)."""
     if not args.stub:
         have = visible_gpus()
-        if have < args.gpus:
+        if have < (1 if args.share_device else args.gpus):
             sys.exit(f"bench.py: --gpus {args.gpus} requested but only {have} HIP device(s) are visible")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
@@ -376,16 +378,19 @@ def main():
                         break
                     time.sleep(0.5)
                 time.sleep(1.0)
-        if torch.cuda.device_count() <= local_rank:
-            sys.exit(f"bench.py: rank {rank} needs GPU {local_rank}, {torch.cuda.device_count()} visible")
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
+        dev_index = 0 if args.share_device else local_rank
+        if torch.cuda.device_count() <= dev_index:
+            sys.exit(f"bench.py: rank {rank} needs GPU {dev_index}, {torch.cuda.device_count()} visible")
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
     if world > 1:
-        if stub:
+        if stub or args.share_device:
             dist.init_process_group("gloo")
+            dev = None if stub else dev                     # (gloo reduces CPU tensors: `rdev` below)
         else:
             dist.init_process_group("nccl", device_id=dev)
         dist.barrier()
+    rdev = dev if (world > 1 and not stub and not args.share_device) else None      # where the job scalars are reduced: the GPU under RCCL, the host under gloo
 
     def device_sync():
         if not stub:
@@ -424,7 +429,7 @@ def main():
         batch = StubBatch(dims, gidx, args.stub_ms)
     else:
         lib = J.load()
-        assert lib.jsnoop_set_device(local_rank) == 0, J.last_error()
+        assert lib.jsnoop_set_device(0 if args.share_device else local_rank) == 0, J.last_error()
         batch = J.JpegBatch(want_planes=False)
         if args.strong:
             for k in keys:
@@ -533,19 +538,19 @@ def main():
     dom = max(stages, key=stages.get)
 
     my_ck = shard_checksum(sums, gidx)
-    tot_px, max_el, job_ck, tot_err = J.reduce_job_stats(pixels * args.steps, elapsed, my_ck, errors, dev if world > 1 else None)
+    tot_px, max_el, job_ck, tot_err = J.reduce_job_stats(pixels * args.steps, elapsed, my_ck, errors, rdev)
     if len(batch) and job_ck == 0:
         tot_err += 1                                      # a fingerprint of 0 carries no information (what the XOR of replicas used to give)
     per_rank_ms = [round(elapsed / args.steps * 1e3, 4)]
     if world > 1:
-        t = torch.tensor([elapsed / args.steps * 1e3], dtype=torch.float64, device=dev if dev is not None else "cpu")
+        t = torch.tensor([elapsed / args.steps * 1e3], dtype=torch.float64, device=rdev if rdev is not None else "cpu")
         got = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(got, t)
         per_rank_ms = [round(float(g[0]), 4) for g in got]
     shards = None
     if args.strong:
         # the union of the shards must be the job: count, sum and sum of squares of the global indices, all-reduced, against the closed forms
-        t = torch.tensor(shard_info["index_sums"] + [shard_info["compressed_bytes"]], dtype=torch.int64, device=dev if (dev is not None and world > 1) else "cpu")
+        t = torch.tensor(shard_info["index_sums"] + [shard_info["compressed_bytes"]], dtype=torch.int64, device=rdev if rdev is not None else "cpu")
         mine = t.clone()
         if world > 1:
             got = [torch.zeros_like(t) for _ in range(world)]
@@ -596,7 +601,7 @@ def main():
             "metric": METRIC,
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(max_el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
-            "vs_baseline": None, "dtype": "u8/i16 entropy+DIB, f32 IDCT+colour", "data": "synthetic" + (" (stub: no decode, rank logic only)" if stub else ""),
+            "vs_baseline": None, "dtype": "u8/i16 entropy+DIB, f32 IDCT+colour", "data": "synthetic" + (" (stub: no decode, rank logic only)" if stub else "") + (" (share-device: every rank on device 0 over gloo -- a test of the rank path, not a scaling figure)" if args.share_device else ""),
             "config": {"workload": (f"ONE job of {args.job_images} baseline 4:2:0 q85 JPEGs of mixed size (5/8 1920x1080, 2/8 1280x720, 1/8 3840x2160; "
                                     f"{args.distinct} distinct seeds per size), LPT-partitioned by compressed bytes over the ranks, HBM->HBM (T1)") if args.strong else
                                    (f"{args.images} x {args.width}x{args.height} baseline 4:2:0 q85 JPEG per GPU "

@@ -55,6 +55,10 @@ JsnoopDecoder* jsnoop_create(void);
 void           jsnoop_destroy(JsnoopDecoder*);
 void           jsnoop_reset(JsnoopDecoder*);
 void           jsnoop_reset_state(JsnoopDecoder*);
+/* the two halves of ResetState the class also has on their own: ResetDqtTables :343 (table selection, coefficients, number of SOF components)
+ * and ResetDhtLookup :373 (code lists, fast look-up, table selection, the code-length histogram)                                          */
+void           jsnoop_reset_dqt_tables(JsnoopDecoder*);
+void           jsnoop_reset_dht_lookup(JsnoopDecoder*);
 void           jsnoop_set_log_callback(JsnoopDecoder*, jsnoop_log_fn fn, void* user);
 
 /* ---- options: the CSnoopConfig fields read at ImgDecode.cpp:2730-2741 ---------
@@ -77,6 +81,20 @@ void jsnoop_set_sof_samp_factors(JsnoopDecoder*, unsigned comp_ind, unsigned sam
 void jsnoop_set_precision(JsnoopDecoder*, unsigned precision);
 void jsnoop_set_image_details(JsnoopDecoder*, unsigned dim_x, unsigned dim_y, unsigned comps_sof, unsigned comps_sos,
                               int rst_en, unsigned rst_interval);
+
+/* SetImageDimensions :2706 (the PSD path's way of sizing the preview, source/JfifDecode.cpp:7374): the base rectangle of the preview, which
+ * DecodeScanImg sets to the MCU-rounded image size itself (:2874).  jsnoop_get_image_dimensions reads it back.                            */
+void jsnoop_set_image_dimensions(JsnoopDecoder*, unsigned width, unsigned height);
+void jsnoop_get_image_dimensions(JsnoopDecoder*, unsigned* width, unsigned* height);
+/* The public members CjfifDecode pokes when the preview does NOT come from the scan decoder (source/ImgDecode.h:508-510, used at
+ * source/JfifDecode.cpp:7369-7373: a Photoshop file's image decoded into m_pDibTemp): jsnoop_dib_temp_create is m_pDibTemp.Kill() +
+ * CreateDIB(width, height, 32) + GetDIBBitArray() -- a zeroed bottom-up BGRA buffer owned by the decoder that the caller fills and
+ * jsnoop_get_bitmap_ptr then hands out (GetBitmapPtr :4940 returns m_pDibTemp's bits whatever filled them) --, the two setters are the
+ * members m_bDibTempReady and m_bPreviewIsJpeg (IsPreviewReady :3753 returns the latter).  Reset() drops the buffer (:80-83).             */
+uint8_t* jsnoop_dib_temp_create(JsnoopDecoder*, unsigned width, unsigned height);
+void     jsnoop_set_dib_temp_ready(JsnoopDecoder*, int ready);
+int      jsnoop_get_dib_temp_ready(JsnoopDecoder*);
+void     jsnoop_set_preview_is_jpeg(JsnoopDecoder*, int is_jpeg);
 
 /* ---- minimal JFIF front end: walks SOI/DQT/SOF0-1/DHT/DRI up to the first SOS and
  *      issues the setter calls above exactly as CjfifDecode::DecodeMarker does (source/JfifDecode.cpp:3581,
@@ -224,7 +242,8 @@ int          jsnoop_batch_split_parts(const JsnoopBatch*);              /* what 
  *      decode path reads the environment.  A batch takes a copy at jsnoop_batch_set_tuning (call before upload; -1 + last_error on a
  *      value out of range); jsnoop_set_tuning does the same for the private batch behind a single-image decoder.                      */
 typedef struct JsnoopTuning {
-    uint32_t struct_size;     /* sizeof(JsnoopTuning) of the caller (forward compatibility)                                          */
+    uint32_t struct_size;     /* sizeof(JsnoopTuning) of the caller: a shorter (older) struct is accepted, the fields it lacks are automatic, and
+                                 jsnoop_batch_get_tuning writes no byte past it; a longer one than the library knows is refused              */
     int32_t  sub_wl;          /* log2(32-bit words) of a sub-sequence: 4..8 = 64 B .. 1 KiB; 0 = by job size (4 / 6 / 7)              */
     int32_t  cand_rounds;     /* synchronisation form: -1 = rounds of k_sync only, n > 0 = candidates with at most n walk rounds (<= 64),
                                  0 = automatic (candidates with 16 rounds while the job is small enough, see cand_max_walks)          */

@@ -39,6 +39,14 @@ SIGNATURES = {
     "jsnoop_destroy": (None, [_p]),
     "jsnoop_reset": (None, [_p]),
     "jsnoop_reset_state": (None, [_p]),
+    "jsnoop_reset_dqt_tables": (None, [_p]),
+    "jsnoop_reset_dht_lookup": (None, [_p]),
+    "jsnoop_set_image_dimensions": (None, [_p, _u, _u]),
+    "jsnoop_get_image_dimensions": (None, [_p, _PU, _PU]),
+    "jsnoop_dib_temp_create": (_p, [_p, _u, _u]),
+    "jsnoop_set_dib_temp_ready": (None, [_p, _i]),
+    "jsnoop_get_dib_temp_ready": (_i, [_p]),
+    "jsnoop_set_preview_is_jpeg": (None, [_p, _i]),
     "jsnoop_set_log_callback": (None, [_p, LOG_FN, _p]),
     "jsnoop_set_options": (None, [_p, _i, _i, _i, _u]),
     "jsnoop_set_dqt_entry": (_i, [_p, _u, _u, _u, _u]),

@@ -27,25 +27,55 @@ struct CwindowBufView {
     uint8_t Buf(size_t nOffset) const { return nOffset < nLen ? pData[nOffset] : 0; }     // WindowBuf.cpp:639
 };
 
-class CimgDecodeGpu {
+// The slice of CDIB (source/Dib.h:33-55) that reaches the decoder: the preview DIB CjfifDecode lets the Photoshop decoder fill
+// (m_pPsDec->DecodePsd(nStartPos, &m_pImgDec->m_pDibTemp, ...), source/JfifDecode.cpp:7369).  The bits live in the decoder
+// (jsnoop_dib_temp_create), so GetBitmapPtr hands them out as the reference's would.
+class CDibGpu {
+public:
+    void  Kill() { if (m_h) jsnoop_dib_temp_create(m_h, 0, 0); m_pBits = nullptr; m_nW = m_nH = 0; }                                     // Dib.cpp:88
+    bool  CreateDIB(unsigned long dwWidth, unsigned long dwHeight, unsigned short nBits)                                               // Dib.cpp:53: 32 bits per pixel is what this path creates
+    { if (!m_h || nBits != 32) return false; m_pBits = jsnoop_dib_temp_create(m_h, (unsigned)dwWidth, (unsigned)dwHeight); m_nW = (unsigned)dwWidth; m_nH = (unsigned)dwHeight; return m_pBits != nullptr; }
+    void* GetDIBBitArray() const { return m_pBits; }                                                                                   // Dib.cpp:131
+    unsigned GetWidth() const { return m_nW; }
+    unsigned GetHeight() const { return m_nH; }
+    void  Attach(JsnoopDecoder* h) { m_h = h; }
+private:
+    JsnoopDecoder* m_h = nullptr; uint8_t* m_pBits = nullptr; unsigned m_nW = 0, m_nH = 0;
+};
+
+// TDib: the type of the public member m_pDibTemp -- CDibGpu here; a build inside the reference's tree may name its own CDIB-shaped class
+// (it needs Kill / CreateDIB / GetDIBBitArray and an Attach(JsnoopDecoder*) hook).
+template <class TDib>
+class CimgDecodeGpuT {
 public:
     using LogFn = std::function<void(int /*0 info, 1 warn, 2 err*/, const std::string&)>;
 
-    explicit CimgDecodeGpu(LogFn pLog = nullptr, const CwindowBufView* pWBuf = nullptr) : m_pWBuf(pWBuf), m_log(std::move(pLog))
+    explicit CimgDecodeGpuT(LogFn pLog = nullptr, const CwindowBufView* pWBuf = nullptr) : m_pWBuf(pWBuf), m_log(std::move(pLog))
     {
         m_h = jsnoop_create();                                   // CimgDecode ctor (ImgDecode.cpp:142)
         if (!m_h) throw std::runtime_error(std::string("jsnoop_create: ") + jsnoop_last_error());
-        if (m_log) jsnoop_set_log_callback(m_h, &CimgDecodeGpu::LogThunk, this);
+        if (m_log) jsnoop_set_log_callback(m_h, &CimgDecodeGpuT::LogThunk, this);
+        m_pDibTemp.Attach(m_h);
     }
-    ~CimgDecodeGpu() { jsnoop_destroy(m_h); }
-    CimgDecodeGpu(const CimgDecodeGpu&) = delete;
-    CimgDecodeGpu& operator=(const CimgDecodeGpu&) = delete;
+    ~CimgDecodeGpuT() { jsnoop_destroy(m_h); }
+    CimgDecodeGpuT(const CimgDecodeGpuT&) = delete;
+    CimgDecodeGpuT& operator=(const CimgDecodeGpuT&) = delete;
+
+    // ---- the three public members CjfifDecode writes for a preview that is not the scan decoder's (source/ImgDecode.h:507-510, "FIXME (workaround)"
+    //      there too; set at source/JfifDecode.cpp:7369-7373).  Plain members like the reference's: SyncPreviewMembers() carries them into the
+    //      library -- IsPreviewReady / GetBitmapPtr call it, so poking them and asking is all a caller does.
+    bool m_bDibTempReady = false;
+    TDib m_pDibTemp;
+    bool m_bPreviewIsJpeg = false;
+    void SyncPreviewMembers() { jsnoop_set_dib_temp_ready(m_h, m_bDibTempReady); jsnoop_set_preview_is_jpeg(m_h, m_bPreviewIsJpeg); }
 
     void SetWindowBuf(const CwindowBufView* pWBuf) { m_pWBuf = pWBuf; }
 
     // ---- lifecycle ------------------------------------------------------------------------------
-    void Reset() { jsnoop_reset(m_h); }                         // :49
+    void Reset() { jsnoop_reset(m_h); m_bDibTempReady = false; }   // :49 (kills m_pDibTemp when it was ready, :80-83)
     void ResetState() { jsnoop_reset_state(m_h); }              // :286
+    void ResetDqtTables() { jsnoop_reset_dqt_tables(m_h); }     // :343 (private in the reference: ResetState calls it)
+    void ResetDhtLookup() { jsnoop_reset_dht_lookup(m_h); }     // :373
 
     // ---- options: the CSnoopConfig fields DecodeScanImg reads (:2730-2741) -------------------------
     void SetConfig(bool bDecodeScanImgAc, bool bHistoEn = false, bool bStatClipEn = false, unsigned nErrMaxDecodeScan = 20, bool bDumpHistoY = false)
@@ -64,6 +94,8 @@ public:
     void SetSofSampFactors(unsigned nCompInd, unsigned nSampFactH, unsigned nSampFactV) { jsnoop_set_sof_samp_factors(m_h, nCompInd, nSampFactH, nSampFactV); } // :619
     void SetImageDetails(unsigned nDimX, unsigned nDimY, unsigned nCompsSOF, unsigned nCompsSOS, bool bRstEn, unsigned nRstInterval)
     { jsnoop_set_image_details(m_h, nDimX, nDimY, nCompsSOF, nCompsSOS, bRstEn, nRstInterval); }                // :590
+    void SetImageDimensions(unsigned nWidth, unsigned nHeight) { jsnoop_set_image_dimensions(m_h, nWidth, nHeight); }          // :2706
+    void GetImageDimensions(unsigned& nWidth, unsigned& nHeight) { jsnoop_get_image_dimensions(m_h, &nWidth, &nHeight); }      // (m_rectImgBase, read by the view code)
 
     // ---- minimal header walk: the subset of CjfifDecode::DecodeMarker that feeds this object --------------
     bool WalkJfifHeader(unsigned& nPosScanStart)
@@ -74,12 +106,13 @@ public:
     {
         if (!m_pWBuf || !m_pWBuf->pData) { if (m_log) m_log(2, "*** ERROR: DecodeScanImg without a file buffer ***"); return; }
         jsnoop_decode_scan_img(m_h, m_pWBuf->pData, m_pWBuf->nLen, nStart, bDisplay, bQuiet);
+        m_bPreviewIsJpeg = jsnoop_is_preview_ready(m_h) != 0; m_bDibTempReady = jsnoop_get_dib_temp_ready(m_h) != 0;     // :3647-3648
     }
 
     // ---- results (owned by the decoder, valid until the next Reset / DecodeScanImg / destruction) ------------
-    bool IsPreviewReady() { return jsnoop_is_preview_ready(m_h) != 0; }                                          // :3753
+    bool IsPreviewReady() { SyncPreviewMembers(); return jsnoop_is_preview_ready(m_h) != 0; }                    // :3753 (returns m_bPreviewIsJpeg)
     void GetImageSize(unsigned& nX, unsigned& nY) { jsnoop_get_image_size(m_h, &nX, &nY); }                      // :4929
-    void GetBitmapPtr(unsigned char*& pBitmap) { pBitmap = const_cast<unsigned char*>(jsnoop_get_bitmap_ptr(m_h)); } // :4940
+    void GetBitmapPtr(unsigned char*& pBitmap) { SyncPreviewMembers(); pBitmap = const_cast<unsigned char*>(jsnoop_get_bitmap_ptr(m_h)); } // :4940
     const void* GetBitmapDevicePtr() { return jsnoop_get_bitmap_dev(m_h); }                                      // HBM copy of the DIB
     void GetPixMapPtrs(short*& pMapY, short*& pMapCb, short*& pMapCr)                                            // :4913
     {
@@ -118,11 +151,12 @@ public:
     JsnoopDecoder* Handle() { return m_h; }
 
 private:
-    static void LogThunk(void* user, int level, const char* text) { auto* self = static_cast<CimgDecodeGpu*>(user); if (self->m_log) self->m_log(level, text); }
+    static void LogThunk(void* user, int level, const char* text) { auto* self = static_cast<CimgDecodeGpuT*>(user); if (self->m_log) self->m_log(level, text); }
     JsnoopDecoder* m_h = nullptr;
     const CwindowBufView* m_pWBuf;
     LogFn m_log;
 };
+using CimgDecodeGpu = CimgDecodeGpuT<CDibGpu>;
 
 // The slice of CJPEGsnoopCore that belongs to the scan-decode path (source/JPEGsnoopCore.h:79-117, JPEGsnoopCore.cpp:1211-1399):
 // the data-bearing I_* accessors over the core's one CimgDecode (source/JPEGsnoopCore.cpp:46), an AnalyzeFile-shaped entry

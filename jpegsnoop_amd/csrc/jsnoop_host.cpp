@@ -13,6 +13,7 @@
 #include <vector>
 #include <chrono>
 #include <algorithm>
+#include <atomic>
 #include "../../include/jsnoop_gpu.h"
 #include "jsnoop_types.h"
 #include "jsnoop_launch.h"
@@ -55,7 +56,7 @@ void JsnoopDecoder::log(int level, const char* fmt, ...)
     char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
     log_fn(log_user, level, buf);
 }
-void JsnoopDecoder::reset_state()                                              // ResetState :286-306
+void JsnoopDecoder::reset_dht_lookup()                                         // ResetDhtLookup :373-415
 {
     memset(t.dht_histo_unused, 0, sizeof t.dht_histo_unused);
     memset(t.dht_setmax, 0, sizeof t.dht_setmax); memset(t.dht_size, 0, sizeof t.dht_size);
@@ -63,8 +64,16 @@ void JsnoopDecoder::reset_state()                                              /
     memset(t.dht_mask, 0, sizeof t.dht_mask); memset(t.dht_code, 0, sizeof t.dht_code);
     memset(t.dht_fast, 0xFF, sizeof t.dht_fast);                               // DHT_CODE_UNUSED :391
     for (int c = 0; c < 2; c++) for (int i = 0; i < 5; i++) t.dht_sel[c][i] = -1;
+}
+void JsnoopDecoder::reset_dqt_tables()                                         // ResetDqtTables :343-361
+{
     for (int i = 0; i < 256; i++) t.dqt_sel[i] = -1;
     memset(t.dqt_nat, 0, sizeof t.dqt_nat); memset(t.dqt_zz, 0, sizeof t.dqt_zz);
+    t.num_sof = 0;
+}
+void JsnoopDecoder::reset_state()                                              // ResetState :286-306
+{
+    reset_dht_lookup(); reset_dqt_tables();
     memset(t.samp_h, 0, sizeof t.samp_h); memset(t.samp_v, 0, sizeof t.samp_v);
     t.details_set = 0; t.num_sof = 0; t.num_sos = 0; t.precision = 0;
 }
@@ -174,9 +183,29 @@ const JsnoopTuning& js_env_tuning()
                          (on("JSNOOP_UNSTUFF_3PASS") ? JSNOOP_XC_UNSTUFF_3PASS : 0u);
         const long long dc = num("JSNOOP_DEBUG_CAND", 0);
         t.debug = (dc >= 1 ? JSNOOP_DBG_CAND : 0u) | (dc >= 2 ? JSNOOP_DBG_CAND_LINKS : 0u) | (on("JSNOOP_DEBUG_TAIL") ? JSNOOP_DBG_TAIL : 0u) | (on("JSNOOP_DEBUG_TIMING") ? JSNOOP_DBG_TIMING : 0u);
+        // the same limits as js_check_tuning: a preset out of range falls back to "automatic" (every later set_tuning writes the whole struct back and
+        // would be refused for a field its caller never touched)
+        if (t.sync_launches > 64) t.sync_launches = 0;
+        if (t.mcus_per_wave > 4096) t.mcus_per_wave = 0;
         return t;
     }();
     return env;
+}
+// struct_size is the caller's sizeof(JsnoopTuning): a caller built against an older (shorter) header gets "automatic" for the fields it does not know,
+// nothing is read or written past what it owns; a caller with a LONGER struct than this library knows is refused (its extra fields mean something).
+int js_import_tuning(const JsnoopTuning* in, JsnoopTuning* out)
+{
+    const uint32_t sz = in->struct_size;
+    if (sz < 8 || sz > sizeof(JsnoopTuning)) { js_set_error("tuning: struct_size %u, this library has %zu", sz, sizeof(JsnoopTuning)); return -1; }
+    memset(out, 0, sizeof *out); memcpy(out, in, sz); out->struct_size = (uint32_t)sizeof(JsnoopTuning);
+    return js_check_tuning(*out);
+}
+void js_export_tuning(const JsnoopTuning& t, JsnoopTuning* out)      // honours out->struct_size when the caller set one (0 / garbage: the full struct, as jsnoop_tuning_defaults always did)
+{
+    const uint32_t want = out->struct_size;
+    const size_t sz = (want >= 8 && want <= sizeof(JsnoopTuning)) ? want : sizeof(JsnoopTuning);
+    JsnoopTuning tmp = t; tmp.struct_size = (uint32_t)sz;
+    memcpy(out, &tmp, sz);
 }
 int js_check_tuning(const JsnoopTuning& t)
 {
@@ -231,6 +260,19 @@ int JsnoopBatch::init()
     for (int yx = 0; yx < 64; yx++) for (int vu = 0; vu < 64; vu++) lt[vu * 64 + yx] = lut[yx][vu];
     HIP_TRY(hipMalloc(&d_lut, 64 * 64 * sizeof(float)));
     HIP_TRY(hipMemcpy(d_lut, lt.data(), 64 * 64 * sizeof(float), hipMemcpyHostToDevice));
+    {   // once per device: the write pass's unaligned 16-byte store must arrive as written (k_unaligned_probe)
+        static std::atomic<int> ok[JS_MAX_DEVICES];                // 0 = not probed, 1 = fine, -1 = refused
+        int st = device >= 0 && device < JS_MAX_DEVICES ? ok[device].load() : 0;
+        if (st == 0) {
+            uint16_t* p = nullptr; uint16_t h[24];
+            HIP_TRY(hipMalloc((void**)&p, sizeof h)); HIP_TRY(hipMemset(p, 0, sizeof h));
+            js_launch_unaligned_probe(stream, p);
+            HIP_TRY(hipMemcpyAsync(h, p, sizeof h, hipMemcpyDeviceToHost, stream)); HIP_TRY(hipStreamSynchronize(stream)); hipFree(p);
+            st = 1; for (int k = 0; k < 24; k++) if (h[k] != (k >= 3 && k < 11 ? k - 2 : 0)) st = -1;
+            if (device >= 0 && device < JS_MAX_DEVICES) ok[device].store(st);
+        }
+        if (st < 0) { js_set_error("device %d does not take unaligned 16-byte global stores (the write pass relies on them)", device); return -1; }
+    }
     return 0;
 }
 JsnoopBatch::~JsnoopBatch()
@@ -580,8 +622,23 @@ JsnoopDecoder* jsnoop_create(void)
 }
 void jsnoop_destroy(JsnoopDecoder* d) { if (!d) return; delete d->batch; delete d; }
 void jsnoop_reset(JsnoopDecoder* d)                                             // Reset :49-138
-{ d->have_image = false; d->host_valid = 0; memset(d->geom, 0, sizeof d->geom); d->geom[0] = d->geom[1] = 1; d->warn_ycc_clip = 0; }
+{
+    d->have_image = false; d->host_valid = 0; memset(d->geom, 0, sizeof d->geom); d->geom[0] = d->geom[1] = 1; d->warn_ycc_clip = 0;
+    if (d->dib_temp_ready) { d->dib_temp.clear(); d->dib_temp.shrink_to_fit(); d->dib_temp_ready = false; }          // :80-83
+}
 void jsnoop_reset_state(JsnoopDecoder* d) { d->reset_state(); }
+void jsnoop_reset_dqt_tables(JsnoopDecoder* d) { d->reset_dqt_tables(); }
+void jsnoop_reset_dht_lookup(JsnoopDecoder* d) { d->reset_dht_lookup(); }
+void jsnoop_set_image_dimensions(JsnoopDecoder* d, unsigned w, unsigned h) { d->base_w = w; d->base_h = h; }            // :2706-2709
+void jsnoop_get_image_dimensions(JsnoopDecoder* d, unsigned* w, unsigned* h) { *w = d->base_w; *h = d->base_h; }
+uint8_t* jsnoop_dib_temp_create(JsnoopDecoder* d, unsigned w, unsigned h)
+{
+    d->dib_temp.assign((size_t)w * h * 4, 0); d->have_image = false; d->host_valid = 0;     // (the decoded image's DIB is no longer the preview)
+    return d->dib_temp.empty() ? nullptr : d->dib_temp.data();
+}
+void jsnoop_set_dib_temp_ready(JsnoopDecoder* d, int ready) { d->dib_temp_ready = ready != 0; }
+int  jsnoop_get_dib_temp_ready(JsnoopDecoder* d) { return d->dib_temp_ready || d->have_image; }
+void jsnoop_set_preview_is_jpeg(JsnoopDecoder* d, int is_jpeg) { d->preview_is_jpeg = is_jpeg != 0; }
 void jsnoop_set_log_callback(JsnoopDecoder* d, jsnoop_log_fn fn, void* user) { d->log_fn = fn; d->log_user = user; }
 void jsnoop_set_options(JsnoopDecoder* d, int ac, int histo, int clip, unsigned err_max)
 { d->opt_decode_ac = ac; d->opt_histo_en = histo; d->opt_stat_clip_en = clip; d->opt_err_max = err_max; }
@@ -673,7 +730,8 @@ void jsnoop_decode_scan_img(JsnoopDecoder* d, const uint8_t* file, size_t len, u
     auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tp[10]; int ntp = 0; if (dbg_t) tp[ntp++] = now_us();
     if (b->add(d, file, len, start, display, quiet) < 0) return;   // early returns of DecodeScanImg: no preview
-    d->preview_is_jpeg = false;                                     // :2978
+    d->preview_is_jpeg = false; d->dib_temp.clear(); d->dib_temp_ready = false;        // :2976-2978
+    d->base_w = d->geom[6]; d->base_h = d->geom[7];                 // m_rectImgBase :2874
     if (display) memset(d->stats, 0, sizeof d->stats);              // :3145-3155
     if (dbg_t) tp[ntp++] = now_us();
     if (b->upload()) { d->log(2, "*** ERROR: device decode failed: %s", g_err.c_str()); return; }
@@ -705,7 +763,7 @@ void jsnoop_get_image_size(JsnoopDecoder* d, unsigned* x, unsigned* y) { *x = d-
 void jsnoop_get_geometry(JsnoopDecoder* d, unsigned* o) { memcpy(o, d->geom, sizeof d->geom); }
 const uint8_t* jsnoop_get_bitmap_ptr(JsnoopDecoder* d)
 {
-    if (!d->have_image) return nullptr;
+    if (!d->have_image) return d->dib_temp.empty() ? nullptr : d->dib_temp.data();     // (m_pDibTemp as the PSD path left it, if it did)
     if (!(d->host_valid & 1)) {
         const JsImage& im = d->batch->imgs[d->img];
         if (d->h_dib.ensure((size_t)im.img_x * im.img_y * 4) || d->batch->read_dib(d->img, (uint8_t*)d->h_dib.p)) return nullptr;
@@ -866,18 +924,19 @@ int jsnoop_batch_set_split(JsnoopBatch* b, int parts)
     return 0;
 }
 int jsnoop_batch_split_parts(const JsnoopBatch* b) { return b ? b->split_parts : 1; }
-void jsnoop_tuning_defaults(JsnoopTuning* out) { if (out) *out = js_env_tuning(); }
+void jsnoop_tuning_defaults(JsnoopTuning* out) { if (out) *out = js_env_tuning(); }      // (writes sizeof(JsnoopTuning) bytes: the struct of THIS header; jsnoop_batch_get_tuning honours struct_size)
 int jsnoop_batch_set_tuning(JsnoopBatch* b, const JsnoopTuning* t)
 {
     if (!b || !t) { js_set_error("jsnoop_batch_set_tuning: null argument"); return -1; }
-    if (js_check_tuning(*t)) return -1;
-    b->tune = *t; b->uploaded = false;                           // sub-sequence length, synchronisation form and work split are fixed by upload()
-    if (b->helper) b->helper->tune = *t;
+    JsnoopTuning in;
+    if (js_import_tuning(t, &in)) return -1;
+    b->tune = in; b->uploaded = false;                           // sub-sequence length, synchronisation form and work split are fixed by upload()
+    if (b->helper) b->helper->tune = in;
     js_prog_dirty(b);
     js_resolve_split(b);
     return 0;
 }
-void jsnoop_batch_get_tuning(const JsnoopBatch* b, JsnoopTuning* out) { if (b && out) *out = b->tune; }
+void jsnoop_batch_get_tuning(const JsnoopBatch* b, JsnoopTuning* out) { if (b && out) js_export_tuning(b->tune, out); }
 int jsnoop_set_tuning(JsnoopDecoder* d, const JsnoopTuning* t)
 {
     if (!d || !d->batch) { js_set_error("jsnoop_set_tuning: no decoder"); return -1; }
@@ -1070,7 +1129,10 @@ void JsnoopDecoder::fetch_side()
     const JsImage& im = batch->imgs[img];
     h_side.assign(js_side_words(im.mcu_xmax * im.mcu_ymax, im.blk_xmax * im.blk_ymax), 0);
     hipSetDevice(batch->device);
-    if (batch->d2h_staged(h_side.data(), batch->dev.side + im.side_off, h_side.size() * 4)) log(2, "*** ERROR: reading the side block back failed: %s", g_err.c_str());
+    // before the side pass has run only the sixteen status words are this decode's (the decode clears nothing else of the side block: histogram and
+    // maps would be an earlier decode's, or another image's of an earlier batch) -- they stay zero in the host copy until side_ready
+    const size_t words = side_ready ? h_side.size() : (size_t)JS_SIDE_HISTO;
+    if (batch->d2h_staged(h_side.data(), batch->dev.side + im.side_off, words * 4)) log(2, "*** ERROR: reading the side block back failed: %s", g_err.c_str());
 }
 void JsnoopDecoder::rerender()                                  // CalcChannelPreview :4965 on the retained data: colour kernel only
 {

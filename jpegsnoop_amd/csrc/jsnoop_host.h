@@ -43,6 +43,11 @@ struct JsnoopDecoder {
     struct Pinned { void* p = nullptr; size_t cap = 0; int ensure(size_t need); ~Pinned(); };
     Pinned h_dib, h_planes; std::vector<uint32_t> h_side;
     uint32_t zero_histo[2 * 4 * 17] = {0};
+    // what the reference keeps for a preview that does not come from the scan decoder (m_pDibTemp filled by the PSD decoder, m_bDibTempReady,
+    // m_rectImgBase: source/ImgDecode.h:508-510, SetImageDimensions :2706)
+    std::vector<uint8_t> dib_temp; bool dib_temp_ready = false; unsigned base_w = 0, base_h = 0;
+    void reset_dqt_tables();                                       // ResetDqtTables :343
+    void reset_dht_lookup();                                       // ResetDhtLookup :373
     JsnoopDecoder();
     void reset_state();
     void log(int level, const char* fmt, ...);
@@ -81,7 +86,7 @@ struct JsnoopBatch {
     std::vector<std::vector<uint32_t>> side_anoms;                // per image: the coefficient-index overflows of the side walk, in block order (4 words each)
     std::vector<uint8_t> side_done;                               // per image: the side-output pass has run since the last decode
     std::vector<uint32_t> host_anom;                              // per image: first block (decode order) the parallel path could not vouch for (0xFFFFFFFF: none)
-    std::vector<uint8_t> host_anom_kind;                          // ... and what it was: 0 = the mirror takes over there, 1 / 2 = the reference's decode ends in that block (at its DC symbol / behind it)
+    std::vector<uint8_t> host_anom_kind;                          // ... and what it was: 0 = the mirror takes over there, 1..8 = the reference's decode ends in that block (ANOM_KEY, jsnoop_kernels.hip)
     std::vector<uint32_t> host_flags, host_path, h_us_base, h_sy_base, h_sn_base, h_wg_base;
     // A large batch decodes as two halves on two streams (stream, aux[0]): the kernels of one half fill the tails and the thinly
     // populated phases (second synchronisation launch, DC scan) of the other -- 14.2 -> 13.7 ms per 1024 images.  Both halves live in
@@ -146,6 +151,8 @@ int  js_read_flags(JsnoopBatch* b);                               // -> host_fla
 void js_set_error(const char* fmt, ...);
 const JsnoopTuning& js_env_tuning();                             // the process defaults: environment variables, read once
 int  js_check_tuning(const JsnoopTuning& t);                      // 0 / -1 + error text
+int  js_import_tuning(const JsnoopTuning* in, JsnoopTuning* out); // a caller's struct (its struct_size bytes) -> this library's, checked
+void js_export_tuning(const JsnoopTuning& t, JsnoopTuning* out);  // ... and back, no byte past the caller's struct_size
 void js_debug_cand_links(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32_t n);   // JSNOOP_DBG_CAND_LINKS (jsnoop_parallel.cpp)
 // roctx ranges around the host-side stages (rocprofv3 --marker-trace makes a timeline self-describing: upload / clear / entropy
 // stages / back end / read-back).  One push and pop per stage and call: nothing per image.

@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
         // Tail mode: the MCU the mirror takes over at, and everything from there on emptied first -- the mirror stores what it decodes, and
         // MCUs it never reaches (the scan-stop logic after an overread, :3623-3625) must read as the cleared arrays of the reference.
         if (threadIdx.x == 0) {
-            uint32_t m0 = min((~tail.flags[2u * sel[j] + 1u] >> 2) / im.blk_per_mcu, nmcu);   // (the word holds the complement of block << 2 | kind)
+            uint32_t m0 = min((~tail.flags[2u * sel[j] + 1u] >> 4) / im.blk_per_mcu, nmcu);   // (the word holds the complement of block << 4 | kind)
             while (m0 && tail.mcu_pos[m0] == 0u) m0--;             // (an MCU top the side walk did not reach: fall back to an earlier one)
             s_m0 = m0;
         }
@@ -652,7 +652,10 @@ __device__ __forceinline__ PairList pair_list(const void* mem, uint32_t lane)
 
 // d: the lane's two coefficients, c[2l] | c[2l+1] << 16 (DC and, in DC-only mode, everything already masked out).
 // Returns in acc0 / acc1 the sums (x 2, see idct_run) of the lane's samples 2l and 2l+1 of its block.
-__device__ __forceinline__ void idct_pair(uint32_t d, const PairList L, uint32_t lane, float& acc0, float& acc1)
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// consumed(): called once the lists are written -- the caller's source of `d` is free from there on (the next MCU's prefetch lands in it)
+template <class F = NoHook>
+__device__ __forceinline__ void idct_pair(uint32_t d, const PairList L, uint32_t lane, float& acc0, float& acc1, F&& consumed = NoHook())
 {
     acc0 = 0.0f; acc1 = 0.0f;
     const bool nz0 = (d & 0xFFFFu) != 0u, nz1 = (d >> 16) != 0u;
@@ -672,7 +675,8 @@ __device__ __forceinline__ void idct_pair(uint32_t d, const PairList L, uint32_t
         asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(cf0) : "v"(d));
         asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(cf1) : "v"(d));
         const uint32_t w0 = L.a_half + (s0 << 2), w1 = L.a_half + (s1 << 2);
-        lds_w32(w0, cf0); lds_w32(w1, cf1); lds_w32(w0 + 256u, L.row0); lds_w32(w1 + 256u, L.row0 + 256u);
+        lds_w32(w0, cf0); lds_w32(w0 + 256u, L.row0); lds_w32(w1, cf1); lds_w32(w1 + 256u, L.row0 + 256u);      // (in this order the compiler pairs them: two ds_write2st64_b32)
+        consumed();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         typedef float f32x2_t __attribute__((ext_vector_type(2)));
         f32x2_t a0, a1, a2, a3, b0, b1, b2, b3; uint32_t ad;
@@ -680,7 +684,7 @@ __device__ __forceinline__ void idct_pair(uint32_t d, const PairList L, uint32_t
         if (n > 16) { const float ey = __uint_as_float(lds_r32(L.a_ey + 64u)); const uint32_t rw = lds_r32(L.a_rw + 64u), nl = n - 16; PAIR_ROUND(); }
         if (n > 32) { const float ey = __uint_as_float(lds_r32(L.a_ey + 128u)); const uint32_t rw = lds_r32(L.a_rw + 128u), nl = n - 32; PAIR_ROUND(); }
         if (n > 48) { const float ey = __uint_as_float(lds_r32(L.a_ey + 192u)); const uint32_t rw = lds_r32(L.a_rw + 192u), nl = n - 48; PAIR_ROUND(); }
-    }
+    } else consumed();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
@@ -964,31 +968,39 @@ __device__ __forceinline__ void back_end_pairs(const BackEndCtx& C, uint64_t& br
     const size_t coef_off = im.coef_off;
     uint32_t raw[np]; int dcl[np];
     // A lane fetches the dword that holds its two coefficients (an idle half re-reads block A: nothing is read past the arena) and the
-    // cumulative DC of its block; the next MCU's fetch is issued before the colour phase of the current one and first used after it.
+    // cumulative DC of its block.  Round 5: the NEXT MCU's row of pair p is fetched as soon as this MCU's pair p sits in its lists -- into
+    // the very register it came from -- and its DC word behind the pair's tile store: the loads fly under the terms of this and the later
+    // pairs and under the colour phase.  (Issued in front of the colour phase only, one MCU's 768 bytes per wave were in flight for a third
+    // of an iteration: too little for the memory system, profiles/r05_backend_parts.txt; 6.64 -> 6.57 ms, with the contiguous ranges 6.50.)
     auto fetch = [&](uint32_t m) {
         const uint32_t* p32 = reinterpret_cast<const uint32_t*>(C.cbase + (size_t)m * nb * 64);
         const int16_t* d16 = C.dccum + coef_off + (size_t)m * nb;
         #pragma unroll
         for (uint32_t p = 0; p < np; p++) { raw[p] = p32[p * 64u + (live[p] ? lane : l)]; dcl[p] = (int)d16[2u * p + (live[p] ? hi : 0u)]; }
     };
-    const uint32_t wstride = C.wgs_in_img * BK_WAVES;
-    uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(C.wg_in_img * BK_WAVES + C.wave));
+    // A workgroup owns a CONTIGUOUS range of the image's MCUs and its waves step through it side by side (round 5; before: 8-MCU pieces a whole
+    // grid stride apart): what a workgroup reads and writes over time is one sequential stream per MCU row.
+    const uint32_t per = (nmcu + C.wgs_in_img - 1u) / C.wgs_in_img, m_begin = C.wg_in_img * per, m_end = min(m_begin + per, nmcu);
+    const uint32_t wstride = BK_WAVES;
+    uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(m_begin + C.wave));
     const uint32_t xmax = im.mcu_xmax, step_x = wstride % xmax, step_y = wstride / xmax;
     uint32_t mx = m % xmax, my = m / xmax;                       // MCU coordinates, stepped along with m (no division in the loop)
-    if (m < nmcu) fetch(m);
+    if (m < m_end) fetch(m);
     #pragma nounroll
-    for (; m < nmcu; m += wstride, mx += step_x, my += step_y) {
+    for (; m < m_end; m += wstride, mx += step_x, my += step_y) {
         if (mx >= xmax) { mx -= xmax; my++; }
+        const uint32_t m_next = m + wstride < m_end ? m + wstride : m;   // (the last round fetches its own MCU again: no branch around the fetches)
+        const uint32_t* p32n = reinterpret_cast<const uint32_t*>(C.cbase + (size_t)m_next * nb * 64);
+        const int16_t* d16n = C.dccum + coef_off + (size_t)m_next * nb;
         #pragma unroll
         for (uint32_t p = 0; p < np; p++) {
             float acc0, acc1;
-            idct_pair(raw[p] & cmask[p], L, lane, acc0, acc1);
+            idct_pair(raw[p] & cmask[p], L, lane, acc0, acc1, [&]() { raw[p] = p32n[p * 64u + (live[p] ? lane : l)]; });
             // fp32 sums (x 2: the table holds 2 x the reference's entries) -> samples, to_sample on both; the int16 wrap of the sum is the low half
             const uint32_t x0 = (uint32_t)((int)acc0 + dcl[p]), x1 = (uint32_t)((int)acc1 + dcl[p]);
             if (live[p]) *reinterpret_cast<uint32_t*>(tile + toff2[p]) = __builtin_amdgcn_perm(x1, x0, 0x05040100u);
+            dcl[p] = (int)d16n[2u * p + (live[p] ? hi : 0u)];
         }
-        const uint32_t m_next = m + wstride < nmcu ? m + wstride : m;   // (the last round fetches its own MCU again: no branch around the fetch)
-        fetch(m_next);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         mcu_to_dib_fast<EH, EV>(im, img_x, img_y, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, C.dibp, C.planes, pw, want_planes, bright, best_y, sum_y);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1354,6 +1366,16 @@ int js_launch_idct_color(hipStream_t st, const JsImage* imgs, const uint32_t* wg
     if (wg_part) hipLaunchKernelGGL(k_status_reduce, dim3(nimg), dim3(256), 0, st, imgs, wg_base, wg_part, side);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+// k_write2 stores eight DC differences as ONE 16-byte vector at an address that is only 2-byte aligned (global memory takes unaligned vector accesses
+// in the mode the HIP runtime runs gfx9 devices in).  A device set up to enforce alignment would fault or split it wrongly: this probe does the same
+// store once per device when the first batch is created (JsnoopBatch::init) and the library refuses to work if the bytes do not arrive as written.
+__global__ void k_unaligned_probe(uint16_t* buf /*>= 24 halves, zeroed*/)
+{
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t t; t.x = 0x00020001u; t.y = 0x00040003u; t.z = 0x00060005u; t.w = 0x00080007u;
+    *reinterpret_cast<u32x4_t*>(buf + 3) = t;                      // byte offset 6
+}
+void js_launch_unaligned_probe(hipStream_t st, void* buf) { hipLaunchKernelGGL(k_unaligned_probe, dim3(1), dim3(1), 0, st, (uint16_t*)buf); }
 void js_launch_idct_probe(hipStream_t st, const float* lut_t, const int16_t* coef64, float* out64)
 { hipLaunchKernelGGL(k_idct_probe, dim3(1), dim3(64), 64 * 64 * sizeof(float) + LIST_BYTES, st, lut_t, coef64, out64); }
 void js_launch_color_probe(hipStream_t st, int y, int cb, int cr, uint32_t* out)
@@ -1429,14 +1451,15 @@ void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, 
 // coefficient-index overflow was seen (stored complemented; 0 = none): everything before it is what the reference decodes, and the exact-mirror
 // reader can take over from the MCU that holds it (k_entropy_exact, tail mode) instead of from the first byte of the scan.
 #define FLAG_OR(flags, img, bits) atomicOr(&(flags)[2u * (img)], (bits))
-// The anomaly word is a KEY, block << 2 | kind, so that the first anomaly of an image also says what it was: kind 0 = "the mirror takes over here",
-// AK_DEAD_DC / AK_DEAD_AC = the reference's decode ENDS in this block (value bits of a symbol ran past the end of a restart interval: its register
-// over-reads, scan_end and scan_bad are set for good, :1229-1282 and :3623-3625) -- at the block's DC symbol / behind it.  An anomaly of kind 0 in
-// the same block sorts first.
+// The anomaly word is a KEY, block << 4 | kind, so that the first anomaly of an image also says what it was: kind 0 = "the mirror takes over here";
+// 1..8 = the reference's decode ENDS in this block (value bits of a symbol ran past the end of a restart interval: its register over-reads,
+// scan_end and scan_bad are set for good, :1229-1282 and :3623-3625): AK_DEAD + bit 0 "behind the block's DC symbol (its DC difference stands)"
+// + bit 1 "a restart was handled INSIDE this block before that (its mark on the MCU is the reference's; otherwise a mark on this block comes from
+// the walk going on over bits the reference never reads)" + bit 2 "reported by a lane that entered the block in its middle" -- the lane that owns
+// the block saw all of it, reports the same symbol, and sorts first.  An anomaly of kind 0 in the same block sorts in front of both.
 #define AK_MIRROR  0u
-#define AK_DEAD_DC 1u
-#define AK_DEAD_AC 2u
-#define ANOM_KEY(blk, kind) (((uint32_t)(blk) << 2) | (kind))
+#define AK_DEAD    1u
+#define ANOM_KEY(blk, kind) (((uint32_t)(blk) << 4) | (kind))
 #define ANOM_MIN(flags, img, key) atomicMax(&(flags)[2u * (img) + 1u], ~(uint32_t)(key))   // kept as the maximum of ~key: "none" is 0, one memset clears the arena
 #define F_BAD_CODE      0x0001u
 #define F_OVERRUN       0x0002u
@@ -1601,14 +1624,27 @@ __global__ void __launch_bounds__(US_THREADS) k_unstuff_write(const JsImage* __r
     __shared__ uint32_t s_excl[2];
     if (lane == 63) { wk[wave] = pk; wr[wave] = pr; }
     __syncthreads();
+    const uint32_t agg_k = wk[0] + wk[1] + wk[2] + wk[3], agg_r = us_sat_add(us_sat_add(wr[0], wr[1]), us_sat_add(wr[2], wr[3]));
+    const uint32_t ci = wg - us_base[img], nc = us_base[img + 1] - us_base[img];
+    // FUSED: the chunk's own counts go out FIRST (the chunks behind this one may be waiting for them) ...
+    if (FUSED && ci && threadIdx.x == 0) __hip_atomic_store(&us_state[wg], us_pack(epoch, US_ST_AGG, agg_k, agg_r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t lk = pk - nk, lr = pr - nr;                                  // exclusive prefixes of this thread INSIDE the chunk
+    for (uint32_t w = 0; w < wave; w++) { lk += wk[w]; lr += wr[w]; }
+    // ... then the kept bytes of the chunk are gathered in LDS (chunk-relative: where the chunk lands in the stream is not needed for that), and only
+    // then does the first wave look back for the chunk's base: by now the chunks before it have long published, the look-back costs its reads.
+    __shared__ __attribute__((aligned(4))) uint8_t s_out[US_CHUNK + 8];
+    if (!us_out && c.keep_mask) {
+        const uint4 v = *reinterpret_cast<const uint4*>(raw + o16);
+        const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
+        uint32_t lo = lk;
+        #pragma unroll
+        for (int j = 0; j < 16; j++) if (c.keep_mask & (1u << j)) s_out[lo++] = (uint8_t)(w4[j >> 2] >> ((j & 3) * 8));
+    }
     uint32_t bk, br;
     if (FUSED) {
-        const uint32_t ci = wg - us_base[img], nc = us_base[img + 1] - us_base[img];
         if (wave == 0) {
-            const uint32_t agg_k = wk[0] + wk[1] + wk[2] + wk[3], agg_r = us_sat_add(us_sat_add(wr[0], wr[1]), us_sat_add(wr[2], wr[3]));
             uint32_t ek = 0, er = 0;
             if (ci) {
-                if (lane == 0) __hip_atomic_store(&us_state[wg], us_pack(epoch, US_ST_AGG, agg_k, agg_r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // look-back, 64 chunks per trip: lane j reads the state of chunk wg - 1 - j (of the same image), and the wave waits until every
                 // chunk between itself and the closest inclusive prefix has published something
                 uint32_t back = 1;                                       // distance of lane 0's chunk
@@ -1618,17 +1654,16 @@ __global__ void __launch_bounds__(US_THREADS) k_unstuff_write(const JsImage* __r
                     for (;;) {
                         if (valid) { v = __hip_atomic_load(&us_state[wg - back - lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ready = (uint32_t)(v >> 56) == epoch && ((v >> 54) & 3u) != 0u; }
                         const uint64_t m_inc = WBALLOT(valid && ready && ((v >> 54) & 3u) == US_ST_INC), m_wait = WBALLOT(valid && !ready);
-                        const uint64_t below = m_inc ? ((m_inc & (0 - m_inc)) - 1ull) : ~0ull;   // lanes closer than the closest inclusive prefix (all, if there is none)
-                        if (!(m_wait & (below | (m_inc & (0 - m_inc))))) {
-                            const bool take = valid && (((1ull << lane) & below) || ((1ull << lane) & m_inc & (0 - m_inc)));
+                        const uint64_t first_inc = m_inc & (0 - m_inc), below = m_inc ? first_inc - 1ull : ~0ull;   // lanes closer than the closest inclusive prefix (all, if there is none)
+                        if (!(m_wait & (below | first_inc))) {
+                            const bool take = valid && (((1ull << lane) & (below | first_inc)) != 0ull);
                             uint32_t tk = take ? (uint32_t)v : 0u, tr = take ? (uint32_t)(v >> 32) & 0x3FFFFFu : 0u;
                             for (int off = 32; off > 0; off >>= 1) { tk += __shfl_xor(tk, off); tr = us_sat_add(tr, __shfl_xor(tr, off)); }
                             ek += tk; er = us_sat_add(er, tr);
-                            if (m_inc) back = 0;                         // done
-                            else back += 64;
+                            back = m_inc ? 0u : back + 64u;              // 0: done
                             break;
                         }
-                        __builtin_amdgcn_s_sleep(2);
+                        __builtin_amdgcn_s_sleep(1);
                     }
                     if (back == 0 || back > ci) break;                   // (past the image's first chunk without an inclusive prefix cannot happen: chunk 0 publishes one)
                 }
@@ -1648,36 +1683,24 @@ __global__ void __launch_bounds__(US_THREADS) k_unstuff_write(const JsImage* __r
         }
         __syncthreads();
         bk = s_excl[0]; br = s_excl[1];
-    } else { bk = chunk_keep[wg]; br = chunk_rst[wg]; }
+    } else { bk = chunk_keep[wg]; br = chunk_rst[wg]; __syncthreads(); }
     const uint32_t cbase_out = bk, phase = cbase_out & 3u;               // the image's stream starts 16-byte aligned
-    for (uint32_t w = 0; w < wave; w++) { bk += wk[w]; br += wr[w]; }
-    uint32_t out = bk + pk - nk, seg = br + pr - nr;                       // exclusive prefixes of this thread
-    if (us_out) { us_out[blockIdx.x * US_THREADS + threadIdx.x] = out; return; }
-    // The kept bytes of the chunk are gathered in LDS at the byte phase they have in the output (chunk base & 3), so that
-    // the chunk leaves as whole aligned 32-bit words; only the ragged first / last word goes out byte by byte.
-    __shared__ __attribute__((aligned(4))) uint8_t s_out[US_CHUNK + 8];
-    __shared__ uint32_t s_total;
-    uint32_t* st = seg_tab + im.seg_off;
-    if (c.keep_mask | c.rst_mask) {
-        const uint4 v = *reinterpret_cast<const uint4*>(raw + o16);
-        const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
-        uint32_t lo = phase + (out - cbase_out);
+    if (us_out) { us_out[blockIdx.x * US_THREADS + threadIdx.x] = bk + lk; return; }
+    if (c.rst_mask) {                                                      // interval table: interval `seg` starts at the next kept byte behind its marker
+        uint32_t* st = seg_tab + im.seg_off; uint32_t seg = br + lr;
         #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            if (c.rst_mask & (1u << j)) { seg++; if (seg + 1 < im.seg_cap) st[seg] = cbase_out + (lo - phase); }     // interval `seg` starts at the next kept byte
-            if (c.keep_mask & (1u << j)) s_out[lo++] = (uint8_t)(w4[j >> 2] >> ((j & 3) * 8));
-        }
+        for (int j = 0; j < 16; j++) if (c.rst_mask & (1u << j)) { seg++; if (seg + 1 < im.seg_cap) st[seg] = cbase_out + lk + __popc(c.keep_mask & ((1u << j) - 1u)); }
     }
-    if (threadIdx.x == US_THREADS - 1) s_total = out + nk - cbase_out;       // bytes this chunk keeps
-    __syncthreads();
-    const uint32_t total = s_total;
+    const uint32_t total = agg_k;                                          // bytes this chunk keeps
     if (!total) return;
+    // The chunk leaves as whole aligned 32-bit words of the stream: output word w holds the gathered bytes [4w - phase, 4w - phase + 4)
+    // (phase = chunk base & 3: two LDS words and a byte alignment); only the ragged first / last word goes out byte by byte.
     uint8_t* dst = ustr + im.ustr_off + (cbase_out - phase);               // 4-byte aligned
-    const uint32_t lo_b = phase, hi_b = phase + total;                     // valid byte range inside s_out / dst
+    const uint32_t lo_b = phase, hi_b = phase + total;                     // valid byte range inside dst
     const uint32_t* s32 = reinterpret_cast<const uint32_t*>(s_out);
     for (uint32_t w = threadIdx.x; w * 4 < hi_b; w += US_THREADS) {
-        if (w * 4 >= lo_b && w * 4 + 4 <= hi_b) reinterpret_cast<uint32_t*>(dst)[w] = s32[w];
-        else for (uint32_t b = max(w * 4, lo_b); b < min(w * 4 + 4, hi_b); b++) dst[b] = s_out[b];
+        if (w * 4 >= lo_b && w * 4 + 4 <= hi_b) reinterpret_cast<uint32_t*>(dst)[w] = phase ? __builtin_amdgcn_alignbyte(s32[w], s32[w - 1], 4u - phase) : s32[w];
+        else for (uint32_t b = max(w * 4, lo_b); b < min(w * 4 + 4, hi_b); b++) dst[b] = s_out[b - phase];
     }
 }
 
@@ -2814,8 +2837,11 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
     // DC differences of finished blocks wait in registers -- eight per lane, in memory order: the oldest in the low half of dcq0 (a lane's
     // finished blocks have consecutive numbers) -- and leave as ONE 16-byte store of the lanes that hold eight: what the vector memory pipe
     // is charged for is the store instruction, not its bytes (a 2-byte store per block: +0.45 ms per 1024 images; eight 2-byte stores per
-    // lane and eight blocks: +0.4).  The address is only 2-byte aligned: global memory takes unaligned 16-byte accesses.
+    // lane and eight blocks: +0.4).  The address is only 2-byte aligned: global memory takes unaligned 16-byte accesses (checked once per device:
+    // k_unaligned_probe).  Consecutive by construction: a lane's block number goes up by one with every block it ends, it flushes every block it ends
+    // except a first one it entered in the middle (skip) and blocks past the image's last -- after which it flushes none.
     uint32_t dcq0 = 0, dcq1 = 0, dcq2 = 0, dcq3 = 0, dccnt = 0, dclast = 0, dq0 = 0;
+    uint32_t rst_in_blk = 0;                                     // a restart was followed inside the block in progress (see ANOM_KEY)
     auto dc_store_rest = [&]() {                                 // what is left at the end: the newest dccnt values sit in the top halves
         #pragma unroll
         for (uint32_t h = 0; h < 8; h++) {
@@ -2867,7 +2893,9 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
             bool over = false, bad = false;                      // (lane masks change in wave-uniform code only)
             if (IBAL(m_slow)) {                                  // interval / stream end, or a code that matches nothing
                 const bool notcap = !IBAL(m_cap);
+                const uint32_t seg_was = seg;
                 const int ws = walk_slow<true, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, blk, notcap, rstf, fl, an);
+                rst_in_blk |= seg != seg_was ? 2u : 0u;
                 if (ws == WS_OVER && notcap) { res_p = P_END; res_s = 0; res_n = nblk; }
                 over = ws == WS_OVER; bad = ws == WS_BAD_CODE;
                 comp = comp_of(T, c); wb = comp == 0 ? wb0 : (comp == 1 ? wb1 : wb2);
@@ -2877,7 +2905,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
                     // value bits past the end of the interval.  With an RSTn behind it the reference's register over-reads -- its decode of the image ENDS
                     // in this block (ANOM_KEY); at the end of the scan data it reads on through the marker bytes (F_SHORT / second attempt).  The walk
                     // itself goes on as the synchronisation walks did: what it writes from here on is replaced (js_parallel_fixup).
-                    if (p1 > seg_end) { fl |= F_OVERRUN; an = min(an, ANOM_KEY(blk, seg + 1u < nseg ? (IBAL(m_dc) ? AK_DEAD_DC : AK_DEAD_AC) : AK_MIRROR)); }
+                    if (p1 > seg_end) { fl |= F_OVERRUN; an = min(an, ANOM_KEY(blk, seg + 1u < nseg ? AK_DEAD + (IBAL(m_dc) ? 0u : 1u) + rst_in_blk + (IBAL(m_skip) ? 4u : 0u) : AK_MIRROR)); }
                     if (k2 > 64u) fl |= F_COEF_OVERFLOW;
                 }
             }
@@ -2921,7 +2949,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
             if (IBAL(m_done)) {
                 c = c + 1 == T.nb ? 0u : c + 1; comp = comp_of(T, c); wb = comp == 0 ? wb0 : (comp == 1 ? wb1 : wb2);
                 nblk += IBAL(m_cap) ? 0u : 1u;
-                blk++;
+                blk++; rst_in_blk = 0;
             }
             m_skip &= ~m_done;
             // ---- the whole wave moves every block that completed in this step: 16 lanes x 8 bytes per block, four blocks per store
@@ -3361,7 +3389,8 @@ void js_launch_tail_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab
 // are empty with the predictors standing, the rest of that MCU row is never decoded (:3623-3625: the row loop stops, the cleared arrays stay), and
 // of every later row only the first MCU is "decoded" -- empty blocks, predictors standing.  No restart is handled any more.
 //  k_dead_fill (before the DC scan is repeated for the image): rows from bstar on emptied, DC differences of all blocks back in the dccum
-//  array (they survive in slot 0 of the rows), restart marks behind bstar removed;  k_dead_rows (after it): cumulative DC of the MCUs the
+//  array (they survive in slot 0 of the rows), restart marks behind bstar removed -- and the one ON bstar unless the restart it stands for was
+//  handled before the decode ended (ANOM_KEY: the walk went on and met the next marker inside the same block);  k_dead_rows (after it): cumulative DC of the MCUs the
 //  reference never reaches back to the cleared arrays' zero.
 __global__ void __launch_bounds__(256) k_dead_fill(const JsImage* __restrict__ imgs, uint32_t img, uint32_t bstar, uint32_t kind,
                                                    int16_t* __restrict__ coef, int16_t* __restrict__ dccum, uint8_t* __restrict__ mcu_rst)
@@ -3370,7 +3399,7 @@ __global__ void __launch_bounds__(256) k_dead_fill(const JsImage* __restrict__ i
     const uint32_t nb = im.blk_per_mcu, total = im.total_blocks, nmcu = im.mcu_xmax * im.mcu_ymax, mstar = bstar / nb;
     int16_t* cb = coef + im.coef_off * 64; int16_t* d = dccum + im.coef_off; uint8_t* rf = mcu_rst + im.mcu_off;
     const uint32_t gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
-    const bool keep_dc = kind == AK_DEAD_AC;
+    const bool keep_dc = ((kind - AK_DEAD) & 1u) != 0u, own_mark = ((kind - AK_DEAD) & 2u) != 0u;
     for (uint32_t b = gid; b < total; b += gsz) d[b] = (b < bstar || (b == bstar && keep_dc)) ? cb[(size_t)b * 64] : (int16_t)0;
     uint4* rows = reinterpret_cast<uint4*>(cb + (size_t)bstar * 64);
     for (size_t q = gid; q < (size_t)(total - bstar) * 8; q += gsz) {
@@ -3380,7 +3409,7 @@ __global__ void __launch_bounds__(256) k_dead_fill(const JsImage* __restrict__ i
     }
     for (uint32_t m = mstar + gid; m < nmcu; m += gsz) {
         const uint32_t mark = rf[m];
-        if (mark && (m > mstar || mstar * nb + mark - 1u > bstar)) rf[m] = 0;
+        if (mark && (m > mstar || mstar * nb + mark - 1u > bstar || (mstar * nb + mark - 1u == bstar && !own_mark))) rf[m] = 0;
     }
 }
 __global__ void __launch_bounds__(256) k_dead_rows(const JsImage* __restrict__ imgs, uint32_t img, uint32_t bstar, int16_t* __restrict__ dccum)

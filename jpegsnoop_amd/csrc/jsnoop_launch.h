@@ -10,6 +10,7 @@ int  js_launch_idct_color(hipStream_t st, const JsImage* imgs, const uint32_t* w
                           const float* lut_t, const int16_t* coef, const int16_t* dccum, uint8_t* dib, int16_t* planes, uint32_t* side,
                           int layout /* 0 = mixed; 1..4 = every image has the fast layout with chroma expansion (2,2) / (2,1) / (1,2) / (1,1) */,
                           unsigned long long* wg_part /* null, or 2 words per workgroup (indexed like wg_base): brightest-pixel / luminance records folded by a second kernel */);
+void js_launch_unaligned_probe(hipStream_t st, void* buf48);    // one 16-byte store at byte offset 6 of buf48 (halves 1..8), see k_unaligned_probe
 void js_launch_idct_probe(hipStream_t st, const float* lut_t, const int16_t* coef64, float* out64);
 void js_launch_clear3(hipStream_t st, void* a, size_t a_bytes, void* b, size_t b_bytes, void* c, size_t c_bytes, const JsImage* imgs = nullptr, uint32_t nimg = 0);   // three arenas to zero in one launch (sizes rounded up to 16 bytes)
 void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, const uint8_t* dib, unsigned long long* sums);
@@ -47,7 +48,7 @@ void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab
                          uint32_t* anoms /* [0] count, 4 words per record from [4]: block, bit position of the symbol, index it ran to, bit position behind the block; or null */);
 #define JS_DC_PARTS_IMAGES 8         /* batches of up to this many images take the two-level DC scan */
 #define JS_DC_PARTS_BYTES (JS_DC_PARTS_IMAGES * 64 * 16)
-void js_launch_dead_fill(hipStream_t st, const JsImage* imgs, uint32_t img, uint32_t bstar, uint32_t kind /*1: the decode ends at the block's DC symbol, 2: behind it*/,
+void js_launch_dead_fill(hipStream_t st, const JsImage* imgs, uint32_t img, uint32_t bstar, uint32_t kind /*ANOM_KEY's death kinds 1..8*/,
                          const JsTableSet* tables, int16_t* coef, int16_t* dccum, uint8_t* mcu_rst);
 void js_launch_dc_scan(hipStream_t st, const JsImage* imgs, uint32_t nimg, const JsTableSet* tables, int16_t* dccum, const uint8_t* mcu_rst, void* parts_scratch /*JS_DC_PARTS_BYTES or null*/);
 #define JS_US_CHUNK 4096

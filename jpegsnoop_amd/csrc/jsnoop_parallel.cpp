@@ -405,9 +405,9 @@ int js_read_flags(JsnoopBatch* b)
     std::vector<uint32_t> both(2 * n);
     if (b->d2h_staged(both.data(), b->dev.flags, 2 * n * 4)) return -1;          // (through the page-locked landing buffer)
     b->host_flags.resize(n); b->host_anom.resize(n); b->host_anom_kind.resize(n);
-    for (size_t i = 0; i < n; i++) {                              // (the arena keeps the complement of block << 2 | kind: 0 = none)
+    for (size_t i = 0; i < n; i++) {                              // (the arena keeps the complement of block << 4 | kind: 0 = none)
         const uint32_t key = ~both[2 * i + 1];
-        b->host_flags[i] = both[2 * i]; b->host_anom[i] = key == 0xFFFFFFFFu ? 0xFFFFFFFFu : key >> 2; b->host_anom_kind[i] = key == 0xFFFFFFFFu ? 0 : (uint8_t)(key & 3u);
+        b->host_flags[i] = both[2 * i]; b->host_anom[i] = key == 0xFFFFFFFFu ? 0xFFFFFFFFu : key >> 4; b->host_anom_kind[i] = key == 0xFFFFFFFFu ? 0 : (uint8_t)(key & 15u);
     }
     if (b->cand_rounds >= 0 && (b->tune.debug & JSNOOP_DBG_CAND)) {      // candidate chain of image 0: walks queued by the last chain launch, open sub-sequences after each launch
         uint32_t h[12]; if (b->d2h_staged(h, b->dev.cand_req, sizeof h)) return -1;

@@ -97,3 +97,19 @@ def test_tuning_defaults_come_from_the_environment_once_and_nothing_on_the_decod
                 if "getenv(" in line:
                     hits.append((f, n))
     assert hits and all(f == "jsnoop_host.cpp" for f, _ in hits) and len(hits) == 2, hits       # the two lambdas of js_env_tuning
+    # presets out of range fall back to "automatic" (a later set_tuning writes the whole struct back: it must not be refused for them)
+    env.update(JSNOOP_SYNC_LAUNCHES="100", JSNOOP_MPW="8192")
+    out = subprocess.check_output([sys.executable, "-c", child], env=env).decode().split()
+    assert int(out[3]) == 0 and int(out[6]) == 0
+
+
+def test_no_experiment_switches_in_the_product_sources():
+    """Ablations and candidate rewrites are patch files under tools/variants/ (tools/build_variant.sh applies them to a private copy of the kernels):
+    what ships holds no JS_EXP_ / JS_TRY_ switch -- code that compiles to wrong results does not sit in the loop a maintainer reads."""
+    for d in (os.path.join(ROOT, "jpegsnoop_amd"), os.path.join(ROOT, "include")):
+        for root, _dirs, files in os.walk(d):
+            for f in files:
+                if f.endswith((".cpp", ".hip", ".h", ".py")):
+                    txt = open(os.path.join(root, f), errors="replace").read()
+                    assert "JS_EXP_" not in txt and "JS_TRY_" not in txt, os.path.join(root, f)
+    assert any(f.endswith(".patch") for f in os.listdir(os.path.join(ROOT, "tools", "variants")))

@@ -18,6 +18,39 @@ def build_demo():
                            "-Wl,-rpath,/opt/rocm/lib"])
 
 
+SITES = os.path.join(ROOT, "tests", "cpp", "jfif_callsites")
+
+
+def build_callsites():
+    import __graft_entry__ as G
+    G.build()
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-o", SITES, os.path.join(ROOT, "tests", "cpp", "jfif_callsites.cpp"),
+                           "-L" + os.path.join(ROOT, "jpegsnoop_amd"), "-ljsnoop_gpu", "-Wl,-rpath," + os.path.join(ROOT, "jpegsnoop_amd"),
+                           "-Wl,-rpath,/opt/rocm/lib"])
+
+
+def test_every_call_site_of_cjfifdecode_compiles_against_the_wrapper():
+    """The reference's CjfifDecode reaches its CimgDecode through twelve methods and three public members (source/JfifDecode.cpp:115 ... :7379);
+    tests/cpp/jfif_callsites.cpp holds one function per call site with the reference's argument types -- it must build (-Wall -Werror) and link
+    against ImgDecodeGpu.h + the C ABI."""
+    build_callsites()
+    assert subprocess.check_output([SITES], text=True).strip() == "built"
+    src = open(os.path.join(ROOT, "tests", "cpp", "jfif_callsites.cpp")).read()
+    for m in ("Reset()", "ResetState()", "SetDhtEntry(", "SetDhtSize(", "SetDqtEntry(", "SetDqtTables(", "SetPrecision(", "SetSofSampFactors(", "SetDhtTables(",
+              "SetImageDetails(", "DecodeScanImg(", "SetImageDimensions(", "->m_pDibTemp", "->m_bDibTempReady", "->m_bPreviewIsJpeg"):
+        assert "m_pImgDec->" + m.lstrip("->") in src or m in src, m
+
+
+@pytest.mark.gpu
+def test_call_sites_drive_a_psd_style_preview_and_a_scan_decode(harness, tmp_path):
+    build_callsites()
+    p = tmp_path / "x.jpg"
+    p.write_bytes(harness.synth_jpeg(width=333, height=217, seed=78))
+    out = subprocess.check_output([SITES, str(p)], text=True).strip().splitlines()
+    assert out[0] == "psd ready=0 bits=1 first=1 dims=5x3", out          # IsPreviewReady() is m_bPreviewIsJpeg (:3753); GetBitmapPtr hands out what the PSD decoder wrote
+    assert out[1] == "jpeg ready=1 temp_ready=1 is_jpeg=1 bits=1 dims=336x224", out
+
+
 def test_wrapper_builds_and_refuses_without_gpu(tmp_path):
     import torch
     build_demo()

@@ -70,9 +70,19 @@ def test_tuning_struct_round_trip_and_range_checks():
     b.set_tuning(sub_wl=6, cand_rounds=3, split=2, write_lanes=1, cross_checks=capi.XC_BACKEND_GENERIC)
     t = b.tuning()
     assert (t.sub_wl, t.cand_rounds, t.split, t.write_lanes, t.cross_checks) == (6, 3, 2, 1, capi.XC_BACKEND_GENERIC)
-    for bad in (dict(sub_wl=3), dict(sub_wl=9), dict(cand_rounds=65), dict(split=3), dict(write_lanes=3), dict(pg_lanes=5), dict(struct_size=8)):
+    for bad in (dict(sub_wl=3), dict(sub_wl=9), dict(cand_rounds=65), dict(split=3), dict(write_lanes=3), dict(pg_lanes=5), dict(struct_size=4),
+                dict(struct_size=C.sizeof(capi.Tuning) + 8)):
         with pytest.raises(RuntimeError):
             b.set_tuning(**bad)
         assert "tuning" in capi.last_error()
         assert b.tuning().sub_wl == 6                             # unchanged
+    # struct_size is the CALLER's sizeof: a shorter (older) struct is taken for what it holds, the fields it lacks are automatic, and reading the
+    # tuning back into such a struct writes no byte past it
+    short = capi.Tuning(); short.struct_size = 12; short.sub_wl = 5; short.cand_rounds = 2; short.split = 2     # (split lies beyond the 12 bytes: not read)
+    assert lib.jsnoop_batch_set_tuning(b._h, C.byref(short)) == 0, capi.last_error()
+    t = b.tuning()
+    assert (t.sub_wl, t.cand_rounds, t.split, t.write_lanes, t.cross_checks) == (5, 2, 0, 0, 0)
+    back = capi.Tuning(); back.struct_size = 12; back.split = 77
+    lib.jsnoop_batch_get_tuning(b._h, C.byref(back))
+    assert (back.struct_size, back.sub_wl, back.cand_rounds, back.split) == (12, 5, 2, 77)
     b.close()

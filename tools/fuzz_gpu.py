@@ -25,5 +25,5 @@ for k in range(n_cases):
         print("case", k, "mode", mode, "exception", ex); bad += 1; continue
     paths[gpu.lib.jsnoop_last_path(gpu.h)] += 1
     r = F.differs(orc, gpu, stats=bool(histo))
-    if r: bad += 1; print("case", k, "mode", mode, "MISMATCH:", r)
+    if r: bad += 1; print("case", k, "mode", mode, "MISMATCH:", r, "path", gpu.lib.jsnoop_last_path(gpu.h), "flags 0x%04x" % gpu.lib.jsnoop_last_flags(gpu.h), "opts", histo, ac, em)
 print("cases", n_cases, "mismatches", bad, "paths", dict(paths))
