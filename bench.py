@@ -308,11 +308,35 @@ def extras_single_gpu(J, H, orc, np):
         kinds = [("flip", 0.95), ("cut", 0.5), ("marker", 0.3)]
         # the cases the parallel path hands to the sequential mirror for most of the file: 256 random bytes (FF among them) at 30 % of a scan
         # without restart markers; a restart marker that falls INSIDE a block early in the file (two bytes deleted in front of the second RSTn)
-        kinds += [("garbage", 0.3)] if label == "1080p" else [("rst_in_block", 0.0)]
+        # ... and round 4's worst class (0.7-2.4 s then): behind a marker met inside a block, the value bits of a symbol run past the end of a later restart
+        # interval -- the reference's register over-reads and its decode of the image is over (source/ImgDecode.cpp:1229-1282, :3623-3625)
+        kinds += [("garbage", 0.3)] if label == "1080p" else [("rst_in_block", 0.0), ("overrun", 0.0)]
         for kind, frac in kinds:
             d = bytearray(based)
             i = pd.scan_start + int((pd.scan_end - pd.scan_start) * frac)
-            if kind == "garbage":
+            if kind == "overrun":
+                j = bytes(d).index(b"\xff\xd1", pd.scan_start)
+                del d[j - 2:j]
+                marks = [k for k in range(pd.scan_start, len(d) - 1) if d[k] == 0xFF and 0xD0 <= d[k + 1] <= 0xD7]
+                found = None
+                probe = J.JpegBatch()
+                for which in (len(marks) // 3, len(marks) // 2, 2 * len(marks) // 3):
+                    for cut in range(1, 7):
+                        e = bytearray(d); k = marks[which]
+                        if 0xFF in e[k - cut - 1:k]:
+                            continue
+                        del e[k - cut:k]
+                        probe.clear(); probe.add_jpeg(bytes(e)); probe.upload(); probe.decode(); probe.sync()
+                        if probe.info(0)["flags"] & 0x0002:
+                            found = e
+                            break
+                    if found is not None:
+                        break
+                probe.close()
+                if found is None:
+                    continue
+                d = found
+            elif kind == "garbage":
                 d[i:i + 256] = np.random.RandomState(5).randint(0, 256, 256).astype(np.uint8).tobytes()
             elif kind == "rst_in_block":
                 j = bytes(d).index(b"\xff\xd1", pd.scan_start)

@@ -57,8 +57,10 @@ struct ExactReader {
     const uint8_t* zz;                                         // zig-zag index -> natural index
 };
 
+// (Everything below is force-inlined into the kernel: a real call takes the reader by reference, which puts ALL of its state into private memory -- a
+//  scratch round trip per field access, several per symbol: the un-inlined block decoder cost the mirror 2.6 us per symbol, profiles/r05_experiments.txt.)
 // One line (group) of what the reference writes to its log while decoding; formatted on the host (jsnoop_report.cpp).
-__device__ void ex_event(ExactReader& r, uint32_t kind, uint32_t a0 = 0, uint32_t a1 = 0, uint32_t a2 = 0, uint32_t a3 = 0, uint32_t a4 = 0)
+__device__ __forceinline__ void ex_event(ExactReader& r, uint32_t kind, uint32_t a0 = 0, uint32_t a1 = 0, uint32_t a2 = 0, uint32_t a3 = 0, uint32_t a4 = 0)
 {
     if (!r.ev || (r.ev_only && r.ev_only != kind)) return;
     const uint32_t n = r.ev[0];
@@ -74,14 +76,14 @@ __device__ __forceinline__ uint32_t ex_byte(ExactReader& r, uint32_t off)       
     return (uint32_t)(r.win >> ((off & 7u) * 8)) & 255u;
 }
 
-__device__ void ex_restart_scan_buf(ExactReader& r, uint32_t file_pos, bool restart)   // DecodeRestartScanBuf :4038-4075
+__device__ __forceinline__ void ex_restart_scan_buf(ExactReader& r, uint32_t file_pos, bool restart)   // DecodeRestartScanBuf :4038-4075
 {
     r.scan_end = 0; r.scan_bad = 0; r.buff = 0; r.ptr = file_pos;
     if (!restart) r.ptr_first = file_pos;
     r.align = 0; r.pos0 = r.pos1 = r.pos2 = r.pos3 = 0; r.err0 = r.err1 = r.err2 = r.err3 = SB_OK;
     r.latch = SB_OK; r.num = 0; r.vacant = 32; r.cur_err = 0; r.restart_read = 0; r.mcus_left = r.rst_interval;
 }
-__device__ void ex_consume(ExactReader& r, uint32_t nbits)                              // ScanBuffConsume :921-955
+__device__ __forceinline__ void ex_consume(ExactReader& r, uint32_t nbits)                              // ScanBuffConsume :921-955
 {
     r.buff = nbits >= 32 ? 0u : r.buff << nbits; r.vacant += nbits;
     uint32_t nbytes = (r.align + nbits) >> 3;
@@ -93,7 +95,7 @@ __device__ void ex_consume(ExactReader& r, uint32_t nbits)                      
     }
     r.align = (r.align + nbits) & 7;
 }
-__device__ void ex_add(ExactReader& r, uint32_t byte, uint32_t ptr, uint32_t e)         // ScanBuffAdd(Err) :974-1004
+__device__ __forceinline__ void ex_add(ExactReader& r, uint32_t byte, uint32_t ptr, uint32_t e)         // ScanBuffAdd(Err) :974-1004
 {
     r.buff += byte << (r.vacant - 8); r.vacant -= 8;
     if (r.num < 4) {
@@ -103,7 +105,7 @@ __device__ void ex_add(ExactReader& r, uint32_t byte, uint32_t ptr, uint32_t e) 
     }
     if (e != SB_OK) switch ((r.num - 1) & 3) { case 0: r.err0 = e; break; case 1: r.err1 = e; break; case 2: r.err2 = e; break; default: r.err3 = e; break; }
 }
-__device__ void ex_add_byte(ExactReader& r)                                             // BuffAddByte :1386-1573
+__device__ __forceinline__ void ex_add_byte(ExactReader& r)                                             // BuffAddByte :1386-1573
 {
     if (r.restart_read) return;
     uint32_t b0 = ex_byte(r, r.ptr), b1 = ex_byte(r, r.ptr + 1);
@@ -117,7 +119,7 @@ __device__ void ex_add_byte(ExactReader& r)                                     
     else if (b0 == 0xFF)               { if (r.warn_bad < r.err_max) { ex_event(r, JS_EV_MARKER, b1, r.ptr); r.warn_bad++; r.warn_marker++; } ex_add(r, b0, r.ptr, SB_BADMARK); r.ptr += 1; }
     else                               { ex_add(r, b0, r.ptr, SB_OK); r.ptr += 1; }
 }
-__device__ void ex_topup(ExactReader& r)                                                // BuffTopup :1292-1323
+__device__ __forceinline__ void ex_topup(ExactReader& r)                                                // BuffTopup :1292-1323
 {
     bool done = r.vacant < 8 || r.scan_end;
     while (!done) {
@@ -126,7 +128,7 @@ __device__ void ex_topup(ExactReader& r)                                        
         if (r.vacant < 8) done = true;
     }
 }
-__device__ int ex_read_scan_val(ExactReader& r, uint32_t t, uint32_t& zrl, int32_t& val)  // ReadScanVal :1072-1286
+__device__ __forceinline__ int ex_read_scan_val(ExactReader& r, uint32_t t, uint32_t& zrl, int32_t& val)  // ReadScanVal :1072-1286
 {
     uint32_t code = JS_CODE_UNUSED, ind = 0; bool done = false, found = false;
     r.used1 = r.used2 = 0; zrl = 0; val = 0;
@@ -138,6 +140,17 @@ __device__ int ex_read_scan_val(ExactReader& r, uint32_t t, uint32_t& zrl, int32
         if (f != JS_CODE_UNUSED) { r.used1 += f >> 8; code = f & 0xFF; done = true; found = true; }
     }
     const uint32_t size = r.meta[t];
+    if (!done && r.ts->lut_ok) {
+        // The linear search of :1145-1164 (first entry of the code list whose bits match and whose length fits what the register holds) through the
+        // two-level table of the parallel path: for a canonical prefix code -- lut_ok says the list is one -- at most ONE entry matches the register
+        // (zero padding included), so "the first that matches and fits" is "the one that matches, if it fits".  The list search walks up to 162 entries
+        // of global memory for every code longer than nine bits: 3 % of the symbols, half of the mirror's time.
+        uint32_t e = r.ts->lut1[r.ts->slot_row[t]][r.buff >> (32 - JS_L1_BITS)];
+        if (e & 0x8000u) { const uint32_t nbx = (e >> 12) & 7u; e = r.ts->lut2[(e & 0xFFFu) + ((r.buff >> (32 - JS_L1_BITS - nbx)) & ((1u << nbx) - 1u))]; }
+        const uint32_t bl = (e >> 8) & 31u;
+        if (bl != 0u && bl <= 32 - r.vacant) { code = e & 255u; r.used1 += bl; found = true; }
+        done = true;
+    }
     while (!done) {
         if ((r.buff & r.ts->mask[t][ind]) == r.ts->bits[t][ind]) {
             uint32_t bl = r.ts->bitlen[t][ind];
@@ -172,7 +185,7 @@ __device__ int ex_read_scan_val(ExactReader& r, uint32_t t, uint32_t& zrl, int32
 
 // DecodeScanComp :1604-1835 for one 8x8 block; coefficients go straight to HBM (natural order).
 // Returns the dequantised value stored at natural index 0 (what the caller adds to the DC predictor).
-__device__ int16_t ex_decode_block(ExactReader& r, uint32_t comp, uint32_t decode_ac, int16_t* __restrict__ out,
+__device__ __forceinline__ int16_t ex_decode_block(ExactReader& r, uint32_t comp, uint32_t decode_ac, int16_t* __restrict__ out,
                                    int16_t& dc_y, int16_t& dc_cb, int16_t& dc_cr)
 {
     const uint32_t tdc = (comp - 1) * 2, tac = tdc + 1;
@@ -233,7 +246,9 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
     // different images do not share a wave (their branches would serialise).
     __shared__ uint32_t s_fast[6 * (1 << JS_FAST_BITS)]; __shared__ uint32_t s_histo[2 * 4 * 17];
     __shared__ uint32_t s_meta[12]; __shared__ uint16_t s_q[3 * 64]; __shared__ uint8_t s_zz[64];
-    int16_t scratch[64];
+    // (indexed at run time: in LDS, not in private memory -- every access of a private array is a trip to scratch, and the mirror is a chain of
+    //  dependent steps on one lane)
+    __shared__ int16_t scratch[64]; __shared__ int16_t s_css[3][16];
     const uint32_t j = blockIdx.x;
     if (j >= nsel) return;
     const JsImage& im = imgs[sel ? sel[j] : j];
@@ -285,7 +300,7 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
     r.ev = (im.ev_cap && events) ? events + im.ev_off : nullptr; r.ev_cap = im.ev_cap; r.ev_only = 0;       // (side-only passes log when the caller hands the event area over)
     ex_restart_scan_buf(r, im.scan_start, false);
     int16_t dc_y = 0, dc_cb = 0, dc_cr = 0;
-    int16_t css[3][16];
+    int16_t (*css)[16] = s_css;
     for (int c = 0; c < 3; c++) for (int i = 0; i < 16; i++) css[c][i] = 0;
     ex_topup(r);
     uint32_t num_pixels = 0;
@@ -309,6 +324,10 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
             const uint32_t n1 = im.samp_h[1] * im.samp_v[1], n2 = im.ncomp == 3 ? n1 + im.samp_h[2] * im.samp_v[2] : nb;
             const int16_t* dprev = dbase + (size_t)(m0 - 1) * nb;   // cumulative DC of the last block of each component in the MCU before
             dc_y = dprev[n1 - 1]; if (im.ncomp == 3) { dc_cb = dprev[n2 - 1]; dc_cr = dprev[nb - 1]; }
+            // ... unless a restart was followed INSIDE that MCU behind the component's last block (its mark: predictors cleared in front of block j): the
+            // component's predictor is then the zero the restart left, not the sum its last block had reached before it
+            const uint32_t rj = tail.mcu_rst[im.mcu_off + m0 - 1u] & 127u;
+            if (rj) { if (n1 < rj) dc_y = 0; if (im.ncomp == 3 && n2 < rj) dc_cb = 0; }
             r.ptr_first = im.scan_start;
         }
     }
@@ -1850,15 +1869,18 @@ __device__ __forceinline__ uint32_t sym_lookup(const SubTabs& T, uint32_t win, u
 // The restart mark of MCU m: 0 = none, j + 1 = the DC predictors are cleared in front of block j of the MCU.  One byte per MCU, set by
 // compare-and-swap on its word (lanes of different sub-sequences may meet markers in neighbouring MCUs); false when the MCU already carries
 // a different mark (two markers inside one MCU: hostile, left to the mirror).
-__device__ __forceinline__ bool mark_reset(uint8_t* __restrict__ mcu_rst, uint32_t m, uint32_t v)
+// Bit 7 of a mark: the marker was met INSIDE the block (after its DC symbol), not in front of it -- the predictors are cleared in front of the block
+// either way (the DC scan looks at the low seven bits), but when the reference's decode ENDS in that block (ANOM_KEY) a mark the walk set inside it may
+// stem from bits the reference never read, while one set in front of it cannot: "in front" wins when both set the same mark.
+__device__ __forceinline__ bool mark_reset(uint8_t* __restrict__ mcu_rst, uint32_t m, uint32_t v, bool inside)
 {
     uint32_t* w = reinterpret_cast<uint32_t*>(mcu_rst + (m & ~3u)); const uint32_t sh = (m & 3u) * 8u;      // (the arena is 16-byte aligned per image)
     uint32_t old = *reinterpret_cast<volatile uint32_t*>(w);
     for (;;) {
         const uint32_t cur = (old >> sh) & 255u;
-        if (cur == v) return true;
+        if ((cur & 127u) == v) { if (!inside && (cur & 128u)) atomicAnd(w, ~(128u << sh)); return true; }
         if (cur != 0u) return false;
-        const uint32_t seen = atomicCAS(w, old, old | (v << sh));
+        const uint32_t seen = atomicCAS(w, old, old | ((v | (inside ? 128u : 0u)) << sh));
         if (seen == old) return true;
         old = seen;
     }
@@ -1903,7 +1925,7 @@ __device__ __forceinline__ int walk_slow(const JsImage& im, const uint32_t* __re
         // MCU, or two markers back to back (the reference meets the second one inside its retry and files the DC value under index 1): F_BAD_EDGE.
         if (WRITE) {
             if (k != 0 || c != 0 || remain >= 8) flags |= F_RST_MISALIGN;                       // well-formed: < 8 pad bits, on an MCU boundary
-            if (mark && blk < im.total_blocks && !mark_reset(mcu_rst, blk / im.blk_per_mcu, c + 1u)) { flags |= F_BAD_EDGE; anom = min(anom, ANOM_KEY(blk, AK_MIRROR)); }
+            if (mark && blk < im.total_blocks && !mark_reset(mcu_rst, blk / im.blk_per_mcu, c + 1u, k != 0u)) { flags |= F_BAD_EDGE; anom = min(anom, ANOM_KEY(blk, AK_MIRROR)); }
         }
         seg++; const uint32_t np = seg_end; seg_end = st[seg + 1] * 8;
         if (spec) { c = 0; k = 0; }                              // a speculative walk (its exit state is only a guess): in a well-formed stream an MCU starts here
@@ -3023,7 +3045,7 @@ __device__ __forceinline__ void dc_scan_range(const JsImage& im, int16_t* __rest
         const uint32_t m = base + t; const bool valid = m < m_end;
         // the MCU's restart mark: 0 = none, j + 1 = the predictors are cleared in front of its block j (a marker on the MCU boundary: 1;
         // a marker the reference met inside the MCU -- a damaged interval -- : the block that was in progress, walk_slow)
-        const uint32_t rj = valid ? rf[m] : 0u;
+        const uint32_t rj = valid ? rf[m] & 127u : 0u;         // (bit 7: met inside the block, see mark_reset)
         int v[NBMAX];
         DcSeg own = { 0, 0, 0, rj ? 1 : 0 };                     // the MCU as a scan element: sums since its reset if it has one, else of all its blocks
         #pragma unroll
@@ -3254,7 +3276,7 @@ __device__ uint32_t raw_of_compacted(const JsImage& im, const uint8_t* __restric
 // the closest earlier MCU top that either begins a restart interval (freshly restarted buffer, DecodeRestartScanBuf
 // :4038) or lies at least 5 bytes before the next RSTn, and decodes forward from there with the mirror itself.
 // Returns the number of RSTn markers the reference has seen before the point the walk started from.
-__device__ uint32_t mirror_to_mcu_top(const JsImage& im, const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ raw, const uint32_t* __restrict__ st,
+__device__ __forceinline__ uint32_t mirror_to_mcu_top(const JsImage& im, const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ raw, const uint32_t* __restrict__ st,
                                       uint32_t nseg, uint32_t total_bytes, const uint8_t* __restrict__ mcu_rst, const uint32_t* __restrict__ mcu_pos,
                                       const uint32_t* __restrict__ us_out, uint32_t us_threads, uint32_t m_top, ExactReader& r, uint32_t* dummy_histo, int16_t* scratch,
                                       uint32_t* events)
@@ -3309,15 +3331,23 @@ __global__ void __launch_bounds__(256) k_side_maps(const JsImage* __restrict__ i
     const uint32_t stride = 2 * ((nblk + 1) / 2);
     const uint32_t gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
     // ---- MCU file map: position of the first buffered byte and the bit alignment when the MCU loop reaches MCU m (:3229)
-    for (uint32_t m = gid; m <= nmcu; m += gsz) {
-        const uint32_t p = m ? mcu_pos[m] : 0u, ub = p >> 3, a = p & 7u;
+    // (the mirror reader's run-time-indexed arrays: one set per WAVE in LDS, its lanes take turns -- as private arrays they, and with them the reader's
+    //  whole state, lived in scratch memory: a round trip per access for the one lane in thousands that needs the reader)
+    __shared__ uint32_t s_mh[4][2 * 4 * 17 + 12]; __shared__ int16_t s_ms[4][64];
+    const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
+    for (uint32_t m0 = blockIdx.x * 256; m0 <= nmcu; m0 += gsz) {
+        const uint32_t m = m0 + threadIdx.x; const bool in = m <= nmcu;
+        const uint32_t p = (in && m) ? mcu_pos[m] : 0u, ub = p >> 3, a = p & 7u;
         bool empty = false;                                         // the previous interval was consumed to its last bit: the register is empty
-        if (m && m < nmcu && a == 0) { const uint32_t sg = find_interval(st, nseg, ub); empty = sg >= 1 && st[sg] == ub; }
-        if (m == nmcu || empty) {
+        if (in && m && m < nmcu && a == 0) { const uint32_t sg = find_interval(st, nseg, ub); empty = sg >= 1 && st[sg] == ub; }
+        const bool mirror = in && (m == nmcu || empty);
+        if (in && !mirror) mcu_map[m] = (raw_of_compacted(im, raw, us_out, us_threads, ub) << 4) + a;
+        for (uint64_t todo = WBALLOT(mirror); todo; todo &= todo - 1) {
+            if (ln != (uint32_t)__builtin_ctzll(todo)) continue;
             // what an empty register still shows depends on how its last bytes were loaded, and the end of the scan is where the
             // look-ahead meets EOI / trailing bytes: take both from the mirror reader itself
-            uint32_t dummy_histo[2 * 4 * 17 + 12]; int16_t scratch[64]; ExactReader r;
-            const uint32_t before = mirror_to_mcu_top(im, tables, raw, st, nseg, sd[10], mcu_rst, mcu_pos, us_out, us_threads, m, r, dummy_histo, scratch,
+            ExactReader r;
+            const uint32_t before = mirror_to_mcu_top(im, tables, raw, st, nseg, sd[10], mcu_rst, mcu_pos, us_out, us_threads, m, r, s_mh[wv], s_ms[wv],
                                                       m == nmcu ? events : nullptr);
             if (m < nmcu) mcu_map[m] = (r.pos0 << 4) + r.align;
             else {                                                  // status words after the last MCU
@@ -3325,7 +3355,7 @@ __global__ void __launch_bounds__(256) k_side_maps(const JsImage* __restrict__ i
                 sd[4] = r.pos0; sd[5] = r.align; sd[6] = r.warn_bad; sd[7] = im.scan_start;
                 if (anoms) anoms[1] = r.warn_marker;              // (an image with overflow records: its counter is put together on the host)
             }
-        } else mcu_map[m] = (raw_of_compacted(im, raw, us_out, us_threads, ub) << 4) + a;
+        }
     }
     // ---- block-DC maps: the cumulative DC of the block that wrote the cell last (MCU raster order, :3524-3608)
     const int16_t* dc = dccum + im.coef_off;
@@ -3389,8 +3419,8 @@ void js_launch_tail_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab
 // are empty with the predictors standing, the rest of that MCU row is never decoded (:3623-3625: the row loop stops, the cleared arrays stay), and
 // of every later row only the first MCU is "decoded" -- empty blocks, predictors standing.  No restart is handled any more.
 //  k_dead_fill (before the DC scan is repeated for the image): rows from bstar on emptied, DC differences of all blocks back in the dccum
-//  array (they survive in slot 0 of the rows), restart marks behind bstar removed -- and the one ON bstar unless the restart it stands for was
-//  handled before the decode ended (ANOM_KEY: the walk went on and met the next marker inside the same block);  k_dead_rows (after it): cumulative DC of the MCUs the
+//  array (they survive in slot 0 of the rows), restart marks behind bstar removed -- and the one ON bstar when it stands for a marker met INSIDE the
+//  block (mark_reset) that the block's owner did not see before the decode ended (ANOM_KEY: the walk went on and met the next marker in the same block);  k_dead_rows (after it): cumulative DC of the MCUs the
 //  reference never reaches back to the cleared arrays' zero.
 __global__ void __launch_bounds__(256) k_dead_fill(const JsImage* __restrict__ imgs, uint32_t img, uint32_t bstar, uint32_t kind,
                                                    int16_t* __restrict__ coef, int16_t* __restrict__ dccum, uint8_t* __restrict__ mcu_rst)
@@ -3408,8 +3438,8 @@ __global__ void __launch_bounds__(256) k_dead_fill(const JsImage* __restrict__ i
         rows[q] = v;
     }
     for (uint32_t m = mstar + gid; m < nmcu; m += gsz) {
-        const uint32_t mark = rf[m];
-        if (mark && (m > mstar || mstar * nb + mark - 1u > bstar || (mstar * nb + mark - 1u == bstar && !own_mark))) rf[m] = 0;
+        const uint32_t mark = rf[m], mblk = mstar * nb + (mark & 127u) - 1u;       // the block in front of which the mark clears the predictors
+        if (mark && (m > mstar || mblk > bstar || (mblk == bstar && (mark & 128u) && !own_mark))) rf[m] = 0;
     }
 }
 __global__ void __launch_bounds__(256) k_dead_rows(const JsImage* __restrict__ imgs, uint32_t img, uint32_t bstar, int16_t* __restrict__ dccum)

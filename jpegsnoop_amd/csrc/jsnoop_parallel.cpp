@@ -493,8 +493,8 @@ int js_parallel_fixup(JsnoopBatch* b)
         if (dead[i] || !(b->host_flags[i] & ~JS_FLAGS_PIXEL_EXACT)) continue;
         const JsImage& im = b->imgs[i];
         if ((b->host_flags[i] & JSNOOP_FLAG_MARKER) && b->host_anom[i] == 0xFFFFFFFFu) continue;    // resolved by the second attempt
-        // (restarts the walks followed off an MCU boundary, or over leftover bytes, leave marks and MCU tops the take-over's seeding does not read: whole mirror)
-        const bool tail_ok = !no_tail && !(b->host_flags[i] & (JSNOOP_FLAG_TABLES | JSNOOP_FLAG_NOSYNC | JSNOOP_FLAG_FORCED | JSNOOP_FLAG_RST_MISALIGN)) && b->tables[im.tableset].lut_ok &&
+        // (round 5: also behind restarts the walks followed off an MCU boundary -- the take-over reads the mark of the MCU before its own for the predictors)
+        const bool tail_ok = !no_tail && !(b->host_flags[i] & (JSNOOP_FLAG_TABLES | JSNOOP_FLAG_NOSYNC | JSNOOP_FLAG_FORCED)) && b->tables[im.tableset].lut_ok &&
                              b->host_anom[i] != 0xFFFFFFFFu && b->host_anom[i] / im.blk_per_mcu >= 1u && b->host_anom[i] < im.total_blocks;
         if (dbg_tail) fprintf(stderr, "[tail] image %u flags 0x%04x first anomalous block %u (MCU %u of %u) -> %s\n", i, b->host_flags[i], b->host_anom[i],
                                                  b->host_anom[i] / im.blk_per_mcu, im.mcu_xmax * im.mcu_ymax, tail_ok ? "tail take-over" : "whole mirror");

@@ -299,3 +299,17 @@ def test_one_hostile_file_does_not_cost_the_batch_its_time(harness, oracle):
         assert all(int(s) == want for s in sums[j:191:8]), j
     bh.close()
     assert dirty <= 2.0 * clean, f"clean {clean:.2f} ms, with one hostile file {dirty:.2f} ms"
+
+
+def test_decode_end_in_the_first_block_behind_a_restart(harness, oracle, gpu):
+    """tools/fuzz_gpu.py seed 4244 case 352: a 4:4:4 file with a restart marker behind every MCU and a stray RSTn in the middle of an MCU.  The value bits of a
+    symbol of the MCU's FIRST block run into the stray marker -- the decode ends in a block whose restart mark (set in front of the block, possibly by the lane
+    before its owner) is the reference's, while a mark the walk sets on the same block afterwards is not: the fill-in keeps the first kind (mark_reset's bit 7)."""
+    from fuzz_util import differs
+    base = harness.synth_jpeg(width=128, height=64, hs=1, vs=1, restart_interval=1, seed=3)
+    for at in (844, 700, 1200, 2000):
+        d = bytearray(base); d[at:at] = b"\xff\xd0"
+        data = bytes(d)
+        harness.drive(oracle, data)
+        harness.drive(gpu, data)
+        assert differs(oracle, gpu) is None, at

@@ -3,7 +3,7 @@
 # Every variant is the pair-form kernel WITHOUT its term loop (JS_EXP_NOTERMS) minus one more part; run with tools/ab_round.sh.
 set -e
 cd $(dirname $0)/../..
-P="-p tools/variants/r05_backend_parts.patch"
+P="-p tools/variants/ablations.patch"
 tools/build_variant.sh a_noterms            $P -DJS_EXP_NOTERMS
 tools/build_variant.sh b_nocolor            $P -DJS_EXP_NOTERMS -DJS_EXP_NOCOLOR
 tools/build_variant.sh c_nodibstore         $P -DJS_EXP_NOTERMS -DJS_EXP_NODIBSTORE
