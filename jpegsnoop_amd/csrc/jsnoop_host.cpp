@@ -417,8 +417,8 @@ int JsnoopBatch::upload()
     const size_t n = imgs.size();
     if (!n) { js_set_error("upload: empty batch"); return -1; }
     uint64_t blocks = 0, dibb = 0, plane = 0, side = 0, ustr = 0, subs = 0;
-    std::vector<uint32_t> wg(n + 1), usb(n + 1), syb(2 * (n + 1));       // syb: write-pass bases, then sync-pass bases
-    uint64_t segw = 0, mcub = 0; uint32_t usc = 0, syw = 0, snw = 0;
+    std::vector<uint32_t> wg(n + 1), usb(2 * (n + 1)), syb(2 * (n + 1));       // syb: write-pass bases, then sync-pass bases; usb: 4 KiB chunks, then super-chunks of four (k_unstuff_fused)
+    uint64_t segw = 0, mcub = 0; uint32_t usc = 0, us4 = 0, syw = 0, snw = 0;
     strips_per_wg = 0; uint64_t total_mcus = 0; for (const JsImage& im : imgs) total_mcus += (uint64_t)im.mcu_xmax * im.mcu_ymax;
     // back end: 8 waves per workgroup; enough MCUs per wave to amortise a workgroup's table load; a small job as ONE round of workgroups over the
     // chip's 1024 workgroup slots (one 3840x2160 image: 4 MCUs per wave, 1013 workgroups, 47 us; 3 per wave = 1350 workgroups: 51)
@@ -453,13 +453,14 @@ int JsnoopBatch::upload()
         im.seg_cap = (uint32_t)std::min<uint64_t>((1u << 20) - 1, want_seg * 2 + 16); im.seg_off = segw; segw += align_up(im.seg_cap, 4);   // 20-bit interval index in the state word
         im.mcu_off = mcub; mcub += align_up(nmcu, 16);
         im.ev_cap = opt_events ? JS_EV_MAX : 0; im.ev_off = (uint64_t)i * (1 + JS_EV_WORDS * JS_EV_MAX);
-        usb[i] = usc; usc += std::max(1u, (uint32_t)(((im.scan_start & 15) + (uint64_t)im.scan_len + JS_US_CHUNK - 1) / JS_US_CHUNK));   // (at least one chunk: its last chunk leaves the image's totals)
+        { const uint32_t nck = std::max(1u, (uint32_t)(((im.scan_start & 15) + (uint64_t)im.scan_len + JS_US_CHUNK - 1) / JS_US_CHUNK));   // (at least one chunk: its last chunk leaves the image's totals)
+          usb[i] = usc; usc += nck; usb[n + 1 + i] = us4; us4 += (nck + 3) / 4; }
         syb[i] = syw; syw += (im.n_subseq + JS_SY_THREADS - 1) / JS_SY_THREADS;
         syb[n + 1 + i] = snw; snw += (im.n_subseq + JS_SY_THREADS - 2) / (JS_SY_THREADS - 1);   // sync pass: one thread per workgroup walks a halo
         max_mcu_h = std::max(max_mcu_h, im.mcu_h); max_mcu_w = std::max(max_mcu_w, im.mcu_w);
         wg[i] = wgs; wgs += std::max(1u, (nmcu + 8 * mcus_per_wave - 1) / (8 * mcus_per_wave));     // 8 waves per workgroup, one MCU per wave at a time
     }
-    usb[n] = usc; syb[n] = syw; syb[2 * n + 1] = snw; us_chunks = usc; sy_wgs = syw; sn_wgs = snw; seg_words = segw; mcu_bytes = mcub;
+    usb[n] = usc; usb[2 * n + 1] = us4; syb[n] = syw; syb[2 * n + 1] = snw; us_chunks = usc; sy_wgs = syw; sn_wgs = snw; seg_words = segw; mcu_bytes = mcub;
     wg[n] = wgs; total_wgs = wgs; total_blocks = blocks; dib_bytes = dibb; side_words = side; total_subseq = subs; ustr_bytes = ustr;
     if (grow(&dev.raw, &cap.raw, raw_bytes + 64) || grow(&dev.coef, &cap.coef, blocks * 128) || grow(&dev.dccum, &cap.dccum, blocks * 2 + 64) ||
         grow(&dev.dib, &cap.dib, dibb) || grow(&dev.side, &cap.side, side * 4) || grow(&dev.imgs, &cap.imgs, n * sizeof(JsImage)) ||
@@ -467,7 +468,7 @@ int JsnoopBatch::upload()
         grow(&dev.sel, &cap.sel, n * 4) || grow(&dev.sums, &cap.sums, n * 8) || grow(&dev.ustr, &cap.ustr, ustr + 64) ||
         grow(&dev.sub, &cap.sub, subs * 24 + 64) || grow(&dev.probe, &cap.probe, 1024) || grow(&dev.seg, &cap.seg, segw * 4 + 64) ||
         grow(&dev.chunk_keep, &cap.chunk_keep, (size_t)usc * 4 + 64) || grow(&dev.chunk_rst, &cap.chunk_rst, (size_t)usc * 4 + 64) ||
-        grow(&dev.us_base, &cap.us_base, (n + 1) * 4) || grow(&dev.sy_base, &cap.sy_base, 2 * (n + 1) * 4) ||
+        grow(&dev.us_base, &cap.us_base, 2 * (n + 1) * 4) || grow(&dev.sy_base, &cap.sy_base, 2 * (n + 1) * 4) ||
         grow(&dev.mcu_rst, &cap.mcu_rst, mcub + 64) || grow(&dev.dc_parts, &cap.dc_parts, JS_DC_PARTS_BYTES) || grow(&dev.ustr_lin, &cap.ustr_lin, ustr + 64) || grow(&dev.flags, &cap.flags, n * 8 + 64) ||
         grow(&dev.us_state, &cap.us_state, (size_t)usc * 8 + 64)) return -1;
     HIP_TRY(hipMemsetAsync(dev.us_state, 0, (size_t)usc * 8, stream)); us_epoch = 0;      // (no word of an earlier layout may look current)
@@ -486,10 +487,10 @@ int JsnoopBatch::upload()
     HIP_TRY(hipMemcpyAsync(dev.imgs, imgs.data(), n * sizeof(JsImage), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(dev.tables, tables.data(), tables.size() * sizeof(JsTableSet), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(dev.wg_base, wg.data(), (n + 1) * 4, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(dev.us_base, usb.data(), (n + 1) * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(dev.us_base, usb.data(), 2 * (n + 1) * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(dev.sy_base, syb.data(), 2 * (n + 1) * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));          // host vectors above may go out of scope
-    h_us_base = usb; h_sy_base.assign(syb.begin(), syb.begin() + n + 1); h_sn_base.assign(syb.begin() + n + 1, syb.end()); h_wg_base = wg;
+    h_us_base.assign(usb.begin(), usb.begin() + n + 1); h_us4_base.assign(usb.begin() + n + 1, usb.end()); h_sy_base.assign(syb.begin(), syb.begin() + n + 1); h_sn_base.assign(syb.begin() + n + 1, syb.end()); h_wg_base = wg;
     // two halves on two streams: by default from the batch size at which the long sub-sequences are chosen (96 MB of scan data)
     split_parts = (n >= 2 && (tune.split == 2 || (tune.split == 0 && scan_total >= (96ull << 20)))) ? 2 : 1;
     uploaded = true;

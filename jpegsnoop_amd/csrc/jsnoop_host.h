@@ -87,7 +87,7 @@ struct JsnoopBatch {
     std::vector<uint8_t> side_done;                               // per image: the side-output pass has run since the last decode
     std::vector<uint32_t> host_anom;                              // per image: first block (decode order) the parallel path could not vouch for (0xFFFFFFFF: none)
     std::vector<uint8_t> host_anom_kind;                          // ... and what it was: 0 = the mirror takes over there, 1..8 = the reference's decode ends in that block (ANOM_KEY, jsnoop_kernels.hip)
-    std::vector<uint32_t> host_flags, host_path, h_us_base, h_sy_base, h_sn_base, h_wg_base;
+    std::vector<uint32_t> host_flags, host_path, h_us_base, h_us4_base, h_sy_base, h_sn_base, h_wg_base;
     // A large batch decodes as two halves on two streams (stream, aux[0]): the kernels of one half fill the tails and the thinly
     // populated phases (second synchronisation launch, DC scan) of the other -- 14.2 -> 13.7 ms per 1024 images.  Both halves live in
     // the same arenas; a launch over a half passes pointers to its first image and its first prefix entry.

@@ -1506,11 +1506,12 @@ __device__ __forceinline__ uint32_t us_zero_bytes(uint32_t x)
     const uint32_t nz = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;          // bit 7 of every byte: byte != 0
     return (((~nz & 0x80808080u) >> 7) * 0x10204080u) >> 28;
 }
-__device__ __forceinline__ UsBytes us_classify(const uint8_t* __restrict__ raw, uint64_t o16, uint64_t s, uint64_t e)
+__device__ __forceinline__ UsBytes us_classify(const uint8_t* __restrict__ raw, uint64_t o16, uint64_t s, uint64_t e, uint4* words = nullptr)
 {
     UsBytes r; r.keep_mask = 0; r.rst_mask = 0;
     if (o16 + 16 <= s || o16 >= e) return r;
     const uint4 v = *reinterpret_cast<const uint4*>(raw + o16);
+    if (words) *words = v;
     const uint32_t w[4] = { v.x, v.y, v.z, v.w };
     uint32_t prev = o16 > s ? raw[o16 - 1] : 0u;             // bytes before the scan start never count as FF
     const uint32_t next16 = (o16 + 16 < e) ? raw[o16 + 16] : 0u;
@@ -1614,6 +1615,35 @@ __device__ __forceinline__ uint64_t us_pack(uint32_t epoch, uint32_t kind, uint3
 { return ((uint64_t)epoch << 56) | ((uint64_t)kind << 54) | ((uint64_t)min(rst, 0x3FFFFFu) << 32) | keep; }
 __device__ __forceinline__ uint32_t us_sat_add(uint32_t a, uint32_t b) { return min(a + b, 0x3FFFFFu); }
 
+// Decoupled look-back of the fused un-stuffing passes (one wave): the sums (kept bytes, RSTn markers) over the `ci` state words in front of
+// word `wg`, all of the same image.  64 words per trip: lane j reads word wg - back - j, and the wave waits until every word between itself and
+// the closest inclusive prefix has been published in this decode's epoch.
+__device__ __forceinline__ void us_lookback(unsigned long long* __restrict__ us_state, uint32_t wg, uint32_t ci, uint32_t epoch, uint32_t lane, uint32_t& ek, uint32_t& er)
+{
+    ek = 0; er = 0;
+    if (!ci) return;
+    uint32_t back = 1;                                           // distance of lane 0's word
+    for (;;) {
+        const bool valid = back + lane <= ci;
+        uint64_t v = 0; bool ready = false;
+        for (;;) {
+            if (valid) { v = __hip_atomic_load(&us_state[wg - back - lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ready = (uint32_t)(v >> 56) == epoch && ((v >> 54) & 3u) != 0u; }
+            const uint64_t m_inc = WBALLOT(valid && ready && ((v >> 54) & 3u) == US_ST_INC), m_wait = WBALLOT(valid && !ready);
+            const uint64_t first_inc = m_inc & (0 - m_inc), below = m_inc ? first_inc - 1ull : ~0ull;   // lanes closer than the closest inclusive prefix (all, if there is none)
+            if (!(m_wait & (below | first_inc))) {
+                const bool take = valid && (((1ull << lane) & (below | first_inc)) != 0ull);
+                uint32_t tk = take ? (uint32_t)v : 0u, tr = take ? (uint32_t)(v >> 32) & 0x3FFFFFu : 0u;
+                for (int off = 32; off > 0; off >>= 1) { tk += __shfl_xor(tk, off); tr = us_sat_add(tr, __shfl_xor(tr, off)); }
+                ek += tk; er = us_sat_add(er, tr);
+                back = m_inc ? 0u : back + 64u;                  // 0: done
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (back == 0 || back > ci) break;                       // (past the image's first word without an inclusive prefix cannot happen: word 0 publishes one)
+    }
+}
+
 // The un-stuffing pass proper: classifies the chunk's bytes, finds where its kept bytes go, writes them (and the interval table entries of its
 // RSTn markers).  FUSED (the decode): ONE pass over the file bytes -- the chunk's place in its image comes from a decoupled look-back over the
 // chunks before it (us_state; workgroups are dispatched in index order, so every chunk a workgroup waits for is running or done), the last
@@ -1663,30 +1693,7 @@ __global__ void __launch_bounds__(US_THREADS) k_unstuff_write(const JsImage* __r
     if (FUSED) {
         if (wave == 0) {
             uint32_t ek = 0, er = 0;
-            if (ci) {
-                // look-back, 64 chunks per trip: lane j reads the state of chunk wg - 1 - j (of the same image), and the wave waits until every
-                // chunk between itself and the closest inclusive prefix has published something
-                uint32_t back = 1;                                       // distance of lane 0's chunk
-                for (;;) {
-                    const bool valid = back + lane <= ci;
-                    uint64_t v = 0; bool ready = false;
-                    for (;;) {
-                        if (valid) { v = __hip_atomic_load(&us_state[wg - back - lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ready = (uint32_t)(v >> 56) == epoch && ((v >> 54) & 3u) != 0u; }
-                        const uint64_t m_inc = WBALLOT(valid && ready && ((v >> 54) & 3u) == US_ST_INC), m_wait = WBALLOT(valid && !ready);
-                        const uint64_t first_inc = m_inc & (0 - m_inc), below = m_inc ? first_inc - 1ull : ~0ull;   // lanes closer than the closest inclusive prefix (all, if there is none)
-                        if (!(m_wait & (below | first_inc))) {
-                            const bool take = valid && (((1ull << lane) & (below | first_inc)) != 0ull);
-                            uint32_t tk = take ? (uint32_t)v : 0u, tr = take ? (uint32_t)(v >> 32) & 0x3FFFFFu : 0u;
-                            for (int off = 32; off > 0; off >>= 1) { tk += __shfl_xor(tk, off); tr = us_sat_add(tr, __shfl_xor(tr, off)); }
-                            ek += tk; er = us_sat_add(er, tr);
-                            back = m_inc ? 0u : back + 64u;              // 0: done
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    if (back == 0 || back > ci) break;                   // (past the image's first chunk without an inclusive prefix cannot happen: chunk 0 publishes one)
-                }
-            }
+            us_lookback(us_state, wg, ci, epoch, lane, ek, er);
             if (lane == 0) {
                 __hip_atomic_store(&us_state[wg], us_pack(epoch, US_ST_INC, ek + agg_k, us_sat_add(er, agg_r)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_excl[0] = ek; s_excl[1] = er;
@@ -1721,6 +1728,108 @@ __global__ void __launch_bounds__(US_THREADS) k_unstuff_write(const JsImage* __r
         if (w * 4 >= lo_b && w * 4 + 4 <= hi_b) reinterpret_cast<uint32_t*>(dst)[w] = phase ? __builtin_amdgcn_alignbyte(s32[w], s32[w - 1], 4u - phase) : s32[w];
         else for (uint32_t b = max(w * 4, lo_b); b < min(w * 4 + 4, hi_b); b++) dst[b] = s_out[b - phase];
     }
+}
+
+// The un-stuffing pass of large jobs (sub-sequences of 128 bytes and more): ONE pass from the file bytes to the word-interleaved sub-sequence layout
+// (phys_word) -- no linear copy, no transposition pass.  A workgroup takes a SUPER-chunk of four consecutive 4 KiB chunks of one image (four 16-byte
+// loads per thread in flight: a 4 KiB workgroup lived on one), scans them as k_unstuff_write does, publishes its counts, gathers up to 16 KiB of kept
+// bytes in LDS (one pad word per sub-sequence length, so that the transposed read-out below walks the banks), looks back for its base, and writes the
+// bytes where the walks read them: for every word row w of the sub-sequences it touches, the words of consecutive sub-sequences are consecutive in
+// memory (33 x 4 bytes per row for 512-byte pieces).  The exclusive prefixes of its 4 KiB chunks are kept in chunk_keep / chunk_rst for the side
+// passes (k_unstuff_write<false>); us4_base: the images' prefix over super-chunks (the state words are indexed by super-chunk).
+#define US_SUPER 4
+template <int WL>
+__global__ void __launch_bounds__(US_THREADS) k_unstuff_fused(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ us_base, const uint32_t* __restrict__ us4_base, uint32_t nimg,
+                                                              const uint8_t* __restrict__ raw, uint32_t* __restrict__ chunk_keep, uint32_t* __restrict__ chunk_rst,
+                                                              uint8_t* __restrict__ ustr, uint32_t* __restrict__ seg_tab, unsigned long long* __restrict__ us_state, uint32_t epoch,
+                                                              uint32_t* __restrict__ side, uint32_t* __restrict__ flags)
+{
+    constexpr uint32_t PADSH = WL + 2;                            // one pad word per 4 << WL gathered bytes
+    __shared__ __attribute__((aligned(4))) uint8_t s_out[US_SUPER * US_CHUNK + ((US_SUPER * US_CHUNK) >> WL) + 16];
+    __shared__ uint32_t wk[US_SUPER][US_THREADS / 64], wr[US_SUPER][US_THREADS / 64];
+    __shared__ uint32_t s_excl[2];
+    const uint32_t sw = blockIdx.x + us4_base[0];
+    const uint32_t img = find_image(us4_base, nimg, sw);
+    const JsImage& im = imgs[img];
+    const uint32_t sc = sw - us4_base[img], nsc = us4_base[img + 1] - us4_base[img];
+    const uint32_t c0 = sc * US_SUPER, nc = us_base[img + 1] - us_base[img], wgc = us_base[img] + c0;     // first 4 KiB chunk of the super-chunk: in the image / in the batch
+    const uint64_t s = im.file_off + im.scan_start, e = s + im.scan_len;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    UsBytes c[US_SUPER]; uint4 v[US_SUPER]; uint32_t pk[US_SUPER], pr[US_SUPER];
+    #pragma unroll
+    for (uint32_t q = 0; q < US_SUPER; q++) {
+        v[q] = make_uint4(0u, 0u, 0u, 0u); c[q].keep_mask = 0; c[q].rst_mask = 0;
+        if (c0 + q < nc) c[q] = us_classify(raw, (s & ~15ull) + (uint64_t)(c0 + q) * US_CHUNK + threadIdx.x * 16, s, e, &v[q]);
+    }
+    #pragma unroll
+    for (uint32_t q = 0; q < US_SUPER; q++) {                    // inclusive wave scans, kept bytes in the low half, markers in the high half (<= 1024 / <= 512 per wave)
+        uint32_t x = __popc(c[q].keep_mask) | (__popc(c[q].rst_mask) << 16);
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t a = __shfl_up(x, off); if (lane >= (uint32_t)off) x += a; }
+        pk[q] = x & 0xFFFFu; pr[q] = x >> 16;
+        if (lane == 63) { wk[q][wave] = pk[q]; wr[q][wave] = pr[q]; }
+    }
+    __syncthreads();
+    uint32_t agg_k = 0, agg_r = 0, lk[US_SUPER], lr[US_SUPER], ck[US_SUPER], cr[US_SUPER];       // exclusive prefixes inside the super-chunk: of the thread (lk, lr), of the 4 KiB chunk (ck, cr)
+    #pragma unroll
+    for (uint32_t q = 0; q < US_SUPER; q++) {
+        ck[q] = agg_k; cr[q] = agg_r;
+        lk[q] = agg_k + pk[q] - __popc(c[q].keep_mask); lr[q] = agg_r + pr[q] - __popc(c[q].rst_mask);
+        #pragma unroll
+        for (uint32_t w = 0; w < US_THREADS / 64; w++) { if (w < wave) { lk[q] += wk[q][w]; lr[q] += wr[q][w]; } agg_k += wk[q][w]; agg_r = us_sat_add(agg_r, wr[q][w]); }
+    }
+    if (sc && threadIdx.x == 0) __hip_atomic_store(&us_state[sw], us_pack(epoch, US_ST_AGG, agg_k, agg_r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    #pragma unroll
+    for (uint32_t q = 0; q < US_SUPER; q++) if (c[q].keep_mask) {
+        const uint32_t w4[4] = { v[q].x, v[q].y, v[q].z, v[q].w };
+        uint32_t g = lk[q];
+        #pragma unroll
+        for (int j = 0; j < 16; j++) if (c[q].keep_mask & (1u << j)) { s_out[g + ((g >> PADSH) << 2)] = (uint8_t)(w4[j >> 2] >> ((j & 3) * 8)); g++; }
+    }
+    if (wave == 0) {
+        uint32_t ek, er;
+        us_lookback(us_state, sw, sc, epoch, lane, ek, er);
+        if (lane == 0) {
+            __hip_atomic_store(&us_state[sw], us_pack(epoch, US_ST_INC, ek + agg_k, us_sat_add(er, agg_r)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_excl[0] = ek; s_excl[1] = er;
+            if (sc + 1 == nsc) {                                     // the image's totals: un-stuffed length, intervals, interval 0 and the end sentinel
+                const uint32_t run_k = ek + agg_k, run_r = us_sat_add(er, agg_r);
+                uint32_t* sd = side + im.side_off; uint32_t* st = seg_tab + im.seg_off;
+                sd[10] = run_k; sd[11] = run_r + 1;
+                st[0] = 0;
+                if (run_r + 2 <= im.seg_cap) st[run_r + 1] = run_k; else { FLAG_OR(flags, img, F_OVERRUN); ANOM_MIN(flags, img, ANOM_KEY(0u, AK_MIRROR)); }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t cb = s_excl[0], br = s_excl[1], phase = cb & 3u, total = agg_k;
+    if (threadIdx.x < US_SUPER && c0 + threadIdx.x < nc) {         // (the side passes of this decode read them)
+        uint32_t k_ = 0, r_ = 0;
+        #pragma unroll
+        for (uint32_t q = 0; q < US_SUPER; q++) if (q == threadIdx.x) { k_ = ck[q]; r_ = cr[q]; }
+        chunk_keep[wgc + threadIdx.x] = cb + k_; chunk_rst[wgc + threadIdx.x] = us_sat_add(br, r_);
+    }
+    #pragma unroll
+    for (uint32_t q = 0; q < US_SUPER; q++) if (c[q].rst_mask) {    // interval table: interval `seg` starts at the next kept byte behind its marker
+        uint32_t* st = seg_tab + im.seg_off; uint32_t seg = br + lr[q];
+        #pragma unroll
+        for (int j = 0; j < 16; j++) if (c[q].rst_mask & (1u << j)) { seg++; if (seg + 1 < im.seg_cap) st[seg] = cb + lk[q] + __popc(c[q].keep_mask & ((1u << j) - 1u)); }
+    }
+    if (!total) return;
+    // read-out: stream word W = W0 + j holds the gathered bytes [4j - phase, 4j - phase + 4); it goes to phys_word(W).  Rows of the transposition:
+    // for word index w inside a sub-sequence, the sub-sequences l0 .. l0 + nl - 1 this super-chunk touches -- consecutive lanes, consecutive words.
+    const uint32_t W0 = cb >> 2, Wend = (cb + total + 3u) >> 2, jl = (phase + total) >> 2, jf = phase ? 1u : 0u;     // full words: j in [jf, jl)
+    const uint32_t l0 = W0 >> WL, nl = ((Wend - 1u) >> WL) - l0 + 1u;
+    uint32_t* dst32 = reinterpret_cast<uint32_t*>(ustr + im.ustr_off); uint8_t* dst8 = ustr + im.ustr_off;
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(s_out);
+    const uint32_t dq = US_THREADS / nl, dr = US_THREADS % nl;                  // (w, l) of item i = w * nl + l, i = tid, tid + 256, ...: all lanes busy whatever nl is
+    for (uint32_t w = threadIdx.x / nl, l = threadIdx.x % nl; w < (1u << WL); w += dq, l += dr) {
+            if (l >= nl) { l -= nl; w++; if (w >> WL) break; }
+            const uint32_t W = ((l0 + l) << WL) + w;
+            if (W < W0 || W >= Wend) continue;
+            const uint32_t j = W - W0, pw = phys_word<WL>(W);
+            if (j >= jf && j < jl) dst32[pw] = phase ? __builtin_amdgcn_alignbyte(s32[j + (j >> WL)], s32[(j - 1u) + ((j - 1u) >> WL)], 4u - phase) : s32[j + (j >> WL)];
+            else for (uint32_t b = max(4u * j, phase); b < min(4u * j + 4u, phase + total); b++) { const uint32_t g = b - phase; dst8[(pw << 2) + (b & 3u)] = s_out[g + ((g >> PADSH) << 2)]; }
+        }
 }
 
 // Linear compacted stream -> word-interleaved sub-sequence layout (see phys_word).  One workgroup per group of 64
@@ -3120,10 +3229,16 @@ __global__ void __launch_bounds__(DC_THREADS) k_dc_scan_parts(const JsImage* __r
 
 void js_launch_unstuff(hipStream_t st, int wl, const JsImage* imgs, const uint32_t* us_base, uint32_t nimg, uint32_t total_chunks, const uint8_t* raw,
                        uint32_t* chunk_keep, uint32_t* chunk_rst, uint8_t* ustr_lin, uint8_t* ustr, uint32_t* seg_tab, uint32_t* side, uint32_t* flags,
-                       const uint32_t* sy_base, uint32_t sy_wgs, unsigned long long* us_state, uint32_t epoch)
+                       const uint32_t* sy_base, uint32_t sy_wgs, unsigned long long* us_state, uint32_t epoch, const uint32_t* us4_base, uint32_t total_super)
 {
     if (!total_chunks) return;
-    if (us_state) {          // one pass over the file bytes: the chunks' places come from a decoupled look-back (k_unstuff_write<true>)
+    if (us_state && wl != 4 && us4_base) {   // large jobs: one pass from the file bytes to the interleaved layout (k_unstuff_fused), no transposition pass
+#define JS_USF(W) hipLaunchKernelGGL(k_unstuff_fused<W>, dim3(total_super), dim3(US_THREADS), 0, st, imgs, us_base, us4_base, nimg, raw, chunk_keep, chunk_rst, ustr, seg_tab, us_state, epoch, side, flags)
+        if (wl == 5) JS_USF(5); else if (wl == 6) JS_USF(6); else if (wl == 7) JS_USF(7); else JS_USF(8);
+#undef JS_USF
+        return;
+    }
+    if (us_state) {          // small jobs (64-byte pieces read the linear stream): one pass, the chunks' places come from a decoupled look-back (k_unstuff_write<true>)
         hipLaunchKernelGGL(k_unstuff_write<true>, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, wl == 4 ? ustr : ustr_lin, seg_tab, 0u,
                            (uint32_t*)nullptr, us_state, epoch, side, flags);
     } else {                 // the three-pass form (cross-check): count, scan per image, write

@@ -96,24 +96,28 @@ def test_two_stream_split_gives_the_same_batch(harness, oracle):
 
 
 def test_fused_unstuffing_agrees_with_the_three_pass_form(harness, oracle):
-    """The decode un-stuffs in ONE pass over the file bytes (k_unstuff_write<true>: a chunk's place in its image comes from a decoupled
-    look-back over the chunks before it); the count / scan / write form it replaced stays behind JSNOOP_XC_UNSTUFF_3PASS.  Same DIBs, and
-    -- repeated decodes of the same resident batch -- the epoch tag of the scan state keeps one decode's words apart from the next one's."""
+    """The decode un-stuffs in ONE pass over the file bytes (k_unstuff_write<true> for 64-byte sub-sequences, k_unstuff_fused for longer ones,
+    which also writes the interleaved layout directly: a chunk's place in its image comes from a decoupled look-back over the chunks before
+    it); the count / scan / write (/ transpose) form it replaced stays behind JSNOOP_XC_UNSTUFF_3PASS.  Same DIBs, and -- repeated decodes
+    of the same resident batch -- the epoch tag of the scan state keeps one decode's words apart from the next one's."""
     import jpegsnoop_amd as J
     from jpegsnoop_amd import capi
-    fused = _decode_all(J, harness)
-    three = _decode_all(J, harness, cross_checks=capi.XC_UNSTUFF_3PASS)
-    assert fused["sums"] == three["sums"] and set(fused["paths"]) == {1} and not any(fused["flags"]) and not any(three["flags"])
+    for wl in (0, 5, 6, 7, 8):
+        fused = _decode_all(J, harness, sub_wl=wl)
+        three = _decode_all(J, harness, sub_wl=wl, cross_checks=capi.XC_UNSTUFF_3PASS)
+        assert fused["sums"] == three["sums"] and set(fused["paths"]) == {1} and not any(fused["flags"]) and not any(three["flags"]), wl
     files = _files(harness) + [harness.synth_jpeg(seed=77, width=3840, height=2160, hs=2, vs=2, restart_interval=7)]     # (a scan of ~600 chunks: look-back over several trips)
-    b = J.JpegBatch()
-    for f in files:
-        b.add_jpeg(f)
-    b.upload()
-    for _ in range(300):                                           # past the wrap of the 8-bit epoch
-        b.decode()
-    b.sync()
-    for i, f in enumerate(files):
-        harness.drive(oracle, f)
-        assert b.info(i)["path"] == 1 and b.info(i)["flags"] == 0, i
-        assert int(b.dib_checksums()[i]) == J.dib_checksum_numpy(oracle.dib()), i
-    b.close()
+    for wl in (0, 7):
+        b = J.JpegBatch()
+        b.set_tuning(sub_wl=wl)
+        for f in files:
+            b.add_jpeg(f)
+        b.upload()
+        for _ in range(300):                                       # past the wrap of the 8-bit epoch
+            b.decode()
+        b.sync()
+        for i, f in enumerate(files):
+            harness.drive(oracle, f)
+            assert b.info(i)["path"] == 1 and b.info(i)["flags"] == 0, (wl, i)
+            assert int(b.dib_checksums()[i]) == J.dib_checksum_numpy(oracle.dib()), (wl, i)
+        b.close()
