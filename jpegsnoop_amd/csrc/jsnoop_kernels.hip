@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
             dc_y = dprev[n1 - 1]; if (im.ncomp == 3) { dc_cb = dprev[n2 - 1]; dc_cr = dprev[nb - 1]; }
             // ... unless a restart was followed INSIDE that MCU behind the component's last block (its mark: predictors cleared in front of block j): the
             // component's predictor is then the zero the restart left, not the sum its last block had reached before it
-            const uint32_t rj = tail.mcu_rst[im.mcu_off + m0 - 1u] & 127u;
+            const uint32_t rj = tail.mcu_rst[im.mcu_off + m0 - 1u] & 63u;
             if (rj) { if (n1 < rj) dc_y = 0; if (im.ncomp == 3 && n2 < rj) dc_cb = 0; }
             r.ptr_first = im.scan_start;
         }
@@ -1975,9 +1975,10 @@ __device__ __forceinline__ uint32_t sym_lookup(const SubTabs& T, uint32_t win, u
     return e;
 }
 
-// The restart mark of MCU m: 0 = none, j + 1 = the DC predictors are cleared in front of block j of the MCU.  One byte per MCU, set by
+// The restart mark of MCU m: 0 = none, j + 1 (low six bits) = the DC predictors are cleared in front of block j of the MCU.  One byte per MCU, set by
 // compare-and-swap on its word (lanes of different sub-sequences may meet markers in neighbouring MCUs); false when the MCU already carries
-// a different mark (two markers inside one MCU: hostile, left to the mirror).
+// a different mark (two markers inside one MCU: hostile, left to the mirror) -- except for the pair that a stray RSTn shortly behind a regular
+// one makes: bit 6 = "and in front of block 0 as well" beside a mark j + 1 > 1 (the regular marker on the MCU boundary, the stray one further in).
 // Bit 7 of a mark: the marker was met INSIDE the block (after its DC symbol), not in front of it -- the predictors are cleared in front of the block
 // either way (the DC scan looks at the low seven bits), but when the reference's decode ENDS in that block (ANOM_KEY) a mark the walk set inside it may
 // stem from bits the reference never read, while one set in front of it cannot: "in front" wins when both set the same mark.
@@ -1987,9 +1988,13 @@ __device__ __forceinline__ bool mark_reset(uint8_t* __restrict__ mcu_rst, uint32
     uint32_t old = *reinterpret_cast<volatile uint32_t*>(w);
     for (;;) {
         const uint32_t cur = (old >> sh) & 255u;
-        if ((cur & 127u) == v) { if (!inside && (cur & 128u)) atomicAnd(w, ~(128u << sh)); return true; }
-        if (cur != 0u) return false;
-        const uint32_t seen = atomicCAS(w, old, old | ((v | (inside ? 128u : 0u)) << sh));
+        if ((cur & 63u) == v) { if (!inside && (cur & 128u)) atomicAnd(w, ~(128u << sh)); return true; }
+        uint32_t nv;
+        if (cur == 0u) nv = v | (inside ? 128u : 0u);
+        else if (v == 1u && (cur & 63u) > 1u && !inside) { if (cur & 64u) return true; nv = cur | 64u; }        // the boundary mark joins one further in
+        else if (v > 1u && cur == 1u) nv = v | 64u | (inside ? 128u : 0u);                                       // a mark further in joins the (plain) boundary mark
+        else return false;
+        const uint32_t seen = atomicCAS(w, old, (old & ~(255u << sh)) | (nv << sh));
         if (seen == old) return true;
         old = seen;
     }
@@ -2031,7 +2036,8 @@ __device__ __forceinline__ int walk_slow(const JsImage& im, const uint32_t* __re
         // position in the MCU are kept.  On an MCU boundary that is the well-formed case; anywhere else (a damaged interval that lost or gained
         // blocks) the walks follow all the same: the reset is recorded for the block in progress (block-in-MCU index + 1 in the MCU's mark; the
         // DC scan clears its sums in front of that block), and F_RST_MISALIGN then only stands for bookkeeping (messages).  Two resets inside one
-        // MCU, or two markers back to back (the reference meets the second one inside its retry and files the DC value under index 1): F_BAD_EDGE.
+        // MCU other than {on its boundary, further in} (mark_reset), or two markers back to back (the reference meets the second one inside its
+        // retry and files the DC value under index 1): F_BAD_EDGE.
         if (WRITE) {
             if (k != 0 || c != 0 || remain >= 8) flags |= F_RST_MISALIGN;                       // well-formed: < 8 pad bits, on an MCU boundary
             if (mark && blk < im.total_blocks && !mark_reset(mcu_rst, blk / im.blk_per_mcu, c + 1u, k != 0u)) { flags |= F_BAD_EDGE; anom = min(anom, ANOM_KEY(blk, AK_MIRROR)); }
@@ -3154,7 +3160,8 @@ __device__ __forceinline__ void dc_scan_range(const JsImage& im, int16_t* __rest
         const uint32_t m = base + t; const bool valid = m < m_end;
         // the MCU's restart mark: 0 = none, j + 1 = the predictors are cleared in front of its block j (a marker on the MCU boundary: 1;
         // a marker the reference met inside the MCU -- a damaged interval -- : the block that was in progress, walk_slow)
-        const uint32_t rj = valid ? rf[m] & 127u : 0u;         // (bit 7: met inside the block, see mark_reset)
+        const uint32_t rw = valid ? rf[m] : 0u, rj = rw & 63u;   // (bit 7: met inside the block; bit 6: a second reset in front of block 0 -- see mark_reset)
+        const bool r0 = (rw & 64u) != 0u;
         int v[NBMAX];
         DcSeg own = { 0, 0, 0, rj ? 1 : 0 };                     // the MCU as a scan element: sums since its reset if it has one, else of all its blocks
         #pragma unroll
@@ -3181,7 +3188,7 @@ __device__ __forceinline__ void dc_scan_range(const JsImage& im, int16_t* __rest
         if (WRITE && valid) {
             #pragma unroll
             for (uint32_t c = 0; c < NBMAX; c++) if (c < nb) {
-                if (c + 1u == rj) { c0 = 0; c1 = 0; c2 = 0; }
+                if (c + 1u == rj || (c == 0 && r0)) { c0 = 0; c1 = 0; c2 = 0; }
                 int16_t o;
                 if (c < n1) { c0 += v[c]; o = (int16_t)c0; } else if (c < n2) { c1 += v[c]; o = (int16_t)c1; } else { c2 += v[c]; o = (int16_t)c2; }
                 d[(size_t)m * nb + c] = o;
@@ -3407,7 +3414,7 @@ __device__ __forceinline__ uint32_t mirror_to_mcu_top(const JsImage& im, const J
     for (;; m0--) {
         if (m0 == 0) { ex_restart_scan_buf(r, im.scan_start, false); ex_topup(r); break; }
         const uint32_t p = mcu_pos[m0];
-        if (mcu_rst[im.mcu_off + m0] == 1u) {                       // first MCU of an interval: the RSTn in front of it has been handled (:1644-1680); (a mark > 1: the marker lies INSIDE the MCU, the reader meets it itself)
+        if (mcu_rst[im.mcu_off + m0] == 1u || (mcu_rst[im.mcu_off + m0] & 64u)) {   // first MCU of an interval: the RSTn in front of it has been handled (:1644-1680); (a mark > 1: the marker lies INSIDE the MCU, the reader meets it itself)
             const uint32_t u1 = (p + 7) >> 3;                       //   fewer than 8 pad bits, else the parallel path had flagged the image
             rst_before = find_interval(st, nseg, min(u1, total_bytes ? total_bytes - 1 : 0));
             ex_restart_scan_buf(r, raw_of_compacted(im, raw, us_out, us_threads, u1), true); ex_topup(r);
@@ -3553,8 +3560,9 @@ __global__ void __launch_bounds__(256) k_dead_fill(const JsImage* __restrict__ i
         rows[q] = v;
     }
     for (uint32_t m = mstar + gid; m < nmcu; m += gsz) {
-        const uint32_t mark = rf[m], mblk = mstar * nb + (mark & 127u) - 1u;       // the block in front of which the mark clears the predictors
-        if (mark && (m > mstar || mblk > bstar || (mblk == bstar && (mark & 128u) && !own_mark))) rf[m] = 0;
+        const uint32_t mark = rf[m], mblk = mstar * nb + (mark & 63u) - 1u;        // the block in front of which the mark clears the predictors
+        if (mark && m > mstar) rf[m] = 0;
+        else if (mark && (mblk > bstar || (mblk == bstar && (mark & 128u) && !own_mark))) rf[m] = (mark & 64u) ? 1 : 0;      // (a second mark on the MCU's boundary stays: it lies in front of b*)
     }
 }
 __global__ void __launch_bounds__(256) k_dead_rows(const JsImage* __restrict__ imgs, uint32_t img, uint32_t bstar, int16_t* __restrict__ dccum)

@@ -53,8 +53,50 @@ struct PReader {
     __device__ bool overrun() const { return over * 8 > (uint32_t)(n > 0 ? n : 0); }      // consumed bits that were never in the interval
 };
 
+// The same reader for a WAVE that decodes ONE interval (a scan without restart markers is a single interval: a 1080p scan is one chain of
+// ~10^5 dependent symbols, and a lane that waits ~1 us for every eight file bytes and for every block it updates spends its time waiting).
+// All 64 lanes run the decoder identically (same data, same branches: wave-uniform control flow); the file bytes come through a 2 KiB ring
+// in LDS that the WAVE fills -- every lane fetches 16 bytes of a 1 KiB chunk, the chunk after the two in the ring is already in flight in
+// registers when the reader gets there -- so a byte costs an LDS read instead of a trip to memory.
+struct WReader {
+    const uint8_t* base; uint4* ring; uint32_t pos, end, limit, ring_c, lane; uint64_t acc; int n; uint32_t over; uint64_t win; uint32_t win_at; uint4 nxt;
+    __device__ __forceinline__ uint4 chunk(uint32_t c) const { const uint32_t o = (c << 10) + lane * 16u; return o < limit ? *reinterpret_cast<const uint4*>(base + o) : make_uint4(0u, 0u, 0u, 0u); }
+    __device__ __forceinline__ void init(uint4* lds, const uint8_t* file, uint32_t s, uint32_t e, uint32_t file_len, uint32_t lane_)
+    {
+        base = file; ring = lds; pos = s; end = e; limit = (file_len + 15u) & ~15u; lane = lane_; acc = 0; n = 0; over = 0; win = 0; win_at = 0xFFFFFFFFu;   // (file images are 16-byte aligned and zero padded in the raw arena)
+        ring_c = s >> 10;
+        ring[(ring_c & 1u) * 64u + lane] = chunk(ring_c); ring[((ring_c + 1u) & 1u) * 64u + lane] = chunk(ring_c + 1u); nxt = chunk(ring_c + 2u);
+        __syncthreads();
+    }
+    __device__ __forceinline__ uint32_t byte_at(uint32_t i)
+    {
+        const uint32_t a = i & ~7u;
+        if (a != win_at) {
+            while ((a >> 10) >= ring_c + 2u) {                     // (wave-uniform; the workgroup IS the wave)
+                __syncthreads(); ring[(ring_c & 1u) * 64u + lane] = nxt; ring_c++; nxt = chunk(ring_c + 2u); __syncthreads();
+            }
+            win = reinterpret_cast<const uint64_t*>(ring)[(a & 2047u) >> 3]; win_at = a;
+        }
+        return (uint32_t)(win >> ((i & 7u) * 8)) & 255u;
+    }
+    __device__ __forceinline__ void fill()
+    {
+        while (n <= 56) {
+            uint32_t b = 0;
+            if (pos < end) { b = byte_at(pos++); if (b == 0xFF && pos < end && byte_at(pos) == 0x00) pos++; }
+            else over++;
+            acc |= (uint64_t)b << (56 - n); n += 8;
+        }
+    }
+    __device__ __forceinline__ uint32_t peek(int k) { if (n < k) fill(); return (uint32_t)(acc >> (64 - k)); }
+    __device__ __forceinline__ void skip(int k) { acc <<= k; n -= k; }
+    __device__ __forceinline__ uint32_t bits(int k) { if (!k) return 0; const uint32_t v = peek(k); skip(k); return v; }
+    __device__ __forceinline__ uint32_t bit() { return bits(1); }
+    __device__ __forceinline__ bool overrun() const { return over * 8 > (uint32_t)(n > 0 ? n : 0); }
+};
+
 // Canonical Huffman decode (T.81 F.2.2.3): 8-bit look-ahead table, then bit-serial through MAXCODE.
-__device__ int huff(PReader& r, const JsProgTable& t)
+template <class R> __device__ __forceinline__ int huff(R& r, const JsProgTable& t)
 {
     const uint32_t la = r.peek(16);
     const uint32_t e = t.look[la >> 8];
@@ -66,84 +108,74 @@ __device__ int huff(PReader& r, const JsProgTable& t)
     r.skip(16);
     return -1;                                                   // no code matches
 }
-__device__ int extend(uint32_t v, int s) { return v < (1u << (s - 1)) ? (int)v - (int)((1u << s) - 1) : (int)v; }   // F.2.2.1
+__device__ __forceinline__ int extend(uint32_t v, int s) { return v < (1u << (s - 1)) ? (int)v - (int)((1u << s) - 1) : (int)v; }   // F.2.2.1
 
 // decode-order row of block (bx, by) of frame component `comp` (0-based) in the coefficient arena
-__device__ size_t block_row(const JsImage& im, const JsProgFrame& fr, uint32_t comp, uint32_t bx, uint32_t by)
+__device__ __forceinline__ size_t block_row(const JsImage& im, const JsProgFrame& fr, uint32_t comp, uint32_t bx, uint32_t by)
 {
     const uint32_t hs = fr.hs[comp], vs = fr.vs[comp];
     return ((size_t)(by / vs) * im.mcu_xmax + bx / hs) * im.blk_per_mcu + fr.first_blk[comp] + (by % vs) * hs + (bx % hs);
 }
 
-}  // namespace
+// The same with the geometry in registers (a sequential decoder must not wait for a descriptor word per block: the stores to the arena
+// keep the compiler from holding what it reads through `im` / `fr`).
+struct PGeo { uint32_t hs, vs, first, mcu_xmax, bpm; };
+__device__ __forceinline__ PGeo geo_of(const JsImage& im, const JsProgFrame& fr, uint32_t comp) { PGeo g; g.hs = fr.hs[comp]; g.vs = fr.vs[comp]; g.first = fr.first_blk[comp]; g.mcu_xmax = im.mcu_xmax; g.bpm = im.blk_per_mcu; return g; }
+__device__ __forceinline__ size_t block_row(const PGeo& g, uint32_t bx, uint32_t by) { return ((size_t)(by / g.vs) * g.mcu_xmax + bx / g.hs) * g.bpm + g.first + (by % g.vs) * g.hs + (bx % g.hs); }
 
-// One wave per restart interval of one scan; one launch covers every scan of a dependency level of the batch.
-__global__ void __launch_bounds__(64) k_prog_scan(const JsImage* __restrict__ imgs, const JsProgFrame* __restrict__ frames, const JsProgScan* __restrict__ scans,
-                                                  const uint32_t* __restrict__ lvl_scans, const uint32_t* __restrict__ lvl_wg, uint32_t nsc, uint32_t pg_lanes,
-                                                  const JsProgTable* __restrict__ tabs, const JsProgSeg* __restrict__ segs, const uint8_t* __restrict__ raw,
-                                                  int16_t* __restrict__ coef, uint32_t* __restrict__ status_all)
+// The scan's description without arrays: every field a register (an indexed array in a by-value copy sends the whole copy to scratch, and
+// then every `k <= se` of the symbol loop is a scratch load).
+struct PScanR { uint32_t img, ncomp, c0, c1, c2, ntabs, t0, t1, t2, t3, dc0, dc1, dc2, ac0, ss, se, ah, al, seg_first, nseg, rst_interval, nbx, nby; };
+__device__ __forceinline__ PScanR scan_regs(const JsProgScan& S)
 {
-    uint32_t lo = 0, hi = nsc;                                   // lvl_wg is an exclusive prefix, nsc + 1 entries
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (lvl_wg[mid] <= blockIdx.x) lo = mid; else hi = mid; }
-    const JsProgScan sc = scans[lvl_scans[lo]];                  // wave-uniform: lives in SGPRs
-    const uint32_t wg_in_scan = blockIdx.x - lvl_wg[lo];
-    const JsProgFrame& fr = frames[sc.img];
-    uint32_t* status = status_all + sc.img * 4u;
-    __shared__ JsProgTable s_tab[4];
-    __shared__ uint8_t s_zz[64];
-    if (threadIdx.x < 64) s_zz[threadIdx.x] = c_zz_nat[threadIdx.x];
-    for (uint32_t t = 0; t < sc.ntabs; t++) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(tabs + sc.tab[t]); uint32_t* dst = reinterpret_cast<uint32_t*>(&s_tab[t]);
-        for (uint32_t i = threadIdx.x; i < sizeof(JsProgTable) / 4; i += blockDim.x) dst[i] = src[i];
-    }
-    __syncthreads();
-    // The intervals are independent sequential decoders with data-dependent control flow: lanes that share a wave would
-    // serialise each other's branches, so only PG_LANES lanes of a wave carry one (a 1080p scan with one interval per MCU
-    // row has ~135 of them -- far fewer than the chip has SIMDs).
-    const bool wave_coop = sc.ss != 0 && sc.ah != 0;             // AC refinement: the whole wave works on one interval's blocks
-    const uint32_t per = wave_coop ? 1u : pg_lanes;                // intervals this wave carries
-    if (!wave_coop && threadIdx.x % (64u / per)) return;
-    const uint32_t slot = wave_coop ? 0u : threadIdx.x / (64u / per);
-    const uint32_t iv = wg_in_scan * per + slot;
-    if (iv >= sc.nseg) return;
-    const JsImage& im = imgs[sc.img];
-    const JsProgSeg sg = segs[sc.seg_first + iv];
-    PReader r; r.init(raw + im.file_off, sg.start, sg.end);      // file images are 16-byte aligned and zero padded in the raw arena
-    int16_t* cbase = coef + im.coef_off * 64;
-    const uint32_t units = sc.ncomp > 1 ? im.mcu_xmax * im.mcu_ymax : sc.nbx * sc.nby;     // MCUs of the scan (A.2.2 / A.2.3)
-    const uint32_t ri = sc.rst_interval ? sc.rst_interval : units;
-    const uint32_t u0 = iv * ri, u1 = min(units, u0 + ri);
+    PScanR r; r.img = S.img; r.ncomp = S.ncomp; r.c0 = S.comp[0]; r.c1 = S.comp[1]; r.c2 = S.comp[2]; r.ntabs = S.ntabs; r.t0 = S.tab[0]; r.t1 = S.tab[1]; r.t2 = S.tab[2]; r.t3 = S.tab[3];
+    r.dc0 = S.dc_slot[0]; r.dc1 = S.dc_slot[1]; r.dc2 = S.dc_slot[2]; r.ac0 = S.ac_slot[0]; r.ss = S.ss; r.se = S.se; r.ah = S.ah; r.al = S.al;
+    r.seg_first = S.seg_first; r.nseg = S.nseg; r.rst_interval = S.rst_interval; r.nbx = S.nbx; r.nby = S.nby;
+    return r;
+}
+
+// One restart interval of one scan, units [u0, u1), through reader `r`.  `writer`: this lane stores what the DC and AC-first kinds decode (the
+// wave form runs them in every lane; AC refinement is a wave's work in either form: `lane` = the zig-zag position this lane holds).
+template <class R>
+__device__ __forceinline__ uint32_t prog_interval(R& r, const bool writer, const uint32_t lane, const PScanR& sc, const JsImage& im, const JsProgFrame& fr,
+                                                  const JsProgTable* s_tab, const uint8_t* s_zz, int16_t* cbase, const uint32_t u0, const uint32_t u1)
+{
     uint32_t bad = 0;
     const int al = (int)sc.al;
-
     if (sc.ss == 0) {
         // ---- DC scans (G.1.2.1): interleaved or not; first (Ah = 0): DIFF, point transform; refinement: one bit per block
-        int pred[3] = { 0, 0, 0 };
+        int p0 = 0, p1 = 0, p2 = 0;
+        const PGeo g0 = geo_of(im, fr, sc.c0), g1 = geo_of(im, fr, sc.ncomp > 1 ? sc.c1 : sc.c0), g2 = geo_of(im, fr, sc.ncomp > 2 ? sc.c2 : sc.c0);
+        const uint32_t ncomp = sc.ncomp, nbx = sc.nbx, ah = sc.ah, dcpack = sc.dc0 | sc.dc1 << 8 | sc.dc2 << 16;       // (a select over dc0..dc2 comes back as an indexed load from a scratch copy of the scan)
         for (uint32_t u = u0; u < u1 && !bad; u++) {
-            for (uint32_t ci = 0; ci < sc.ncomp; ci++) {
-                const uint32_t comp = sc.comp[ci];
-                const uint32_t hs = sc.ncomp > 1 ? fr.hs[comp] : 1u, vs = sc.ncomp > 1 ? fr.vs[comp] : 1u;
+            for (uint32_t ci = 0; ci < ncomp; ci++) {
+                const PGeo& g = ci == 0 ? g0 : ci == 1 ? g1 : g2;                                                  // (selects, no indexed arrays)
+                const JsProgTable& Tdc = s_tab[(dcpack >> (8u * ci)) & 255u];
+                const uint32_t hs = ncomp > 1 ? g.hs : 1u, vs = ncomp > 1 ? g.vs : 1u;
                 for (uint32_t v = 0; v < vs; v++) for (uint32_t h = 0; h < hs; h++) {
-                    const uint32_t bx = sc.ncomp > 1 ? (u % im.mcu_xmax) * hs + h : u % sc.nbx;
-                    const uint32_t by = sc.ncomp > 1 ? (u / im.mcu_xmax) * vs + v : u / sc.nbx;
-                    int16_t* blk = cbase + block_row(im, fr, comp, bx, by) * 64;
-                    if (sc.ah == 0) {
-                        const int s = huff(r, s_tab[sc.dc_slot[ci]]);
+                    const uint32_t bx = ncomp > 1 ? (u % g.mcu_xmax) * hs + h : u % nbx;
+                    const uint32_t by = ncomp > 1 ? (u / g.mcu_xmax) * vs + v : u / nbx;
+                    int16_t* blk = cbase + block_row(g, bx, by) * 64;
+                    if (ah == 0) {
+                        const int s = huff(r, Tdc);
                         if (s < 0 || s > 15) { bad = 1; break; }
                         const int diff = s ? extend(r.bits(s), s) : 0;
-                        pred[ci] += diff;
-                        blk[0] = (int16_t)(pred[ci] * (1 << al));
-                    } else if (r.bit()) blk[0] = (int16_t)(blk[0] | (1 << al));
+                        const int pv = (ci == 0 ? p0 : ci == 1 ? p1 : p2) + diff;
+                        if (ci == 0) p0 = pv; else if (ci == 1) p1 = pv; else p2 = pv;
+                        if (writer) blk[0] = (int16_t)(pv * (1 << al));
+                    } else if (r.bit() && writer) atomicOr(reinterpret_cast<unsigned int*>(blk), 1u << al);      // (no value comes back: the decoder does not wait for the block)
                 }
+                if (bad) break;
             }
         }
     } else if (sc.ah == 0) {
         // ---- AC first scan (G.1.2.2): one component, band Ss..Se, end-of-band runs
-        const uint32_t comp = sc.comp[0]; const JsProgTable& T = s_tab[sc.ac_slot[0]];
+        const PGeo g = geo_of(im, fr, sc.c0); const JsProgTable& T = s_tab[sc.ac0];
+        const uint32_t nbx = sc.nbx;
         uint32_t eobrun = 0;
         for (uint32_t u = u0; u < u1 && !bad; u++) {
-            if (eobrun) { eobrun--; continue; }
-            int16_t* blk = cbase + block_row(im, fr, comp, u % sc.nbx, u / sc.nbx) * 64;
+            if (eobrun) { const uint32_t hop = min(eobrun, u1 - u); eobrun -= hop; u += hop - 1u; continue; }
+            int16_t* blk = cbase + block_row(g, u % nbx, u / nbx) * 64;
             for (uint32_t k = sc.ss; k <= sc.se; k++) {
                 const int rs = huff(r, T);
                 if (rs < 0) { bad = 1; break; }
@@ -151,7 +183,8 @@ __global__ void __launch_bounds__(64) k_prog_scan(const JsImage* __restrict__ im
                 if (s) {
                     k += run;
                     if (k > sc.se) { bad = 1; break; }
-                    blk[s_zz[k]] = (int16_t)(extend(r.bits((int)s), (int)s) * (1 << al));
+                    const int val = extend(r.bits((int)s), (int)s) * (1 << al);
+                    if (writer) blk[s_zz[k]] = (int16_t)val;
                 } else if (run == 15) k += 15;                                          // ZRL
                 else { eobrun = (1u << run) + r.bits((int)run) - 1; break; }             // EOBn: this block ends here, eobrun more follow
             }
@@ -162,19 +195,24 @@ __global__ void __launch_bounds__(64) k_prog_scan(const JsImage* __restrict__ im
         // identically in every lane.  A symbol (run, s) means "pass `run` coefficients with zero history; every non-zero one on
         // the way takes a correction bit; put the new value on the next zero one": the history is one 64-bit ballot, the target
         // position the (run+1)-th set bit of the zero mask (mbcnt + ballot), the correction bits of the whole stretch come out of
-        // the reader at once and each lane picks its own by the rank of its position.
-        const uint32_t lane = threadIdx.x & 63u;
-        const uint32_t comp = sc.comp[0]; const JsProgTable& T = s_tab[sc.ac_slot[0]];
+        // the reader at once and each lane picks its own by the rank of its position.  The blocks come in scan order whatever the
+        // symbols say, so the coefficients of the next two are fetched while this one is worked on.
+        const PGeo g = geo_of(im, fr, sc.c0); const JsProgTable& T = s_tab[sc.ac0];
+        const uint32_t nbx = sc.nbx;
         const int p1 = 1 << al, m1 = -(1 << al);
         const uint64_t below_ss = (1ull << sc.ss) - 1ull, upto_se = sc.se >= 63u ? ~0ull : ((1ull << (sc.se + 1u)) - 1ull);
         const uint64_t bandmask = upto_se & ~below_ss;
         const bool inband = lane >= sc.ss && lane <= sc.se;
         const uint32_t nat = s_zz[lane];
+        auto at = [&](uint32_t u) -> int16_t* { return cbase + block_row(g, u % nbx, u / nbx) * 64 + nat; };
+        auto fetch = [&](uint32_t u) -> int { return (inband && u < u1) ? (int)*at(u) : 0; };
         uint32_t eobrun = 0;
+        int v_1 = fetch(u0), v_2 = fetch(u0 + 1u);
         for (uint32_t u = u0; u < u1 && !bad; u++) {
-            int16_t* gblk = cbase + block_row(im, fr, comp, u % sc.nbx, u / sc.nbx) * 64;
-            int v = inband ? (int)gblk[nat] : 0;
+            int v = v_1; v_1 = v_2; v_2 = fetch(u + 2u);
             const uint64_t H = __ballot(v != 0) & bandmask;       // non-zero history (positions only grow inside a block: new values never re-enter)
+            if (eobrun && !H) { eobrun--; continue; }             // inside an end-of-band run and nothing to correct: the block stays as it is
+            const int v_in = v;
             // correction bits for the non-zero-history positions in [from, to): the first bit read belongs to the lowest position
             auto correct = [&](uint32_t from, uint32_t to) {
                 const uint64_t range = (to >= 64u ? ~0ull : ((1ull << to) - 1ull)) & ~((1ull << from) - 1ull);
@@ -210,11 +248,63 @@ __global__ void __launch_bounds__(64) k_prog_scan(const JsImage* __restrict__ im
                 }
             }
             if (eobrun) { correct(k, sc.se + 1u); eobrun--; }      // rest of the band: correction bits only
-            if (inband) gblk[nat] = (int16_t)v;                    // the band only: other scans own the rest of the block
+            if (inband && v != v_in) *at(u) = (int16_t)v;          // the band only: other scans own the rest of the block
         }
     }
-    if (bad) atomicOr(&status[0], 1u);                              // a code that matches nothing / illegal symbol
-    if (r.overrun()) atomicOr(&status[0], 2u);                      // the interval ended before its blocks did
+    return bad;
+}
+
+}  // namespace
+
+// One wave per restart interval of one scan (pg_lanes == 1: the whole wave decodes it, WReader) or 2 / 4 / 8 intervals per wave, a lane each
+// (mid-size batches: more decoders than SIMDs); one launch covers every scan of a dependency level of the batch.
+__global__ void __launch_bounds__(64) k_prog_scan(const JsImage* __restrict__ imgs, const JsProgFrame* __restrict__ frames, const JsProgScan* __restrict__ scans,
+                                                  const uint32_t* __restrict__ lvl_scans, const uint32_t* __restrict__ lvl_wg, uint32_t nsc, uint32_t pg_lanes,
+                                                  const JsProgTable* __restrict__ tabs, const JsProgSeg* __restrict__ segs, const uint8_t* __restrict__ raw,
+                                                  int16_t* __restrict__ coef, uint32_t* __restrict__ status_all)
+{
+    uint32_t lo = 0, hi = nsc;                                   // lvl_wg is an exclusive prefix, nsc + 1 entries
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (lvl_wg[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+    const PScanR sc = scan_regs(scans[lvl_scans[lo]]);          // wave-uniform
+    const uint32_t wg_in_scan = blockIdx.x - lvl_wg[lo];
+    const JsProgFrame& fr = frames[sc.img];
+    uint32_t* status = status_all + sc.img * 4u;
+    __shared__ JsProgTable s_tab[4];
+    __shared__ uint8_t s_zz[64];
+    __shared__ uint4 s_ring[128];
+    if (threadIdx.x < 64) s_zz[threadIdx.x] = c_zz_nat[threadIdx.x];
+    for (uint32_t t = 0; t < sc.ntabs; t++) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(tabs + (((t & 2u) ? (t & 1u ? sc.t3 : sc.t2) : (t & 1u ? sc.t1 : sc.t0)))); uint32_t* dst = reinterpret_cast<uint32_t*>(&s_tab[t]);
+        for (uint32_t i = threadIdx.x; i < sizeof(JsProgTable) / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const bool wave_coop = sc.ss != 0 && sc.ah != 0;             // AC refinement: the whole wave works on one interval's blocks
+    const uint32_t per = wave_coop ? 1u : pg_lanes;                // intervals this wave carries
+    const uint32_t lane = threadIdx.x & 63u;
+    const JsImage& im = imgs[sc.img];
+    int16_t* cbase = coef + im.coef_off * 64;
+    const uint32_t units = sc.ncomp > 1 ? im.mcu_xmax * im.mcu_ymax : sc.nbx * sc.nby;     // MCUs of the scan (A.2.2 / A.2.3)
+    const uint32_t ri = sc.rst_interval ? sc.rst_interval : units;
+    if (per == 1u) {
+        const uint32_t iv = wg_in_scan;
+        if (iv >= sc.nseg) return;
+        const JsProgSeg sg = segs[sc.seg_first + iv];
+        WReader r; r.init(s_ring, raw + im.file_off, sg.start, sg.end, im.file_len, lane);
+        const uint32_t u0 = iv * ri, u1 = min(units, u0 + ri);
+        const uint32_t bad = prog_interval(r, lane == 0u, lane, sc, im, fr, s_tab, s_zz, cbase, u0, u1);
+        if (lane == 0u) { if (bad) atomicOr(&status[0], 1u); if (r.overrun()) atomicOr(&status[0], 2u); }     // a code that matches nothing / the interval ended before its blocks did
+        return;
+    }
+    // Lanes that share a wave serialise each other's branches, so only `per` lanes of the wave carry a decoder.
+    if (threadIdx.x % (64u / per)) return;
+    const uint32_t iv = wg_in_scan * per + threadIdx.x / (64u / per);
+    if (iv >= sc.nseg) return;
+    const JsProgSeg sg = segs[sc.seg_first + iv];
+    PReader r; r.init(raw + im.file_off, sg.start, sg.end);      // file images are 16-byte aligned and zero padded in the raw arena
+    const uint32_t u0 = iv * ri, u1 = min(units, u0 + ri);
+    const uint32_t bad = prog_interval(r, true, lane, sc, im, fr, s_tab, s_zz, cbase, u0, u1);
+    if (bad) atomicOr(&status[0], 1u);
+    if (r.overrun()) atomicOr(&status[0], 2u);
 }
 
 // Quantised, point-transformed coefficients -> what the baseline path leaves behind: dequantised AC terms in place

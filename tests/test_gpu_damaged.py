@@ -313,3 +313,32 @@ def test_decode_end_in_the_first_block_behind_a_restart(harness, oracle, gpu):
         harness.drive(oracle, data)
         harness.drive(gpu, data)
         assert differs(oracle, gpu) is None, at
+
+
+def test_stray_restart_marker_shortly_behind_a_regular_one(harness, oracle, gpu):
+    """tools/fuzz_1080p_timing.py seed 23 case 974 (255 ms in the sequential mirror): an RSTn inserted 43 bytes behind a regular restart marker -- inside the
+    FIRST MCU of the interval, so that MCU has two resets of the DC predictors: the regular one on its boundary and the stray one in front of (or inside) a later
+    block.  The MCU's mark holds both (mark_reset's bit 6), the DC scan clears its sums twice, and the file stays on the device's fast path."""
+    import re
+    import jpegsnoop_amd as J
+    from fuzz_util import differs
+    base = harness.synth_jpeg(width=1920, height=1080, restart_interval=8, seed=63)
+    p = harness.parse_jpeg(base)
+    marks = [m.start() + p.scan_start for m in re.finditer(rb"\xff[\xd0-\xd7]", base[p.scan_start:p.scan_end])]
+    fast = 0
+    for which, off in ((len(marks) // 2, 43), (len(marks) // 3, 9), (5, 20), (len(marks) - 3, 31), (17, 64)):
+        at = marks[which] + 2 + off
+        d = bytearray(base); d[at:at] = b"\xff\xd0"
+        data = bytes(d)
+        b = J.JpegBatch(); b.add_jpeg(data); b.upload(); b.decode(); b.sync()
+        t = time.perf_counter(); b.decode(); b.sync(); ms = (time.perf_counter() - t) * 1e3
+        harness.drive(oracle, data)
+        inf = b.info(0)
+        assert np.array_equal(b.dib(0), oracle.dib()), (which, off, inf)
+        if not (inf["flags"] & 0x0100):
+            fast += 1
+            assert inf["path"] == 1 and ms < 20.0, (which, off, inf, ms)
+        b.close()
+        harness.drive(gpu, data)
+        assert differs(oracle, gpu) is None, (which, off)
+    assert fast >= 3, fast
