@@ -28,6 +28,7 @@ namespace {
 
 // MSB-first bit reader over one restart interval of a scan (file bytes, stuffing removed on the fly).
 struct PReader {
+    static constexpr bool UNIFORM = false;
     const uint8_t* base; uint32_t pos, end; uint64_t acc; int n; uint32_t over; uint64_t win; uint32_t win_at;
     __device__ void init(const uint8_t* file, uint32_t s, uint32_t e) { base = file; pos = s; end = e; acc = 0; n = 0; over = 0; win = 0; win_at = 0xFFFFFFFFu; }
     // file byte `i` through an 8-byte register window (one aligned 64-bit load per 8 bytes instead of a load per byte)
@@ -53,12 +54,19 @@ struct PReader {
     __device__ bool overrun() const { return over * 8 > (uint32_t)(n > 0 ? n : 0); }      // consumed bits that were never in the interval
 };
 
+// A value every lane of the wave holds alike, handed to the compiler as such: what is computed from it is scalar work (one issue slot of the
+// scalar unit instead of a four-cycle vector instruction -- a lone wave that decodes a chain of dependent symbols is bound by exactly that).
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint64_t uni(uint64_t x) { return (uint64_t)uni((uint32_t)x) | ((uint64_t)uni((uint32_t)(x >> 32)) << 32); }
+template <bool U> __device__ __forceinline__ uint32_t uni_if(uint32_t x) { return U ? uni(x) : x; }
+
 // The same reader for a WAVE that decodes ONE interval (a scan without restart markers is a single interval: a 1080p scan is one chain of
 // ~10^5 dependent symbols, and a lane that waits ~1 us for every eight file bytes and for every block it updates spends its time waiting).
 // All 64 lanes run the decoder identically (same data, same branches: wave-uniform control flow); the file bytes come through a 2 KiB ring
 // in LDS that the WAVE fills -- every lane fetches 16 bytes of a 1 KiB chunk, the chunk after the two in the ring is already in flight in
 // registers when the reader gets there -- so a byte costs an LDS read instead of a trip to memory.
 struct WReader {
+    static constexpr bool UNIFORM = true;
     const uint8_t* base; uint4* ring; uint32_t pos, end, limit, ring_c, lane; uint64_t acc; int n; uint32_t over; uint64_t win; uint32_t win_at; uint4 nxt;
     __device__ __forceinline__ uint4 chunk(uint32_t c) const { const uint32_t o = (c << 10) + lane * 16u; return o < limit ? *reinterpret_cast<const uint4*>(base + o) : make_uint4(0u, 0u, 0u, 0u); }
     __device__ __forceinline__ void init(uint4* lds, const uint8_t* file, uint32_t s, uint32_t e, uint32_t file_len, uint32_t lane_)
@@ -75,7 +83,7 @@ struct WReader {
             while ((a >> 10) >= ring_c + 2u) {                     // (wave-uniform; the workgroup IS the wave)
                 __syncthreads(); ring[(ring_c & 1u) * 64u + lane] = nxt; ring_c++; nxt = chunk(ring_c + 2u); __syncthreads();
             }
-            win = reinterpret_cast<const uint64_t*>(ring)[(a & 2047u) >> 3]; win_at = a;
+            win = uni(reinterpret_cast<const uint64_t*>(ring)[(a & 2047u) >> 3]); win_at = a;
         }
         return (uint32_t)(win >> ((i & 7u) * 8)) & 255u;
     }
@@ -99,11 +107,11 @@ struct WReader {
 template <class R> __device__ __forceinline__ int huff(R& r, const JsProgTable& t)
 {
     const uint32_t la = r.peek(16);
-    const uint32_t e = t.look[la >> 8];
+    const uint32_t e = uni_if<R::UNIFORM>(t.look[la >> 8]);
     if (e) { r.skip((int)(e >> 8)); return (int)(e & 255u); }
     for (int l = 9; l <= 16; l++) {
         const int32_t code = (int32_t)(la >> (16 - l));
-        if (code <= t.maxcode[l]) { r.skip(l); return t.sym[(code + t.valoff[l]) & 255]; }
+        if (code <= (int32_t)uni_if<R::UNIFORM>((uint32_t)t.maxcode[l])) { r.skip(l); return (int)uni_if<R::UNIFORM>(t.sym[(code + (int32_t)uni_if<R::UNIFORM>((uint32_t)t.valoff[l])) & 255]); }
     }
     r.skip(16);
     return -1;                                                   // no code matches
@@ -122,6 +130,23 @@ __device__ __forceinline__ size_t block_row(const JsImage& im, const JsProgFrame
 struct PGeo { uint32_t hs, vs, first, mcu_xmax, bpm; };
 __device__ __forceinline__ PGeo geo_of(const JsImage& im, const JsProgFrame& fr, uint32_t comp) { PGeo g; g.hs = fr.hs[comp]; g.vs = fr.vs[comp]; g.first = fr.first_blk[comp]; g.mcu_xmax = im.mcu_xmax; g.bpm = im.blk_per_mcu; return g; }
 __device__ __forceinline__ size_t block_row(const PGeo& g, uint32_t bx, uint32_t by) { return ((size_t)(by / g.vs) * g.mcu_xmax + bx / g.hs) * g.bpm + g.first + (by % g.vs) * g.hs + (bx % g.hs); }
+
+// Block u of a non-interleaved scan (the component's nbx x nby grid in scan order, A.2.3) and its row in the arena WITHOUT a division per block
+// (six of them -- ~200 vector instructions on a chip without an integer divider -- were most of what a block of a sparse scan cost): the block's
+// place in its MCU row is carried along, a jump over an end-of-band run re-seeks.
+struct PCursor {
+    uint32_t nbx, hs, vs, mcu_xmax, bpm, first, u, bx, rx, mx, ry, my;                      // bx = mx * hs + rx; the block row by = my * vs + ry
+    __device__ __forceinline__ void seek(uint32_t to) { u = to; bx = to % nbx; const uint32_t by = to / nbx; rx = bx % hs; mx = bx / hs; ry = by % vs; my = by / vs; }
+    __device__ __forceinline__ void init(const PGeo& g, uint32_t nbx_, uint32_t to) { nbx = nbx_; hs = g.hs; vs = g.vs; mcu_xmax = g.mcu_xmax; bpm = g.bpm; first = g.first; seek(to); }
+    __device__ __forceinline__ size_t row() const { return ((size_t)my * mcu_xmax + mx) * bpm + first + ry * hs + rx; }
+    __device__ __forceinline__ void step()
+    {
+        u++; bx++; rx++;
+        if (rx == hs) { rx = 0; mx++; }
+        if (bx == nbx) { bx = 0; rx = 0; mx = 0; ry++; if (ry == vs) { ry = 0; my++; } }
+    }
+    __device__ __forceinline__ void skip(uint32_t n) { if (n <= 3u) { for (; n; n--) step(); } else seek(u + n); }
+};
 
 // The scan's description without arrays: every field a register (an indexed array in a by-value copy sends the whole copy to scratch, and
 // then every `k <= se` of the symbol loop is a scratch load).
@@ -146,16 +171,16 @@ __device__ __forceinline__ uint32_t prog_interval(R& r, const bool writer, const
         // ---- DC scans (G.1.2.1): interleaved or not; first (Ah = 0): DIFF, point transform; refinement: one bit per block
         int p0 = 0, p1 = 0, p2 = 0;
         const PGeo g0 = geo_of(im, fr, sc.c0), g1 = geo_of(im, fr, sc.ncomp > 1 ? sc.c1 : sc.c0), g2 = geo_of(im, fr, sc.ncomp > 2 ? sc.c2 : sc.c0);
-        const uint32_t ncomp = sc.ncomp, nbx = sc.nbx, ah = sc.ah, dcpack = sc.dc0 | sc.dc1 << 8 | sc.dc2 << 16;       // (a select over dc0..dc2 comes back as an indexed load from a scratch copy of the scan)
+        PCursor cur; cur.init(g0, sc.nbx, sc.ncomp > 1 ? 0u : u0);
+        const uint32_t ncomp = sc.ncomp, ah = sc.ah, dcpack = sc.dc0 | sc.dc1 << 8 | sc.dc2 << 16;       // (a select over dc0..dc2 comes back as an indexed load from a scratch copy of the scan)
         for (uint32_t u = u0; u < u1 && !bad; u++) {
             for (uint32_t ci = 0; ci < ncomp; ci++) {
                 const PGeo& g = ci == 0 ? g0 : ci == 1 ? g1 : g2;                                                  // (selects, no indexed arrays)
                 const JsProgTable& Tdc = s_tab[(dcpack >> (8u * ci)) & 255u];
                 const uint32_t hs = ncomp > 1 ? g.hs : 1u, vs = ncomp > 1 ? g.vs : 1u;
                 for (uint32_t v = 0; v < vs; v++) for (uint32_t h = 0; h < hs; h++) {
-                    const uint32_t bx = ncomp > 1 ? (u % g.mcu_xmax) * hs + h : u % nbx;
-                    const uint32_t by = ncomp > 1 ? (u / g.mcu_xmax) * vs + v : u / nbx;
-                    int16_t* blk = cbase + block_row(g, bx, by) * 64;
+                    // interleaved (A.2.2): block (v, h) of the component in MCU u -- the arena's rows ARE in that order; else the component's own grid
+                    int16_t* blk = cbase + (ncomp > 1 ? (size_t)u * g.bpm + g.first + v * hs + h : cur.row()) * 64;
                     if (ah == 0) {
                         const int s = huff(r, Tdc);
                         if (s < 0 || s > 15) { bad = 1; break; }
@@ -167,15 +192,16 @@ __device__ __forceinline__ uint32_t prog_interval(R& r, const bool writer, const
                 }
                 if (bad) break;
             }
+            if (ncomp == 1) cur.step();
         }
     } else if (sc.ah == 0) {
         // ---- AC first scan (G.1.2.2): one component, band Ss..Se, end-of-band runs
         const PGeo g = geo_of(im, fr, sc.c0); const JsProgTable& T = s_tab[sc.ac0];
-        const uint32_t nbx = sc.nbx;
+        PCursor cur; cur.init(g, sc.nbx, u0);
         uint32_t eobrun = 0;
-        for (uint32_t u = u0; u < u1 && !bad; u++) {
-            if (eobrun) { const uint32_t hop = min(eobrun, u1 - u); eobrun -= hop; u += hop - 1u; continue; }
-            int16_t* blk = cbase + block_row(g, u % nbx, u / nbx) * 64;
+        for (uint32_t u = u0; u < u1 && !bad; u++, cur.step()) {
+            if (eobrun) { const uint32_t hop = min(eobrun, u1 - u); eobrun -= hop; u += hop - 1u; cur.skip(hop - 1u); continue; }
+            int16_t* blk = cbase + cur.row() * 64;
             for (uint32_t k = sc.ss; k <= sc.se; k++) {
                 const int rs = huff(r, T);
                 if (rs < 0) { bad = 1; break; }
@@ -184,7 +210,7 @@ __device__ __forceinline__ uint32_t prog_interval(R& r, const bool writer, const
                     k += run;
                     if (k > sc.se) { bad = 1; break; }
                     const int val = extend(r.bits((int)s), (int)s) * (1 << al);
-                    if (writer) blk[s_zz[k]] = (int16_t)val;
+                    if (writer) blk[uni_if<R::UNIFORM>(s_zz[k])] = (int16_t)val;
                 } else if (run == 15) k += 15;                                          // ZRL
                 else { eobrun = (1u << run) + r.bits((int)run) - 1; break; }             // EOBn: this block ends here, eobrun more follow
             }
@@ -198,18 +224,18 @@ __device__ __forceinline__ uint32_t prog_interval(R& r, const bool writer, const
         // the reader at once and each lane picks its own by the rank of its position.  The blocks come in scan order whatever the
         // symbols say, so the coefficients of the next two are fetched while this one is worked on.
         const PGeo g = geo_of(im, fr, sc.c0); const JsProgTable& T = s_tab[sc.ac0];
-        const uint32_t nbx = sc.nbx;
         const int p1 = 1 << al, m1 = -(1 << al);
         const uint64_t below_ss = (1ull << sc.ss) - 1ull, upto_se = sc.se >= 63u ? ~0ull : ((1ull << (sc.se + 1u)) - 1ull);
         const uint64_t bandmask = upto_se & ~below_ss;
         const bool inband = lane >= sc.ss && lane <= sc.se;
         const uint32_t nat = s_zz[lane];
-        auto at = [&](uint32_t u) -> int16_t* { return cbase + block_row(g, u % nbx, u / nbx) * 64 + nat; };
-        auto fetch = [&](uint32_t u) -> int { return (inband && u < u1) ? (int)*at(u) : 0; };
+        PCursor cur, ahead; cur.init(g, sc.nbx, u0); ahead.init(g, sc.nbx, u0);            // ahead: the block whose coefficients are fetched next
+        auto fetch = [&]() -> int { const int x = (inband && ahead.u < u1) ? (int)cbase[ahead.row() * 64 + nat] : 0; ahead.step(); return x; };
         uint32_t eobrun = 0;
-        int v_1 = fetch(u0), v_2 = fetch(u0 + 1u);
+        int v_1 = fetch(), v_2 = fetch();
         for (uint32_t u = u0; u < u1 && !bad; u++) {
-            int v = v_1; v_1 = v_2; v_2 = fetch(u + 2u);
+            int v = v_1; v_1 = v_2; v_2 = fetch();
+            int16_t* const mine = cbase + cur.row() * 64 + nat; cur.step();
             const uint64_t H = __ballot(v != 0) & bandmask;       // non-zero history (positions only grow inside a block: new values never re-enter)
             if (eobrun && !H) { eobrun--; continue; }             // inside an end-of-band run and nothing to correct: the block stays as it is
             const int v_in = v;
@@ -248,7 +274,7 @@ __device__ __forceinline__ uint32_t prog_interval(R& r, const bool writer, const
                 }
             }
             if (eobrun) { correct(k, sc.se + 1u); eobrun--; }      // rest of the band: correction bits only
-            if (inband && v != v_in) *at(u) = (int16_t)v;          // the band only: other scans own the rest of the block
+            if (inband && v != v_in) *mine = (int16_t)v;            // the band only: other scans own the rest of the block
         }
     }
     return bad;

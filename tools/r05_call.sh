@@ -1,7 +1,20 @@
-mkdir -p gpurun_out/r05_k
-timeout 600 python -m pytest tests/test_gpu_damaged.py tests/test_gpu_parity.py tests/test_gpu_batch_results.py -m gpu -q --maxfail=10 > gpurun_out/r05_k/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r05_k/pytest.log; tail -8 gpurun_out/r05_k/pytest.log
-timeout 400 python tools/fuzz_1080p_timing.py 1000 23 > gpurun_out/r05_k/fuzz_1080p_timing_s23.log 2>&1; head -5 gpurun_out/r05_k/fuzz_1080p_timing_s23.log
-JSNOOP_SUB_WL=5 timeout 250 python tools/fuzz_gpu.py 2500 9105 > gpurun_out/r05_k/fuzz_gpu_wl5.log 2>&1; tail -3 gpurun_out/r05_k/fuzz_gpu_wl5.log
-JSNOOP_SUB_WL=7 timeout 250 python tools/fuzz_gpu.py 2500 9107 > gpurun_out/r05_k/fuzz_gpu_wl7.log 2>&1; tail -3 gpurun_out/r05_k/fuzz_gpu_wl7.log
-timeout 250 python tools/fuzz_gpu.py 2500 9100 > gpurun_out/r05_k/fuzz_gpu.log 2>&1; tail -3 gpurun_out/r05_k/fuzz_gpu.log
-timeout 200 python tools/fuzz_batch.py 32 > gpurun_out/r05_k/fuzz_batch.log 2>&1; tail -2 gpurun_out/r05_k/fuzz_batch.log
+mkdir -p gpurun_out/r05_m
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r05_m/prof -o nodri -- python $GRAFT_REPO_ROOT/tools/prog_nodri_trace.py > $GRAFT_REPO_ROOT/gpurun_out/r05_m/run.txt 2>&1
+cd $GRAFT_REPO_ROOT
+tail -5 gpurun_out/r05_m/run.txt
+find gpurun_out/r05_m/prof -name "*kernel_trace.csv" | head -2
+python - <<'PY'
+import csv, glob
+f = glob.glob("gpurun_out/r05_m/prof/**/*kernel_trace.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+t0 = int(rows[0]["Start_Timestamp"])
+out = open("gpurun_out/r05_m/launches.txt", "w")
+for r in rows:
+    line = "%10.3f ms  +%9.3f ms  %s  grid %s" % ((int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, r["Kernel_Name"][:40], r.get("Grid_Size_X", r.get("Grid_Size", "")))
+    out.write(line + "\n")
+out.close()
+print(open("gpurun_out/r05_m/launches.txt").read()[-4000:])
+PY
+rm -rf gpurun_out/r05_m/prof
