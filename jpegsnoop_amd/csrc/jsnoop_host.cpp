@@ -456,7 +456,7 @@ int JsnoopBatch::upload()
         { const uint32_t nck = std::max(1u, (uint32_t)(((im.scan_start & 15) + (uint64_t)im.scan_len + JS_US_CHUNK - 1) / JS_US_CHUNK));   // (at least one chunk: its last chunk leaves the image's totals)
           usb[i] = usc; usc += nck; usb[n + 1 + i] = us4; us4 += (nck + 3) / 4; }
         syb[i] = syw; syw += (im.n_subseq + JS_SY_THREADS - 1) / JS_SY_THREADS;
-        syb[n + 1 + i] = snw; snw += (im.n_subseq + JS_SY_THREADS - 2) / (JS_SY_THREADS - 1);   // sync pass: one thread per workgroup walks a halo
+        syb[n + 1 + i] = snw; snw += (im.n_subseq + JS_SY_THREADS - JS_SY_HALO - 1) / (JS_SY_THREADS - JS_SY_HALO);   // sync pass: two threads per workgroup walk a halo
         max_mcu_h = std::max(max_mcu_h, im.mcu_h); max_mcu_w = std::max(max_mcu_w, im.mcu_w);
         wg[i] = wgs; wgs += std::max(1u, (nmcu + 8 * mcus_per_wave - 1) / (8 * mcus_per_wave));     // 8 waves per workgroup, one MCU per wave at a time
     }

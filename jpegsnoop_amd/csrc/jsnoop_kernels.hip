@@ -1458,6 +1458,8 @@ void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, 
 #define US_THREADS 256
 #define US_CHUNK   (US_THREADS * 16)
 #define SY_THREADS 256
+#define SY_HALO    2                   // k_sync: lanes of a workgroup that walk the sub-sequences in front of its first one
+static_assert(SY_THREADS == JS_SY_THREADS && SY_HALO == JS_SY_HALO, "the host deals the sub-sequences to the workgroups with these");
 // sub-sequence length is a per-batch choice: WL = log2(32-bit words per sub-sequence) = 4 (64 B, a handful of images), 5 (128 B) or 7 (512 B, large batches);
 // 6 and 8 are instantiated for experiments (JSNOOP_SUB_WL)
 #define SUB_BITS   (32u << WL)
@@ -2178,15 +2180,17 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
     const uint32_t* sd = side + im.side_off;
     const uint32_t total_bits = sd[10] * 8, nseg = min(sd[11], im.seg_cap - 1);
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    // Threads 1..255 own one sub-sequence each; thread 0 walks the one BEFORE the workgroup's first, speculatively and only in
-    // the first iteration of the first launch: its exit state is where the first owned sub-sequence really starts in all but a
-    // few % of the cases, so the later launches (which carry the true states across workgroup boundaries) find next to nothing to do.
-    const uint32_t own0 = (bx - sy_base[img]) * (SY_THREADS - 1);
+    // Threads 2..255 own one sub-sequence each; threads 1 and 0 walk the TWO before the workgroup's first, in the first launch only: thread 0 the tail of its
+    // sub-sequence in the first iteration, thread 1 the tail of its own and then -- like every owned lane -- the whole of it from thread 0's exit state.  A
+    // guess that comes out of a whole sub-sequence walked from a guess fails when the tail walk AND 4 Kbit of re-synchronisation fail: the later launches
+    // (which carry the true states across workgroup boundaries) find nothing to do.  (One halo lane that walked a tail only was wrong in a few % of the 20 000
+    // workgroups of a large batch: every second launch had workgroups that re-loaded their tables and walked again, 0.25 ms of a 0.3 ms launch.)
+    const uint32_t own0 = (bx - sy_base[img]) * (SY_THREADS - SY_HALO);
     if (own0 * SUB_BITS >= total_bits && own0) return;          // whole workgroup lies past the end of the data
     const uint32_t i_last = total_bits ? (total_bits - 1u) / SUB_BITS : 0u;     // the last sub-sequence that holds data
     const size_t g0 = im.subseq_off + own0;                      // slot of the first owned sub-sequence
-    const bool halo = t == 0;
-    const uint32_t i = own0 + t - 1u;                            // this thread's sub-sequence (thread 0 of the first workgroup: none)
+    const bool halo = t < SY_HALO;
+    const uint32_t i = own0 + t - SY_HALO;                       // this thread's sub-sequence (the halo threads of the first workgroup: none)
     const bool valid = halo ? own0 != 0 : i < im.n_subseq;
     // Later launches only carry exit states across workgroup boundaries: if the state entering this workgroup is the
     // one its first sub-sequence was last walked from, the whole workgroup is already at its fixed point.
@@ -2202,7 +2206,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
         // Verification mode (after the candidate chain, k_cand_*): the arrays hold a chain that is a fixed point except at the
         // sub-sequences marked with an entry state nothing equals -- every thread checks its own link.
         bool open = false;
-        if (valid && !halo) { const size_t gq = g0 + t - 1; const uint32_t lp = i ? A.out_p[gq - 1] : 0u, ls = i ? A.out_s[gq - 1] : 0u; open = lp != A.in_p[gq] || ls != A.in_s[gq]; }
+        if (valid && !halo) { const size_t gq = g0 + t - SY_HALO; const uint32_t lp = i ? A.out_p[gq - 1] : 0u, ls = i ? A.out_s[gq - 1] : 0u; open = lp != A.in_p[gq] || ls != A.in_s[gq]; }
         if (!__syncthreads_or(open ? 1 : 0)) return;
     }
     SubTabs T; load_subtabs<true>(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, t, SY_THREADS);
@@ -2210,7 +2214,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
     const uint32_t a_ctab = lds_addr(s_ctab);                    // (visible after the barrier below)
     const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);
     const uint32_t* st = seg_tab + im.seg_off;
-    const size_t gs = g0 + t - 1;                                // this thread's slot (not for the halo thread of the first workgroup)
+    const size_t gs = g0 + t - SY_HALO;                          // this thread's slot (not for the halo threads of the first workgroup)
     const bool spec_pass = first_pass == 1;
     if (spec_pass || !valid) { s_inp[t] = 0xFFFFFFFEu; s_ins[t] = 0; s_outp[t] = valid ? 0u : P_END; s_outs[t] = 0; s_nblk[t] = 0; }
     else if (halo) { s_inp[t] = 0xFFFFFFFEu; s_ins[t] = 0; s_outp[t] = A.out_p[gs]; s_outs[t] = A.out_s[gs]; s_nblk[t] = 0; }   // the true state left of the workgroup
@@ -2220,7 +2224,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
         // ---- phase A: which sub-sequences see a new entry state?  (reads last iteration's exit states only)
         uint32_t ip = 0, is = 0;
         bool active;
-        if (!valid || (halo && !(spec_pass && it == 0))) active = false;
+        if (!valid || (halo && !(spec_pass && (it == 0 || t == SY_HALO - 1)))) active = false;
         else {
             if (spec_pass && it == 0 && i != 0) {
                 // Speculative start.  This first walk only has to hand an exit state to the right neighbour (every lane walks
@@ -2235,7 +2239,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
                 // a sub-sequence behind the last one that holds data owns no symbol: the state passes through, so it takes the exit state of
                 // that last one directly (handed on one sub-sequence per round, a scan that ends on the last bit of a byte -- one image in
                 // eight -- kept its last workgroup busy for up to 63 rounds more)
-                const uint32_t tl = (i > i_last + 1u && i_last >= own0) ? i_last - own0 + 1u : t - 1u;
+                const uint32_t tl = (i > i_last + 1u && i_last >= own0) ? i_last - own0 + SY_HALO : t - 1u;
                 ip = s_outp[tl]; is = s_outs[tl];
             }
             active = ip != s_inp[t] || is != s_ins[t];
@@ -2255,7 +2259,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
         __syncthreads();
         // ---- phase B: the first `nact` threads each walk one of them (whole waves drop out as the chain converges)
         if (t < nact) {
-            const uint32_t u = s_act[t], iu = own0 + u - 1u;
+            const uint32_t u = s_act[t], iu = own0 + u - SY_HALO;
             uint32_t p = s_inp[u], s = s_ins[u], nblk = 0;
             const uint32_t own_end = min((iu + 1) * SUB_BITS, total_bits);
             if (!(p != P_END && p >= own_end))                   // else: owns no symbol, the state passes through

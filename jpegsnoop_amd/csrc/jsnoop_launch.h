@@ -28,6 +28,7 @@ void js_launch_unstuff(hipStream_t st, int wl, const JsImage* imgs, const uint32
 void js_launch_sync(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
                     const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub, int first_pass);
 #define JS_SY_THREADS 256
+#define JS_SY_HALO    2            // lanes of a k_sync workgroup that walk in front of its first sub-sequence
 // Candidate synchronisation (the small-job form of the synchronisation stage: k_cand_spec / _walk / _chain / _fill / _apply); leaves the
 // sub-sequence arrays as js_launch_sync would, open links marked for a js_launch_sync(..., first_pass = 2) behind it.
 #define JS_CAND_MAX_BLK 6            /* images with more blocks per MCU than this synchronise the classic way */
