@@ -1438,22 +1438,26 @@ void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, 
 // =====================================================================================
 //  Parallel entropy path.
 //
-//  (1) k_unstuff_count / k_unstuff_scan / k_unstuff_write : apply the reference's byte rules
-//      (BuffAddByte :1386-1573) once, in parallel: drop the 00 after FF, cut the stream at every
+//  (1) k_unstuff_fused (large jobs) / k_unstuff_write<true> (small jobs) : apply the reference's byte
+//      rules (BuffAddByte :1386-1573) once, in parallel and in ONE pass (a chunk's place in its image from a
+//      decoupled look-back over the chunks before it): drop the 00 after FF, cut the stream at every
 //      RSTn into restart intervals (interval table = start byte of each interval in the
 //      compacted stream).  After this the bit cursor can be advanced with plain word loads.
-//  (2) k_sync : every thread owns one 1024-bit sub-sequence.  It first decodes speculatively
-//      from its own first bit, then repeatedly re-decodes from its left neighbour's exit state
+//      (k_unstuff_count / _scan / _write<false> / k_interleave: the multi-pass form, kept as a cross-check.)
+//  (2) k_sync : every thread owns one sub-sequence (64 bytes ... 1 KiB).  It first decodes speculatively
+//      over its tail, then repeatedly re-decodes from its left neighbour's exit state
 //      until the exit states stop changing (Huffman codes self-synchronise after a few
-//      symbols).  A fixed point of the chain is exactly the sequential decode.
+//      symbols).  A fixed point of the chain is exactly the sequential decode.  (Small jobs: k_cand_*.)
 //  (3) k_block_scan : exclusive prefix sum of "blocks completed per sub-sequence" = the
 //      absolute block index at which every sub-sequence starts writing.
-//  (4) k_write : final decode from the synchronised entry states; dequantise + de-zigzag
+//  (4) k_write2 : final decode from the synchronised entry states; dequantise + de-zigzag
 //      (DecodeIdctSet :2270-2303) straight into the coefficient arena; verifies the chain.
 //  (5) k_dc_scan : int16 wrapping prefix sum of the DC differences per component, reset at
 //      every interval boundary actually present in the stream (:3280, :2693-2703, :1660).
 //  Anything that deviates from a well-formed scan raises a JSNOOP_FLAG_* bit for the image;
-//  flagged images are re-decoded by k_entropy_exact so malformed streams stay reference-exact.
+//  what the walks followed the reference's way stays (bad codes, restarts off an MCU boundary, a decode that ends
+//  at an over-read: js_parallel_fixup), the rest is re-decoded by k_entropy_exact from the first anomaly on, so
+//  malformed streams stay reference-exact.
 // =====================================================================================
 #define US_THREADS 256
 #define US_CHUNK   (US_THREADS * 16)
