@@ -298,7 +298,9 @@ static int js_prog_upload(JsnoopBatch* b)
     // block (AC refinement) or leaves them idle.  64 = lanes; 1 / 8 = intervals per wave of the wave-per-interval kernel.
     // (a lane-per-interval wave is a latency chain of its own: below ~64 x 1080p files with a marker per MCU row the chip is not full of
     //  them and the wave-per-interval kernel is as fast; 128 files: 20 against 12 Gpixel/s, 1024 files: 35 against 13)
-    g->pg_lanes = (nsc && total_iv / nsc >= 16 && total_iv >= 98304) ? 64u : (total_iv > 32768 ? 8u : 1u);
+    // Round 5 (the wave form reads through LDS and runs scalar: tools/prog_batch.py with JSNOOP_PG_LANES, N x config 5, ms per batch at 1 / 4 / 8 / 64:
+    //  N = 4: 2.29 / 2.23 / 2.27 / 9.0, 8: 3.21 / 2.92 / 2.99 / 9.0, 16: 4.88 / 4.36 / 4.39 / 9.2, 32: 8.25 / 7.21 / 7.04 / 9.4, 48: 11.6 / 10.0 / 9.83 / 9.69)
+    g->pg_lanes = (nsc && total_iv / nsc >= 16 && total_iv >= 88000) ? 64u : (total_iv > 40000 ? 8u : (total_iv > 7000 ? 4u : 1u));
     if (b->tune.pg_lanes) g->pg_lanes = (uint32_t)b->tune.pg_lanes;
     std::vector<uint32_t> ls, lw; g->lvl_first.clear(); g->lvl_count.clear(); g->lvl_wgs.clear();
     for (int lv = 0; lv < g->nlev; lv++) {
