@@ -614,67 +614,32 @@ __device__ __forceinline__ float idct_run(const IdctPrep& P, const WaveList L, u
 // runs on its zero padding), and the row address is a vector add (v_add_u32_dpp with the row word of term k broadcast in its half) in
 // place of the scalar M0 write -- which also retires the v_readlane per two terms.
 // Lists, per half: 64 coefficients as fp32, 64 row words (natural index * 256) as dwords; slots as in the one-block form.
-struct PairList { uint32_t a_half, z0, a_ey, a_rw, l8, row0; };
+struct PairList { uint32_t a_half, z0, a_rw, l8, row0; };
 #define PAIR_LIST_BYTES (2 * 512)
 __device__ __forceinline__ PairList pair_list(const void* mem, uint32_t lane)
 {
     PairList L; const uint32_t l = lane & 31u;
-    L.a_half = lds_addr(mem) + (lane >> 5) * 512u; L.z0 = 63u - 2u * l; L.a_ey = L.a_half + (lane & 15u) * 4u; L.a_rw = L.a_half + 256u + (lane & 15u) * 4u;
+    L.a_half = lds_addr(mem) + (lane >> 5) * 512u; L.z0 = 63u - 2u * l; L.a_rw = L.a_half + 256u + (lane & 15u) * 4u;
     L.l8 = l * 8u; L.row0 = (2u * l) << 8;
     return L;
 }
-// (the table pairs live in FIXED registers v48..v63: inline asm cannot name the halves of a 64-bit operand, and the multiplies work on them)
-#define P_AD(K) "v_add_u32_dpp %[ad], %[rw], %[l8] row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
-#define P_S(x) #x
-#define P_XS(x) P_S(x)
-#define P_LO_RA0 48
-#define P_HI_RA0 49
-#define P_LO_RA1 50
-#define P_HI_RA1 51
-#define P_LO_RA2 52
-#define P_HI_RA2 53
-#define P_LO_RA3 54
-#define P_HI_RA3 55
-#define P_LO_RB0 56
-#define P_HI_RB0 57
-#define P_LO_RB1 58
-#define P_HI_RB1 59
-#define P_LO_RB2 60
-#define P_HI_RB2 61
-#define P_LO_RB3 62
-#define P_HI_RB3 63
-#define P_VLO(X) "v" P_XS(P_LO_##X)
-#define P_VHI(X) "v" P_XS(P_HI_##X)
-#define P_RD_(X) "ds_read_b64 v[" P_XS(P_LO_##X) ":" P_XS(P_HI_##X) "], %[ad]\n\t"
-#define P_MUL_(X, K) "v_mul_f32_dpp " P_VLO(X) ", %[ey], " P_VLO(X) DPP_BC(K) "v_mul_f32_dpp " P_VHI(X) ", %[ey], " P_VHI(X) DPP_BC(K)
-#define P_ADD_(X) "v_add_f32 %[acc0], %[acc0], " P_VLO(X) "\n\t" "v_add_f32 %[acc1], %[acc1], " P_VHI(X) "\n\t"
-// One step = term K of both lists: leave when the longer list has no term K (the scalar unit is nearly idle in this form: two scalar
-// instructions per step are free, a padded step is 17 vector cycles); the table pair of term K + 4 is fetched meanwhile (what is fetched
-// past the end of the lists is dropped behind the last step).
-#define P_EXIT(K) "s_cmp_le_u32 %[nl], " #K "\n\t" "s_cbranch_scc1 .Lpe%=\n\t"
-#define P_STEPF(X, Y, K, KN) P_EXIT(K) "s_waitcnt lgkmcnt(3)\n\t" P_MUL_(X, K) P_AD(KN) P_RD_(Y) P_ADD_(X)
-#define P_STEPL(X, K, CNT) P_EXIT(K) "s_waitcnt lgkmcnt(" #CNT ")\n\t" P_MUL_(X, K) P_ADD_(X)
-// sixteen terms of both blocks: row words and coefficients of the round in lanes 0..15 of every row of rw / ey (per half),
-// nl = terms left including this round's (> 0): the length of the longer list (the shorter one runs on its zero entries)
-#define PAIR_ROUND()                                                                                                             \
-    asm volatile(                                                                                                                \
-        P_AD(0) P_RD_(RA0) P_AD(1) P_RD_(RA1) P_AD(2) P_RD_(RA2) P_AD(3) P_RD_(RA3)                                              \
-        "s_waitcnt lgkmcnt(3)\n\t" P_MUL_(RA0, 0) P_AD(4) P_RD_(RB0) P_ADD_(RA0)                                                 \
-        P_STEPF(RA1, RB1, 1, 5) P_STEPF(RA2, RB2, 2, 6) P_STEPF(RA3, RB3, 3, 7)                                                  \
-        P_STEPF(RB0, RA0, 4, 8) P_STEPF(RB1, RA1, 5, 9) P_STEPF(RB2, RA2, 6, 10) P_STEPF(RB3, RA3, 7, 11)                        \
-        P_STEPF(RA0, RB0, 8, 12) P_STEPF(RA1, RB1, 9, 13) P_STEPF(RA2, RB2, 10, 14) P_STEPF(RA3, RB3, 11, 15)                    \
-        P_STEPL(RB0, 12, 3) P_STEPL(RB1, 13, 2) P_STEPL(RB2, 14, 1) P_STEPL(RB3, 15, 0)                                          \
-        ".Lpe%=:\n\t" "s_waitcnt lgkmcnt(0)"                                                                                     \
-        : [acc0] "+v"(acc0), [acc1] "+v"(acc1), [ad] "=&v"(ad),                                                                  \
-          "={v[48:49]}"(a0), "={v[50:51]}"(a1), "={v[52:53]}"(a2), "={v[54:55]}"(a3), "={v[56:57]}"(b0), "={v[58:59]}"(b1), "={v[60:61]}"(b2), "={v[62:63]}"(b3) \
-        : [rw] "v"(rw), [ey] "v"(ey), [l8] "v"(L.l8), [nl] "s"(nl) : "scc")
+// The rounds are generated text (tools/gen/gen_pair_round.py -> jsnoop_pair_round.h): sixteen steps, every step leaves when the longer list
+// has no such term (the scalar unit is nearly idle in this form: two scalar instructions per step are free); what is fetched past the end
+// of the lists is dropped behind the last step.  Round 6: the coefficient of a term no longer rides on the two multiplies as a DPP operand
+// (v_mul_f32_dpp issues in 4.2 cycles, v_mul_f32 in 2.2: profiles/r04_instr_rates.txt) -- the coefficients of two consecutive terms come as
+// ONE ds_read_b64 that every lane of a half aims at the same eight bytes of its list (a broadcast: one LDS cycle per half), three such pairs
+// in flight; a step is then 13 vector cycles (two multiplies, two adds, the DPP address add) and 1.5 LDS instructions where it was 17 and 1
+// (tools/probes/idct_bcast.hip, profiles/r06_term_loop.txt).  Registers: five table pairs v[54:63] (four reads in flight), three
+// coefficient pairs v[48:53] -- fixed, inline asm cannot name the halves of a 64-bit operand.
+#include "jsnoop_pair_round.h"
+#define PAIR_ROUND(R)                                                                                                            \
+    asm volatile(PAIR_ROUND_ASM_##R                                                                                              \
+        : [acc0] "+v"(acc0), [acc1] "+v"(acc1), [ad] "=&v"(ad), [rw] "=&v"(rw)                                                   \
+        : [ah] "v"(L.a_half), [arw] "v"(L.a_rw), [l8] "v"(L.l8), [nl] "s"(nl) : "scc", PAIR_ROUND_CLOBBERS)
 
 // d: the lane's two coefficients, c[2l] | c[2l+1] << 16 (DC and, in DC-only mode, everything already masked out).
 // Returns in acc0 / acc1 the sums (x 2, see idct_run) of the lane's samples 2l and 2l+1 of its block.
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
-// consumed(): called once the lists are written -- the caller's source of `d` is free from there on (the next MCU's prefetch lands in it)
-template <class F = NoHook>
-__device__ __forceinline__ void idct_pair(uint32_t d, const PairList L, uint32_t lane, float& acc0, float& acc1, F&& consumed = NoHook())
+__device__ __forceinline__ void idct_pair(uint32_t d, const PairList L, uint32_t lane, float& acc0, float& acc1)
 {
     acc0 = 0.0f; acc1 = 0.0f;
     const bool nz0 = (d & 0xFFFFu) != 0u, nz1 = (d >> 16) != 0u;
@@ -695,15 +660,13 @@ __device__ __forceinline__ void idct_pair(uint32_t d, const PairList L, uint32_t
         asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(cf1) : "v"(d));
         const uint32_t w0 = L.a_half + (s0 << 2), w1 = L.a_half + (s1 << 2);
         lds_w32(w0, cf0); lds_w32(w0 + 256u, L.row0); lds_w32(w1, cf1); lds_w32(w1 + 256u, L.row0 + 256u);      // (in this order the compiler pairs them: two ds_write2st64_b32)
-        consumed();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        typedef float f32x2_t __attribute__((ext_vector_type(2)));
-        f32x2_t a0, a1, a2, a3, b0, b1, b2, b3; uint32_t ad;
-        { const float ey = __uint_as_float(lds_r32(L.a_ey)); const uint32_t rw = lds_r32(L.a_rw), nl = n; PAIR_ROUND(); }
-        if (n > 16) { const float ey = __uint_as_float(lds_r32(L.a_ey + 64u)); const uint32_t rw = lds_r32(L.a_rw + 64u), nl = n - 16; PAIR_ROUND(); }
-        if (n > 32) { const float ey = __uint_as_float(lds_r32(L.a_ey + 128u)); const uint32_t rw = lds_r32(L.a_rw + 128u), nl = n - 32; PAIR_ROUND(); }
-        if (n > 48) { const float ey = __uint_as_float(lds_r32(L.a_ey + 192u)); const uint32_t rw = lds_r32(L.a_rw + 192u), nl = n - 48; PAIR_ROUND(); }
-    } else consumed();
+        uint32_t ad, rw;
+        { const uint32_t nl = n; PAIR_ROUND(0); }
+        if (n > 16) { const uint32_t nl = n - 16; PAIR_ROUND(1); }
+        if (n > 32) { const uint32_t nl = n - 32; PAIR_ROUND(2); }
+        if (n > 48) { const uint32_t nl = n - 48; PAIR_ROUND(3); }
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
@@ -987,16 +950,25 @@ __device__ __forceinline__ void back_end_pairs(const BackEndCtx& C, uint64_t& br
     const size_t coef_off = im.coef_off;
     uint32_t raw[np]; int dcl[np];
     // A lane fetches the dword that holds its two coefficients (an idle half re-reads block A: nothing is read past the arena) and the
-    // cumulative DC of its block.  Round 5: the NEXT MCU's row of pair p is fetched as soon as this MCU's pair p sits in its lists -- into
-    // the very register it came from -- and its DC word behind the pair's tile store: the loads fly under the terms of this and the later
-    // pairs and under the colour phase.  (Issued in front of the colour phase only, one MCU's 768 bytes per wave were in flight for a third
-    // of an iteration: too little for the memory system, profiles/r05_backend_parts.txt; 6.64 -> 6.57 ms, with the contiguous ranges 6.50.)
-    auto fetch = [&](uint32_t m) {
-        const uint32_t* p32 = reinterpret_cast<const uint32_t*>(C.cbase + (size_t)m * nb * 64);
-        const int16_t* d16 = C.dccum + coef_off + (size_t)m * nb;
-        #pragma unroll
-        for (uint32_t p = 0; p < np; p++) { raw[p] = p32[p * 64u + (live[p] ? lane : l)]; dcl[p] = (int)d16[2u * p + (live[p] ? hi : 0u)]; }
-    };
+    // cumulative DC of its block.  The NEXT MCU's row of pair p is fetched as soon as this MCU's pair p sits in its lists -- into the very
+    // register it came from -- and its DC word behind the pair's tile store: the loads fly under the terms of this and the later pairs and
+    // under the colour phase (round 5: issued in front of the colour phase only, one MCU's 768 bytes per wave were in flight for a third of an
+    // iteration, profiles/r05_backend_parts.txt).
+    // Round 6: the loads are issued and WAITED FOR by hand.  vmcnt counts in order, loads and stores alike, and the compiler's own waits were
+    // derived from the loop's entry path: `vmcnt(3)` in front of every tile store and `vmcnt(1)` on the back edge (the sign extension of the
+    // three DC words, hoisted there) -- each drained everything but the newest loads, i.e. the rows fetched one pair earlier and the previous
+    // MCU's DIB store had to land within a pair's time (s_memtime stamps: ~1000 of the ~10000 cycles of a wave's MCU in each of the three
+    // tile phases, profiles/r06_backend_stamps.txt).  Per iteration the wave issues R0 D0 R1 D1 .. (rows, DC words) and one DIB store, always
+    // in this order, so behind any load 2 * np younger operations have been issued when its value is needed: every use waits for
+    // vmcnt(2 * np) -- a load has a whole iteration to land, the store of the previous MCU as well.  (Operations of the compiler's own in
+    // between -- the plane stores -- only make that wait cover more.)  The loop's entry issues one more load in the store's place.  Nothing but these
+    // statements may touch raw[] / dcl[] while a load is in flight to them: the compiler does not know (check the ISA for copies after a change).
+    uint32_t voff[np], doff[np];
+    #pragma unroll
+    for (uint32_t p = 0; p < np; p++) { voff[p] = (live[p] ? lane : l) * 4u; doff[p] = (live[p] ? hi : 0u) * 2u; }
+    auto ld_row = [&](uint32_t p, const uint32_t* base /*wave-uniform*/) { asm volatile("global_load_dword %0, %1, %2" : "+v"(raw[p]) : "v"(voff[p]), "s"(base + p * 64u) : "memory"); };
+    auto ld_dc = [&](uint32_t p, const int16_t* base /*wave-uniform*/) { asm volatile("global_load_sshort %0, %1, %2" : "+v"(dcl[p]) : "v"(doff[p]), "s"(base + 2u * p) : "memory"); };
+#define BK_VM_WAIT(X) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(X) : "n"(2 * np))
     // A workgroup owns a CONTIGUOUS range of the image's MCUs and its waves step through it side by side (round 5; before: 8-MCU pieces a whole
     // grid stride apart): what a workgroup reads and writes over time is one sequential stream per MCU row.
     const uint32_t per = (nmcu + C.wgs_in_img - 1u) / C.wgs_in_img, m_begin = C.wg_in_img * per, m_end = min(m_begin + per, nmcu);
@@ -1004,7 +976,15 @@ __device__ __forceinline__ void back_end_pairs(const BackEndCtx& C, uint64_t& br
     uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(m_begin + C.wave));
     const uint32_t xmax = im.mcu_xmax, step_x = wstride % xmax, step_y = wstride / xmax;
     uint32_t mx = m % xmax, my = m / xmax;                       // MCU coordinates, stepped along with m (no division in the loop)
-    if (m < m_end) fetch(m);
+    #pragma unroll
+    for (uint32_t p = 0; p < np; p++) { raw[p] = 0; dcl[p] = 0; }
+    if (m < m_end) {
+        const uint32_t* p32 = reinterpret_cast<const uint32_t*>(C.cbase + (size_t)m * nb * 64);
+        const int16_t* d16 = C.dccum + coef_off + (size_t)m * nb;
+        #pragma unroll
+        for (uint32_t p = 0; p < np; p++) { ld_row(p, p32); ld_dc(p, d16); }
+        ld_dc(np - 1u, d16);                                     // (in the DIB store's place: the last DC word once more, into the register it is in flight to)
+    }
     #pragma nounroll
     for (; m < m_end; m += wstride, mx += step_x, my += step_y) {
         if (mx >= xmax) { mx -= xmax; my++; }
@@ -1014,16 +994,24 @@ __device__ __forceinline__ void back_end_pairs(const BackEndCtx& C, uint64_t& br
         #pragma unroll
         for (uint32_t p = 0; p < np; p++) {
             float acc0, acc1;
-            idct_pair(raw[p] & cmask[p], L, lane, acc0, acc1, [&]() { raw[p] = p32n[p * 64u + (live[p] ? lane : l)]; });
+            BK_VM_WAIT(raw[p]);
+            uint32_t d = raw[p] & cmask[p];
+            asm volatile("" : "+v"(d));                              // (the masked copy exists from here on: the row's register is free for the next MCU's row)
+            ld_row(p, p32n);
+            idct_pair(d, L, lane, acc0, acc1);
             // fp32 sums (x 2: the table holds 2 x the reference's entries) -> samples, to_sample on both; the int16 wrap of the sum is the low half
+            BK_VM_WAIT(dcl[p]);
             const uint32_t x0 = (uint32_t)((int)acc0 + dcl[p]), x1 = (uint32_t)((int)acc1 + dcl[p]);
             if (live[p]) *reinterpret_cast<uint32_t*>(tile + toff2[p]) = __builtin_amdgcn_perm(x1, x0, 0x05040100u);
-            dcl[p] = (int)d16n[2u * p + (live[p] ? hi : 0u)];
+            ld_dc(p, d16n);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         mcu_to_dib_fast<EH, EV>(im, img_x, img_y, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, C.dibp, C.planes, pw, want_planes, bright, best_y, sum_y);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    #pragma unroll
+    for (uint32_t p = 0; p < np; p++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[p]), "+v"(dcl[p]) :: "memory");   // (the last round's fetches land in registers that are free from here on)
+#undef BK_VM_WAIT
 }
 
 #ifndef JS_BK_OCC
