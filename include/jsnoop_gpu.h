@@ -196,6 +196,10 @@ int             jsnoop_color_sweep(JsnoopDecoder*, uint32_t* out_bgra);
  * path flags as malformed), 0 = nothing decoded */
 int             jsnoop_last_path(JsnoopDecoder*);
 uint32_t        jsnoop_last_flags(JsnoopDecoder*);                     /* JSNOOP_FLAG_* raised by the parallel path */
+/* who produced the side outputs (MCU file map, histogram, status words, messages: what GetPixMapPtrs / LookupFilePosMcu and the log of
+ * DecodeScanImg, ImgDecode.cpp:2723, show) of the last image: 0 = not asked for yet, 1 = the parallel side pass, 2 = the sequential
+ * exact-mirror reader, 3 = the parallel side pass plus exact readers on chunks of a few MCUs (flagged files, in milliseconds) */
+int             jsnoop_last_side_mode(JsnoopDecoder*);
 
 #define JSNOOP_FLAG_BAD_CODE      0x0001u  /* no Huffman code matches (alone: decoded the reference's way by the parallel path) */
 #define JSNOOP_FLAG_OVERRUN       0x0002u  /* code or extra bits run past the interval / scan end       */

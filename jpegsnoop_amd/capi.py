@@ -97,6 +97,7 @@ SIGNATURES = {
     "jsnoop_color_sweep": (C.c_int, [_p, _p]),
     "jsnoop_last_path": (_i, [_p]),
     "jsnoop_last_flags": (C.c_uint32, [_p]),
+    "jsnoop_last_side_mode": (_i, [_p]),
     "jsnoop_batch_create": (_p, [_p]),
     "jsnoop_batch_destroy": (None, [_p]),
     "jsnoop_batch_clear": (None, [_p]),

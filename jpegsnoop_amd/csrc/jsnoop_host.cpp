@@ -286,6 +286,7 @@ JsnoopBatch::~JsnoopBatch()
     delete helper; helper = nullptr;
     if (d_lut) hipFree(d_lut);
     if (d_side_tmp) hipFree(d_side_tmp);
+    if (d_chunk_tmp) hipFree(d_chunk_tmp);
     js_prog_free(this);
     if (pinned) hipHostFree(pinned);
     if (d2h_land) hipHostFree(d2h_land);
@@ -305,7 +306,7 @@ int JsnoopBatch::ensure_aux()
 }
 void JsnoopBatch::clear()
 {
-    imgs.clear(); hinfo.clear(); tables.clear(); raw_bytes = 0; uploaded = false; host_flags.clear(); side_done.clear(); side_mode.clear(); side_anoms.clear();
+    imgs.clear(); hinfo.clear(); tables.clear(); raw_bytes = 0; uploaded = false; host_flags.clear(); side_done.clear(); side_mode.clear(); side_anoms.clear(); side_chunk_ok.clear(); side_events.clear();
     js_prog_clear(this);
 }
 int JsnoopBatch::reserve_pinned(size_t need)
@@ -503,7 +504,7 @@ int JsnoopBatch::decode(bool timed)
     HIP_TRY(hipSetDevice(device));
     if (!uploaded && upload()) return -1;
     const uint32_t n = (uint32_t)imgs.size();
-    side_done.assign(n, 0); side_mode.assign(n, 0); side_anoms.assign(n, std::vector<uint32_t>());   // (nothing of an earlier decode's side pass survives)
+    side_done.assign(n, 0); side_mode.assign(n, 0); side_anoms.assign(n, std::vector<uint32_t>()); side_chunk_ok.assign(n, 0); side_events.assign(n, std::vector<uint32_t>());   // (nothing of an earlier decode's side pass survives)
     JsRange r_("jsnoop:decode (enqueue)");
     if (js_prog_count(this)) return decode_progressive(timed);     // SOF2 files: every scan of every image, one launch per dependency level
     if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
@@ -871,6 +872,12 @@ int jsnoop_color_sweep(JsnoopDecoder* d, uint32_t* out_bgra)
 }
 int jsnoop_last_path(JsnoopDecoder* d) { return d->last_path; }
 uint32_t jsnoop_last_flags(JsnoopDecoder* d) { return d->last_flags; }
+int jsnoop_last_side_mode(JsnoopDecoder* d)
+{
+    if (!d->have_image) return 0;
+    if (d->last_path == 2) return 2;
+    return (size_t)d->img < d->batch->side_mode.size() ? (int)d->batch->side_mode[d->img] : 0;
+}
 
 void jsnoop_set_preview_mode(JsnoopDecoder* d, unsigned mode) { d->preview_mode = mode; d->rerender(); }      // :633-639
 unsigned jsnoop_get_preview_mode(JsnoopDecoder* d) { return d->preview_mode; }

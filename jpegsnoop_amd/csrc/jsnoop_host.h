@@ -82,9 +82,12 @@ struct JsnoopBatch {
     std::vector<JsImage> imgs; std::vector<JsTableSet> tables;
     struct JsImgHost { uint32_t dht_setmax[2] = { 0, 0 }; unsigned err_max = 20; bool display = true; };   // what the per-image report needs beyond the descriptor
     std::vector<JsImgHost> hinfo;
-    std::vector<uint8_t> side_mode;                               // per image: who produced its side outputs last (1 = parallel side pass, 2 = the exact-mirror reader)
+    std::vector<uint8_t> side_mode;                               // per image: who produced its side outputs last (1 = parallel side pass, 2 = the exact-mirror reader, 3 = parallel side pass + chunked exact readers)
     std::vector<std::vector<uint32_t>> side_anoms;                // per image: the coefficient-index overflows of the side walk, in block order (4 words each)
     std::vector<uint8_t> side_done;                               // per image: the side-output pass has run since the last decode
+    std::vector<uint8_t> side_chunk_ok;                           // per image: a flagged image whose every MCU top the parallel walks vouch for (up to the end of the reference's own decode): its report comes from k_side_chunks
+    std::vector<std::vector<uint32_t>> side_events;               // per image: the messages of the chunked side pass in the reference's order (JS_EV_WORDS each, not yet gated by the warning counter)
+    uint32_t* d_chunk_tmp = nullptr; size_t chunk_tmp_cap = 0;    // scratch of the chunked side pass
     std::vector<uint32_t> host_anom;                              // per image: first block (decode order) the parallel path could not vouch for (0xFFFFFFFF: none)
     std::vector<uint8_t> host_anom_kind;                          // ... and what it was: 0 = the mirror takes over there, 1..8 = the reference's decode ends in that block (ANOM_KEY, jsnoop_kernels.hip)
     std::vector<uint32_t> host_flags, host_path, h_us_base, h_us4_base, h_sy_base, h_sn_base, h_wg_base;

@@ -2033,6 +2033,10 @@ __device__ __forceinline__ int walk_slow(const JsImage& im, const uint32_t* __re
         // MCU other than {on its boundary, further in} (mark_reset), or two markers back to back (the reference meets the second one inside its
         // retry and files the DC value under index 1): F_BAD_EDGE.
         if (WRITE) {
+            // An interval that is left before ONE bit of it was consumed -- a few bits that hold no code, e.g. FF FF kept as data between two markers: the
+            // reference entered it inside the retry of :1644-1680, and that retry's RSV_RST_TERM is not handled as a restart (the ASSERT of :1676): the
+            // symbol counts as a coefficient and the restart happens one read later -- like two markers back to back (below), the mirror's
+            if (seg > 0 && cur.p == st[seg] * 8 && blk < im.total_blocks) { flags |= F_RST_MISALIGN | F_BAD_EDGE; anom = min(anom, ANOM_KEY(blk, AK_MIRROR)); }
             if (k != 0 || c != 0 || remain >= 8) flags |= F_RST_MISALIGN;                       // well-formed: < 8 pad bits, on an MCU boundary
             if (mark && blk < im.total_blocks && !mark_reset(mcu_rst, blk / im.blk_per_mcu, c + 1u, k != 0u)) { flags |= F_BAD_EDGE; anom = min(anom, ANOM_KEY(blk, AK_MIRROR)); }
         }
@@ -2792,7 +2796,8 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
         bool norm = active, bad = false;                         // bad: a code that matches nothing ended the block (walk_slow)
         if (WBALLOT(len == 0 || cur.p + tot > seg_end || k2 > 64u) & amask) {
             if (active && (len == 0 || cur.p + len > seg_end)) {  // interval / stream end, or a code that matches nothing
-                const int ws = walk_slow<true, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, blk, !captured, rstf, fl, an);
+                // (the side pass repeats a walk whose restart marks are set -- and, for an image whose decode ends early, pruned behind that end, k_dead_fill: it sets none)
+                const int ws = walk_slow<true, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, blk, !SIDE && !captured, rstf, fl, an);
                 if (ws == WS_OVER) { if (!captured) { captured = true; res_p = P_END; res_s = 0; res_n = nblk; } active = false; }
                 bad = ws == WS_BAD_CODE;
                 comp = comp_of(T, c); wb = comp == 0 ? wb0 : (comp == 1 ? wb1 : wb2);
@@ -2974,7 +2979,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
     // k_unaligned_probe).  Consecutive by construction: a lane's block number goes up by one with every block it ends, it flushes every block it ends
     // except a first one it entered in the middle (skip) and blocks past the image's last -- after which it flushes none.
     uint32_t dcq0 = 0, dcq1 = 0, dcq2 = 0, dcq3 = 0, dccnt = 0, dclast = 0, dq0 = 0;
-    uint32_t rst_in_blk = 0;                                     // a restart was followed inside the block in progress (see ANOM_KEY)
+    uint32_t rst_blk = 0xFFFFFFFFu;                              // the block in progress when a restart was last followed (see ANOM_KEY): written on the slow path only
     auto dc_store_rest = [&]() {                                 // what is left at the end: the newest dccnt values sit in the top halves
         #pragma unroll
         for (uint32_t h = 0; h < 8; h++) {
@@ -3028,7 +3033,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
                 const bool notcap = !IBAL(m_cap);
                 const uint32_t seg_was = seg;
                 const int ws = walk_slow<true, WL>(im, words, st, nseg, cur, len, seg, seg_end, c, k, blk, notcap, rstf, fl, an);
-                rst_in_blk |= seg != seg_was ? 2u : 0u;
+                rst_blk = seg != seg_was ? blk : rst_blk;
                 if (ws == WS_OVER && notcap) { res_p = P_END; res_s = 0; res_n = nblk; }
                 over = ws == WS_OVER; bad = ws == WS_BAD_CODE;
                 comp = comp_of(T, c); wb = comp == 0 ? wb0 : (comp == 1 ? wb1 : wb2);
@@ -3038,7 +3043,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
                     // value bits past the end of the interval.  With an RSTn behind it the reference's register over-reads -- its decode of the image ENDS
                     // in this block (ANOM_KEY); at the end of the scan data it reads on through the marker bytes (F_SHORT / second attempt).  The walk
                     // itself goes on as the synchronisation walks did: what it writes from here on is replaced (js_parallel_fixup).
-                    if (p1 > seg_end) { fl |= F_OVERRUN; an = min(an, ANOM_KEY(blk, seg + 1u < nseg ? AK_DEAD + (IBAL(m_dc) ? 0u : 1u) + rst_in_blk + (IBAL(m_skip) ? 4u : 0u) : AK_MIRROR)); }
+                    if (p1 > seg_end) { fl |= F_OVERRUN; an = min(an, ANOM_KEY(blk, seg + 1u < nseg ? AK_DEAD + (IBAL(m_dc) ? 0u : 1u) + (rst_blk == blk ? 2u : 0u) + (IBAL(m_skip) ? 4u : 0u) : AK_MIRROR)); }
                     if (k2 > 64u) fl |= F_COEF_OVERFLOW;
                 }
             }
@@ -3082,7 +3087,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
             if (IBAL(m_done)) {
                 c = c + 1 == T.nb ? 0u : c + 1; comp = comp_of(T, c); wb = comp == 0 ? wb0 : (comp == 1 ? wb1 : wb2);
                 nblk += IBAL(m_cap) ? 0u : 1u;
-                blk++; rst_in_blk = 0;
+                blk++;
             }
             m_skip &= ~m_done;
             // ---- the whole wave moves every block that completed in this step: 16 lanes x 8 bytes per block, four blocks per store
@@ -3397,11 +3402,12 @@ __device__ uint32_t raw_of_compacted(const JsImage& im, const uint8_t* __restric
 __device__ __forceinline__ uint32_t mirror_to_mcu_top(const JsImage& im, const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ raw, const uint32_t* __restrict__ st,
                                       uint32_t nseg, uint32_t total_bytes, const uint8_t* __restrict__ mcu_rst, const uint32_t* __restrict__ mcu_pos,
                                       const uint32_t* __restrict__ us_out, uint32_t us_threads, uint32_t m_top, ExactReader& r, uint32_t* dummy_histo, int16_t* scratch,
-                                      uint32_t* events)
+                                      uint32_t* events, const ExactReader* lds_tabs = nullptr)
 {
     uint32_t* meta12 = dummy_histo + 2 * 4 * 17;                  // the caller's scratch has room for the 12 slot words behind the histogram
     r.file = raw + im.file_off; r.flen = im.file_len; r.ts = tables + im.tableset; r.histo = dummy_histo; r.fast = &r.ts->fast[0][0]; r.meta = meta12; r.q = &r.ts->qzz[0][0]; r.zz = c_zigzag; r.win_at = 0xFFFFFFFFu; r.win = 0;
     for (int i = 0; i < 6; i++) { meta12[i] = r.ts->size[i]; meta12[6 + i] = r.ts->dest_id[i]; }
+    if (lds_tabs) { r.fast = lds_tabs->fast; r.q = lds_tabs->q; r.zz = lds_tabs->zz; }                  // (copies of the same tables in LDS: k_side_chunks)
     // the markers the look-ahead runs into at the end of the scan (":  Scan Data encountered marker", :1536) are logged from here
     r.ev = (events && im.ev_cap) ? events + im.ev_off : nullptr; r.ev_cap = im.ev_cap; r.ev_only = JS_EV_MARKER;
     r.rst_interval = im.rst_interval; r.precision = im.precision; r.err_max = im.err_max; r.warn_bad = 0; r.warn_marker = 0;
@@ -3438,11 +3444,13 @@ __device__ __forceinline__ uint32_t mirror_to_mcu_top(const JsImage& im, const J
 __global__ void __launch_bounds__(256) k_side_maps(const JsImage* __restrict__ imgs, uint32_t img, const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ raw,
                                                    const uint32_t* __restrict__ seg_tab, const int16_t* __restrict__ dccum, const uint8_t* __restrict__ mcu_rst,
                                                    const uint32_t* __restrict__ mcu_pos, const uint32_t* __restrict__ us_out, uint32_t us_threads,
-                                                   uint32_t* __restrict__ side, uint32_t* __restrict__ events, uint32_t* __restrict__ anoms)
+                                                   uint32_t* __restrict__ side, uint32_t* __restrict__ events, uint32_t* __restrict__ anoms, uint32_t dead_blk)
 {
     const JsImage& im = imgs[img];
     uint32_t* sd = side + im.side_off;
     const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax, nblk = im.blk_xmax * im.blk_ymax, nseg = min(sd[11], im.seg_cap - 1);
+    // dead_blk: the block in which the reference's own decode ends (none: ~0) -- behind its MCU the row is not visited, and of every later row only the first MCU
+    const uint32_t mstar = dead_blk == 0xFFFFFFFFu ? 0xFFFFFFFFu : dead_blk / im.blk_per_mcu;
     const uint32_t* st = seg_tab + im.seg_off;
     uint32_t* mcu_map = sd + JS_SIDE_MCUMAP;
     int16_t* bdc0 = reinterpret_cast<int16_t*>(mcu_map + nmcu);
@@ -3488,16 +3496,130 @@ __global__ void __launch_bounds__(256) k_side_maps(const JsImage* __restrict__ i
             const uint32_t mx = (bx - ch) / eh, my = (by - cv) / ev;
             if (mx >= im.mcu_xmax || my >= im.mcu_ymax) continue;
             const int mi = (int)(my * im.mcu_xmax + mx);
+            if (mstar != 0xFFFFFFFFu && (uint32_t)mi > mstar && (mx != 0 || my == mstar / im.mcu_xmax)) continue;     // an MCU the reference never reaches writes nothing
             if (mi > best) { best = mi; best_blk = (uint32_t)mi * im.blk_per_mcu + c; }
         }
-        if (best >= 0) bdc0[(comp - 1) * stride + cell] = dc[best_blk];
+        // (a restart handled while block j of the MCU was in progress -- its mark, j + 1 > 1 -- clears the reference's per-MCU array of sums, :3524-3608 /
+        //  DecodeRestartDcState: the blocks of that MCU in front of j show 0 in the maps, whatever their sums were)
+        if (best >= 0) { const uint32_t mark = mcu_rst[im.mcu_off + (uint32_t)best] & 63u; bdc0[(comp - 1) * stride + cell] = (mark > 1u && best_blk % im.blk_per_mcu + 1u < mark) ? (int16_t)0 : dc[best_blk]; }
     }
 }
 
+// =====================================================================================
+//  Side outputs and messages of a DAMAGED image, in parallel (round 6).  The reference's log of such a file -- "Bad huffman code",
+//  "Can't find huffman bitstring", "Bad marker", "nNumCoeffs>64", "Bad scan data in MCU(..)", restart bookkeeping (:1167-1187, :1644-1757,
+//  :2605-2660) -- quotes the reader's position array and its register (ScanBuffConsume :921-955), which only the exact reader reproduces; run
+//  over a whole 1080p image on one lane that reader takes 1.2 s.  But the walks of the parallel path follow a damaged stream the reference's
+//  way, so the bit position of EVERY MCU top is known (side walk, mcu_pos) -- and at an MCU top the reader's state is a function of the
+//  bit position and of a few bytes of history (mirror_to_mcu_top).  The image is therefore cut into chunks of a few MCUs; one lane per
+//  chunk (a wave of its own: the reader is one long chain of branches) brings an exact reader to its chunk's first MCU top and runs the
+//  reference's MCU loop over the chunk in side-only mode: MCU file map, code-length histogram, the events with the exact positions.
+//  What a lane cannot know locally is put together on the host (js_side_only): the warning counter the messages share (every lane counts
+//  and gates from zero: the first nErrMaxDecodeScan counted events of the image are among the first nErrMaxDecodeScan of their lanes),
+//  scan_bad (cleared by every restart, set by the errors), the number of RSTn read, the restart countdown at the chunk's start (handed in).
+//  A decode that ENDS (value bits past an interval end: scan_end + scan_bad, :3623-3625) is followed by the lane that meets the end, alone,
+//  through the rest of the image -- one MCU per row; what later chunks' lanes produced is dropped by the host.
+//  Record of a chunk (u32): 0 died at MCU (~0: no), 1 bits (1: a restart was handled, 2: scan_bad, 4: scan_end), 2 pos0, 3 align, 4 RSTn read,
+//  5 num_pixels, 6 counted events, 8..143 histogram, 144 events logged, 145.. the events (JS_EV_WORDS each).
+// =====================================================================================
+#define SC_WAVES 4
+#define SC_HDR 145
+__global__ void __launch_bounds__(64 * SC_WAVES) k_side_chunks(const JsImage* __restrict__ imgs, uint32_t img, const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ raw,
+                                                             const uint32_t* __restrict__ seg_tab, const uint8_t* __restrict__ mcu_rst, const uint32_t* __restrict__ mcu_pos,
+                                                             const uint32_t* __restrict__ us_out, uint32_t us_threads, const uint32_t* __restrict__ side,
+                                                             uint32_t ch_mcus, uint32_t nchunks, uint32_t ev_cap, const uint32_t* __restrict__ mcus_left0,
+                                                             uint32_t* __restrict__ recs, uint32_t* __restrict__ map_own, unsigned long long* __restrict__ map_beyond)
+{
+    __shared__ uint32_t s_fast[6 * (1 << JS_FAST_BITS)]; __shared__ uint16_t s_q[3 * 64]; __shared__ uint8_t s_zz[64];
+    __shared__ uint32_t s_h[SC_WAVES][2 * 4 * 17 + 12]; __shared__ int16_t s_scr[SC_WAVES][64];
+    const JsImage& im = imgs[img];
+    const JsTableSet& tset = tables[im.tableset];
+    {
+        const uint32_t* src = &tset.fast[0][0];
+        for (uint32_t i = threadIdx.x; i < 6 * (1u << JS_FAST_BITS); i += blockDim.x) s_fast[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < 3 * 64; i += blockDim.x) s_q[i] = (&tset.qzz[0][0])[i];
+        if (threadIdx.x < 64) s_zz[threadIdx.x] = c_zigzag[threadIdx.x];
+    }
+    __syncthreads();
+    const uint32_t wv = threadIdx.x >> 6, chunk = blockIdx.x * SC_WAVES + wv;
+    if ((threadIdx.x & 63u) != 0u || chunk >= nchunks) return;
+    const uint32_t* sd = side + im.side_off;
+    const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax, nseg = min(sd[11], im.seg_cap - 1), xmax = im.mcu_xmax;
+    const uint32_t* st = seg_tab + im.seg_off;
+    const uint32_t m_a = chunk * ch_mcus, m_b = min(m_a + ch_mcus, nmcu);
+    uint32_t* rec = recs + (size_t)chunk * (SC_HDR + (size_t)ev_cap * JS_EV_WORDS);
+    uint32_t* histo = s_h[wv];
+    ExactReader tabs; tabs.fast = s_fast; tabs.q = s_q; tabs.zz = s_zz;
+    ExactReader r;
+    rec[SC_HDR - 1] = 0;
+    if (m_a == 0) {
+        // the first chunk starts like the reference itself (its first refill may already meet markers: logged)
+        uint32_t* meta12 = histo + 2 * 4 * 17;
+        r.file = raw + im.file_off; r.flen = im.file_len; r.ts = &tset; r.fast = s_fast; r.meta = meta12; r.q = s_q; r.zz = s_zz; r.win_at = 0xFFFFFFFFu; r.win = 0;
+        for (int i = 0; i < 6; i++) { meta12[i] = tset.size[i]; meta12[6 + i] = tset.dest_id[i]; }
+        r.rst_interval = im.rst_interval; r.precision = im.precision;
+        r.rst_count = 0; r.rst_last = 0; r.rst_expect = 0; r.rst_handled = 0;
+        for (uint32_t i = 0; i < 2 * 4 * 17; i++) histo[i] = 0;
+        r.histo = histo; r.err_max = im.err_max; r.warn_bad = 0; r.warn_marker = 0; r.ev = rec + SC_HDR - 1; r.ev_cap = ev_cap; r.ev_only = 0;
+        ex_restart_scan_buf(r, im.scan_start, false);
+        ex_topup(r);
+    } else {
+        const uint32_t before = mirror_to_mcu_top(im, tables, raw, st, nseg, sd[10], mcu_rst, mcu_pos, us_out, us_threads, m_a, r, histo, s_scr[wv], nullptr, &tabs);
+        // what the walk to the chunk's first MCU top cannot have established: the number the next RSTn is expected to carry, when it met none itself --
+        // one more than the last marker in front of where it started
+        if (r.rst_count == 0 && before > 0 && before < nseg) {
+            const uint32_t rp = raw_of_compacted(im, raw, us_out, us_threads, st[before]);
+            const uint32_t b1 = rp >= 1u ? ex_byte(r, rp - 1u) : 0u;
+            if (b1 >= 0xD0u && b1 <= 0xD7u) { r.rst_last = b1 - 0xD0u; r.rst_expect = (r.rst_last + 1u) & 7u; }
+        }
+        for (uint32_t i = 0; i < 2 * 4 * 17; i++) histo[i] = 0;
+        r.err_max = im.err_max; r.warn_bad = 0; r.warn_marker = 0; r.ev = rec + SC_HDR - 1; r.ev_cap = ev_cap; r.ev_only = 0;
+        r.scan_bad = 0; r.cur_err = 0;
+    }
+    r.mcus_left = mcus_left0[chunk];
+    const uint32_t rst_count0 = r.rst_count, rst_handled0 = r.rst_handled;
+    uint32_t num_pixels = 0, died_at = 0xFFFFFFFFu;
+    int16_t dc_y = 0, dc_cb = 0, dc_cr = 0;
+    auto one_mcu = [&](uint32_t mi) {                             // the body of DecodeScanImg's MCU loop (:3164-3625), side outputs only
+        if (im.rst_en && r.mcus_left == 0 && !r.restart_read) ex_event(r, JS_EV_RST_NOT_DETECTED, r.pos0, r.align);   // :3180-3200
+        // PackFileOffset :5104.  Behind its own chunk (a lane that met the end of the decode) the entry is kept per MCU for the EARLIEST chunk that got
+        // there: every later lane meets "its" end too -- in a state the reference never had -- and only the first one's is the reference's
+        const uint32_t pk = (r.pos0 << 4) + r.align;
+        if (mi < m_b) map_own[mi] = pk; else atomicMin(&map_beyond[mi], ((unsigned long long)chunk << 32) | pk);
+        const uint32_t mx = mi % xmax, my = mi / xmax;
+        for (uint32_t c = 0; c < im.blk_per_mcu; c++) {
+            const uint32_t comp = im.blk_comp[c];
+            ex_decode_block(r, comp, im.decode_ac, s_scr[wv], dc_y, dc_cb, dc_cr);
+            if (r.cur_err) {                                      // CheckScanErrors :2605
+                if (r.warn_bad < r.err_max) { ex_event(r, JS_EV_BAD_SCAN_MCU, mx | (my << 16), comp | (im.blk_ch[c] << 8) | (im.blk_cv[c] << 16), r.pos0, r.align); r.warn_bad++; }
+                r.cur_err = 0; }
+            if (comp == 1) num_pixels += 64;
+        }
+        if (im.rst_en) r.mcus_left--;
+    };
+    for (uint32_t mi = m_a; mi < m_b; mi++) {
+        one_mcu(mi);
+        if (r.scan_end && r.scan_bad) { died_at = mi; break; }     // :3623-3625: the row stops here ...
+    }
+    if (died_at != 0xFFFFFFFFu)                                   // ... and of every later row the first MCU is all that is reached
+        for (uint32_t my = died_at / xmax + 1; my < im.mcu_ymax; my++) one_mcu(my * xmax);
+    rec[0] = died_at;
+    rec[1] = (r.rst_handled != rst_handled0 ? 1u : 0u) | (r.scan_bad ? 2u : 0u) | (r.scan_end ? 4u : 0u);
+    rec[2] = r.pos0; rec[3] = r.align; rec[4] = r.rst_count - rst_count0; rec[5] = num_pixels; rec[6] = r.warn_bad; rec[7] = r.warn_marker;
+    for (uint32_t i = 0; i < 2 * 4 * 17; i++) rec[8 + i] = histo[i];
+}
+void js_launch_side_chunks(hipStream_t st, const JsImage* imgs, uint32_t img, const JsTableSet* tables, const uint8_t* raw, const uint32_t* seg_tab, const uint8_t* mcu_rst,
+                           const uint32_t* mcu_pos, const uint32_t* us_out, uint32_t us_threads, const uint32_t* side, uint32_t ch_mcus, uint32_t nchunks, uint32_t ev_cap,
+                           const uint32_t* mcus_left0, uint32_t* recs, uint32_t* map_own, unsigned long long* map_beyond)
+{
+    if (!nchunks) return;
+    hipLaunchKernelGGL(k_side_chunks, dim3((nchunks + SC_WAVES - 1) / SC_WAVES), dim3(64 * SC_WAVES), 0, st, imgs, img, tables, raw, seg_tab, mcu_rst, mcu_pos, us_out, us_threads, side,
+                       ch_mcus, nchunks, ev_cap, mcus_left0, recs, map_own, map_beyond);
+}
 void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* us_base, const uint32_t* sy_base, uint32_t nimg,
                          uint32_t img, uint32_t us_wg0, uint32_t us_wgs, uint32_t sy_wg0, uint32_t sy_wgs, const JsTableSet* tables, const uint8_t* raw,
                          const uint32_t* chunk_keep, const uint32_t* chunk_rst, const uint8_t* ustr, uint32_t* seg_tab, uint32_t* side, uint32_t* sub, uint64_t nsub,
-                         const int16_t* dccum, uint8_t* mcu_rst, uint32_t* mcu_pos, uint32_t* us_out, uint32_t* events, uint32_t* anoms)
+                         const int16_t* dccum, uint8_t* mcu_rst, uint32_t* mcu_pos, uint32_t* us_out, uint32_t* events, uint32_t* anoms, uint32_t dead_blk)
 {
     if (!us_wgs || !sy_wgs) return;
     hipLaunchKernelGGL(k_unstuff_write<false>, dim3(us_wgs), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, const_cast<uint32_t*>(chunk_keep), const_cast<uint32_t*>(chunk_rst), (uint8_t*)nullptr, seg_tab, us_wg0, us_out,
@@ -3512,7 +3634,7 @@ void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab
                        sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, anoms, tab_rows, tab_lut2, sy_wg0, mcu_pos);
     else hipLaunchKernelGGL((k_write<5, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, anoms, tab_rows, tab_lut2, sy_wg0, mcu_pos);
-    hipLaunchKernelGGL(k_side_maps, dim3(64), dim3(256), 0, st, imgs, img, tables, raw, seg_tab, dccum, mcu_rst, mcu_pos, us_out, us_wgs * US_THREADS, side, events, anoms);
+    hipLaunchKernelGGL(k_side_maps, dim3(64), dim3(256), 0, st, imgs, img, tables, raw, seg_tab, dccum, mcu_rst, mcu_pos, us_out, us_wgs * US_THREADS, side, events, anoms, dead_blk);
 }
 // Tail take-over for image `img` of a decoded batch (see ExactTail): the inverse byte map and the MCU bit positions through the first two
 // kernels of the side pass, then the mirror reader from the MCU that holds the first block the parallel path could not vouch for.

@@ -524,6 +524,15 @@ int js_parallel_fixup(JsnoopBatch* b)
         patched = true;
     }
     (void)patched;
+    // Flagged images whose every MCU top the walks vouch for -- the flags are bookkeeping (JS_FLAGS_PIXEL_EXACT), or the reference's own decode ends at a
+    // block the walks recorded (dead) -- get their report from the chunked side pass (js_side_only); a tail take-over, a second attempt or a whole mirror
+    // decode replaced blocks the side walk knows nothing of: the mirror's side-only pass stays theirs.
+    b->side_chunk_ok.assign(n, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        if (!b->host_flags[i] || b->host_path[i] != 1 || (b->host_flags[i] & (JSNOOP_FLAG_TABLES | JSNOOP_FLAG_NOSYNC | JSNOOP_FLAG_FORCED | JSNOOP_FLAG_MARKER))) continue;
+        if (std::find(tails.begin(), tails.end(), i) != tails.end() || std::find(bad.begin(), bad.end(), i) != bad.end()) continue;
+        b->side_chunk_ok[i] = dead[i] ? 2 : (!(b->host_flags[i] & ~JS_FLAGS_PIXEL_EXACT) ? 1 : 0);      // (2: host_anom[i] is the block the reference's decode ends in)
+    }
     // whole images through the mirror (entropy), then the pixels of everything that changed since the batch's back end ran
     if (b->run_exact(bad)) return -1;
     for (uint32_t i : bad) redo.push_back(i);
@@ -548,6 +557,71 @@ static int js_side_scratch(JsnoopBatch* b, uint32_t i, uint32_t** mcu_pos, uint3
         b->side_tmp_cap = need + need / 8;
     }
     *mcu_pos = b->d_side_tmp; *us_out = *mcu_pos + ((nmcu + 1 + 15) & ~(size_t)15);
+    return 0;
+}
+// The chunked side pass of a flagged image (k_side_chunks): 0 = done (side block complete, b->side_events[i] holds the messages), 1 = not
+// representable (a chunk logged more events than its record holds): the caller falls back to the mirror's side-only pass, -1 = error.
+static int js_side_chunked(JsnoopBatch* b, uint32_t i)
+{
+    const JsImage& im = b->imgs[i];
+    const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax;
+    const uint32_t us0 = b->h_us_base[i], usn = b->h_us_base[i + 1] - us0, sy0 = b->h_sy_base[i], syn = b->h_sy_base[i + 1] - sy0;
+    if (!usn || !syn || !nmcu) return 1;
+    uint32_t *mcu_pos = nullptr, *us_out = nullptr;
+    if (js_side_scratch(b, i, &mcu_pos, &us_out)) return -1;
+    HIP_TRY(hipMemsetAsync(mcu_pos, 0, ((size_t)nmcu + 1) * 4, b->stream));
+    if (b->event_words) HIP_TRY(hipMemsetAsync(b->dev.events + im.ev_off, 0, 4, b->stream));
+    js_launch_side_pass(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.us_base, b->dev.sy_base, (uint32_t)b->imgs.size(), i, us0, usn, sy0, syn,
+                        b->dev.tables, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst, b->dev.ustr, b->dev.seg, b->dev.side, (uint32_t*)b->dev.sub, b->total_subseq,
+                        b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out, nullptr, nullptr, b->side_chunk_ok[i] == 2 ? b->host_anom[i] : 0xFFFFFFFFu);
+    // chunks of at least 8 MCUs, at most 4096 of them; a lane keeps the first err_max counted events and some more of the uncounted kinds
+    const uint32_t ch = std::max<uint32_t>(8u, (nmcu + 4095u) / 4096u), nchunks = (nmcu + ch - 1) / ch;
+    const uint32_t ev_cap = std::min<uint32_t>(im.err_max, 64u) + 64u, stride = JS_SC_HDR + ev_cap * JS_EV_WORDS;
+    const size_t words = (((size_t)nchunks * stride + nmcu + 1) & ~(size_t)1) + 2 * (size_t)nmcu + nchunks + 64;
+    if (words * 4 > b->chunk_tmp_cap) {
+        if (b->d_chunk_tmp) hipFree(b->d_chunk_tmp);
+        b->d_chunk_tmp = nullptr; b->chunk_tmp_cap = 0;
+        HIP_TRY(hipMalloc((void**)&b->d_chunk_tmp, words * 4 + words / 2));
+        b->chunk_tmp_cap = words * 4 + words / 2;
+    }
+    uint32_t* recs = b->d_chunk_tmp; uint32_t* map_own = recs + (size_t)nchunks * stride;
+    const size_t bey_at = ((size_t)nchunks * stride + nmcu + 1) & ~(size_t)1;                      // (64-bit entries: chunk << 32 | packed offset, the smallest chunk wins)
+    unsigned long long* map_beyond = reinterpret_cast<unsigned long long*>(recs + bey_at); uint32_t* left0 = recs + bey_at + 2 * (size_t)nmcu;
+    // the restart countdown at every chunk's first MCU top (m_nRestartMcusLeft: re-armed by every restart HANDLED, :4071, one down per MCU :3618):
+    // the marks of the walks say in which MCU a restart was handled -- one on the chunk's own first MCU is handled inside it, behind its top
+    std::vector<uint8_t> rf(nmcu);
+    if (b->d2h_staged(rf.data(), b->dev.mcu_rst + im.mcu_off, nmcu)) return -1;
+    std::vector<uint32_t> left(nchunks);
+    { uint32_t cur = im.rst_interval; for (uint32_t m = 0; m < nmcu; m++) { if (m % ch == 0) left[m / ch] = cur; if (rf[m]) cur = im.rst_interval; if (im.rst_en) cur--; } }
+    HIP_TRY(hipMemcpyAsync(left0, left.data(), (size_t)nchunks * 4, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemsetAsync(map_own, 0, (size_t)nmcu * 4, b->stream));
+    HIP_TRY(hipMemsetAsync(map_beyond, 0xFF, (size_t)nmcu * 8, b->stream));
+    js_launch_side_chunks(b->stream, b->dev.imgs, i, b->dev.tables, b->dev.raw, b->dev.seg, b->dev.mcu_rst, mcu_pos, us_out, usn * 256u, b->dev.side, ch, nchunks, ev_cap, left0, recs, map_own, map_beyond);
+    std::vector<uint32_t> h(bey_at + 2 * (size_t)nmcu);
+    if (b->d2h_staged(h.data(), recs, h.size() * 4)) return -1;
+    HIP_TRY(hipGetLastError());
+    uint32_t last = nchunks - 1; bool died = false;
+    for (uint32_t c = 0; c < nchunks; c++) if (h[(size_t)c * stride] != 0xFFFFFFFFu) { last = c; died = true; break; }
+    std::vector<uint32_t>& ev = b->side_events[i]; ev.clear();
+    uint32_t sw[16] = { 0 }, histo[2 * 4 * 17] = { 0 }, scan_bad = 0, rst = 0, pix = 0; uint64_t warn = 0;
+    for (uint32_t c = 0; c <= last; c++) {
+        const uint32_t* r = &h[(size_t)c * stride];
+        if (r[JS_SC_HDR - 1] > ev_cap) return 1;
+        ev.insert(ev.end(), r + JS_SC_HDR, r + JS_SC_HDR + (size_t)r[JS_SC_HDR - 1] * JS_EV_WORDS);
+        scan_bad = (r[1] & 1u) ? ((r[1] >> 1) & 1u) : (scan_bad | ((r[1] >> 1) & 1u));       // DecodeRestartScanBuf clears it (:4038-4075), the errors set it
+        rst += r[4]; pix += r[5]; warn += r[6];
+        for (uint32_t q = 0; q < 2 * 4 * 17; q++) histo[q] += r[8 + q];
+    }
+    const uint32_t* rl = &h[(size_t)last * stride];
+    sw[0] = scan_bad; sw[1] = (rl[1] >> 2) & 1u; sw[2] = rst; sw[3] = pix; sw[4] = rl[2]; sw[5] = rl[3]; sw[6] = (uint32_t)std::min<uint64_t>(warn, im.err_max); sw[7] = im.scan_start;
+    std::vector<uint32_t> map(nmcu);
+    const uint32_t* own = &h[(size_t)nchunks * stride]; const uint32_t* bey = &h[bey_at];            // (little-endian pairs: [2m] = packed offset, [2m + 1] = chunk)
+    for (uint32_t m = 0; m < nmcu; m++) map[m] = (m / ch <= last || !died) ? own[m] : (bey[2 * m + 1] == last ? bey[2 * m] : 0u);
+    uint32_t* sd = b->dev.side + im.side_off;
+    HIP_TRY(hipMemcpyAsync(sd, sw, 8 * 4, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(sd + JS_SIDE_HISTO, histo, sizeof histo, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(sd + JS_SIDE_MCUMAP, map.data(), (size_t)nmcu * 4, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));                     // (the host arrays above are the copies' sources)
     return 0;
 }
 int js_side_only(JsnoopBatch* b, uint32_t i)
@@ -616,7 +690,16 @@ int js_side_only(JsnoopBatch* b, uint32_t i)
             } else parallel = false;
         }
     }
+    if (b->side_events.size() != b->imgs.size()) b->side_events.assign(b->imgs.size(), std::vector<uint32_t>());
+    b->side_events[i].clear();
+    bool chunked = false;
+    if (!parallel && i < b->side_chunk_ok.size() && b->side_chunk_ok[i] && !(b->tune.cross_checks & JSNOOP_XC_SIDE_EXACT)) {
+        const int rc = js_side_chunked(b, i);
+        if (rc < 0) return -1;
+        chunked = rc == 0;
+    }
     if (parallel) b->side_mode[i] = 1;
+    else if (chunked) b->side_mode[i] = 3;
     else {
         b->side_mode[i] = 2;
         HIP_TRY(hipMemsetAsync(b->dev.side + im.side_off, 0, 8 * 4, b->stream));

@@ -64,6 +64,20 @@ void js_emit_decode_events(JsnoopDecoder* d)
     if (!d->have_image || !b->event_words) return;
     const JsImage& im = b->imgs[d->img];
     hipSetDevice(b->device);
+    // a flagged image of the parallel path whose report came from the chunked side pass: the messages are on the host already, in the
+    // reference's order, each lane's gated by its own count -- the shared counter is applied here
+    if (d->last_path == 1 && (size_t)d->img < b->side_mode.size() && b->side_mode[d->img] == 3) {
+        const std::vector<uint32_t>& sv = b->side_events[d->img];
+        unsigned cnt = 0;
+        for (size_t k = 0; k + JS_EV_WORDS <= sv.size(); k += JS_EV_WORDS) {
+            Ev e; e.kind = sv[k]; for (int q = 0; q < 5; q++) e.a[q] = sv[k + 1 + q]; e.order = k;
+            const bool counted = e.kind == JS_EV_OVERREAD_BEFORE || e.kind == JS_EV_CANT_FIND || e.kind == JS_EV_MARKER || e.kind == JS_EV_BAD_MARKER ||
+                                 e.kind == JS_EV_BAD_HUFF || e.kind == JS_EV_NUMCOEF || e.kind == JS_EV_BAD_SCAN_MCU;
+            if (counted && cnt >= d->opt_err_max) continue;
+            emit_event(d, im, e, cnt);
+        }
+        return;
+    }
     std::vector<uint32_t> raw(1 + (size_t)JS_EV_WORDS * JS_EV_MAX);
     if (b->d2h_staged(raw.data(), b->dev.events + im.ev_off, raw.size() * 4)) {   /* page-locked landing buffer: no pageable asynchronous copies */ d->log(2, "*** ERROR: reading the decoder's event log back from the device failed ***"); return; }
     std::vector<Ev> evs;

@@ -138,6 +138,7 @@ class CimgDecode:
     def SetPreviewYccOffset(self, nMcuX, nMcuY, nY, nCb, nCr): self._lib.jsnoop_set_preview_ycc_offset(self._h, nMcuX, nMcuY, nY, nCb, nCr)
     def LastPath(self): return self._lib.jsnoop_last_path(self._h)
     def LastFlags(self): return self._lib.jsnoop_last_flags(self._h)
+    def LastSideMode(self): return self._lib.jsnoop_last_side_mode(self._h)
 
 
 class JpegBatch:

@@ -342,3 +342,71 @@ def test_stray_restart_marker_shortly_behind_a_regular_one(harness, oracle, gpu)
         harness.drive(gpu, data)
         assert differs(oracle, gpu) is None, (which, off)
     assert fast >= 3, fast
+
+
+def test_filler_bytes_between_two_restart_markers(harness, oracle, gpu):
+    """tools/fuzz_gpu.py seed 11 case 1038 (round 6; wrong pixels in rounds 1-5): RSTn, FF FF, RSTm -- an interval of two filler bytes kept as data
+    (BuffAddByte :1486-1561) that holds no code.  The reference enters it inside the retry of DecodeScanComp's restart handling (:1644-1680), the retry
+    comes back with RSV_RST_TERM as well, which is NOT handled there (the ASSERT of :1676 is all there is): the read counts as a coefficient and the
+    second restart happens one read later.  An interval left before a bit of it was consumed is the mirror's (BAD_EDGE), like two markers back to back."""
+    import re
+    from fuzz_util import differs
+    base = harness.synth_jpeg(width=144, height=96, hs=2, vs=1, restart_interval=3, seed=71)
+    p = harness.parse_jpeg(base)
+    marks = [m.start() + p.scan_start for m in re.finditer(rb"\xff[\xd0-\xd7]", base[p.scan_start:p.scan_end])]
+    for which in (len(marks) - 1, len(marks) // 2, 3):
+        at = marks[which] + 2
+        d = bytearray(base); d[at:at] = bytes([0xFF, 0xFF, 0xFF, 0xD0 + ((base[marks[which] + 1] - 0xD0 + 1) & 7)])
+        data = bytes(d)
+        harness.drive(oracle, data)
+        harness.drive(gpu, data)
+        assert gpu.lib.jsnoop_last_flags(gpu.h) & 0x0100, "an interval without a code must be left to the mirror"
+        assert differs(oracle, gpu) is None, which
+
+
+def test_report_of_a_damaged_file_comes_from_chunked_exact_readers(harness, oracle, gpu):
+    """Round 6: log text and side outputs of a flagged file -- what a CjfifDecode asks DecodeScanImg for (source/JfifDecode.cpp:5299) -- no longer wait for the
+    sequential mirror over the whole image (1.2 s per 1080p file, against ~140 ms of the CPU reference).  The walks vouch for the bit position of every MCU top
+    of a stream they followed the reference's way (bad codes :1178-1186, restarts inside a block :1644-1680, coefficient overflows :1723-1735, the end of
+    the reference's own decode :3623-3625); k_side_chunks puts one exact reader on every chunk of eight MCUs and the host merges what they logged.  Compared
+    with the compiled reference's log line for line where its library travelled, with the oracle's side outputs and status words always."""
+    from fuzz_util import differs
+    ref = harness.ref_backend() if harness.have_ref() else None
+    base = harness.synth_jpeg(width=1920, height=1080, seed=31)
+    base_rst = harness.synth_jpeg(width=1920, height=1080, restart_interval=120, seed=82)
+    p = harness.parse_jpeg(base)
+    def at(frac, b=base):
+        q = harness.parse_jpeg(b); return q.scan_start + int((q.scan_end - q.scan_start) * frac)
+    cases = []
+    d = bytearray(base); d[at(0.3):at(0.3) + 4] = b"\xff\x00\xff\x00"; cases.append(("ones16", bytes(d)))
+    d = bytearray(base); i = at(0.3); d[i:i + 256] = np.random.RandomState(5).randint(0, 255, 256).astype(np.uint8).tobytes(); cases.append(("garbage", bytes(d)))
+    d = bytearray(base); d[at(0.6)] ^= 0x10; cases.append(("bitflip", bytes(d)))
+    d = bytearray(base_rst); j = bytes(d).index(b"\xff\xd1", harness.parse_jpeg(base_rst).scan_start); del d[j - 2:j]; cases.append(("rst_in_block", bytes(d)))
+    d = bytearray(base_rst); i = at(0.45, base_rst); del d[i:i + 3]; cases.append(("deleted_bytes_rst", bytes(d)))
+    modes = {}
+    try:
+        for name, data in cases:
+            for em in (20, 2):
+                for b in (oracle, gpu) + ((ref,) if ref else ()):
+                    b.set_options(decode_ac=1, err_max=em)
+                harness.drive(gpu, data, quiet=0)                  # (first call: allocations)
+                t = time.perf_counter(); harness.drive(gpu, data, quiet=0); ms = (time.perf_counter() - t) * 1e3
+                got = gpu.log_lines()
+                fl, sm = gpu.lib.jsnoop_last_flags(gpu.h), gpu.lib.jsnoop_last_side_mode(gpu.h)
+                if fl == 0:                                        # (lost bytes may leave a stream that still parses: nothing to report)
+                    continue
+                modes[name] = sm
+                harness.drive(oracle, data)
+                assert differs(oracle, gpu) is None, (name, em)
+                if ref is not None:
+                    harness.drive(ref, data, quiet=0)
+                    want = ref.log_lines()
+                    assert got == want, (name, em, next((i, a, b) for i, (a, b) in enumerate(zip(got + [None], want + [None])) if a != b))
+                if sm == 3:
+                    assert ms < 25.0, (name, em, ms)               # decode + side pass + chunked readers + report (typically 3-4 ms)
+        assert sum(1 for v in modes.values() if v == 3) >= 2, modes
+    finally:
+        for b in (oracle, gpu) + ((ref,) if ref else ()):
+            b.set_options()
+        if ref is not None:
+            ref.close()

@@ -11,10 +11,12 @@ The LDS returns in order: every wait is `lgkmcnt(number of LDS instructions issu
 """
 import sys
 
-T_RING = 5           # table pairs: four reads in flight + the one being consumed
+import os
+T_RING = int(os.environ.get("GEN_T_RING", 5))    # table pairs: four reads in flight + the one being consumed
 C_RING = 3           # coefficient pairs
-T_LEAD = 4           # a table pair is fetched this many steps ahead of its step
+T_LEAD = int(os.environ.get("GEN_T_LEAD", 4))    # a table pair is fetched this many steps ahead of its step
 C_LEAD = 4           # a coefficient pair (steps 2j, 2j+1) is fetched at step 2j - C_LEAD
+MIX = int(os.environ.get("GEN_MIX", 0))          # experiment: every MIX-th coefficient pair rides on its multiplies as a DPP operand of %[ey] instead (0: none)
 T_REG0 = 54          # v[54:63]: five table pairs
 C_REG0 = 48          # v[48:53]: three coefficient pairs
 
@@ -56,11 +58,18 @@ def gen_round(r, steps=16):
         emit(f"s_waitcnt lgkmcnt({behind})")
         del q[:idx + 1]
 
+    def dpp_pair(j):
+        return MIX > 0 and j % MIX == MIX - 1
+
     # prologue: the round's row words, the first two coefficient pairs, four table pairs
+    if MIX:
+        emit(f"ds_read_b32 %[ey], %[aey] offset:{r * 64}")
+        q.append(("EY", 0))
     emit(f"ds_read_b32 %[rw], %[arw] offset:{r * 64}")
     q.append(("RW", 0))
     for j in range(0, C_LEAD // 2):
-        rd_c(j)
+        if not dpp_pair(j):
+            rd_c(j)
     wait(("RW", 0))
     for s in range(T_LEAD):
         rd_t(s)
@@ -68,14 +77,19 @@ def gen_round(r, steps=16):
         if s:
             emit(f"s_cmp_le_u32 %[nl], {s}")
             emit("s_cbranch_scc1 .Lpe%=")
-        wait(("T", s), ("C", s // 2))
         lo, hi = treg(s)
-        c = creg(s // 2)[s & 1]
-        emit(f"v_mul_f32 v{lo}, v{c}, v{lo}")
-        emit(f"v_mul_f32 v{hi}, v{c}, v{hi}")
+        if dpp_pair(s // 2):
+            wait(("T", s), ("EY", 0))
+            emit(f"v_mul_f32_dpp v{lo}, %[ey], v{lo} row_newbcast:{s} row_mask:0xf bank_mask:0xf")
+            emit(f"v_mul_f32_dpp v{hi}, %[ey], v{hi} row_newbcast:{s} row_mask:0xf bank_mask:0xf")
+        else:
+            wait(("T", s), ("C", s // 2))
+            c = creg(s // 2)[s & 1]
+            emit(f"v_mul_f32 v{lo}, v{c}, v{lo}")
+            emit(f"v_mul_f32 v{hi}, v{c}, v{hi}")
         if s + T_LEAD < steps:
             rd_t(s + T_LEAD)
-        if s % 2 == 0 and (s + C_LEAD) // 2 < steps // 2:
+        if s % 2 == 0 and (s + C_LEAD) // 2 < steps // 2 and not dpp_pair((s + C_LEAD) // 2):
             rd_c((s + C_LEAD) // 2)
         emit(f"v_add_f32 %[acc0], %[acc0], v{lo}")
         emit(f"v_add_f32 %[acc1], %[acc1], v{hi}")
