@@ -295,13 +295,23 @@ def extras_single_gpu(J, H, orc, np):
         tn0 = time.perf_counter(); decn.DecodeProgressive(pprog); msn = (time.perf_counter() - tn0) * 1e3
         extra["config5_progressive_no_rst"] = {"scans": nscn, "ms_end_to_end": round(msn, 2), "mpix_per_s": round(1920 * 1080 / msn / 1e3, 2), "bit_exact_vs_libjpeg_baseline_encoding": okn,
                                                "note": "libjpeg-turbo progressive 1920x1080 4:2:2 without DRI: restart intervals are the parallel grain of the progressive path, a scan without markers is one interval"}
+        wantn = J.dib_checksum_numpy(decn.GetBitmapPtr())
         decn.close()
+        # ... the form in which such files get their throughput: many of them in one batch, a scan of every file per launch
+        for nbn in (64, 512):
+            pn = J.JpegBatch(); pn.add_jpeg(pprog); pn.tile(nbn); pn.upload(); pn.decode(); pn.sync()
+            okb = bool(all(int(x) == wantn for x in pn.dib_checksums()))
+            msnb, _ = pn.decode_timed(1)
+            extra["config5_progressive_no_rst_batch%d" % nbn] = {"ms_per_batch": round(msnb, 2), "ms_per_image": round(msnb / nbn, 3), "mpix_per_s": round(nbn * 1920 * 1080 / msnb / 1e3, 1),
+                                                                 "same_pixels_as_the_single_call": okb}
+            pn.close()
     except Exception as e:
         extra["config5_progressive_no_rst"] = {"error": repr(e)}
     # damaged files (JPEGsnoop's daily input): one 1080p file each, decode + sync of a resident batch of one, DIB checked against the oracle.
     # "flip": the scan bit flips of tools/corrupt_timing.py that leave a trace (coefficient-index overflow); "cut": truncated at half its
     # scan (the rest decodes as the zero bytes CwindowBuf::Buf returns past the end); "marker": two bytes overwritten by a stray marker
     dmg = {}
+    gcall = None
     for label, kwd in (("1080p", dict(width=1920, height=1080)), ("1080p_rst", dict(width=1920, height=1080, restart_interval=120))):
         based = H.synth_jpeg(seed=9, **kwd)
         pd = H.parse_jpeg(based)
@@ -361,6 +371,21 @@ def extras_single_gpu(J, H, orc, np):
             dmg["%s_%s" % (label, kind)] = {"ms": round(msd, 3), "path": int(inf["path"]), "flags": "0x%04x" % inf["flags"],
                                             "bit_exact": bool(int(bd.dib_checksums()[0]) == J.dib_checksum_numpy(orc.dib()))}
             bd.close()
+            # ... and the call a CjfifDecode makes (source/JfifDecode.cpp:5299): DecodeScanImg with a log callback -- upload, decode, side outputs,
+            # messages and report of this one file, wall clock; side outputs and status words against the oracle's
+            try:
+                if gcall is None:
+                    gcall = H.Backend(J.load(), "jsnoop_", "hip")
+                H.drive(gcall, d, quiet=0)
+                tc = time.perf_counter(); H.drive(gcall, d, quiet=0); call_ms = (time.perf_counter() - tc) * 1e3
+                import importlib.util as _iu
+                _fu = _iu.spec_from_file_location("fuzz_util", os.path.join(ROOT, "tests", "fuzz_util.py")); _fm = _iu.module_from_spec(_fu); _fu.loader.exec_module(_fm)
+                dmg["%s_%s" % (label, kind)].update({"call_ms": round(call_ms, 3), "side_mode": int(gcall.lib.jsnoop_last_side_mode(gcall.h)), "log_lines": len(gcall.log_lines()),
+                                                     "side_outputs_equal_oracle": _fm.differs(orc, gcall) is None})
+            except Exception as e:
+                dmg["%s_%s" % (label, kind)]["call_error"] = repr(e)
+    if gcall is not None:
+        gcall.close()
     extra["damaged_files"] = dmg
     # the baseline (SOF0) form of config 5 through the batch path, oracle-checked directly
     b5 = J.JpegBatch(); b5.add_jpeg(base5); b5.upload(); b5.decode(); b5.sync()

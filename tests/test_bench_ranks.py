@@ -114,3 +114,30 @@ def test_strong_job_at_world_size_2_is_refused_the_same_way_without_devices():
         pytest.skip("two devices are visible here: the launcher would run the job")
     p = run_bench("--gpus", "2", "--strong", "--steps", "1")
     assert p.returncode != 0 and (b"bench.py: --gpus 2 requested but only %d HIP device(s) are visible" % have) in p.stderr
+
+
+def test_gpus_8_end_to_end_weak_and_strong():
+    """The driver's `python bench.py --gpus 8` path end to end on the CPU (--stub: gloo in RCCL's place, a stand-in batch): eight ranks are spawned,
+    the weak job gives every rank its shard, the strong job is ONE mixed job LPT-partitioned by compressed bytes (files are independent,
+    source/JfifDecode.cpp:7306-7308), both reduce to one JSON line with eight per-rank times -- what is left for the first real run is RCCL itself."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from jpegsnoop_amd.shard import partition_lpt
+    images, steps, w, h = 4, 2, 64, 48
+    weak = last_json(run_bench("--gpus", "8", "--stub", "--stub-ms", "3", "--images", str(images), "--distinct", "2", "--steps", str(steps), "--warmup", "1",
+                               "--width", str(w), "--height", str(h)))
+    assert weak["n_gpus"] == 8 and weak["scaling"] == "weak" and weak["config"]["parallelism"] == "shard8" and weak["steps"] == steps
+    assert len(weak["per_rank_ms_per_step"]) == 8 and all(ms >= 3.0 for ms in weak["per_rank_ms_per_step"])
+    assert weak["bit_exact"] and weak["parity_errors"] == 0
+    assert weak["ms_per_step"] >= max(weak["per_rank_ms_per_step"]) - 1e-3
+    assert abs(weak["value"] - 8 * images * w * h * steps / (weak["ms_per_step"] * steps * 1e-3) / 1e6) < 0.05 * weak["value"] + 0.2
+    nj, distinct = 131, 5
+    strong = last_json(run_bench("--gpus", "8", "--stub", "--strong", "--job-images", str(nj), "--distinct", str(distinct), "--steps", "2", "--warmup", "1", "--stub-ms", "3"))
+    one = last_json(run_bench("--stub", "--strong", "--job-images", str(nj), "--distinct", str(distinct), "--steps", "2", "--warmup", "1", "--stub-ms", "3"))
+    sh = strong["shards"]
+    assert strong["n_gpus"] == 8 and strong["scaling"] == "strong" and strong["bit_exact"] and len(strong["per_rank_ms_per_step"]) == 8
+    assert sh["union_is_the_job"] and sum(sh["images"]) == nj and len(sh["images"]) == 8
+    assert strong["job_checksum"] == one["job_checksum"] and int(one["job_checksum"], 16) != 0
+    plan = bench.job_plan(nj, distinct)
+    bins = partition_lpt([bench.stub_cost(k, sd) for k, sd in plan], 8)
+    assert sh["images"] == [len(b) for b in bins]
