@@ -472,7 +472,7 @@ int JsnoopBatch::upload()
         grow(&dev.us_base, &cap.us_base, 2 * (n + 1) * 4) || grow(&dev.sy_base, &cap.sy_base, 2 * (n + 1) * 4) ||
         grow(&dev.mcu_rst, &cap.mcu_rst, mcub + 64) || grow(&dev.dc_parts, &cap.dc_parts, JS_DC_PARTS_BYTES) || grow(&dev.ustr_lin, &cap.ustr_lin, ustr + 64) || grow(&dev.flags, &cap.flags, n * 8 + 64) ||
         grow(&dev.us_state, &cap.us_state, (size_t)usc * 8 + 64)) return -1;
-    HIP_TRY(hipMemsetAsync(dev.us_state, 0, (size_t)usc * 8, stream)); us_epoch = 0;      // (no word of an earlier layout may look current)
+    HIP_TRY(hipMemsetAsync(dev.us_state, 0, (size_t)usc * 8 + 64, stream)); us_epoch = 0; us_ticket_base[0] = us_ticket_base[1] = 0;   // (the ticket counters sit behind the state words)      // (no word of an earlier layout may look current)
     if (opt_want_planes && grow(&dev.planes, &cap.planes, plane * 2)) return -1;
     { uint32_t most = 0; for (size_t i = 0; i < n; i++) most = std::max(most, wg[i + 1] - wg[i]); if (most > 64 && grow(&dev.wg_part, &cap.wg_part, (size_t)wgs * 16 + 64)) return -1; }
     cand_blk = max_blk; cand_rounds = (cand_fits && sub_wl == 4) ? cand_want : -1;

@@ -105,6 +105,7 @@ struct JsnoopBatch {
     int  d2h_staged(void* dst, const void* src, size_t bytes);
     JsDeviceArenas dev; JsArenaCaps cap;
     bool uploaded;
+    uint32_t us_ticket_base[2] = { 0, 0 };                        // value of the two chunk-ticket counters (behind us_state; one per part of a split decode) before the next launch
     uint32_t us_epoch = 0;                                        // decode counter 1..255 the chained-scan state words are tagged with (cleared at upload)
     uint64_t total_blocks, dib_bytes, side_words, total_subseq, ustr_bytes, seg_words, mcu_bytes; uint32_t total_wgs, strips_per_wg, us_chunks, sy_wgs, sn_wgs, max_mcu_h, max_mcu_w;
     // small jobs (64-byte sub-sequences, a few hundred thousand walks at most) synchronise by candidates (k_cand_*) instead of k_sync's rounds: cand_rounds

@@ -1640,7 +1640,7 @@ __device__ __forceinline__ void us_lookback(unsigned long long* __restrict__ us_
 
 // The un-stuffing pass proper: classifies the chunk's bytes, finds where its kept bytes go, writes them (and the interval table entries of its
 // RSTn markers).  FUSED (the decode): ONE pass over the file bytes -- the chunk's place in its image comes from a decoupled look-back over the
-// chunks before it (us_state; workgroups are dispatched in index order, so every chunk a workgroup waits for is running or done), the last
+// chunks before it (us_state; chunks are taken by ticket, so every chunk a workgroup waits for is running or done), the last
 // chunk of an image also leaves the totals where k_unstuff_scan used to (side block words 10 / 11, interval 0 and the end sentinel), and the
 // exclusive prefixes are kept in chunk_keep / chunk_rst for the side passes.  !FUSED: prefixes are read from chunk_keep / chunk_rst
 // (k_unstuff_count + k_unstuff_scan before it: the three-pass form, kept as a cross-check; and the side passes).
@@ -1652,9 +1652,17 @@ __global__ void __launch_bounds__(US_THREADS) k_unstuff_write(const JsImage* __r
                                                               const uint8_t* __restrict__ raw, uint32_t* __restrict__ chunk_keep,
                                                               uint32_t* __restrict__ chunk_rst, uint8_t* __restrict__ ustr, uint32_t* __restrict__ seg_tab,
                                                               uint32_t wg0, uint32_t* __restrict__ us_out,
-                                                              unsigned long long* __restrict__ us_state, uint32_t epoch, uint32_t* __restrict__ side, uint32_t* __restrict__ flags)
+                                                              unsigned long long* __restrict__ us_state, uint32_t epoch, uint32_t* __restrict__ side, uint32_t* __restrict__ flags,
+                                                              uint32_t* __restrict__ ticket, uint32_t ticket_base)
 {
-    const uint32_t wg = blockIdx.x + wg0 + us_base[0];
+    // FUSED: which chunk a workgroup takes is decided by the order in which the workgroups START (a ticket), not by blockIdx.x: the look-back below waits
+    // for the chunks in front of its own, and a chunk with a smaller ticket is held by a workgroup that is running or done -- whatever order the
+    // hardware dispatches block indices in, and whatever else shares the device (two streams of a split decode, other processes).  The counter is
+    // never cleared between decodes: the host hands in its value before this launch.
+    __shared__ uint32_t s_bid;
+    if (FUSED) { if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u) - ticket_base; __syncthreads(); }
+    const uint32_t bid = FUSED ? s_bid : blockIdx.x;
+    const uint32_t wg = bid + wg0 + us_base[0];
     const uint32_t img = find_image(us_base, nimg, wg);
     const JsImage& im = imgs[img];
     const uint64_t s = im.file_off + im.scan_start, e = s + im.scan_len;
@@ -1736,13 +1744,16 @@ template <int WL>
 __global__ void __launch_bounds__(US_THREADS) k_unstuff_fused(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ us_base, const uint32_t* __restrict__ us4_base, uint32_t nimg,
                                                               const uint8_t* __restrict__ raw, uint32_t* __restrict__ chunk_keep, uint32_t* __restrict__ chunk_rst,
                                                               uint8_t* __restrict__ ustr, uint32_t* __restrict__ seg_tab, unsigned long long* __restrict__ us_state, uint32_t epoch,
-                                                              uint32_t* __restrict__ side, uint32_t* __restrict__ flags)
+                                                              uint32_t* __restrict__ side, uint32_t* __restrict__ flags, uint32_t* __restrict__ ticket, uint32_t ticket_base)
 {
     constexpr uint32_t PADSH = WL + 2;                            // one pad word per 4 << WL gathered bytes
     __shared__ __attribute__((aligned(4))) uint8_t s_out[US_SUPER * US_CHUNK + ((US_SUPER * US_CHUNK) >> WL) + 16];
     __shared__ uint32_t wk[US_SUPER][US_THREADS / 64], wr[US_SUPER][US_THREADS / 64];
     __shared__ uint32_t s_excl[2];
-    const uint32_t sw = blockIdx.x + us4_base[0];
+    __shared__ uint32_t s_bid;                                    // the super-chunk is taken by ticket (k_unstuff_write): the look-back only ever waits for workgroups that have started
+    if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u) - ticket_base;
+    __syncthreads();
+    const uint32_t sw = s_bid + us4_base[0];
     const uint32_t img = find_image(us4_base, nimg, sw);
     const JsImage& im = imgs[img];
     const uint32_t sc = sw - us4_base[img], nsc = us4_base[img + 1] - us4_base[img];
@@ -3237,23 +3248,26 @@ __global__ void __launch_bounds__(DC_THREADS) k_dc_scan_parts(const JsImage* __r
 
 void js_launch_unstuff(hipStream_t st, int wl, const JsImage* imgs, const uint32_t* us_base, uint32_t nimg, uint32_t total_chunks, const uint8_t* raw,
                        uint32_t* chunk_keep, uint32_t* chunk_rst, uint8_t* ustr_lin, uint8_t* ustr, uint32_t* seg_tab, uint32_t* side, uint32_t* flags,
-                       const uint32_t* sy_base, uint32_t sy_wgs, unsigned long long* us_state, uint32_t epoch, const uint32_t* us4_base, uint32_t total_super)
+                       const uint32_t* sy_base, uint32_t sy_wgs, unsigned long long* us_state, uint32_t epoch, const uint32_t* us4_base, uint32_t total_super,
+                       uint32_t* ticket, uint32_t* ticket_base /*host: the counter's value, advanced by what this launch takes*/)
 {
     if (!total_chunks) return;
     if (us_state && wl != 4 && us4_base) {   // large jobs: one pass from the file bytes to the interleaved layout (k_unstuff_fused), no transposition pass
-#define JS_USF(W) hipLaunchKernelGGL(k_unstuff_fused<W>, dim3(total_super), dim3(US_THREADS), 0, st, imgs, us_base, us4_base, nimg, raw, chunk_keep, chunk_rst, ustr, seg_tab, us_state, epoch, side, flags)
+#define JS_USF(W) hipLaunchKernelGGL(k_unstuff_fused<W>, dim3(total_super), dim3(US_THREADS), 0, st, imgs, us_base, us4_base, nimg, raw, chunk_keep, chunk_rst, ustr, seg_tab, us_state, epoch, side, flags, ticket, *ticket_base)
         if (wl == 5) JS_USF(5); else if (wl == 6) JS_USF(6); else if (wl == 7) JS_USF(7); else JS_USF(8);
 #undef JS_USF
+        *ticket_base += total_super;
         return;
     }
     if (us_state) {          // small jobs (64-byte pieces read the linear stream): one pass, the chunks' places come from a decoupled look-back (k_unstuff_write<true>)
         hipLaunchKernelGGL(k_unstuff_write<true>, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, wl == 4 ? ustr : ustr_lin, seg_tab, 0u,
-                           (uint32_t*)nullptr, us_state, epoch, side, flags);
+                           (uint32_t*)nullptr, us_state, epoch, side, flags, ticket, *ticket_base);
+        *ticket_base += total_chunks;
     } else {                 // the three-pass form (cross-check): count, scan per image, write
         hipLaunchKernelGGL(k_unstuff_count, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst);
         hipLaunchKernelGGL(k_unstuff_scan, dim3(nimg), dim3(256), 0, st, imgs, us_base, chunk_keep, chunk_rst, seg_tab, side, flags);
         hipLaunchKernelGGL(k_unstuff_write<false>, dim3(total_chunks), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, chunk_keep, chunk_rst, wl == 4 ? ustr : ustr_lin, seg_tab, 0u,
-                           (uint32_t*)nullptr, (unsigned long long*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                           (uint32_t*)nullptr, (unsigned long long*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
     }
     if (wl == 4) return;                                         // (phys_word<4> is the identity)
     if (wl == 6) hipLaunchKernelGGL(k_interleave<6>, dim3(sy_wgs * 4), dim3(256), 0, st, imgs, sy_base, nimg, side, ustr_lin, ustr);
@@ -3623,7 +3637,7 @@ void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab
 {
     if (!us_wgs || !sy_wgs) return;
     hipLaunchKernelGGL(k_unstuff_write<false>, dim3(us_wgs), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, const_cast<uint32_t*>(chunk_keep), const_cast<uint32_t*>(chunk_rst), (uint8_t*)nullptr, seg_tab, us_wg0, us_out,
-                       (unsigned long long*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                       (unsigned long long*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
     if (wl == 4) hipLaunchKernelGGL((k_write<4, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, anoms, tab_rows, tab_lut2, sy_wg0, mcu_pos);
     else if (wl == 6) hipLaunchKernelGGL((k_write<6, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
@@ -3645,7 +3659,7 @@ void js_launch_tail_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab
 {
     if (!us_wgs || !sy_wgs) return;
     hipLaunchKernelGGL(k_unstuff_write<false>, dim3(us_wgs), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, const_cast<uint32_t*>(chunk_keep), const_cast<uint32_t*>(chunk_rst), (uint8_t*)nullptr, seg_tab, us_wg0, us_out,
-                       (unsigned long long*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                       (unsigned long long*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
 #define JS_TAIL_WALK(W) hipLaunchKernelGGL((k_write<W, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side, \
                        sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, sy_wg0, mcu_pos)
     if (wl == 4) JS_TAIL_WALK(4); else if (wl == 6) JS_TAIL_WALK(6); else if (wl == 8) JS_TAIL_WALK(8); else if (wl == 7) JS_TAIL_WALK(7); else JS_TAIL_WALK(5);

@@ -24,7 +24,8 @@ void js_launch_color_sweep(hipStream_t st, uint32_t* out /*2^24 words*/);
 void js_launch_unstuff(hipStream_t st, int wl, const JsImage* imgs, const uint32_t* us_base, uint32_t nimg, uint32_t total_chunks, const uint8_t* raw,
                        uint32_t* chunk_keep, uint32_t* chunk_rst, uint8_t* ustr_lin, uint8_t* ustr, uint32_t* seg_tab, uint32_t* side, uint32_t* flags,
                        const uint32_t* sy_base, uint32_t sy_wgs, unsigned long long* us_state /*nullptr: the three-pass form*/, uint32_t epoch,
-                       const uint32_t* us4_base /*prefix over super-chunks of four chunks, or nullptr: linear output + transposition pass*/, uint32_t total_super);
+                       const uint32_t* us4_base /*prefix over super-chunks of four chunks, or nullptr: linear output + transposition pass*/, uint32_t total_super,
+                       uint32_t* ticket /*device counter the fused passes take their chunk from*/, uint32_t* ticket_base /*host: its value before the launch; advanced here*/);
 void js_launch_sync(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
                     const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub, int first_pass);
 #define JS_SY_THREADS 256

@@ -295,7 +295,8 @@ int js_parallel_entropy_part(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32
     js_launch_unstuff(st, b->sub_wl, imgs, us_base, n, us_chunks, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst,
                       b->dev.ustr_lin, b->dev.ustr, b->dev.seg, b->dev.side, flags, sy_base, sy_wgs,
                       (b->tune.cross_checks & JSNOOP_XC_UNSTUFF_3PASS) ? nullptr : b->dev.us_state, b->us_epoch,
-                      b->dev.us_base + (N + 1) + i0, b->h_us4_base[i0 + n] - b->h_us4_base[i0]);
+                      b->dev.us_base + (N + 1) + i0, b->h_us4_base[i0 + n] - b->h_us4_base[i0],
+                      reinterpret_cast<uint32_t*>(b->dev.us_state + b->us_chunks) + (i0 ? 1 : 0), &b->us_ticket_base[i0 ? 1 : 0]);
     roctxRangePop();
     if (evs) HIP_TRY(hipEventRecord(evs[2], st));
     roctxRangePushA("jsnoop:sub-sequence sync");
