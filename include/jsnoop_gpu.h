@@ -270,7 +270,11 @@ typedef struct JsnoopTuning {
 #define JSNOOP_DBG_CAND_LINKS     0x02u  /* ... and the links left open per image (stops the stream)                                  */
 #define JSNOOP_DBG_TAIL           0x04u  /* damaged files: tail take-over decisions                                                   */
 #define JSNOOP_DBG_TIMING         0x08u  /* single-image calls: where the wall time goes                                              */
-void         jsnoop_tuning_defaults(JsnoopTuning* out);                 /* struct_size set, everything else the process defaults    */
+void         jsnoop_tuning_defaults(JsnoopTuning* out);                 /* struct_size set, everything else the process defaults: writes
+                                                                          * sizeof(JsnoopTuning) of THIS header                       */
+/* ... for a caller built against an older (shorter) JsnoopTuning: at most struct_size bytes are written, struct_size says how many.
+ * jsnoop_batch_get_tuning reads out->struct_size the same way: set it to sizeof(your JsnoopTuning) (or 0: this header's) before the call. */
+void         jsnoop_tuning_defaults_sized(JsnoopTuning* out, uint32_t struct_size);
 int          jsnoop_batch_set_tuning(JsnoopBatch*, const JsnoopTuning*);
 void         jsnoop_batch_get_tuning(const JsnoopBatch*, JsnoopTuning* out);
 int          jsnoop_set_tuning(JsnoopDecoder*, const JsnoopTuning*);

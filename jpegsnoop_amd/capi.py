@@ -108,6 +108,7 @@ SIGNATURES = {
     "jsnoop_batch_set_split": (_i, [_p, _i]),
     "jsnoop_batch_split_parts": (_i, [_p]),
     "jsnoop_tuning_defaults": (None, [C.POINTER(Tuning)]),
+    "jsnoop_tuning_defaults_sized": (None, [C.POINTER(Tuning), C.c_uint32]),
     "jsnoop_batch_set_tuning": (_i, [_p, C.POINTER(Tuning)]),
     "jsnoop_batch_get_tuning": (None, [_p, C.POINTER(Tuning)]),
     "jsnoop_set_tuning": (_i, [_p, C.POINTER(Tuning)]),

@@ -39,12 +39,13 @@ public:
     unsigned GetWidth() const { return m_nW; }
     unsigned GetHeight() const { return m_nH; }
     void  Attach(JsnoopDecoder* h) { m_h = h; }
+    void  Invalidate() { m_pBits = nullptr; m_nW = m_nH = 0; }                                                                         // the decoder dropped the bits (Reset, DecodeScanImg): GetDIBBitArray is NULL as after Kill
 private:
     JsnoopDecoder* m_h = nullptr; uint8_t* m_pBits = nullptr; unsigned m_nW = 0, m_nH = 0;
 };
 
 // TDib: the type of the public member m_pDibTemp -- CDibGpu here; a build inside the reference's tree may name its own CDIB-shaped class
-// (it needs Kill / CreateDIB / GetDIBBitArray and an Attach(JsnoopDecoder*) hook).
+// (it needs Kill / CreateDIB / GetDIBBitArray, an Attach(JsnoopDecoder*) hook and Invalidate(): called when the decoder has dropped the bits).
 template <class TDib>
 class CimgDecodeGpuT {
 public:
@@ -72,7 +73,7 @@ public:
     void SetWindowBuf(const CwindowBufView* pWBuf) { m_pWBuf = pWBuf; }
 
     // ---- lifecycle ------------------------------------------------------------------------------
-    void Reset() { jsnoop_reset(m_h); m_bDibTempReady = false; }   // :49 (kills m_pDibTemp when it was ready, :80-83)
+    void Reset() { SyncPreviewMembers(); jsnoop_reset(m_h); m_bDibTempReady = false; m_pDibTemp.Invalidate(); }   // :49 (kills m_pDibTemp when it was ready, :80-83 -- "ready" is the member the caller may just have set)
     void ResetState() { jsnoop_reset_state(m_h); }              // :286
     void ResetDqtTables() { jsnoop_reset_dqt_tables(m_h); }     // :343 (private in the reference: ResetState calls it)
     void ResetDhtLookup() { jsnoop_reset_dht_lookup(m_h); }     // :373
@@ -106,6 +107,7 @@ public:
     {
         if (!m_pWBuf || !m_pWBuf->pData) { if (m_log) m_log(2, "*** ERROR: DecodeScanImg without a file buffer ***"); return; }
         jsnoop_decode_scan_img(m_h, m_pWBuf->pData, m_pWBuf->nLen, nStart, bDisplay, bQuiet);
+        m_pDibTemp.Invalidate();                                                                                 // (the decode clears the temporary preview, :2976-2978)
         m_bPreviewIsJpeg = jsnoop_is_preview_ready(m_h) != 0; m_bDibTempReady = jsnoop_get_dib_temp_ready(m_h) != 0;     // :3647-3648
     }
 

@@ -264,10 +264,15 @@ int JsnoopBatch::init()
         static std::atomic<int> ok[JS_MAX_DEVICES];                // 0 = not probed, 1 = fine, -1 = refused
         int st = device >= 0 && device < JS_MAX_DEVICES ? ok[device].load() : 0;
         if (st == 0) {
+            // (what the probe can tell: a device that SPLITS or reorders the bytes of such a store.  One that faults on it raises a memory fault, which
+            //  ends the process -- there is no error to return then.)
             uint16_t* p = nullptr; uint16_t h[24];
-            HIP_TRY(hipMalloc((void**)&p, sizeof h)); HIP_TRY(hipMemset(p, 0, sizeof h));
-            js_launch_unaligned_probe(stream, p);
-            HIP_TRY(hipMemcpyAsync(h, p, sizeof h, hipMemcpyDeviceToHost, stream)); HIP_TRY(hipStreamSynchronize(stream)); hipFree(p);
+            HIP_TRY(hipMalloc((void**)&p, sizeof h));
+            hipError_t pe = hipMemset(p, 0, sizeof h);
+            if (pe == hipSuccess) { js_launch_unaligned_probe(stream, p); pe = hipMemcpyAsync(h, p, sizeof h, hipMemcpyDeviceToHost, stream); }
+            if (pe == hipSuccess) pe = hipStreamSynchronize(stream);
+            hipFree(p);                                          // (on every path)
+            if (pe != hipSuccess) { js_set_error("unaligned-store probe: %s", hipGetErrorString(pe)); return -1; }
             st = 1; for (int k = 0; k < 24; k++) if (h[k] != (k >= 3 && k < 11 ? k - 2 : 0)) st = -1;
             if (device >= 0 && device < JS_MAX_DEVICES) ok[device].store(st);
         }
@@ -635,7 +640,9 @@ void jsnoop_set_image_dimensions(JsnoopDecoder* d, unsigned w, unsigned h) { d->
 void jsnoop_get_image_dimensions(JsnoopDecoder* d, unsigned* w, unsigned* h) { *w = d->base_w; *h = d->base_h; }
 uint8_t* jsnoop_dib_temp_create(JsnoopDecoder* d, unsigned w, unsigned h)
 {
-    d->dib_temp.assign((size_t)w * h * 4, 0); d->have_image = false; d->host_valid = 0;     // (the decoded image's DIB is no longer the preview)
+    try { d->dib_temp.assign((size_t)w * h * 4, 0); }                                       // (no exception crosses the C ABI: CDIB::CreateDIB returns false, Dib.cpp:53)
+    catch (const std::exception&) { d->dib_temp.clear(); d->dib_temp.shrink_to_fit(); js_set_error("jsnoop_dib_temp_create: no memory for %u x %u pixels", w, h); return nullptr; }
+    d->have_image = false; d->host_valid = 0;                                               // (the decoded image's DIB is no longer the preview)
     return d->dib_temp.empty() ? nullptr : d->dib_temp.data();
 }
 void jsnoop_set_dib_temp_ready(JsnoopDecoder* d, int ready) { d->dib_temp_ready = ready != 0; }
@@ -932,7 +939,15 @@ int jsnoop_batch_set_split(JsnoopBatch* b, int parts)
     return 0;
 }
 int jsnoop_batch_split_parts(const JsnoopBatch* b) { return b ? b->split_parts : 1; }
-void jsnoop_tuning_defaults(JsnoopTuning* out) { if (out) *out = js_env_tuning(); }      // (writes sizeof(JsnoopTuning) bytes: the struct of THIS header; jsnoop_batch_get_tuning honours struct_size)
+void jsnoop_tuning_defaults(JsnoopTuning* out) { if (out) *out = js_env_tuning(); }      // (writes sizeof(JsnoopTuning) bytes: the struct of THIS header; a caller built against an older, shorter struct uses the sized form)
+void jsnoop_tuning_defaults_sized(JsnoopTuning* out, uint32_t struct_size)
+{
+    if (!out || struct_size < 8) return;
+    JsnoopTuning t = js_env_tuning();
+    const size_t sz = std::min<size_t>(struct_size, sizeof(JsnoopTuning));
+    t.struct_size = (uint32_t)sz;
+    memcpy(out, &t, sz);                                         // nothing is written past the caller's struct
+}
 int jsnoop_batch_set_tuning(JsnoopBatch* b, const JsnoopTuning* t)
 {
     if (!b || !t) { js_set_error("jsnoop_batch_set_tuning: null argument"); return -1; }
@@ -1149,7 +1164,8 @@ void JsnoopDecoder::rerender()                                  // CalcChannelPr
     im.preview_mode = preview_mode; im.shift_y = shift_y; im.shift_cb = shift_cb; im.shift_cr = shift_cr; im.shift_mcu_x = shift_mcu_x; im.shift_mcu_y = shift_mcu_y;
     hipSetDevice(b->device);
     HIP_NOTE(hipMemcpyAsync(b->dev.imgs, &im, sizeof im, hipMemcpyHostToDevice, b->stream));
-    HIP_NOTE(hipMemsetAsync(b->dev.side + im.side_off + 12, 0, 16, b->stream));      // brightest-pixel key and sum of Y are recomputed
+    HIP_NOTE(hipMemsetAsync(b->dev.side + im.side_off + 12, 0, 8, b->stream));       // brightest-pixel key and sum of Y are recomputed (word 14, the block count, stays)
+    HIP_NOTE(hipMemsetAsync(b->dev.side + im.side_off + 15, 0, 4, b->stream));
     if (b->launch_back_end(1)) log(2, "*** ERROR: device re-render failed: %s", g_err.c_str());
     hipStreamSynchronize(b->stream);
     host_valid = 0; fetch_side();

@@ -337,8 +337,8 @@ int js_parallel_entropy(JsnoopBatch* b, bool timed)
     return js_parallel_entropy_part(b, b->stream, 0, (uint32_t)b->imgs.size(), timed ? b->ev : nullptr);
 }
 
-// Sequential exact-mirror decode of the listed images (their intermediate ranges are cleared first),
-// followed by the back end.  Used for images the parallel path flagged and for side-output requests.
+// Sequential exact-mirror decode (entropy only) of the listed images, their intermediate ranges cleared first: coefficients, cumulative DC and the
+// whole side block are the mirror's afterwards.  The PIXELS are not made here: the caller runs redo_back_end over everything that changed.
 int JsnoopBatch::run_exact(const std::vector<uint32_t>& which)
 {
     if (which.empty()) return 0;
@@ -363,10 +363,11 @@ int JsnoopBatch::redo_back_end(const std::vector<uint32_t>& which)
     HIP_TRY(hipSetDevice(device));
     const uint32_t n = (uint32_t)imgs.size();
     if (which.size() * 8 >= n && which.size() > 1) {
-        for (uint32_t i = 0; i < n; i++) HIP_TRY(hipMemsetAsync(dev.side + imgs[i].side_off + 12, 0, 16, stream));
+        // (words 12-13: brightest-pixel key, 15: sum of Y -- the back end's reductions; word 14, the block count of k_block_scan, stays)
+        for (uint32_t i = 0; i < n; i++) { HIP_TRY(hipMemsetAsync(dev.side + imgs[i].side_off + 12, 0, 8, stream)); HIP_TRY(hipMemsetAsync(dev.side + imgs[i].side_off + 15, 0, 4, stream)); }
         if (launch_back_end(n)) return -1;
     } else for (uint32_t i : which) {
-        HIP_TRY(hipMemsetAsync(dev.side + imgs[i].side_off + 12, 0, 16, stream));
+        HIP_TRY(hipMemsetAsync(dev.side + imgs[i].side_off + 12, 0, 8, stream)); HIP_TRY(hipMemsetAsync(dev.side + imgs[i].side_off + 15, 0, 4, stream));
         if (launch_back_end_part(stream, i, 1)) return -1;
     }
     HIP_TRY(hipStreamSynchronize(stream));
