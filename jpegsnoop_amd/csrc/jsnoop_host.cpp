@@ -116,10 +116,12 @@ bool js_geometry(JsnoopDecoder* d, JsImage* im)
     d->geom[4] = im->blk_xmax; d->geom[5] = im->blk_ymax; d->geom[6] = im->img_x; d->geom[7] = im->img_y;
     return true;
 }
-bool js_describe_image(JsnoopDecoder* d, JsImage* im, JsTableSet* ts, uint32_t file_len, uint32_t scan_start, int display, int quiet)
+bool js_describe_image(JsnoopDecoder* d, JsImage* im, JsTableSet* ts, uint32_t file_len, uint32_t scan_start, int display, int quiet, const uint8_t* file)
 {
     JsTables& t = d->t;
     if (!js_geometry(d, im)) return false;
+    d->head_events = d->head_counted = 0;
+    if (file) js_emit_head_events(d, file, file_len, scan_start);   // the reader is filled BEFORE the heading is written (:3007-3019): a marker in the scan's first bytes is reported above it
     if (!quiet) { d->log(0, "*** Decoding SCAN Data ***"); d->log(0, "  OFFSET: 0x%08X", scan_start); }            // :3021-3025
     if (t.num_sof != 1 && t.num_sof != 3) { d->log(1, "  NOTE: Number of Image Components not supported [%u]", t.num_sof); return false; }
     for (uint32_t i = 1; i <= t.num_sos; i++) if (t.dqt_sel[i] < 0) {
@@ -329,7 +331,7 @@ int JsnoopBatch::add(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned
     if (len >= (1ull << 32) - 64) { js_set_error("file too large for the 32-bit offsets of the reference format"); return -1; }
     if (js_prog_count(this)) { js_set_error("a batch holds either baseline or progressive files, not both"); return -1; }
     JsImage im; JsTableSet* ts = new JsTableSet;
-    if (!js_describe_image(d, &im, ts, (uint32_t)len, scan_start, display, quiet)) { delete ts; js_set_error("image not decodable (see log callback)"); return -1; }
+    if (!js_describe_image(d, &im, ts, (uint32_t)len, scan_start, display, quiet, d->log_fn ? file : nullptr)) { delete ts; js_set_error("image not decodable (see log callback)"); return -1; }
     im.decode_ac = display ? (uint32_t)(d->batch == this ? d->opt_decode_ac : opt_decode_ac) : 0;
     // scan length: up to the first marker that is neither stuffing nor RSTn (what pass 1 of the SOS
     // handler skips over, source/JfifDecode.cpp:5207-5265); bytes past `len` read as zero.

@@ -59,6 +59,7 @@ struct JsnoopDecoder {
     // (:3145-3155), accumulated by every CalcChannelPreview; m_nWarnYccClipNum only restarts in Reset() (:130)
     uint32_t stats[2482]; unsigned warn_ycc_clip; bool hist_latched, clip_latched;
     void stats_pass();
+    unsigned head_events = 0, head_counted = 0;                   // messages of the reader's very first refill (BuffTopup :3019, in front of the heading :3022): how many, how many of them counted
     std::vector<std::pair<int, std::string>> pending_log;          // CapYccRange warnings of the current CalcChannelPreview
     void flush_pending_log();
 };
@@ -163,7 +164,8 @@ void js_debug_cand_links(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32_t n
 #include <rocprofiler-sdk-roctx/roctx.h>
 struct JsRange { explicit JsRange(const char* name) { roctxRangePushA(name); } ~JsRange() { roctxRangePop(); } };
 bool js_geometry(JsnoopDecoder* d, JsImage* im);
-bool js_describe_image(JsnoopDecoder* d, JsImage* im, JsTableSet* ts, uint32_t file_len, uint32_t scan_start, int display, int quiet);
+bool js_describe_image(JsnoopDecoder* d, JsImage* im, JsTableSet* ts, uint32_t file_len, uint32_t scan_start, int display, int quiet, const uint8_t* file = nullptr);
+void js_emit_head_events(JsnoopDecoder* d, const uint8_t* file, size_t len, uint32_t scan_start);      // jsnoop_report.cpp: what the very first refill logs, in front of the heading
 void js_emit_decode_events(JsnoopDecoder* d);                      // jsnoop_report.cpp
 void js_emit_report(JsnoopDecoder* d, bool display, bool quiet);
 void js_build_parallel_luts(JsTableSet* ts, uint32_t ncomp);          // jsnoop_parallel.cpp

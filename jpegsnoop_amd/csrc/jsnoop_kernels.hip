@@ -3458,7 +3458,7 @@ __device__ __forceinline__ uint32_t mirror_to_mcu_top(const JsImage& im, const J
 __global__ void __launch_bounds__(256) k_side_maps(const JsImage* __restrict__ imgs, uint32_t img, const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ raw,
                                                    const uint32_t* __restrict__ seg_tab, const int16_t* __restrict__ dccum, const uint8_t* __restrict__ mcu_rst,
                                                    const uint32_t* __restrict__ mcu_pos, const uint32_t* __restrict__ us_out, uint32_t us_threads,
-                                                   uint32_t* __restrict__ side, uint32_t* __restrict__ events, uint32_t* __restrict__ anoms, uint32_t dead_blk)
+                                                   uint32_t* __restrict__ side, uint32_t* __restrict__ events, uint32_t* __restrict__ anoms, uint32_t dead_blk, uint32_t cut_mcu)
 {
     const JsImage& im = imgs[img];
     uint32_t* sd = side + im.side_off;
@@ -3511,6 +3511,7 @@ __global__ void __launch_bounds__(256) k_side_maps(const JsImage* __restrict__ i
             if (mx >= im.mcu_xmax || my >= im.mcu_ymax) continue;
             const int mi = (int)(my * im.mcu_xmax + mx);
             if (mstar != 0xFFFFFFFFu && (uint32_t)mi > mstar && (mx != 0 || my == mstar / im.mcu_xmax)) continue;     // an MCU the reference never reaches writes nothing
+            if ((uint32_t)mi >= cut_mcu) continue;                                                                     // (MCUs the run-on lane of k_side_chunks writes itself, in the reference's order)
             if (mi > best) { best = mi; best_blk = (uint32_t)mi * im.blk_per_mcu + c; }
         }
         // (a restart handled while block j of the MCU was in progress -- its mark, j + 1 > 1 -- clears the reference's per-MCU array of sums, :3524-3608 /
@@ -3540,12 +3541,14 @@ __global__ void __launch_bounds__(256) k_side_maps(const JsImage* __restrict__ i
 #define SC_HDR 145
 __global__ void __launch_bounds__(64 * SC_WAVES) k_side_chunks(const JsImage* __restrict__ imgs, uint32_t img, const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ raw,
                                                              const uint32_t* __restrict__ seg_tab, const uint8_t* __restrict__ mcu_rst, const uint32_t* __restrict__ mcu_pos,
-                                                             const uint32_t* __restrict__ us_out, uint32_t us_threads, const uint32_t* __restrict__ side,
+                                                             const uint32_t* __restrict__ us_out, uint32_t us_threads, const uint32_t* __restrict__ side, const int16_t* __restrict__ dccum,
                                                              uint32_t ch_mcus, uint32_t nchunks, uint32_t ev_cap, const uint32_t* __restrict__ mcus_left0,
-                                                             uint32_t* __restrict__ recs, uint32_t* __restrict__ map_own, unsigned long long* __restrict__ map_beyond)
+                                                             uint32_t* __restrict__ recs, uint32_t* __restrict__ map_own, unsigned long long* __restrict__ map_beyond,
+                                                             uint32_t run_on_mcu)
 {
     __shared__ uint32_t s_fast[6 * (1 << JS_FAST_BITS)]; __shared__ uint16_t s_q[3 * 64]; __shared__ uint8_t s_zz[64];
     __shared__ uint32_t s_h[SC_WAVES][2 * 4 * 17 + 12]; __shared__ int16_t s_scr[SC_WAVES][64];
+    __shared__ uint32_t s_h2[SC_WAVES][2 * 4 * 17];               // (the histogram at the top of the template MCU of a run of zero bytes, below)
     const JsImage& im = imgs[img];
     const JsTableSet& tset = tables[im.tableset];
     {
@@ -3562,6 +3565,10 @@ __global__ void __launch_bounds__(64 * SC_WAVES) k_side_chunks(const JsImage* __
     const uint32_t* st = seg_tab + im.seg_off;
     const uint32_t m_a = chunk * ch_mcus, m_b = min(m_a + ch_mcus, nmcu);
     uint32_t* rec = recs + (size_t)chunk * (SC_HDR + (size_t)ev_cap * JS_EV_WORDS);
+    // run_on_mcu (none: ~0): the MCU from which the walks do NOT vouch for the stream any more (the image's pixels behind it came from the mirror's
+    // tail take-over).  The lane whose chunk holds it goes on alone to the end of the image; the lanes behind it have nothing to start from.
+    if (m_a > run_on_mcu) { rec[0] = 0xFFFFFFFFu; rec[SC_HDR - 1] = 0; return; }
+    const bool run_on = run_on_mcu != 0xFFFFFFFFu && run_on_mcu < m_b;
     uint32_t* histo = s_h[wv];
     ExactReader tabs; tabs.fast = s_fast; tabs.q = s_q; tabs.zz = s_zz;
     ExactReader r;
@@ -3591,9 +3598,28 @@ __global__ void __launch_bounds__(64 * SC_WAVES) k_side_chunks(const JsImage* __
         r.scan_bad = 0; r.cur_err = 0;
     }
     r.mcus_left = mcus_left0[chunk];
-    const uint32_t rst_count0 = r.rst_count, rst_handled0 = r.rst_handled;
+    const uint32_t rst_count0 = m_a == 0 ? 0u : r.rst_count, rst_handled0 = r.rst_handled;      // (the first chunk's first refill is the reference's own, :3019)
     uint32_t num_pixels = 0, died_at = 0xFFFFFFFFu;
     int16_t dc_y = 0, dc_cb = 0, dc_cr = 0;
+    // The run-on lane also keeps the block-DC maps (:3524-3608) from its chunk on: behind run_on_mcu the restarts were handled by the mirror's tail take-over,
+    // the marks of the walks say nothing about them, and where the reference's decode ends there only this lane finds out -- k_side_maps has left those MCUs
+    // out (its cut), this lane writes its MCUs in the reference's order with the reference's per-MCU array of sums.  Predictors at its first MCU top as in
+    // the tail take-over: the sums the parallel path left for the MCU before, cleared where a restart was followed behind a component's last block.
+    uint32_t* mcu_map_sd = const_cast<uint32_t*>(sd) + JS_SIDE_MCUMAP;
+    const uint32_t nblk = im.blk_xmax * im.blk_ymax, bstride = 2 * ((nblk + 1) / 2);
+    int16_t* bdc0 = reinterpret_cast<int16_t*>(mcu_map_sd + nmcu);
+    __shared__ int16_t s_css[SC_WAVES][3][16];
+    int16_t (*css)[16] = s_css[wv];
+    if (run_on) {
+        for (int cc = 0; cc < 3; cc++) for (int q = 0; q < 16; q++) css[cc][q] = 0;
+        if (m_a) {
+            const uint32_t nb = im.blk_per_mcu, n1 = im.samp_h[1] * im.samp_v[1], n2 = im.ncomp == 3 ? n1 + im.samp_h[2] * im.samp_v[2] : nb;
+            const int16_t* dprev = dccum + im.coef_off + (size_t)(m_a - 1) * nb;
+            dc_y = dprev[n1 - 1]; if (im.ncomp == 3) { dc_cb = dprev[n2 - 1]; dc_cr = dprev[nb - 1]; }
+            const uint32_t rj = mcu_rst[im.mcu_off + m_a - 1u] & 63u;
+            if (rj) { if (n1 < rj) dc_y = 0; if (im.ncomp == 3 && n2 < rj) dc_cb = 0; }
+        }
+    }
     auto one_mcu = [&](uint32_t mi) {                             // the body of DecodeScanImg's MCU loop (:3164-3625), side outputs only
         if (im.rst_en && r.mcus_left == 0 && !r.restart_read) ex_event(r, JS_EV_RST_NOT_DETECTED, r.pos0, r.align);   // :3180-3200
         // PackFileOffset :5104.  Behind its own chunk (a lane that met the end of the decode) the entry is kept per MCU for the EARLIEST chunk that got
@@ -3603,11 +3629,22 @@ __global__ void __launch_bounds__(64 * SC_WAVES) k_side_chunks(const JsImage* __
         const uint32_t mx = mi % xmax, my = mi / xmax;
         for (uint32_t c = 0; c < im.blk_per_mcu; c++) {
             const uint32_t comp = im.blk_comp[c];
-            ex_decode_block(r, comp, im.decode_ac, s_scr[wv], dc_y, dc_cb, dc_cr);
+            const uint32_t rst_before = r.rst_handled;
+            const int16_t d0 = ex_decode_block(r, comp, im.decode_ac, s_scr[wv], dc_y, dc_cb, dc_cr);
+            if (run_on && r.rst_handled != rst_before) for (int cc = 0; cc < 3; cc++) for (int q = 0; q < 16; q++) css[cc][q] = 0;
             if (r.cur_err) {                                      // CheckScanErrors :2605
                 if (r.warn_bad < r.err_max) { ex_event(r, JS_EV_BAD_SCAN_MCU, mx | (my << 16), comp | (im.blk_ch[c] << 8) | (im.blk_cv[c] << 16), r.pos0, r.align); r.warn_bad++; }
                 r.cur_err = 0; }
+            if (run_on) { int16_t* acc = comp == 1 ? &dc_y : comp == 2 ? &dc_cb : &dc_cr; *acc = (int16_t)(*acc + d0); css[comp - 1][im.blk_cv[c] * 4 + im.blk_ch[c]] = *acc; }
             if (comp == 1) num_pixels += 64;
+        }
+        if (run_on) {                                             // per-block cumulative DC maps :3524-3608 (sequential overwrite order preserved)
+            const uint32_t lin = (my * im.expand_v[1]) * im.blk_xmax + mx * im.expand_h[1];
+            for (uint32_t cv = 0; cv < im.samp_v[1]; cv++) for (uint32_t ch = 0; ch < im.samp_h[1]; ch++) { const uint32_t bi = lin + cv * im.blk_xmax + ch; if (bi < nblk) bdc0[bi] = css[0][cv * 4 + ch]; }
+            if (im.ncomp == 3) for (uint32_t comp = 2; comp <= 3; comp++)
+                for (uint32_t cv = 0; cv < im.samp_v[comp]; cv++) for (uint32_t ch = 0; ch < im.samp_h[comp]; ch++) {
+                    const uint32_t bi = (my * im.expand_v[comp] + cv) * im.blk_xmax + (mx * im.expand_h[comp] + ch);
+                    if (bi < nblk) bdc0[(comp - 1) * bstride + bi] = css[comp - 1][cv * 4 + ch]; }
         }
         if (im.rst_en) r.mcus_left--;
     };
@@ -3617,23 +3654,64 @@ __global__ void __launch_bounds__(64 * SC_WAVES) k_side_chunks(const JsImage* __
     }
     if (died_at != 0xFFFFFFFFu)                                   // ... and of every later row the first MCU is all that is reached
         for (uint32_t my = died_at / xmax + 1; my < im.mcu_ymax; my++) one_mcu(my * xmax);
+    else if (run_on) {
+        for (uint32_t mi = m_b; mi < nmcu; mi++) {
+            // Out of file (a truncated picture): every byte the reader will ever load is the zero CwindowBuf::Buf returns past the end (WindowBuf.cpp:639),
+            // its register holds zero bits, nothing is pending -- every further MCU consumes the same bits, logs the same nothing and counts the same code
+            // lengths.  ONE such MCU is decoded; when it left no message its effect is applied to all the MCUs behind it in closed form (positions are
+            // file offsets that go on past the end, one per byte) instead of 0.15 ms of sequential decode each.
+            const bool zero_state = mi + 1 < nmcu && r.buff == 0u && r.ptr >= r.flen && !r.restart_read && !r.scan_end && r.latch == SB_OK &&
+                                    r.err0 == SB_OK && r.err1 == SB_OK && r.err2 == SB_OK && r.err3 == SB_OK && r.num >= 1u;   // (num >= 1: pos0 is the offset of a byte that was loaded)
+            uint32_t ev0 = 0, px0 = 0, p0 = 0; int zs_dc[3] = { 0, 0, 0 };
+            if (zero_state) { ev0 = r.ev[0]; px0 = num_pixels; p0 = r.pos0 * 8u + r.align; zs_dc[0] = dc_y; zs_dc[1] = dc_cb; zs_dc[2] = dc_cr; for (uint32_t i = 0; i < 2 * 4 * 17; i++) s_h2[wv][i] = histo[i]; }
+            one_mcu(mi);
+            if (r.scan_end && r.scan_bad) { died_at = mi; for (uint32_t my = mi / xmax + 1; my < im.mcu_ymax; my++) one_mcu(my * xmax); break; }
+            const uint32_t p1 = r.pos0 * 8u + r.align, rest = nmcu - 1u - mi;
+            if (zero_state && r.ev[0] == ev0 && r.buff == 0u && !r.restart_read && r.latch == SB_OK && r.num >= 1u && p1 > p0 &&
+                !(im.rst_en && r.mcus_left < rest)) {                // (no "restart interval elapsed" message falls into the run either)
+                const uint32_t bits = p1 - p0;
+                for (uint32_t j = 0; j < rest; j++) {
+                    const uint32_t pj = p1 + j * bits;
+                    atomicMin(&map_beyond[mi + 1u + j], ((unsigned long long)chunk << 32) | (((pj >> 3) << 4) + (pj & 7u)));
+                }
+                {   // block-DC maps of the replicated MCUs: every sum moves by its component's step per MCU
+                    const int step[3] = { (int)dc_y - zs_dc[0], (int)dc_cb - zs_dc[1], (int)dc_cr - zs_dc[2] };
+                    for (uint32_t j = 0; j < rest; j++) {
+                        const uint32_t mj = mi + 1u + j, mxj = mj % xmax, myj = mj / xmax; const int k = (int)(j + 1u);
+                        const uint32_t lin = (myj * im.expand_v[1]) * im.blk_xmax + mxj * im.expand_h[1];
+                        for (uint32_t cv = 0; cv < im.samp_v[1]; cv++) for (uint32_t ch = 0; ch < im.samp_h[1]; ch++) { const uint32_t bi = lin + cv * im.blk_xmax + ch; if (bi < nblk) bdc0[bi] = (int16_t)(css[0][cv * 4 + ch] + k * step[0]); }
+                        if (im.ncomp == 3) for (uint32_t comp = 2; comp <= 3; comp++)
+                            for (uint32_t cv = 0; cv < im.samp_v[comp]; cv++) for (uint32_t ch = 0; ch < im.samp_h[comp]; ch++) {
+                                const uint32_t bi = (myj * im.expand_v[comp] + cv) * im.blk_xmax + (mxj * im.expand_h[comp] + ch);
+                                if (bi < nblk) bdc0[(comp - 1) * bstride + bi] = (int16_t)(css[comp - 1][cv * 4 + ch] + k * step[comp - 1]); }
+                    }
+                }
+                for (uint32_t i = 0; i < 2 * 4 * 17; i++) histo[i] += (histo[i] - s_h2[wv][i]) * rest;
+                num_pixels += (num_pixels - px0) * rest;
+                const uint32_t pe = p1 + rest * bits;
+                r.pos0 = pe >> 3; r.align = pe & 7u;
+                if (im.rst_en) r.mcus_left -= rest;
+                break;
+            }
+        }
+    }
     rec[0] = died_at;
     rec[1] = (r.rst_handled != rst_handled0 ? 1u : 0u) | (r.scan_bad ? 2u : 0u) | (r.scan_end ? 4u : 0u);
     rec[2] = r.pos0; rec[3] = r.align; rec[4] = r.rst_count - rst_count0; rec[5] = num_pixels; rec[6] = r.warn_bad; rec[7] = r.warn_marker;
     for (uint32_t i = 0; i < 2 * 4 * 17; i++) rec[8 + i] = histo[i];
 }
 void js_launch_side_chunks(hipStream_t st, const JsImage* imgs, uint32_t img, const JsTableSet* tables, const uint8_t* raw, const uint32_t* seg_tab, const uint8_t* mcu_rst,
-                           const uint32_t* mcu_pos, const uint32_t* us_out, uint32_t us_threads, const uint32_t* side, uint32_t ch_mcus, uint32_t nchunks, uint32_t ev_cap,
-                           const uint32_t* mcus_left0, uint32_t* recs, uint32_t* map_own, unsigned long long* map_beyond)
+                           const uint32_t* mcu_pos, const uint32_t* us_out, uint32_t us_threads, const uint32_t* side, const int16_t* dccum, uint32_t ch_mcus, uint32_t nchunks, uint32_t ev_cap,
+                           const uint32_t* mcus_left0, uint32_t* recs, uint32_t* map_own, unsigned long long* map_beyond, uint32_t run_on_mcu)
 {
     if (!nchunks) return;
-    hipLaunchKernelGGL(k_side_chunks, dim3((nchunks + SC_WAVES - 1) / SC_WAVES), dim3(64 * SC_WAVES), 0, st, imgs, img, tables, raw, seg_tab, mcu_rst, mcu_pos, us_out, us_threads, side,
-                       ch_mcus, nchunks, ev_cap, mcus_left0, recs, map_own, map_beyond);
+    hipLaunchKernelGGL(k_side_chunks, dim3((nchunks + SC_WAVES - 1) / SC_WAVES), dim3(64 * SC_WAVES), 0, st, imgs, img, tables, raw, seg_tab, mcu_rst, mcu_pos, us_out, us_threads, side, dccum,
+                       ch_mcus, nchunks, ev_cap, mcus_left0, recs, map_own, map_beyond, run_on_mcu);
 }
 void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* us_base, const uint32_t* sy_base, uint32_t nimg,
                          uint32_t img, uint32_t us_wg0, uint32_t us_wgs, uint32_t sy_wg0, uint32_t sy_wgs, const JsTableSet* tables, const uint8_t* raw,
                          const uint32_t* chunk_keep, const uint32_t* chunk_rst, const uint8_t* ustr, uint32_t* seg_tab, uint32_t* side, uint32_t* sub, uint64_t nsub,
-                         const int16_t* dccum, uint8_t* mcu_rst, uint32_t* mcu_pos, uint32_t* us_out, uint32_t* events, uint32_t* anoms, uint32_t dead_blk)
+                         const int16_t* dccum, uint8_t* mcu_rst, uint32_t* mcu_pos, uint32_t* us_out, uint32_t* events, uint32_t* anoms, uint32_t dead_blk, uint32_t cut_mcu)
 {
     if (!us_wgs || !sy_wgs) return;
     hipLaunchKernelGGL(k_unstuff_write<false>, dim3(us_wgs), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, const_cast<uint32_t*>(chunk_keep), const_cast<uint32_t*>(chunk_rst), (uint8_t*)nullptr, seg_tab, us_wg0, us_out,
@@ -3648,7 +3726,7 @@ void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab
                        sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, anoms, tab_rows, tab_lut2, sy_wg0, mcu_pos);
     else hipLaunchKernelGGL((k_write<5, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, anoms, tab_rows, tab_lut2, sy_wg0, mcu_pos);
-    hipLaunchKernelGGL(k_side_maps, dim3(64), dim3(256), 0, st, imgs, img, tables, raw, seg_tab, dccum, mcu_rst, mcu_pos, us_out, us_wgs * US_THREADS, side, events, anoms, dead_blk);
+    hipLaunchKernelGGL(k_side_maps, dim3(64), dim3(256), 0, st, imgs, img, tables, raw, seg_tab, dccum, mcu_rst, mcu_pos, us_out, us_wgs * US_THREADS, side, events, anoms, dead_blk, cut_mcu);
 }
 // Tail take-over for image `img` of a decoded batch (see ExactTail): the inverse byte map and the MCU bit positions through the first two
 // kernels of the side pass, then the mirror reader from the MCU that holds the first block the parallel path could not vouch for.

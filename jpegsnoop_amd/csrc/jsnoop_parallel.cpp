@@ -531,8 +531,10 @@ int js_parallel_fixup(JsnoopBatch* b)
     // decode replaced blocks the side walk knows nothing of: the mirror's side-only pass stays theirs.
     b->side_chunk_ok.assign(n, 0);
     for (uint32_t i = 0; i < n; i++) {
-        if (!b->host_flags[i] || b->host_path[i] != 1 || (b->host_flags[i] & (JSNOOP_FLAG_TABLES | JSNOOP_FLAG_NOSYNC | JSNOOP_FLAG_FORCED | JSNOOP_FLAG_MARKER))) continue;
-        if (std::find(tails.begin(), tails.end(), i) != tails.end() || std::find(bad.begin(), bad.end(), i) != bad.end()) continue;
+        if (!b->host_flags[i] || b->host_path[i] != 1 || (b->host_flags[i] & (JSNOOP_FLAG_TABLES | JSNOOP_FLAG_NOSYNC | JSNOOP_FLAG_FORCED))) continue;
+        if (std::find(bad.begin(), bad.end(), i) != bad.end()) continue;
+        if (std::find(tails.begin(), tails.end(), i) != tails.end()) { b->side_chunk_ok[i] = 3; continue; }       // 3: the walks vouch for the MCUs in front of block host_anom[i]; one reader goes on from there
+        if (b->host_flags[i] & JSNOOP_FLAG_MARKER) { if (b->host_anom[i] == 0xFFFFFFFFu && !b->is_helper) b->side_chunk_ok[i] = 4; continue; }   // 4: decoded a second time through its markers -- the helper batch's walks are the ones to ask
         b->side_chunk_ok[i] = dead[i] ? 2 : (!(b->host_flags[i] & ~JS_FLAGS_PIXEL_EXACT) ? 1 : 0);      // (2: host_anom[i] is the block the reference's decode ends in)
     }
     // whole images through the mirror (entropy), then the pixels of everything that changed since the batch's back end ran
@@ -575,7 +577,8 @@ static int js_side_chunked(JsnoopBatch* b, uint32_t i)
     if (b->event_words) HIP_TRY(hipMemsetAsync(b->dev.events + im.ev_off, 0, 4, b->stream));
     js_launch_side_pass(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.us_base, b->dev.sy_base, (uint32_t)b->imgs.size(), i, us0, usn, sy0, syn,
                         b->dev.tables, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst, b->dev.ustr, b->dev.seg, b->dev.side, (uint32_t*)b->dev.sub, b->total_subseq,
-                        b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out, nullptr, nullptr, b->side_chunk_ok[i] == 2 ? b->host_anom[i] : 0xFFFFFFFFu);
+                        b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out, nullptr, nullptr, b->side_chunk_ok[i] == 2 ? b->host_anom[i] : 0xFFFFFFFFu,
+                        b->side_chunk_ok[i] == 3 ? std::min(b->host_anom[i] / im.blk_per_mcu, nmcu - 1) / std::max<uint32_t>(8u, (nmcu + 4095u) / 4096u) * std::max<uint32_t>(8u, (nmcu + 4095u) / 4096u) : 0xFFFFFFFFu);   // (the run-on lane's first MCU)
     // chunks of at least 8 MCUs, at most 4096 of them; a lane keeps the first err_max counted events and some more of the uncounted kinds
     const uint32_t ch = std::max<uint32_t>(8u, (nmcu + 4095u) / 4096u), nchunks = (nmcu + ch - 1) / ch;
     const uint32_t ev_cap = std::min<uint32_t>(im.err_max, 64u) + 64u, stride = JS_SC_HDR + ev_cap * JS_EV_WORDS;
@@ -598,12 +601,14 @@ static int js_side_chunked(JsnoopBatch* b, uint32_t i)
     HIP_TRY(hipMemcpyAsync(left0, left.data(), (size_t)nchunks * 4, hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipMemsetAsync(map_own, 0, (size_t)nmcu * 4, b->stream));
     HIP_TRY(hipMemsetAsync(map_beyond, 0xFF, (size_t)nmcu * 8, b->stream));
-    js_launch_side_chunks(b->stream, b->dev.imgs, i, b->dev.tables, b->dev.raw, b->dev.seg, b->dev.mcu_rst, mcu_pos, us_out, usn * 256u, b->dev.side, ch, nchunks, ev_cap, left0, recs, map_own, map_beyond);
+    const uint32_t run_on = b->side_chunk_ok[i] == 3 ? std::min(b->host_anom[i] / im.blk_per_mcu, nmcu - 1) : 0xFFFFFFFFu;
+    js_launch_side_chunks(b->stream, b->dev.imgs, i, b->dev.tables, b->dev.raw, b->dev.seg, b->dev.mcu_rst, mcu_pos, us_out, usn * 256u, b->dev.side, b->dev.dccum, ch, nchunks, ev_cap, left0, recs, map_own, map_beyond, run_on);
     std::vector<uint32_t> h(bey_at + 2 * (size_t)nmcu);
     if (b->d2h_staged(h.data(), recs, h.size() * 4)) return -1;
     HIP_TRY(hipGetLastError());
-    uint32_t last = nchunks - 1; bool died = false;
-    for (uint32_t c = 0; c < nchunks; c++) if (h[(size_t)c * stride] != 0xFFFFFFFFu) { last = c; died = true; break; }
+    uint32_t last = nchunks - 1; bool died = false;                 // died: one lane went on alone behind its chunk (the end of the decode, or the run-on lane)
+    if (run_on != 0xFFFFFFFFu) { last = run_on / ch; died = true; }
+    for (uint32_t c = 0; c <= last; c++) if (h[(size_t)c * stride] != 0xFFFFFFFFu) { last = c; died = true; break; }
     std::vector<uint32_t>& ev = b->side_events[i]; ev.clear();
     uint32_t sw[16] = { 0 }, histo[2 * 4 * 17] = { 0 }, scan_bad = 0, rst = 0, pix = 0; uint64_t warn = 0;
     for (uint32_t c = 0; c <= last; c++) {
@@ -624,6 +629,34 @@ static int js_side_chunked(JsnoopBatch* b, uint32_t i)
     HIP_TRY(hipMemcpyAsync(sd + JS_SIDE_HISTO, histo, sizeof histo, hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipMemcpyAsync(sd + JS_SIDE_MCUMAP, map.data(), (size_t)nmcu * 4, hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));                     // (the host arrays above are the copies' sources)
+    return 0;
+}
+// An image whose scan was decoded a second time through its markers (js_parallel_fixup: helper batch): the walks that followed the reference are the
+// HELPER's.  The file is decoded there once more (the helper serves one image at a time), its chunked side pass runs on the helper's arenas, and the
+// side block and the messages are carried over.  0 = done, 1 = not representable there (the caller's mirror pass), -1 = error.
+static int js_side_via_helper(JsnoopBatch* b, uint32_t i)
+{
+    const JsImage& im = b->imgs[i];
+    if (!b->helper) {
+        b->helper = new JsnoopBatch(nullptr); b->helper->device = b->device; b->helper->is_helper = true; b->helper->tune = b->tune;
+        if (b->helper->init()) { delete b->helper; b->helper = nullptr; return 1; }
+    }
+    JsnoopBatch* h = b->helper;
+    h->clear(); h->opt_decode_ac = (int)im.decode_ac; h->opt_want_planes = 0; h->opt_force_exact = 0;
+    if (h->add_clone(b, i, true) < 0 || h->upload() || h->decode(false) || h->sync()) return 1;
+    const JsImage& hm = h->imgs[0];
+    if (h->host_path[0] != 1 || (h->host_flags[0] & (JSNOOP_FLAG_TABLES | JSNOOP_FLAG_NOSYNC | JSNOOP_FLAG_FORCED | JSNOOP_FLAG_MARKER)) || hm.total_blocks != im.total_blocks) return 1;
+    const size_t words = js_side_words(hm.mcu_xmax * hm.mcu_ymax, hm.blk_xmax * hm.blk_ymax);
+    HIP_TRY(hipMemsetAsync(h->dev.side + hm.side_off, 0, 8 * 4, h->stream));
+    HIP_TRY(hipMemsetAsync(h->dev.side + hm.side_off + JS_SIDE_HISTO, 0, (words - JS_SIDE_HISTO) * 4, h->stream));
+    if (h->side_events.size() != 1) h->side_events.assign(1, std::vector<uint32_t>());
+    const int rc = js_side_chunked(h, 0);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpyAsync(b->dev.side + im.side_off, h->dev.side + hm.side_off, 8 * 4, hipMemcpyDeviceToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->dev.side + im.side_off + JS_SIDE_HISTO, h->dev.side + hm.side_off + JS_SIDE_HISTO, (words - JS_SIDE_HISTO) * 4, hipMemcpyDeviceToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    b->side_events[i] = h->side_events[0];
     return 0;
 }
 int js_side_only(JsnoopBatch* b, uint32_t i)
@@ -696,7 +729,7 @@ int js_side_only(JsnoopBatch* b, uint32_t i)
     b->side_events[i].clear();
     bool chunked = false;
     if (!parallel && i < b->side_chunk_ok.size() && b->side_chunk_ok[i] && !(b->tune.cross_checks & JSNOOP_XC_SIDE_EXACT)) {
-        const int rc = js_side_chunked(b, i);
+        const int rc = b->side_chunk_ok[i] == 4 ? js_side_via_helper(b, i) : js_side_chunked(b, i);
         if (rc < 0) return -1;
         chunked = rc == 0;
     }

@@ -57,6 +57,29 @@ void emit_event(JsnoopDecoder* d, const JsImage& im, const Ev& e, unsigned& coun
 
 }  // namespace
 
+// What the reader's very first refill logs (DecodeRestartScanBuf + BuffTopup, :3007-3019 -- BEFORE "*** Decoding SCAN Data ***", :3022): BuffAddByte's
+// rules (:1386-1573) over the first bytes of the scan, until the 32-bit register is full or an RSTn is met.  The device readers log the same events
+// first in their lists: js_emit_decode_events leaves those out again.
+void js_emit_head_events(JsnoopDecoder* d, const uint8_t* file, size_t len, uint32_t scan_start)
+{
+    JsImage none{};
+    unsigned count = 0, n = 0; uint32_t ptr = scan_start, vacant = 32;
+    auto byte = [&](uint32_t o) -> uint32_t { return o < len ? file[o] : 0u; };
+    while (vacant >= 8) {
+        const uint32_t b0 = byte(ptr), b1 = byte(ptr + 1);
+        if (b0 == 0xFF && b1 >= 0xD0 && b1 <= 0xD7) {
+            if (b1 - 0xD0 != 0) { Ev e{}; e.kind = JS_EV_RST_INDEX; e.a[0] = 0; e.a[1] = b1 - 0xD0; e.a[2] = ptr; emit_event(d, none, e, count); n++; }     // (RST0 is what the first marker is expected to be, :3013)
+            break;
+        }
+        if (b0 == 0xFF && b1 == 0x00) ptr += 2;
+        else if (b0 == 0xFF && b1 == 0xFF) ptr += 1;
+        else if (b0 == 0xFF) { if (count < d->opt_err_max) { Ev e{}; e.kind = JS_EV_MARKER; e.a[0] = b1; e.a[1] = ptr; emit_event(d, none, e, count); n++; } ptr += 1; }
+        else ptr += 1;
+        vacant -= 8;
+    }
+    d->head_events = n; d->head_counted = count;
+}
+
 // Messages of the decode loop.  Returns after the last of them; the caller adds the report.
 void js_emit_decode_events(JsnoopDecoder* d)
 {
@@ -68,8 +91,8 @@ void js_emit_decode_events(JsnoopDecoder* d)
     // reference's order, each lane's gated by its own count -- the shared counter is applied here
     if (d->last_path == 1 && (size_t)d->img < b->side_mode.size() && b->side_mode[d->img] == 3) {
         const std::vector<uint32_t>& sv = b->side_events[d->img];
-        unsigned cnt = 0;
-        for (size_t k = 0; k + JS_EV_WORDS <= sv.size(); k += JS_EV_WORDS) {
+        unsigned cnt = d->head_counted;                             // (the first refill's messages went out in front of the heading: js_emit_head_events)
+        for (size_t k = (size_t)d->head_events * JS_EV_WORDS; k + JS_EV_WORDS <= sv.size(); k += JS_EV_WORDS) {
             Ev e; e.kind = sv[k]; for (int q = 0; q < 5; q++) e.a[q] = sv[k + 1 + q]; e.order = k;
             const bool counted = e.kind == JS_EV_OVERREAD_BEFORE || e.kind == JS_EV_CANT_FIND || e.kind == JS_EV_MARKER || e.kind == JS_EV_BAD_MARKER ||
                                  e.kind == JS_EV_BAD_HUFF || e.kind == JS_EV_NUMCOEF || e.kind == JS_EV_BAD_SCAN_MCU;
@@ -88,7 +111,7 @@ void js_emit_decode_events(JsnoopDecoder* d)
     // image whose flags are bookkeeping only)
     // ... or the parallel side pass with its overflow records (js_side_only says which of the two produced the side outputs)
     const bool derived = d->last_path == 1 && ((size_t)d->img < b->side_mode.size() && b->side_mode[d->img] ? b->side_mode[d->img] == 1 : d->last_flags == 0);
-    for (uint32_t i = 0; i < n; i++) {
+    for (uint32_t i = derived ? 0u : std::min<uint32_t>(n, d->head_events); i < n; i++) {     // (the mirror's list starts with the first refill's messages: out already)
         Ev e; e.kind = raw[1 + i * JS_EV_WORDS]; for (int k = 0; k < 5; k++) e.a[k] = raw[2 + i * JS_EV_WORDS + k];
         e.order = ((uint64_t)(derived ? nmcu : 0) << 32) | (2u << 28) | i;
         evs.push_back(e);
@@ -147,7 +170,7 @@ void js_emit_decode_events(JsnoopDecoder* d)
         }
         std::stable_sort(evs.begin(), evs.end(), [](const Ev& x, const Ev& y) { return x.order < y.order; });
     }
-    unsigned count = 0;
+    unsigned count = derived ? 0u : d->head_counted;
     for (const Ev& e : evs) {
         // the messages that share the reference's warning counter stop once it has reached nErrMaxDecodeScan (the mirror applies that itself;
         // a merged list -- overflow records, then the markers at the end of the scan, each counted from zero -- gets it here)

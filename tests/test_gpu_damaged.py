@@ -389,8 +389,9 @@ def test_report_of_a_damaged_file_comes_from_chunked_exact_readers(harness, orac
             for em in (20, 2):
                 for b in (oracle, gpu) + ((ref,) if ref else ()):
                     b.set_options(decode_ac=1, err_max=em)
-                harness.drive(gpu, data, quiet=0)                  # (first call: allocations)
-                t = time.perf_counter(); harness.drive(gpu, data, quiet=0); ms = (time.perf_counter() - t) * 1e3
+                q = harness.parse_jpeg(data)                       # (the header walk is the caller's -- Python here -- and not part of the call)
+                harness.drive(gpu, data, q, quiet=0)               # (first call: allocations)
+                t = time.perf_counter(); harness.drive(gpu, data, q, quiet=0); ms = (time.perf_counter() - t) * 1e3
                 got = gpu.log_lines()
                 fl, sm = gpu.lib.jsnoop_last_flags(gpu.h), gpu.lib.jsnoop_last_side_mode(gpu.h)
                 if fl == 0:                                        # (lost bytes may leave a stream that still parses: nothing to report)
@@ -403,7 +404,7 @@ def test_report_of_a_damaged_file_comes_from_chunked_exact_readers(harness, orac
                     want = ref.log_lines()
                     assert got == want, (name, em, next((i, a, b) for i, (a, b) in enumerate(zip(got + [None], want + [None])) if a != b))
                 if sm == 3:
-                    assert ms < 25.0, (name, em, ms)               # decode + side pass + chunked readers + report (typically 3-4 ms)
+                    assert ms < 15.0, (name, em, ms)               # upload + decode + side pass + chunked readers + report (typically 3-4 ms; the mirror: 600-1200)
         assert sum(1 for v in modes.values() if v == 3) >= 2, modes
     finally:
         for b in (oracle, gpu) + ((ref,) if ref else ()):
