@@ -923,7 +923,9 @@ __device__ __forceinline__ void back_end_mcus(const BackEndCtx& C, uint64_t& bri
 
 // The fast layouts (three components, Y un-expanded, Cb and Cr one block each expanded EH x EV): blocks two at a time (idct_pair), decode order
 // kept -- (Y0, Y1), (Y2, Y3), (Cb, Cr) for 4:2:0; a layout with an odd block count leaves half B of its last pair idle.
-template <uint32_t EH, uint32_t EV>
+// HAND: the loop's loads are issued and waited for by inline asm (below) -- the one-layout kernels, whose ISA tools/check_inflight_regs.py can vouch for;
+// the any-layout kernel (four instances of this loop and the general path in one function) leaves its loads and waits to the compiler.
+template <uint32_t EH, uint32_t EV, bool HAND>
 __device__ __forceinline__ void back_end_pairs(const BackEndCtx& C, uint64_t& bright, uint32_t& sum_y)
 {
     const JsImage& im = *C.im;
@@ -966,9 +968,13 @@ __device__ __forceinline__ void back_end_pairs(const BackEndCtx& C, uint64_t& br
     uint32_t voff[np], doff[np];
     #pragma unroll
     for (uint32_t p = 0; p < np; p++) { voff[p] = (live[p] ? lane : l) * 4u; doff[p] = (live[p] ? hi : 0u) * 2u; }
-    auto ld_row = [&](uint32_t p, const uint32_t* base /*wave-uniform*/) { asm volatile("global_load_dword %0, %1, %2" : "+v"(raw[p]) : "v"(voff[p]), "s"(base + p * 64u) : "memory"); };
-    auto ld_dc = [&](uint32_t p, const int16_t* base /*wave-uniform*/) { asm volatile("global_load_sshort %0, %1, %2" : "+v"(dcl[p]) : "v"(doff[p]), "s"(base + 2u * p) : "memory"); };
-#define BK_VM_WAIT(X) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(X) : "n"(2 * np))
+    auto ld_row = [&](uint32_t p, const uint32_t* base /*wave-uniform*/) {
+        if (HAND) asm volatile("global_load_dword %0, %1, %2" : "+v"(raw[p]) : "v"(voff[p]), "s"(base + p * 64u) : "memory");
+        else raw[p] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(base + p * 64u) + voff[p]); };
+    auto ld_dc = [&](uint32_t p, const int16_t* base /*wave-uniform*/) {
+        if (HAND) asm volatile("global_load_sshort %0, %1, %2" : "+v"(dcl[p]) : "v"(doff[p]), "s"(base + 2u * p) : "memory");
+        else dcl[p] = (int)*reinterpret_cast<const int16_t*>(reinterpret_cast<const char*>(base + 2u * p) + doff[p]); };
+#define BK_VM_WAIT(X) do { if (HAND) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(X) : "n"(2 * np)); } while (0)
     // A workgroup owns a CONTIGUOUS range of the image's MCUs and its waves step through it side by side (round 5; before: 8-MCU pieces a whole
     // grid stride apart): what a workgroup reads and writes over time is one sequential stream per MCU row.
     const uint32_t per = (nmcu + C.wgs_in_img - 1u) / C.wgs_in_img, m_begin = C.wg_in_img * per, m_end = min(m_begin + per, nmcu);
@@ -983,7 +989,7 @@ __device__ __forceinline__ void back_end_pairs(const BackEndCtx& C, uint64_t& br
         const int16_t* d16 = C.dccum + coef_off + (size_t)m * nb;
         #pragma unroll
         for (uint32_t p = 0; p < np; p++) { ld_row(p, p32); ld_dc(p, d16); }
-        ld_dc(np - 1u, d16);                                     // (in the DIB store's place: the last DC word once more, into the register it is in flight to)
+        if (HAND) ld_dc(np - 1u, d16);                           // (in the DIB store's place: the last DC word once more, into the register it is in flight to)
     }
     #pragma nounroll
     for (; m < m_end; m += wstride, mx += step_x, my += step_y) {
@@ -1009,8 +1015,10 @@ __device__ __forceinline__ void back_end_pairs(const BackEndCtx& C, uint64_t& br
         mcu_to_dib_fast<EH, EV>(im, img_x, img_y, tile, plane_elems, rs, quads, total, lane, ly0, lq0, my, mx, mw, mh, C.dibp, C.planes, pw, want_planes, bright, best_y, sum_y);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    #pragma unroll
-    for (uint32_t p = 0; p < np; p++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[p]), "+v"(dcl[p]) :: "memory");   // (the last round's fetches land in registers that are free from here on)
+    if (HAND) {
+        #pragma unroll
+        for (uint32_t p = 0; p < np; p++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[p]), "+v"(dcl[p]) :: "memory");   // (the last round's fetches land in registers that are free from here on)
+    }
 #undef BK_VM_WAIT
 }
 
@@ -1053,17 +1061,17 @@ __global__ void __launch_bounds__(BK_THREADS, LAYOUT ? JS_BK_OCC : JS_BK_OCC - 2
 
     uint64_t bright = 0; uint32_t sum_y = 0;
     // the common layouts take the short colour path: Y un-expanded, Cb and Cr one block each, both expanded EH x EV with EH, EV in {1, 2}
-    if (LAYOUT == 1) back_end_pairs<2, 2>(C, bright, sum_y);
-    else if (LAYOUT == 2) back_end_pairs<2, 1>(C, bright, sum_y);
-    else if (LAYOUT == 3) back_end_pairs<1, 2>(C, bright, sum_y);
-    else if (LAYOUT == 4) back_end_pairs<1, 1>(C, bright, sum_y);
+    if (LAYOUT == 1) back_end_pairs<2, 2, true>(C, bright, sum_y);
+    else if (LAYOUT == 2) back_end_pairs<2, 1, true>(C, bright, sum_y);
+    else if (LAYOUT == 3) back_end_pairs<1, 2, true>(C, bright, sum_y);
+    else if (LAYOUT == 4) back_end_pairs<1, 1, true>(C, bright, sum_y);
     else {
         const uint32_t eh = im.expand_h[2], ev = im.expand_v[2];
         const bool fast = js_fast_layout(im);
-        if (fast && eh == 2 && ev == 2) back_end_pairs<2, 2>(C, bright, sum_y);
-        else if (fast && eh == 2) back_end_pairs<2, 1>(C, bright, sum_y);
-        else if (fast && ev == 2) back_end_pairs<1, 2>(C, bright, sum_y);
-        else if (fast) back_end_pairs<1, 1>(C, bright, sum_y);
+        if (fast && eh == 2 && ev == 2) back_end_pairs<2, 2, false>(C, bright, sum_y);
+        else if (fast && eh == 2) back_end_pairs<2, 1, false>(C, bright, sum_y);
+        else if (fast && ev == 2) back_end_pairs<1, 2, false>(C, bright, sum_y);
+        else if (fast) back_end_pairs<1, 1, false>(C, bright, sum_y);
         else back_end_mcus<false, 1, 1>(C, bright, sum_y);
     }
 
