@@ -3552,7 +3552,7 @@ __global__ void __launch_bounds__(64 * SC_WAVES) k_side_chunks(const JsImage* __
                                                              const uint32_t* __restrict__ us_out, uint32_t us_threads, const uint32_t* __restrict__ side, const int16_t* __restrict__ dccum,
                                                              uint32_t ch_mcus, uint32_t nchunks, uint32_t ev_cap, const uint32_t* __restrict__ mcus_left0,
                                                              uint32_t* __restrict__ recs, uint32_t* __restrict__ map_own, unsigned long long* __restrict__ map_beyond,
-                                                             uint32_t run_on_mcu)
+                                                             uint32_t run_on_mcu, uint32_t* __restrict__ fill_desc)
 {
     __shared__ uint32_t s_fast[6 * (1 << JS_FAST_BITS)]; __shared__ uint16_t s_q[3 * 64]; __shared__ uint8_t s_zz[64];
     __shared__ uint32_t s_h[SC_WAVES][2 * 4 * 17 + 12]; __shared__ int16_t s_scr[SC_WAVES][64];
@@ -3675,25 +3675,17 @@ __global__ void __launch_bounds__(64 * SC_WAVES) k_side_chunks(const JsImage* __
             one_mcu(mi);
             if (r.scan_end && r.scan_bad) { died_at = mi; for (uint32_t my = mi / xmax + 1; my < im.mcu_ymax; my++) one_mcu(my * xmax); break; }
             const uint32_t p1 = r.pos0 * 8u + r.align, rest = nmcu - 1u - mi;
-            if (zero_state && r.ev[0] == ev0 && r.buff == 0u && !r.restart_read && r.latch == SB_OK && r.num >= 1u && p1 > p0 &&
-                !(im.rst_en && r.mcus_left < rest)) {                // (no "restart interval elapsed" message falls into the run either)
+            if (zero_state && r.ev[0] == ev0 && r.buff == 0u && !r.restart_read && r.latch == SB_OK && r.num >= 1u && p1 > p0) {
                 const uint32_t bits = p1 - p0;
-                for (uint32_t j = 0; j < rest; j++) {
-                    const uint32_t pj = p1 + j * bits;
-                    atomicMin(&map_beyond[mi + 1u + j], ((unsigned long long)chunk << 32) | (((pj >> 3) << 4) + (pj & 7u)));
-                }
-                {   // block-DC maps of the replicated MCUs: every sum moves by its component's step per MCU
-                    const int step[3] = { (int)dc_y - zs_dc[0], (int)dc_cb - zs_dc[1], (int)dc_cr - zs_dc[2] };
-                    for (uint32_t j = 0; j < rest; j++) {
-                        const uint32_t mj = mi + 1u + j, mxj = mj % xmax, myj = mj / xmax; const int k = (int)(j + 1u);
-                        const uint32_t lin = (myj * im.expand_v[1]) * im.blk_xmax + mxj * im.expand_h[1];
-                        for (uint32_t cv = 0; cv < im.samp_v[1]; cv++) for (uint32_t ch = 0; ch < im.samp_h[1]; ch++) { const uint32_t bi = lin + cv * im.blk_xmax + ch; if (bi < nblk) bdc0[bi] = (int16_t)(css[0][cv * 4 + ch] + k * step[0]); }
-                        if (im.ncomp == 3) for (uint32_t comp = 2; comp <= 3; comp++)
-                            for (uint32_t cv = 0; cv < im.samp_v[comp]; cv++) for (uint32_t ch = 0; ch < im.samp_h[comp]; ch++) {
-                                const uint32_t bi = (myj * im.expand_v[comp] + cv) * im.blk_xmax + (mxj * im.expand_h[comp] + ch);
-                                if (bi < nblk) bdc0[(comp - 1) * bstride + bi] = (int16_t)(css[comp - 1][cv * 4 + ch] + k * step[comp - 1]); }
-                    }
-                }
+                // (the one message that can fall into the run: the restart countdown reaches zero at the top of one of these MCUs, :3180-3200 -- once, it wraps)
+                if (im.rst_en && r.mcus_left < rest) { const uint32_t pz = p1 + r.mcus_left * bits; ex_event(r, JS_EV_RST_NOT_DETECTED, pz >> 3, pz & 7u); }
+                // (the per-MCU part of it -- map entries and block-DC cells of `rest` MCUs -- is k_side_fill's, on the whole chip: one lane took 4-8 ms for
+                //  the 4000 MCUs behind a picture truncated at half its scan)
+                fill_desc[1] = mi; fill_desc[2] = p1; fill_desc[3] = bits; fill_desc[4] = chunk;
+                fill_desc[5] = (uint32_t)((int)dc_y - zs_dc[0]); fill_desc[6] = (uint32_t)((int)dc_cb - zs_dc[1]); fill_desc[7] = (uint32_t)((int)dc_cr - zs_dc[2]);
+                for (int cc = 0; cc < 3; cc++) for (int q = 0; q < 16; q++) fill_desc[8 + cc * 16 + q] = (uint32_t)(int)css[cc][q];
+                __threadfence();
+                fill_desc[0] = 1u;
                 for (uint32_t i = 0; i < 2 * 4 * 17; i++) histo[i] += (histo[i] - s_h2[wv][i]) * rest;
                 num_pixels += (num_pixels - px0) * rest;
                 const uint32_t pe = p1 + rest * bits;
@@ -3708,13 +3700,46 @@ __global__ void __launch_bounds__(64 * SC_WAVES) k_side_chunks(const JsImage* __
     rec[2] = r.pos0; rec[3] = r.align; rec[4] = r.rst_count - rst_count0; rec[5] = num_pixels; rec[6] = r.warn_bad; rec[7] = r.warn_marker;
     for (uint32_t i = 0; i < 2 * 4 * 17; i++) rec[8 + i] = histo[i];
 }
+// The closed form of a run of zero bytes (k_side_chunks, run-on lane), applied: MCU file map entries and block-DC cells of every MCU behind the template MCU.
+// desc: 0 valid, 1 template MCU, 2 bit position behind it, 3 bits per MCU, 4 the lane's chunk, 5..7 step of the three predictors per MCU, 8.. the per-MCU array
+// of sums behind the template.  A cell of the block-DC maps takes the value of the LAST MCU (raster order) that writes it (:3524-3608; neighbouring MCUs' cells overlap).
+__global__ void __launch_bounds__(256) k_side_fill(const JsImage* __restrict__ imgs, uint32_t img, uint32_t* __restrict__ side, unsigned long long* __restrict__ map_beyond,
+                                                   const uint32_t* __restrict__ desc)
+{
+    if (!desc[0]) return;
+    const JsImage& im = imgs[img];
+    const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax, nblk = im.blk_xmax * im.blk_ymax, xmax = im.mcu_xmax, mt = desc[1], p1 = desc[2], bits = desc[3], chunk = desc[4];
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
+    for (uint32_t m = mt + 1 + gid; m < nmcu; m += gsz) {
+        const uint32_t pj = p1 + (m - mt - 1u) * bits;
+        atomicMin(&map_beyond[m], ((unsigned long long)chunk << 32) | (((pj >> 3) << 4) + (pj & 7u)));
+    }
+    uint32_t* mcu_map = side + im.side_off + JS_SIDE_MCUMAP;
+    int16_t* bdc0 = reinterpret_cast<int16_t*>(mcu_map + nmcu);
+    const uint32_t stride = 2 * ((nblk + 1) / 2);
+    for (uint32_t q = gid; q < im.ncomp * nblk; q += gsz) {
+        const uint32_t comp = q / nblk + 1, cell = q % nblk, bx = cell % im.blk_xmax, by = cell / im.blk_xmax;
+        const uint32_t eh = im.expand_h[comp], ev = im.expand_v[comp];
+        int best = -1; uint32_t slot = 0;
+        for (uint32_t cv = 0; cv < im.samp_v[comp]; cv++) for (uint32_t ch = 0; ch < im.samp_h[comp]; ch++) {
+            // MCU (mx, my) writes cell (my * ev' + cv, mx * eh' + ch) of its component: luma through its "corner" (expand bits), chroma through (mcu * expand + index)
+            if (!eh || !ev || bx < ch || by < cv || (bx - ch) % eh || (by - cv) % ev) continue;
+            const uint32_t mx = (bx - ch) / eh, my = (by - cv) / ev;
+            if (mx >= xmax || my >= im.mcu_ymax) continue;
+            const int mi = (int)(my * xmax + mx);
+            if ((uint32_t)mi > mt && mi > best) { best = mi; slot = cv * 4 + ch; }
+        }
+        if (best >= 0) bdc0[(comp - 1) * stride + cell] = (int16_t)((int)desc[8 + (comp - 1) * 16 + slot] + (best - (int)mt) * (int)desc[4 + comp]);
+    }
+}
 void js_launch_side_chunks(hipStream_t st, const JsImage* imgs, uint32_t img, const JsTableSet* tables, const uint8_t* raw, const uint32_t* seg_tab, const uint8_t* mcu_rst,
                            const uint32_t* mcu_pos, const uint32_t* us_out, uint32_t us_threads, const uint32_t* side, const int16_t* dccum, uint32_t ch_mcus, uint32_t nchunks, uint32_t ev_cap,
-                           const uint32_t* mcus_left0, uint32_t* recs, uint32_t* map_own, unsigned long long* map_beyond, uint32_t run_on_mcu)
+                           const uint32_t* mcus_left0, uint32_t* recs, uint32_t* map_own, unsigned long long* map_beyond, uint32_t run_on_mcu, uint32_t* fill_desc)
 {
     if (!nchunks) return;
     hipLaunchKernelGGL(k_side_chunks, dim3((nchunks + SC_WAVES - 1) / SC_WAVES), dim3(64 * SC_WAVES), 0, st, imgs, img, tables, raw, seg_tab, mcu_rst, mcu_pos, us_out, us_threads, side, dccum,
-                       ch_mcus, nchunks, ev_cap, mcus_left0, recs, map_own, map_beyond, run_on_mcu);
+                       ch_mcus, nchunks, ev_cap, mcus_left0, recs, map_own, map_beyond, run_on_mcu, fill_desc);
+    if (run_on_mcu != 0xFFFFFFFFu) hipLaunchKernelGGL(k_side_fill, dim3(128), dim3(256), 0, st, imgs, img, const_cast<uint32_t*>(side), map_beyond, fill_desc);
 }
 void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* us_base, const uint32_t* sy_base, uint32_t nimg,
                          uint32_t img, uint32_t us_wg0, uint32_t us_wgs, uint32_t sy_wg0, uint32_t sy_wgs, const JsTableSet* tables, const uint8_t* raw,

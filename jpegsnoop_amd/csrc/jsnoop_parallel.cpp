@@ -582,7 +582,7 @@ static int js_side_chunked(JsnoopBatch* b, uint32_t i)
     // chunks of at least 8 MCUs, at most 4096 of them; a lane keeps the first err_max counted events and some more of the uncounted kinds
     const uint32_t ch = std::max<uint32_t>(8u, (nmcu + 4095u) / 4096u), nchunks = (nmcu + ch - 1) / ch;
     const uint32_t ev_cap = std::min<uint32_t>(im.err_max, 64u) + 64u, stride = JS_SC_HDR + ev_cap * JS_EV_WORDS;
-    const size_t words = (((size_t)nchunks * stride + nmcu + 1) & ~(size_t)1) + 2 * (size_t)nmcu + nchunks + 64;
+    const size_t words = (((size_t)nchunks * stride + nmcu + 1) & ~(size_t)1) + 2 * (size_t)nmcu + nchunks + 64 + 64;
     if (words * 4 > b->chunk_tmp_cap) {
         if (b->d_chunk_tmp) hipFree(b->d_chunk_tmp);
         b->d_chunk_tmp = nullptr; b->chunk_tmp_cap = 0;
@@ -601,8 +601,10 @@ static int js_side_chunked(JsnoopBatch* b, uint32_t i)
     HIP_TRY(hipMemcpyAsync(left0, left.data(), (size_t)nchunks * 4, hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipMemsetAsync(map_own, 0, (size_t)nmcu * 4, b->stream));
     HIP_TRY(hipMemsetAsync(map_beyond, 0xFF, (size_t)nmcu * 8, b->stream));
+    uint32_t* fill_desc = left0 + nchunks;                          // (the closed form of a run of zero bytes, handed from the run-on lane to k_side_fill)
+    HIP_TRY(hipMemsetAsync(fill_desc, 0, 64 * 4, b->stream));
     const uint32_t run_on = b->side_chunk_ok[i] == 3 ? std::min(b->host_anom[i] / im.blk_per_mcu, nmcu - 1) : 0xFFFFFFFFu;
-    js_launch_side_chunks(b->stream, b->dev.imgs, i, b->dev.tables, b->dev.raw, b->dev.seg, b->dev.mcu_rst, mcu_pos, us_out, usn * 256u, b->dev.side, b->dev.dccum, ch, nchunks, ev_cap, left0, recs, map_own, map_beyond, run_on);
+    js_launch_side_chunks(b->stream, b->dev.imgs, i, b->dev.tables, b->dev.raw, b->dev.seg, b->dev.mcu_rst, mcu_pos, us_out, usn * 256u, b->dev.side, b->dev.dccum, ch, nchunks, ev_cap, left0, recs, map_own, map_beyond, run_on, fill_desc);
     std::vector<uint32_t> h(bey_at + 2 * (size_t)nmcu);
     if (b->d2h_staged(h.data(), recs, h.size() * 4)) return -1;
     HIP_TRY(hipGetLastError());

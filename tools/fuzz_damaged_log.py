@@ -20,7 +20,7 @@ else:
     B = F.bases(H)
 def damage(base):
     p = H.parse_jpeg(base); d = bytearray(base); n = p.scan_end - p.scan_start
-    kind = int(rng.integers(7))
+    kind = int(rng.integers(8))
     i = p.scan_start + int(rng.integers(max(1, n - 64)))
     if kind == 0:
         for _ in range(int(rng.integers(1, 4))): d[p.scan_start + int(rng.integers(n - 2))] ^= 1 << int(rng.integers(8))
@@ -29,7 +29,8 @@ def damage(base):
     elif kind == 3: del d[i:i + int(rng.integers(1, 6))]
     elif kind == 4: d[i:i] = bytes([0xFF, 0xD0 + int(rng.integers(8))])
     elif kind == 5: d[i:i + int(rng.integers(4, 60))] = bytes(int(rng.integers(4, 60)))
-    else: d[i] = int(rng.integers(255))
+    elif kind == 6: d[i] = int(rng.integers(255))
+    else: d = d[:i]                                                                       # truncated (a carved file): the rest reads as zero bytes
     return bytes(d), kind
 modes = collections.Counter(); bad = 0; times = collections.defaultdict(list); checked = 0
 for k in range(n_cases):
