@@ -3489,7 +3489,11 @@ __global__ void __launch_bounds__(256) k_side_maps(const JsImage* __restrict__ i
         bool empty = false;                                         // the previous interval was consumed to its last bit: the register is empty
         if (in && m && m < nmcu && a == 0) { const uint32_t sg = find_interval(st, nseg, ub); empty = sg >= 1 && st[sg] == ub; }
         const bool mirror = in && (m == nmcu || empty);
-        if (in && !mirror) mcu_map[m] = (raw_of_compacted(im, raw, us_out, us_threads, ub) << 4) + a;
+        // (a scan that BEGINS with an RSTn: the very first refill meets the marker and loads nothing, :3007-3019 -- at the top of MCU 0 the register is empty and the
+        //  position array still holds the zeros DecodeRestartScanBuf left, :4038-4075; found by tools/fuzz_gpu.py seed 202 in round 6, wrong since round 1)
+        bool lead_rst = false;
+        if (in && m == 0 && im.scan_start + 1u < im.file_len) { const uint8_t* f = raw + im.file_off + im.scan_start; lead_rst = f[0] == 0xFF && f[1] >= 0xD0 && f[1] <= 0xD7; }
+        if (in && !mirror) mcu_map[m] = lead_rst ? 0u : (raw_of_compacted(im, raw, us_out, us_threads, ub) << 4) + a;
         for (uint64_t todo = WBALLOT(mirror); todo; todo &= todo - 1) {
             if (ln != (uint32_t)__builtin_ctzll(todo)) continue;
             // what an empty register still shows depends on how its last bytes were loaded, and the end of the scan is where the

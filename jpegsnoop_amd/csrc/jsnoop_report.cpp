@@ -125,6 +125,8 @@ void js_emit_decode_events(JsnoopDecoder* d)
         const uint8_t* f = b->pinned + im.file_off;
         uint32_t q = im.scan_start, expect = 0, left = im.rst_interval;
         const uint32_t end = im.scan_start + im.scan_len;
+        // (an RSTn as the scan's first two bytes: met by the very first refill -- its message went out in front of the heading, js_emit_head_events -- and handled inside MCU 0)
+        if (q + 1 < end && f[q] == 0xFF && f[q + 1] >= 0xD0 && f[q + 1] <= 0xD7) { expect = (f[q + 1] - 0xD0u + 1u) & 7u; q += 2; }
         for (uint32_t m = 0; m < nmcu; m++) {
             if (m && rstf[m]) {                                   // the RSTn in front of MCU m
                 while (q + 1 < end && !(f[q] == 0xFF && f[q + 1] >= 0xD0 && f[q + 1] <= 0xD7)) q++;

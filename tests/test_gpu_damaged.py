@@ -411,3 +411,30 @@ def test_report_of_a_damaged_file_comes_from_chunked_exact_readers(harness, orac
             b.set_options()
         if ref is not None:
             ref.close()
+
+
+def test_scan_that_begins_with_a_restart_marker(harness, oracle, gpu):
+    """tools/fuzz_gpu.py seed 202 case 4625 (round 6; wrong MCU file map entry since round 1): an RSTn as the scan's first two bytes.  The reference's very first
+    refill meets the marker and loads nothing (:3007-3019): at the top of MCU 0 its register is empty, the position array holds DecodeRestartScanBuf's zeros
+    (:4038-4075) -- LookupFilePosMcu(0, 0) is 0 --, the marker's index is reported ABOVE the "*** Decoding SCAN Data ***" heading, and the restart is handled
+    inside MCU 0.  No flag is raised (nothing is wrong with the stream the walks see): the parallel side pass has to know."""
+    from fuzz_util import differs
+    ref = harness.ref_backend() if harness.have_ref() else None
+    try:
+        for kw, n in ((dict(width=104, height=64, hs=1, vs=1), 3), (dict(width=160, height=96, hs=2, vs=2), 0), (dict(width=128, height=64, hs=2, vs=1, restart_interval=4), 5)):
+            base = harness.synth_jpeg(seed=91, **kw)
+            p = harness.parse_jpeg(base)
+            d = bytearray(base); d[p.scan_start:p.scan_start] = bytes([0xFF, 0xD0 + n])
+            data = bytes(d)
+            harness.drive(oracle, data)
+            harness.drive(gpu, data, quiet=0)
+            got = gpu.log_lines()
+            assert differs(oracle, gpu) is None, (kw, n)
+            assert int(np.asarray(gpu.mcu_map()).ravel()[0]) == 0
+            if ref is not None:
+                harness.drive(ref, data, quiet=0)
+                want = ref.log_lines()
+                assert got == want, (kw, n, next((i, a, b) for i, (a, b) in enumerate(zip(got + [None], want + [None])) if a != b))
+    finally:
+        if ref is not None:
+            ref.close()

@@ -21,4 +21,9 @@ for k in range(K + 1):
     a, b_ = orc.dib(), gpu.dib()
     w = np.argwhere((a != b_).any(axis=2)) if a is not None and b_ is not None else []
     print("case", k, "mode", mode, "differs", r, "path", gpu.lib.jsnoop_last_path(gpu.h), "flags 0x%04x" % gpu.lib.jsnoop_last_flags(gpu.h), "geom", orc.geometry(), "pixels differing", len(w), "first", w[:3].tolist() if len(w) else [], "status", orc.status())
+    ma, mb = np.asarray(orc.mcu_map()).ravel(), np.asarray(gpu.mcu_map()).ravel()
+    wm = np.nonzero(ma != mb)[0]
+    print("  mcu_map differing", len(wm), "of", len(ma), "first", wm[:8].tolist(), "orc", [hex(int(ma[i])) for i in wm[:8]], "gpu", [hex(int(mb[i])) for i in wm[:8]], "status orc", orc.status(), "gpu", gpu.status(),
+          "side_mode", gpu.lib.jsnoop_last_side_mode(gpu.h) if hasattr(gpu.lib, "jsnoop_last_side_mode") else "?", "rst", getattr(q, "rst_en", None), getattr(q, "rst_interval", None), "scan", q.scan_start)
+    os.makedirs("gpurun_out", exist_ok=True)
     open("gpurun_out/dbg_case_%d_%d.jpg" % (seed, K), "wb").write(data)
