@@ -3553,7 +3553,7 @@ __global__ void __launch_bounds__(256) k_side_maps(const JsImage* __restrict__ i
 #define SC_HDR 145
 __global__ void __launch_bounds__(64 * SC_WAVES) k_side_chunks(const JsImage* __restrict__ imgs, uint32_t img, const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ raw,
                                                              const uint32_t* __restrict__ seg_tab, const uint8_t* __restrict__ mcu_rst, const uint32_t* __restrict__ mcu_pos,
-                                                             const uint32_t* __restrict__ us_out, uint32_t us_threads, const uint32_t* __restrict__ side, const int16_t* __restrict__ dccum,
+                                                             const uint32_t* __restrict__ us_out, uint32_t us_threads, uint32_t* __restrict__ side, const int16_t* __restrict__ dccum,
                                                              uint32_t ch_mcus, uint32_t nchunks, uint32_t ev_cap, const uint32_t* __restrict__ mcus_left0,
                                                              uint32_t* __restrict__ recs, uint32_t* __restrict__ map_own, unsigned long long* __restrict__ map_beyond,
                                                              uint32_t run_on_mcu, uint32_t* __restrict__ fill_desc)
@@ -3617,7 +3617,7 @@ __global__ void __launch_bounds__(64 * SC_WAVES) k_side_chunks(const JsImage* __
     // the marks of the walks say nothing about them, and where the reference's decode ends there only this lane finds out -- k_side_maps has left those MCUs
     // out (its cut), this lane writes its MCUs in the reference's order with the reference's per-MCU array of sums.  Predictors at its first MCU top as in
     // the tail take-over: the sums the parallel path left for the MCU before, cleared where a restart was followed behind a component's last block.
-    uint32_t* mcu_map_sd = const_cast<uint32_t*>(sd) + JS_SIDE_MCUMAP;
+    uint32_t* mcu_map_sd = side + im.side_off + JS_SIDE_MCUMAP;
     const uint32_t nblk = im.blk_xmax * im.blk_ymax, bstride = 2 * ((nblk + 1) / 2);
     int16_t* bdc0 = reinterpret_cast<int16_t*>(mcu_map_sd + nmcu);
     __shared__ int16_t s_css[SC_WAVES][3][16];
@@ -3737,13 +3737,13 @@ __global__ void __launch_bounds__(256) k_side_fill(const JsImage* __restrict__ i
     }
 }
 void js_launch_side_chunks(hipStream_t st, const JsImage* imgs, uint32_t img, const JsTableSet* tables, const uint8_t* raw, const uint32_t* seg_tab, const uint8_t* mcu_rst,
-                           const uint32_t* mcu_pos, const uint32_t* us_out, uint32_t us_threads, const uint32_t* side, const int16_t* dccum, uint32_t ch_mcus, uint32_t nchunks, uint32_t ev_cap,
+                           const uint32_t* mcu_pos, const uint32_t* us_out, uint32_t us_threads, uint32_t* side, const int16_t* dccum, uint32_t ch_mcus, uint32_t nchunks, uint32_t ev_cap,
                            const uint32_t* mcus_left0, uint32_t* recs, uint32_t* map_own, unsigned long long* map_beyond, uint32_t run_on_mcu, uint32_t* fill_desc)
 {
     if (!nchunks) return;
     hipLaunchKernelGGL(k_side_chunks, dim3((nchunks + SC_WAVES - 1) / SC_WAVES), dim3(64 * SC_WAVES), 0, st, imgs, img, tables, raw, seg_tab, mcu_rst, mcu_pos, us_out, us_threads, side, dccum,
                        ch_mcus, nchunks, ev_cap, mcus_left0, recs, map_own, map_beyond, run_on_mcu, fill_desc);
-    if (run_on_mcu != 0xFFFFFFFFu) hipLaunchKernelGGL(k_side_fill, dim3(128), dim3(256), 0, st, imgs, img, const_cast<uint32_t*>(side), map_beyond, fill_desc);
+    if (run_on_mcu != 0xFFFFFFFFu) hipLaunchKernelGGL(k_side_fill, dim3(128), dim3(256), 0, st, imgs, img, side, map_beyond, fill_desc);
 }
 void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* us_base, const uint32_t* sy_base, uint32_t nimg,
                          uint32_t img, uint32_t us_wg0, uint32_t us_wgs, uint32_t sy_wg0, uint32_t sy_wgs, const JsTableSet* tables, const uint8_t* raw,

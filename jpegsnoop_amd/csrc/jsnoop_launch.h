@@ -57,7 +57,7 @@ void js_launch_dc_scan(hipStream_t st, const JsImage* imgs, uint32_t nimg, const
 #define JS_US_CHUNK 4096
 #define JS_SC_HDR 145                 // words of a chunk record in front of its events (k_side_chunks)
 void js_launch_side_chunks(hipStream_t st, const JsImage* imgs, uint32_t img, const JsTableSet* tables, const uint8_t* raw, const uint32_t* seg_tab, const uint8_t* mcu_rst,
-                           const uint32_t* mcu_pos, const uint32_t* us_out, uint32_t us_threads, const uint32_t* side, const int16_t* dccum, uint32_t ch_mcus, uint32_t nchunks, uint32_t ev_cap,
+                           const uint32_t* mcu_pos, const uint32_t* us_out, uint32_t us_threads, uint32_t* side, const int16_t* dccum, uint32_t ch_mcus, uint32_t nchunks, uint32_t ev_cap,
                            const uint32_t* mcus_left0, uint32_t* recs, uint32_t* map_own, unsigned long long* map_beyond, uint32_t run_on_mcu /*~0: none*/, uint32_t* fill_desc /*64 words, zeroed*/);
 void js_launch_tail_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* us_base, const uint32_t* sy_base, uint32_t nimg,
                          uint32_t us_wg0, uint32_t us_wgs, uint32_t sy_wg0, uint32_t sy_wgs, const JsTableSet* tables, const uint8_t* raw,

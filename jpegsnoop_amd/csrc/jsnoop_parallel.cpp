@@ -419,6 +419,16 @@ int js_read_flags(JsnoopBatch* b)
     return 0;
 }
 
+// The private one-image batch a flagged image is decoded in a second time (through the markers of its scan): created on first use, on the batch's device.
+// (A helper that cannot be set up costs the image its short cut, not the batch its result: nullptr.)
+static JsnoopBatch* js_helper_batch(JsnoopBatch* b)
+{
+    if (!b->helper) {
+        b->helper = new JsnoopBatch(nullptr); b->helper->device = b->device; b->helper->is_helper = true; b->helper->tune = b->tune;
+        if (b->helper->init()) { delete b->helper; b->helper = nullptr; }
+    }
+    return b->helper;
+}
 int js_parallel_fixup(JsnoopBatch* b)
 {
     const uint32_t n = (uint32_t)b->imgs.size();
@@ -474,11 +484,8 @@ int js_parallel_fixup(JsnoopBatch* b)
         if ((uint64_t)im.scan_start + im.scan_len + 2 > im.file_len || !b->tables[im.tableset].lut_ok) continue;      // the data really ends with the file
         // (a helper that cannot be set up, or whose decode fails, costs the image its short cut, not the batch its result: the image keeps
         //  its flags and goes through the mirror below)
-        if (!b->helper) {
-            b->helper = new JsnoopBatch(nullptr); b->helper->device = b->device; b->helper->is_helper = true; b->helper->tune = b->tune;
-            if (b->helper->init()) { delete b->helper; b->helper = nullptr; break; }
-        }
-        JsnoopBatch* h = b->helper;
+        JsnoopBatch* h = js_helper_batch(b);
+        if (!h) break;
         h->clear(); h->opt_decode_ac = (int)im.decode_ac; h->opt_want_planes = 0; h->opt_force_exact = 0;
         if (h->add_clone(b, i, true) < 0 || h->upload() || h->decode(false) || h->sync()) continue;
         const JsImage& hm = h->imgs[0];
@@ -575,12 +582,15 @@ static int js_side_chunked(JsnoopBatch* b, uint32_t i)
     if (js_side_scratch(b, i, &mcu_pos, &us_out)) return -1;
     HIP_TRY(hipMemsetAsync(mcu_pos, 0, ((size_t)nmcu + 1) * 4, b->stream));
     if (b->event_words) HIP_TRY(hipMemsetAsync(b->dev.events + im.ev_off, 0, 4, b->stream));
-    js_launch_side_pass(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.us_base, b->dev.sy_base, (uint32_t)b->imgs.size(), i, us0, usn, sy0, syn,
-                        b->dev.tables, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst, b->dev.ustr, b->dev.seg, b->dev.side, (uint32_t*)b->dev.sub, b->total_subseq,
-                        b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out, nullptr, nullptr, b->side_chunk_ok[i] == 2 ? b->host_anom[i] : 0xFFFFFFFFu,
-                        b->side_chunk_ok[i] == 3 ? std::min(b->host_anom[i] / im.blk_per_mcu, nmcu - 1) / std::max<uint32_t>(8u, (nmcu + 4095u) / 4096u) * std::max<uint32_t>(8u, (nmcu + 4095u) / 4096u) : 0xFFFFFFFFu);   // (the run-on lane's first MCU)
     // chunks of at least 8 MCUs, at most 4096 of them; a lane keeps the first err_max counted events and some more of the uncounted kinds
     const uint32_t ch = std::max<uint32_t>(8u, (nmcu + 4095u) / 4096u), nchunks = (nmcu + ch - 1) / ch;
+    // run_on: the MCU from which the walks do not vouch for the stream (a tail take-over): the lane of its chunk goes on alone -- and keeps the block-DC maps from its
+    // chunk's first MCU on, which k_side_maps therefore leaves out (cut)
+    const uint32_t run_on = b->side_chunk_ok[i] == 3 ? std::min(b->host_anom[i] / im.blk_per_mcu, nmcu - 1) : 0xFFFFFFFFu;
+    const uint32_t cut = run_on == 0xFFFFFFFFu ? 0xFFFFFFFFu : run_on / ch * ch;
+    js_launch_side_pass(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.us_base, b->dev.sy_base, (uint32_t)b->imgs.size(), i, us0, usn, sy0, syn,
+                        b->dev.tables, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst, b->dev.ustr, b->dev.seg, b->dev.side, (uint32_t*)b->dev.sub, b->total_subseq,
+                        b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out, nullptr, nullptr, b->side_chunk_ok[i] == 2 ? b->host_anom[i] : 0xFFFFFFFFu, cut);
     const uint32_t ev_cap = std::min<uint32_t>(im.err_max, 64u) + 64u, stride = JS_SC_HDR + ev_cap * JS_EV_WORDS;
     const size_t words = (((size_t)nchunks * stride + nmcu + 1) & ~(size_t)1) + 2 * (size_t)nmcu + nchunks + 64 + 64;
     if (words * 4 > b->chunk_tmp_cap) {
@@ -603,7 +613,6 @@ static int js_side_chunked(JsnoopBatch* b, uint32_t i)
     HIP_TRY(hipMemsetAsync(map_beyond, 0xFF, (size_t)nmcu * 8, b->stream));
     uint32_t* fill_desc = left0 + nchunks;                          // (the closed form of a run of zero bytes, handed from the run-on lane to k_side_fill)
     HIP_TRY(hipMemsetAsync(fill_desc, 0, 64 * 4, b->stream));
-    const uint32_t run_on = b->side_chunk_ok[i] == 3 ? std::min(b->host_anom[i] / im.blk_per_mcu, nmcu - 1) : 0xFFFFFFFFu;
     js_launch_side_chunks(b->stream, b->dev.imgs, i, b->dev.tables, b->dev.raw, b->dev.seg, b->dev.mcu_rst, mcu_pos, us_out, usn * 256u, b->dev.side, b->dev.dccum, ch, nchunks, ev_cap, left0, recs, map_own, map_beyond, run_on, fill_desc);
     std::vector<uint32_t> h(bey_at + 2 * (size_t)nmcu);
     if (b->d2h_staged(h.data(), recs, h.size() * 4)) return -1;
@@ -639,11 +648,8 @@ static int js_side_chunked(JsnoopBatch* b, uint32_t i)
 static int js_side_via_helper(JsnoopBatch* b, uint32_t i)
 {
     const JsImage& im = b->imgs[i];
-    if (!b->helper) {
-        b->helper = new JsnoopBatch(nullptr); b->helper->device = b->device; b->helper->is_helper = true; b->helper->tune = b->tune;
-        if (b->helper->init()) { delete b->helper; b->helper = nullptr; return 1; }
-    }
-    JsnoopBatch* h = b->helper;
+    JsnoopBatch* h = js_helper_batch(b);
+    if (!h) return 1;
     h->clear(); h->opt_decode_ac = (int)im.decode_ac; h->opt_want_planes = 0; h->opt_force_exact = 0;
     if (h->add_clone(b, i, true) < 0 || h->upload() || h->decode(false) || h->sync()) return 1;
     const JsImage& hm = h->imgs[0];
@@ -698,6 +704,10 @@ int js_side_only(JsnoopBatch* b, uint32_t i)
             std::sort(order.begin(), order.end());
             uint32_t sdw[16];
             if (ok && b->d2h_staged(sdw, b->dev.side + im.side_off, sizeof sdw)) return -1;
+            // An overflow within the last bytes of the scan: the reader's look-ahead (up to four bytes, :1292-1323) has met the marker behind the scan BEFORE
+            // that symbol is decoded -- "Scan Data encountered marker" comes first and may use up the warning budget (tools/fuzz_damaged_log.py seed 303 case 2893).
+            // Which of the two is logged first is the exact reader's to say: the chunked pass below.
+            for (uint32_t k = 0; ok && k < cnt; k++) if ((uint64_t)rec[4 + 4 * k + 1] + 40u >= (uint64_t)sdw[10] * 8u) ok = false;
             if (ok && sdw[11] > 1) {                                           // restart intervals: refuse block ends that sit on an interval boundary
                 const uint32_t nseg = std::min<uint32_t>(sdw[11], im.seg_cap - 1);
                 std::vector<uint32_t> st(nseg + 1);
