@@ -1076,6 +1076,8 @@ int jsnoop_batch_log(JsnoopBatch* b, int i, int histo_en, int stat_clip_en, int 
     const bool display = v.preview_is_jpeg;
     if (display && !b->opt_want_planes && (im.ncomp == 3 || histo_en || stat_clip_en)) { js_set_error("jsnoop_batch_log: the report quotes plane samples (want_planes)"); return -1; }
     v.log_fn = fn; v.log_user = user;
+    v.opt_err_max = im.err_max;
+    js_emit_head_events(&v, b->pinned + im.file_off, im.file_len, im.scan_start);       // what the reader's first refill logs goes out in front of the heading (:3007-3022)
     if (!quiet) {                                                   // the lines DecodeScanImg writes before its MCU loop (:3021-3025, :3126-3135)
         v.log(0, "*** Decoding SCAN Data ***"); v.log(0, "  OFFSET: 0x%08X", im.scan_start);
         if (display && im.decode_ac) v.log(0, "  Scan Decode Mode: Full IDCT (AC + DC)");

@@ -704,15 +704,20 @@ int js_side_only(JsnoopBatch* b, uint32_t i)
             std::sort(order.begin(), order.end());
             uint32_t sdw[16];
             if (ok && b->d2h_staged(sdw, b->dev.side + im.side_off, sizeof sdw)) return -1;
-            // An overflow within the last bytes of the scan: the reader's look-ahead (up to four bytes, :1292-1323) has met the marker behind the scan BEFORE
-            // that symbol is decoded -- "Scan Data encountered marker" comes first and may use up the warning budget (tools/fuzz_damaged_log.py seed 303 case 2893).
-            // Which of the two is logged first is the exact reader's to say: the chunked pass below.
+            // An overflow within the reader's look-ahead (up to four bytes, :1292-1323) of the end of its restart interval / of the scan: the marker behind it has been MET
+            // before that symbol is decoded -- "Expected RST marker index ..." / "Scan Data encountered marker" come first, and the latter may use up the warning budget
+            // (tools/fuzz_damaged_log.py seed 303 case 2893, seeds 401 / 405).  Which is logged first is the exact reader's to say: the chunked pass below.
             for (uint32_t k = 0; ok && k < cnt; k++) if ((uint64_t)rec[4 + 4 * k + 1] + 40u >= (uint64_t)sdw[10] * 8u) ok = false;
-            if (ok && sdw[11] > 1) {                                           // restart intervals: refuse block ends that sit on an interval boundary
+            if (ok && sdw[11] > 1) {                                           // restart intervals: the same at every interval's end; and block ends that sit on an interval boundary
                 const uint32_t nseg = std::min<uint32_t>(sdw[11], im.seg_cap - 1);
                 std::vector<uint32_t> st(nseg + 1);
                 if (b->d2h_staged(st.data(), b->dev.seg + im.seg_off, st.size() * 4)) return -1;
-                for (auto& o : order) { const uint32_t pe = rec[4 + 4 * o.second + 3]; if (!(pe & 7u) && std::binary_search(st.begin(), st.end(), pe >> 3)) ok = false; }
+                for (auto& o : order) {
+                    const uint32_t ps = rec[4 + 4 * o.second + 1], pe = rec[4 + 4 * o.second + 3];
+                    if (!(pe & 7u) && std::binary_search(st.begin(), st.end(), pe >> 3)) ok = false;
+                    const size_t sg = (size_t)(std::upper_bound(st.begin(), st.end(), ps >> 3) - st.begin());      // first interval start behind the symbol's byte
+                    if (sg < st.size() && (uint64_t)ps + 40u >= (uint64_t)st[sg] * 8u) ok = false;
+                }
             }
             if (ok) {
                 std::vector<uint32_t>& out = b->side_anoms[i];

@@ -86,3 +86,16 @@ def test_the_committed_header_is_the_generators_output(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen", "gen_pair_round.py"), str(out)],
                           env={k: v for k, v in os.environ.items() if not k.startswith("GEN_")})
     assert out.read_text() == open(HDR).read()
+
+
+def test_no_instruction_of_the_built_back_end_copies_a_register_in_flight():
+    """The one-layout back-end kernels issue their row / DC loads by inline asm and wait for them by hand (back_end_pairs): the compiler does not know those
+    registers are in flight.  tools/check_inflight_regs.py compiles the kernels to assembly (hipcc cross-compiles without a GPU) and lists every instruction
+    that reads a register the MCU loop's loads write: only the mask (v_and_b32) and the DC add (v_add_u32) may -- a copy would read it before the data lands."""
+    import shutil
+    import pytest
+    if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+        pytest.skip("no hipcc")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_inflight_regs.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and out.count("-> ok") == 4, out
