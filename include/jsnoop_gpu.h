@@ -252,7 +252,8 @@ typedef struct JsnoopTuning {
     int32_t  cand_rounds;     /* synchronisation form: -1 = rounds of k_sync only, n > 0 = candidates with at most n walk rounds (<= 64),
                                  0 = automatic (candidates with 16 rounds while the job is small enough, see cand_max_walks)          */
     uint64_t cand_max_walks;  /* largest job (64-byte pieces x blocks per MCU) that synchronises by candidates; 0 = 4 500 000         */
-    int32_t  sync_launches;   /* launches of k_sync in the classic form; 0 = 2                                                        */
+    int32_t  sync_launches;   /* synchronisation by rounds: n > 0 = n launches of k_sync; 0 = automatic (2; a large job -- 96 MB of scan
+                                 data and more -- runs one cut launch and list rounds over the whole job instead)                     */
     int32_t  write_lanes;     /* lanes per sub-sequence in the write pass of the smallest jobs: 1, 2; 0 = automatic (2 up to 40 960 pieces) */
     int32_t  split;           /* as jsnoop_batch_set_split: 0 automatic, 1 one stream, 2 two streams                                  */
     int32_t  mcus_per_wave;   /* MCUs per back-end wave; 0 = one round of workgroups over the chip, at most 64                        */
@@ -266,6 +267,7 @@ typedef struct JsnoopTuning {
 #define JSNOOP_XC_SIDE_EXACT      0x08u  /* side outputs always from the exact-mirror reader                                          */
 #define JSNOOP_XC_CAND_VERIFY     0x10u  /* k_sync's verification mode behind every candidate chain                                   */
 #define JSNOOP_XC_UNSTUFF_3PASS   0x20u  /* un-stuffing as count / scan / write passes instead of the fused look-back pass            */
+#define JSNOOP_XC_SYNC_ROUNDS     0x40u  /* the list rounds of the large-job synchronisation for every job that synchronises by rounds */
 #define JSNOOP_DBG_CAND           0x01u  /* candidate chain: rounds, queued walks                                                     */
 #define JSNOOP_DBG_CAND_LINKS     0x02u  /* ... and the links left open per image (stops the stream)                                  */
 #define JSNOOP_DBG_TAIL           0x04u  /* damaged files: tail take-over decisions                                                   */

@@ -182,7 +182,7 @@ const JsnoopTuning& js_env_tuning()
         { const long long v = num("JSNOOP_PG_LANES", 0); t.pg_lanes = (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 64) ? (int32_t)v : 0; }
         t.cross_checks = (on("JSNOOP_BACKEND_GENERIC") ? JSNOOP_XC_BACKEND_GENERIC : 0u) | (on("JSNOOP_WRITE_V1") ? JSNOOP_XC_WRITE_V1 : 0u) | (on("JSNOOP_NO_TAIL") ? JSNOOP_XC_NO_TAIL : 0u) |
                          (on("JSNOOP_SIDE_EXACT") ? JSNOOP_XC_SIDE_EXACT : 0u) | (on("JSNOOP_CAND_VERIFY") ? JSNOOP_XC_CAND_VERIFY : 0u) |
-                         (on("JSNOOP_UNSTUFF_3PASS") ? JSNOOP_XC_UNSTUFF_3PASS : 0u);
+                         (on("JSNOOP_UNSTUFF_3PASS") ? JSNOOP_XC_UNSTUFF_3PASS : 0u) | (on("JSNOOP_SYNC_ROUNDS") ? JSNOOP_XC_SYNC_ROUNDS : 0u);
         const long long dc = num("JSNOOP_DEBUG_CAND", 0);
         t.debug = (dc >= 1 ? JSNOOP_DBG_CAND : 0u) | (dc >= 2 ? JSNOOP_DBG_CAND_LINKS : 0u) | (on("JSNOOP_DEBUG_TAIL") ? JSNOOP_DBG_TAIL : 0u) | (on("JSNOOP_DEBUG_TIMING") ? JSNOOP_DBG_TIMING : 0u);
         // the same limits as js_check_tuning: a preset out of range falls back to "automatic" (every later set_tuning writes the whole struct back and
@@ -230,7 +230,7 @@ JsnoopBatch::JsnoopBatch(void* user_stream)
     stream = (hipStream_t)user_stream; own_stream = false; device = g_device;
     opt_decode_ac = 1; opt_want_planes = 0; opt_force_exact = 0;
     memset(&dev, 0, sizeof dev); memset(&cap, 0, sizeof cap);
-    pinned = nullptr; pinned_cap = 0; raw_bytes = 0; uploaded = false; sync_launches = 2;
+    pinned = nullptr; pinned_cap = 0; raw_bytes = 0; uploaded = false; sync_launches = 2; sync_rounds = 0;
     tune = js_env_tuning();
     for (auto& e : ev) e = nullptr;
     for (auto& e : ev2) e = nullptr;
@@ -445,6 +445,9 @@ int JsnoopBatch::upload()
     if (cand_fits) sub_wl = 4;
     if (tune.sub_wl) sub_wl = tune.sub_wl;
     sync_launches = tune.sync_launches > 0 ? tune.sync_launches : 2;
+    // The large-job form of the classic synchronisation (js_launch_sync_rounds: k_sync cut after two rounds, then list rounds over the whole job) unless the tuning
+    // struct asks for a number of plain k_sync launches: from ~200 1080p images on the workgroups of k_sync come in more than one round over the chip.
+    sync_rounds = (tune.sync_launches == 0 && !(cand_fits && sub_wl == 4) && (scan_total >= (96ull << 20) || (tune.cross_checks & JSNOOP_XC_SYNC_ROUNDS))) ? JS_SYR_ROUNDS : 0;
     const uint32_t sub_bytes = 4u << sub_wl;
     uint32_t wgs = 0; max_mcu_h = 8; max_mcu_w = 8;
     for (size_t i = 0; i < n; i++) {
@@ -474,7 +477,7 @@ int JsnoopBatch::upload()
         grow(&dev.dib, &cap.dib, dibb) || grow(&dev.side, &cap.side, side * 4) || grow(&dev.imgs, &cap.imgs, n * sizeof(JsImage)) ||
         grow(&dev.tables, &cap.tables, tables.size() * sizeof(JsTableSet)) || grow(&dev.wg_base, &cap.wg_base, (n + 1) * 4) ||
         grow(&dev.sel, &cap.sel, n * 4) || grow(&dev.sums, &cap.sums, n * 8) || grow(&dev.ustr, &cap.ustr, ustr + 64) ||
-        grow(&dev.sub, &cap.sub, subs * 24 + 64) || grow(&dev.probe, &cap.probe, 1024) || grow(&dev.seg, &cap.seg, segw * 4 + 64) ||
+        grow(&dev.sub, &cap.sub, subs * 24 + 64 + js_sync_list_words(subs, (uint32_t)n) * 4) || grow(&dev.probe, &cap.probe, 1024) || grow(&dev.seg, &cap.seg, segw * 4 + 64) ||
         grow(&dev.chunk_keep, &cap.chunk_keep, (size_t)usc * 4 + 64) || grow(&dev.chunk_rst, &cap.chunk_rst, (size_t)usc * 4 + 64) ||
         grow(&dev.us_base, &cap.us_base, 2 * (n + 1) * 4) || grow(&dev.sy_base, &cap.sy_base, 2 * (n + 1) * 4) ||
         grow(&dev.mcu_rst, &cap.mcu_rst, mcub + 64) || grow(&dev.dc_parts, &cap.dc_parts, JS_DC_PARTS_BYTES) || grow(&dev.ustr_lin, &cap.ustr_lin, ustr + 64) || grow(&dev.flags, &cap.flags, n * 8 + 64) ||

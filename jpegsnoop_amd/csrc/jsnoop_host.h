@@ -112,6 +112,7 @@ struct JsnoopBatch {
     // small jobs (64-byte sub-sequences, a few hundred thousand walks at most) synchronise by candidates (k_cand_*) instead of k_sync's rounds: cand_rounds
     // = fill rounds of the chain, -1 = off (JSNOOP_CAND=0, more than JS_CAND_MAX_BLK blocks per MCU, a larger job); cand_blk = most blocks per MCU in the batch
     int cand_rounds = -1; uint32_t cand_blk = 0; bool cand_half = false;   // cand_half: the smallest jobs (one large image, a handful) also run the write pass with two lanes per sub-sequence
+    int sync_rounds;                 // > 0: js_launch_sync_rounds with that many list rounds (large jobs), else sync_launches launches of k_sync
     int sync_launches; int sub_wl;   // log2(words per sub-sequence): 4 / 5 / 7 = 64- / 128- / 512-byte sub-sequences (chosen per batch; 6 and 8 through the tuning struct)
     uint32_t tab_rows, tab_lut2, tab_rows_w;     // largest decode-table footprint in the batch (sizes the kernels' LDS); _w: DC rows | AC rows << 8
     hipEvent_t ev[JSNOOP_NUM_STAGES + 1];

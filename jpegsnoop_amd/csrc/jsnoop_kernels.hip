@@ -1916,21 +1916,29 @@ __device__ __forceinline__ void load_wtabs(WriteTabs& W, uint8_t* lds, const JsT
     W.wb0 = off[0] | (off[1] << 16); W.wb1 = off[2] | (off[3] << 16); W.wb2 = off[4] | (off[5] << 16);
 }
 
+// PAIRS (every user today: k_sync and the candidate kernels): LDS holds the state-only pair rows and their second level ONLY -- 2 KiB per row.  The single-symbol
+// tables (lut1 / lut2) are read where the batch's table sets lie in global memory: only walk_sync's careful step (an interval ends, a code matches nothing)
+// looks there, once per restart interval or so.  Round 6: a k_sync workgroup is a chain of ~2900 dependent steps (one workgroup alone on the chip 0.65 ms,
+// seven per CU 0.79 ms each: the kernel is the number of workgroup rounds times that latency, profiles/r06_experiments.txt 16); without the 5.4 KiB of tables
+// nothing reads in the common step ten workgroups fit a CU where seven did.
 template <bool PAIRS>
 __device__ __forceinline__ void load_subtabs(SubTabs& T, uint8_t* lds, const JsImage& im, const JsTableSet& ts, uint32_t tab_rows, uint32_t tab_lut2,
                                              uint32_t tid, uint32_t nthreads)
 {
-    uint16_t* l1 = reinterpret_cast<uint16_t*>(lds);
-    uint16_t* l2 = l1 + (size_t)tab_rows * (1u << JS_L1_BITS);
-    uint32_t* q = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(l2) + (((size_t)tab_lut2 * 2 + 15) & ~15ull));
-    const uint32_t* src1 = reinterpret_cast<const uint32_t*>(&ts.lut1[0][0]);
-    uint32_t* dst1 = reinterpret_cast<uint32_t*>(l1);
-    for (uint32_t i = tid; i < ts.n_rows * (1u << JS_L1_BITS) / 2; i += nthreads) dst1[i] = src1[i];
-    for (uint32_t i = tid; i < ts.lut2_used; i += nthreads) l2[i] = ts.lut2[i];
-    for (uint32_t i = tid; i < 3 * 64; i += nthreads) q[i] = (uint32_t)(&ts.qzz[0][0])[i] | ((uint32_t)c_zigzag[i & 63u] << 16);
-    T.lut1 = l1; T.lut2 = l2; T.qz = q; T.lutp = nullptr; T.lut2p = nullptr; T.rb0 = T.rb1 = T.rb2 = 0;
-    if (PAIRS) {
-        uint32_t* lp = q + 3 * 64;
+    T.lutp = nullptr; T.lut2p = nullptr; T.rb0 = T.rb1 = T.rb2 = 0;
+    if (!PAIRS) {
+        uint16_t* l1 = reinterpret_cast<uint16_t*>(lds);
+        uint16_t* l2 = l1 + (size_t)tab_rows * (1u << JS_L1_BITS);
+        uint32_t* q = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(l2) + (((size_t)tab_lut2 * 2 + 15) & ~15ull));
+        const uint32_t* src1 = reinterpret_cast<const uint32_t*>(&ts.lut1[0][0]);
+        uint32_t* dst1 = reinterpret_cast<uint32_t*>(l1);
+        for (uint32_t i = tid; i < ts.n_rows * (1u << JS_L1_BITS) / 2; i += nthreads) dst1[i] = src1[i];
+        for (uint32_t i = tid; i < ts.lut2_used; i += nthreads) l2[i] = ts.lut2[i];
+        for (uint32_t i = tid; i < 3 * 64; i += nthreads) q[i] = (uint32_t)(&ts.qzz[0][0])[i] | ((uint32_t)c_zigzag[i & 63u] << 16);
+        T.lut1 = l1; T.lut2 = l2; T.qz = q;
+    } else {
+        T.lut1 = &ts.lut1[0][0]; T.lut2 = &ts.lut2[0]; T.qz = nullptr;
+        uint32_t* lp = reinterpret_cast<uint32_t*>(lds);
         uint32_t* lp2 = lp + (size_t)tab_rows * (1u << JS_L1_BITS);
         const uint32_t* srcp = &ts.lutp[0][0];
         for (uint32_t i = tid; i < ts.n_rows * (1u << JS_L1_BITS); i += nthreads) lp[i] = srcp[i];
@@ -2180,7 +2188,7 @@ template <int WL>
 __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sy_base, uint32_t nimg,
                                                      const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr,
                                                      const uint32_t* __restrict__ seg_tab, const uint32_t* __restrict__ side, SubArrays A, int first_pass,
-                                                     uint32_t tab_rows, uint32_t tab_lut2)
+                                                     uint32_t tab_rows, uint32_t tab_lut2, uint32_t it_max /* rounds at most (the list rounds of k_sync_round follow); 0: to the fixed point */)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     __shared__ uint32_t s_inp[SY_THREADS], s_ins[SY_THREADS], s_outp[SY_THREADS], s_outs[SY_THREADS], s_nblk[SY_THREADS];
@@ -2235,7 +2243,8 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
     else if (halo) { s_inp[t] = 0xFFFFFFFEu; s_ins[t] = 0; s_outp[t] = A.out_p[gs]; s_outs[t] = A.out_s[gs]; s_nblk[t] = 0; }   // the true state left of the workgroup
     else { s_inp[t] = A.in_p[gs]; s_ins[t] = A.in_s[gs]; s_outp[t] = A.out_p[gs]; s_outs[t] = A.out_s[gs]; s_nblk[t] = A.nblk[gs]; }
     __syncthreads();
-    for (int it = 0; it < SY_THREADS + 2; it++) {
+    const int it_end = it_max ? (int)it_max : SY_THREADS + 2;
+    for (int it = 0; it < it_end; it++) {
         // ---- phase A: which sub-sequences see a new entry state?  (reads last iteration's exit states only)
         uint32_t ip = 0, is = 0;
         bool active;
@@ -2287,6 +2296,85 @@ __global__ void __launch_bounds__(SY_THREADS) k_sync(const JsImage* __restrict__
         __syncthreads();
     }
     if (valid && !halo) { A.out_p[gs] = s_outp[t]; A.out_s[gs] = s_outs[t]; A.in_p[gs] = s_inp[t]; A.in_s[gs] = s_ins[t]; A.nblk[gs] = s_nblk[t]; }
+}
+
+// ---- list rounds (round 6): the large-job form of the rounds behind the first two.
+// A k_sync workgroup is a chain of dependent steps -- one alone on the chip takes 0.65 ms, seven per CU 0.79 ms each (profiles/r06_experiments.txt 16): the
+// kernel's time is its workgroup rounds times that latency, and a workgroup holds its place (LDS, four waves) through rounds in which a third, a twentieth, a
+// two-hundredth of its lanes walk.  So the first launch stops after the tail walks and ONE whole walk (it_max = 2), k_sync_links lists per image the
+// sub-sequences whose entry state is not the exit state of their left neighbour, and k_sync_round walks a list with dense waves (256 entries per workgroup,
+// workgroups without entries leave at once) and lists the right neighbours of the sub-sequences whose exit state changed -- one launch per round, the chip
+// shared by whatever still has work.  Links across workgroup boundaries are links like any other here.  Same fixed point as k_sync's own rounds (walk_sync is a
+// function of the entry state); what a bounded number of rounds leaves open, the verification mode of k_sync behind them closes.
+#define SYR_SLOTS JS_SYR_SLOTS          // list counters per image: round r reads [r], appends to [r + 1]
+__device__ __forceinline__ void list_append(bool put, uint32_t value, uint32_t* __restrict__ list, uint32_t* __restrict__ counter, uint32_t cap)
+{
+    const uint64_t m = WBALLOT(put);
+    if (!m) return;
+    const uint32_t lane = threadIdx.x & 63u, n = (uint32_t)__builtin_popcountll(m);
+    uint32_t base = 0;
+    if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(counter, n);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(m));
+    const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (put && at < cap) list[at] = value;
+}
+template <int WL>
+__global__ void __launch_bounds__(256) k_sync_links(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sy_base, uint32_t nimg, const JsTableSet* __restrict__ tables,
+                                                    const uint32_t* __restrict__ side, SubArrays A, uint32_t* __restrict__ list, uint32_t* __restrict__ rcnt)
+{
+    const uint32_t wg = blockIdx.x + sy_base[0];
+    const uint32_t img = find_image(sy_base, nimg, wg);
+    const JsImage& im = imgs[img];
+    if (!tables[im.tableset].lut_ok) return;
+    const uint32_t total_bits = side[im.side_off + 10] * 8;
+    const uint32_t i = (wg - sy_base[img]) * 256u + threadIdx.x, i_last = total_bits ? (total_bits - 1u) / SUB_BITS : 0u;
+    const size_t g = im.subseq_off + i;
+    bool open = false;
+    if (i >= 1u && i <= i_last && i < im.n_subseq) open = A.out_p[g - 1] != A.in_p[g] || A.out_s[g - 1] != A.in_s[g];
+    list_append(open, i, list + im.subseq_off, rcnt + (size_t)img * SYR_SLOTS, im.n_subseq);
+}
+template <int WL>
+__global__ void __launch_bounds__(SY_THREADS) k_sync_round(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sy_base, uint32_t nimg,
+                                                           const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr, const uint32_t* __restrict__ seg_tab,
+                                                           const uint32_t* __restrict__ side, SubArrays A, const uint32_t* __restrict__ lin, uint32_t* __restrict__ lout,
+                                                           uint32_t* __restrict__ rcnt, uint32_t r, uint32_t tab_rows, uint32_t tab_lut2)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    __shared__ __attribute__((aligned(8))) uint2 s_ctab[JS_MAX_BLK_PER_MCU];
+    const uint32_t wg = blockIdx.x + sy_base[0];
+    const uint32_t img = find_image(sy_base, nimg, wg);
+    const JsImage& im = imgs[img];
+    if (!tables[im.tableset].lut_ok) return;
+    uint32_t* cnt = rcnt + (size_t)img * SYR_SLOTS;
+    const uint32_t n_ent = min(cnt[r], im.n_subseq), j = wg - sy_base[img], wgs_img = sy_base[img + 1] - sy_base[img], t = threadIdx.x;
+    if (j * SY_THREADS >= n_ent) return;
+    const uint32_t* sd = side + im.side_off;
+    const uint32_t total_bits = sd[10] * 8, nseg = min(sd[11], im.seg_cap - 1), i_last = total_bits ? (total_bits - 1u) / SUB_BITS : 0u;
+    SubTabs T; load_subtabs<true>(T, s_dyn, im, tables[im.tableset], tab_rows, tab_lut2, t, SY_THREADS);
+    if (t < T.nb) { const uint32_t rbc = t < T.n1 ? T.rb0 : (t < T.n2 ? T.rb1 : T.rb2); s_ctab[t] = make_uint2(lds_addr(T.lutp) + (rbc & 0xFFFFu), lds_addr(T.lutp) + (rbc >> 16)); }
+    __syncthreads();
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);
+    const uint32_t* st = seg_tab + im.seg_off;
+    const uint32_t* li = lin + im.subseq_off; uint32_t* lo = lout + im.subseq_off;
+    for (uint32_t e0 = j * SY_THREADS; e0 < n_ent; e0 += wgs_img * SY_THREADS) {
+        const uint32_t e = e0 + t;
+        bool changed = false; uint32_t i = 0;
+        if (e < n_ent) {
+            i = li[e];
+            const size_t g = im.subseq_off + i;
+            // (the left neighbour may be walked in this very launch: whichever of its exit states is read here, a changed one lists this sub-sequence again)
+            const uint32_t ip = A.out_p[g - 1], is = A.out_s[g - 1];
+            if (ip != A.in_p[g] || is != A.in_s[g]) {
+                uint32_t p = ip, s = is, nblk = 0;
+                const uint32_t own_end = min((i + 1u) * SUB_BITS, total_bits);
+                if (!(p != P_END && p >= own_end)) walk_sync<WL>(im, T, lds_addr(s_ctab), words, st, nseg, total_bits, own_end, p, s, nblk);
+                changed = p != A.out_p[g] || s != A.out_s[g];
+                A.in_p[g] = ip; A.in_s[g] = is; A.nblk[g] = nblk;
+                if (changed) { A.out_p[g] = p; A.out_s[g] = s; }
+            }
+        }
+        if (r + 1u < SYR_SLOTS) list_append(changed && i + 1u <= i_last, i + 1u, lo, cnt + r + 1u, im.n_subseq);
+    }
 }
 
 // =====================================================================================
@@ -3285,21 +3373,46 @@ void js_launch_unstuff(hipStream_t st, int wl, const JsImage* imgs, const uint32
 }
 static SubArrays sub_arrays(uint32_t* sub, uint64_t n) { SubArrays a; a.out_p = sub; a.out_s = sub + n; a.in_p = sub + 2 * n; a.in_s = sub + 3 * n; a.nblk = sub + 4 * n; a.base = sub + 5 * n; return a; }
 static size_t subtabs_bytes_host(uint32_t tab_rows, uint32_t tab_lut2, bool pairs = false)
-{ return (size_t)tab_rows * (2u << JS_L1_BITS) + (((size_t)tab_lut2 * 2 + 15) & ~15ull) + 3 * 64 * 4 + (pairs ? (size_t)tab_rows * (4u << JS_L1_BITS) + (size_t)tab_lut2 * 4 : 0); }
+{ return pairs ? (size_t)tab_rows * (4u << JS_L1_BITS) + (size_t)tab_lut2 * 4 : (size_t)tab_rows * (2u << JS_L1_BITS) + (((size_t)tab_lut2 * 2 + 15) & ~15ull) + 3 * 64 * 4; }   // (load_subtabs)
 void js_launch_sync(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
-                    const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub, int first_pass)
+                    const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub, int first_pass, uint32_t it_max)
 {
     if (!total_wgs) return;
     if (wl == 4) hipLaunchKernelGGL(k_sync<4>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2, true), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
-                       sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2);
+                       sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2, it_max);
     else if (wl == 6) hipLaunchKernelGGL(k_sync<6>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2, true), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
-                       sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2);
+                       sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2, it_max);
     else if (wl == 8) hipLaunchKernelGGL(k_sync<8>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2, true), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
-                       sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2);
+                       sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2, it_max);
     else if (wl == 7) hipLaunchKernelGGL(k_sync<7>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2, true), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
-                       sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2);
+                       sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2, it_max);
     else hipLaunchKernelGGL(k_sync<5>, dim3(total_wgs), dim3(SY_THREADS), subtabs_bytes_host(tab_rows, tab_lut2, true), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
-                       sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2);
+                       sub_arrays(sub, nsub), first_pass, tab_rows, tab_lut2, it_max);
+}
+size_t js_sync_list_words(uint64_t nsub, uint32_t nimg) { return (size_t)2 * nsub + (size_t)nimg * SYR_SLOTS; }
+// The large-job form: first launch of k_sync cut after its second round, then `rounds` list rounds (<= SYR_SLOTS - 1) and the verification mode.
+// sn_base / sn_wgs: k_sync's workgroup prefix (254 owned sub-sequences each); sy_base / sy_wgs: 256 per workgroup.  lists: js_sync_list_words() words, the
+// counters behind the two lists (this part's images: lists + 2 * nsub + first image * SYR_SLOTS) are zeroed here.
+void js_launch_sync_rounds(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sn_base, uint32_t sn_wgs, const uint32_t* sy_base, uint32_t sy_wgs,
+                           uint32_t nimg, const JsTableSet* tables, const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub,
+                           uint32_t* lists, uint32_t* rcnt, int rounds)
+{
+    if (!sn_wgs || !sy_wgs) return;
+    if (rounds > SYR_SLOTS - 1) rounds = SYR_SLOTS - 1;
+    (void)hipMemsetAsync(rcnt, 0, (size_t)nimg * SYR_SLOTS * 4, st);
+    js_launch_sync(st, wl, tab_rows, tab_lut2, imgs, sn_base, nimg, sn_wgs, tables, ustr, seg_tab, side, sub, nsub, 1, 2u);
+    const SubArrays A = sub_arrays(sub, nsub);
+    const size_t lds = subtabs_bytes_host(tab_rows, tab_lut2, true);
+    uint32_t* l0 = lists; uint32_t* l1 = lists + nsub;
+#define SYR_WL(K, GRID, BLOCK, LDS, ...) \
+    do { if (wl == 4) hipLaunchKernelGGL(K<4>, GRID, BLOCK, LDS, st, __VA_ARGS__); else if (wl == 5) hipLaunchKernelGGL(K<5>, GRID, BLOCK, LDS, st, __VA_ARGS__); \
+         else if (wl == 6) hipLaunchKernelGGL(K<6>, GRID, BLOCK, LDS, st, __VA_ARGS__); else if (wl == 7) hipLaunchKernelGGL(K<7>, GRID, BLOCK, LDS, st, __VA_ARGS__); \
+         else hipLaunchKernelGGL(K<8>, GRID, BLOCK, LDS, st, __VA_ARGS__); } while (0)
+    SYR_WL(k_sync_links, dim3(sy_wgs), dim3(256), 0, imgs, sy_base, nimg, tables, side, A, l0, rcnt);
+    for (int r = 0; r < rounds; r++)
+        SYR_WL(k_sync_round, dim3(sy_wgs), dim3(SY_THREADS), lds, imgs, sy_base, nimg, tables, ustr, seg_tab, side, A, (const uint32_t*)((r & 1) ? l1 : l0), (r & 1) ? l0 : l1, rcnt, (uint32_t)r, tab_rows, tab_lut2);
+#undef SYR_WL
+    js_launch_sync(st, wl, tab_rows, tab_lut2, imgs, sn_base, nimg, sn_wgs, tables, ustr, seg_tab, side, sub, nsub, 2, 0u);
 }
 // ---- candidate synchronisation (small jobs).  cand: js_cand_bytes(nsub) bytes; req: nimg * JS_CAND_REQ_WORDS words
 static CandArrays cand_arrays(uint32_t* c, uint64_t n)

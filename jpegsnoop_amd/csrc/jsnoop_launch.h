@@ -27,7 +27,14 @@ void js_launch_unstuff(hipStream_t st, int wl, const JsImage* imgs, const uint32
                        const uint32_t* us4_base /*prefix over super-chunks of four chunks, or nullptr: linear output + transposition pass*/, uint32_t total_super,
                        uint32_t* ticket /*device counter the fused passes take their chunk from*/, uint32_t* ticket_base /*host: its value before the launch; advanced here*/);
 void js_launch_sync(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
-                    const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub, int first_pass);
+                    const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub, int first_pass, uint32_t it_max = 0 /* rounds at most; 0: to the fixed point */);
+// the large-job form of the synchronisation stage: k_sync cut after two rounds, list rounds (k_sync_links / k_sync_round), k_sync's verification mode
+#define JS_SYR_SLOTS 12                /* list counters per image */
+#define JS_SYR_ROUNDS 8                /* list rounds of a large job (k_sync alone needs 4.8 rounds per workgroup on average, 7 at most in 834 workgroups read) */
+size_t js_sync_list_words(uint64_t nsub, uint32_t nimg);
+void js_launch_sync_rounds(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sn_base, uint32_t sn_wgs, const uint32_t* sy_base, uint32_t sy_wgs,
+                           uint32_t nimg, const JsTableSet* tables, const uint8_t* ustr, const uint32_t* seg_tab, const uint32_t* side, uint32_t* sub, uint64_t nsub,
+                           uint32_t* lists /* js_sync_list_words(nsub, images of the BATCH) words */, uint32_t* rcnt /* this part's counters inside it */, int rounds);
 #define JS_SY_THREADS 256
 #define JS_SY_HALO    2            // lanes of a k_sync workgroup that walk in front of its first sub-sequence
 // Candidate synchronisation (the small-job form of the synchronisation stage: k_cand_spec / _walk / _chain / _fill / _apply); leaves the

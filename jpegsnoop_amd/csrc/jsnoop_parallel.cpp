@@ -313,6 +313,10 @@ int js_parallel_entropy_part(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32
             js_launch_sync(st, b->sub_wl, b->tab_rows, b->tab_lut2, imgs, sn_base, n, sn_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, 2);
             js_launch_sync(st, b->sub_wl, b->tab_rows, b->tab_lut2, imgs, sn_base, n, sn_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, 0);
         }
+    } else if (b->sync_rounds > 0) {
+        uint32_t* lists = sub + 6 * (size_t)b->total_subseq + 16;            // (behind the six state arrays and their slack)
+        js_launch_sync_rounds(st, b->sub_wl, b->tab_rows, b->tab_lut2, imgs, sn_base, sn_wgs, sy_base, sy_wgs, n, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
+                              lists, lists + 2 * (size_t)b->total_subseq + (size_t)i0 * JS_SYR_SLOTS, b->sync_rounds);
     } else
     for (int l = 0; l < b->sync_launches; l++)
         js_launch_sync(st, b->sub_wl, b->tab_rows, b->tab_lut2, imgs, sn_base, n, sn_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, l == 0);
