@@ -248,12 +248,12 @@ int          jsnoop_batch_split_parts(const JsnoopBatch*);              /* what 
 typedef struct JsnoopTuning {
     uint32_t struct_size;     /* sizeof(JsnoopTuning) of the caller: a shorter (older) struct is accepted, the fields it lacks are automatic, and
                                  jsnoop_batch_get_tuning writes no byte past it; a longer one than the library knows is refused              */
-    int32_t  sub_wl;          /* log2(32-bit words) of a sub-sequence: 4..8 = 64 B .. 1 KiB; 0 = by job size (4 / 6 / 7)              */
+    int32_t  sub_wl;          /* log2(32-bit words) of a sub-sequence: 4..8 = 64 B .. 1 KiB; 0 = by job size (4 / 5 / 6 / 7)              */
     int32_t  cand_rounds;     /* synchronisation form: -1 = rounds of k_sync only, n > 0 = candidates with at most n walk rounds (<= 64),
                                  0 = automatic (candidates with 16 rounds while the job is small enough, see cand_max_walks)          */
-    uint64_t cand_max_walks;  /* largest job (64-byte pieces x blocks per MCU) that synchronises by candidates; 0 = 4 500 000         */
-    int32_t  sync_launches;   /* synchronisation by rounds: n > 0 = n launches of k_sync; 0 = automatic (2; a large job -- 96 MB of scan
-                                 data and more -- runs one cut launch and list rounds over the whole job instead)                     */
+    uint64_t cand_max_walks;  /* largest job (64-byte pieces x blocks per MCU) that synchronises by candidates; 0 = 2 600 000         */
+    int32_t  sync_launches;   /* synchronisation by rounds: 0 = one cut launch of k_sync, then list rounds over the whole job
+                                 (k_sync_links / k_sync_round); n > 0 = n plain launches of k_sync (the form before round 6)           */
     int32_t  write_lanes;     /* lanes per sub-sequence in the write pass of the smallest jobs: 1, 2; 0 = automatic (2 up to 40 960 pieces) */
     int32_t  split;           /* as jsnoop_batch_set_split: 0 automatic, 1 one stream, 2 two streams                                  */
     int32_t  mcus_per_wave;   /* MCUs per back-end wave; 0 = one round of workgroups over the chip, at most 64                        */
@@ -267,7 +267,6 @@ typedef struct JsnoopTuning {
 #define JSNOOP_XC_SIDE_EXACT      0x08u  /* side outputs always from the exact-mirror reader                                          */
 #define JSNOOP_XC_CAND_VERIFY     0x10u  /* k_sync's verification mode behind every candidate chain                                   */
 #define JSNOOP_XC_UNSTUFF_3PASS   0x20u  /* un-stuffing as count / scan / write passes instead of the fused look-back pass            */
-#define JSNOOP_XC_SYNC_ROUNDS     0x40u  /* the list rounds of the large-job synchronisation for every job that synchronises by rounds */
 #define JSNOOP_DBG_CAND           0x01u  /* candidate chain: rounds, queued walks                                                     */
 #define JSNOOP_DBG_CAND_LINKS     0x02u  /* ... and the links left open per image (stops the stream)                                  */
 #define JSNOOP_DBG_TAIL           0x04u  /* damaged files: tail take-over decisions                                                   */

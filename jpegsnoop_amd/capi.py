@@ -21,7 +21,7 @@ class Tuning(C.Structure):
                 ("pg_lanes", C.c_int32), ("cross_checks", C.c_uint32), ("debug", C.c_uint32)]
 
 
-XC_BACKEND_GENERIC, XC_WRITE_V1, XC_NO_TAIL, XC_SIDE_EXACT, XC_CAND_VERIFY, XC_UNSTUFF_3PASS, XC_SYNC_ROUNDS = 1, 2, 4, 8, 16, 32, 64
+XC_BACKEND_GENERIC, XC_WRITE_V1, XC_NO_TAIL, XC_SIDE_EXACT, XC_CAND_VERIFY, XC_UNSTUFF_3PASS = 1, 2, 4, 8, 16, 32
 DBG_CAND, DBG_CAND_LINKS, DBG_TAIL, DBG_TIMING = 1, 2, 4, 8
 
 _u, _i, _p, _sz = C.c_uint, C.c_int, C.c_void_p, C.c_size_t

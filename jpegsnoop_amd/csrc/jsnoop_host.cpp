@@ -182,7 +182,7 @@ const JsnoopTuning& js_env_tuning()
         { const long long v = num("JSNOOP_PG_LANES", 0); t.pg_lanes = (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 64) ? (int32_t)v : 0; }
         t.cross_checks = (on("JSNOOP_BACKEND_GENERIC") ? JSNOOP_XC_BACKEND_GENERIC : 0u) | (on("JSNOOP_WRITE_V1") ? JSNOOP_XC_WRITE_V1 : 0u) | (on("JSNOOP_NO_TAIL") ? JSNOOP_XC_NO_TAIL : 0u) |
                          (on("JSNOOP_SIDE_EXACT") ? JSNOOP_XC_SIDE_EXACT : 0u) | (on("JSNOOP_CAND_VERIFY") ? JSNOOP_XC_CAND_VERIFY : 0u) |
-                         (on("JSNOOP_UNSTUFF_3PASS") ? JSNOOP_XC_UNSTUFF_3PASS : 0u) | (on("JSNOOP_SYNC_ROUNDS") ? JSNOOP_XC_SYNC_ROUNDS : 0u);
+                         (on("JSNOOP_UNSTUFF_3PASS") ? JSNOOP_XC_UNSTUFF_3PASS : 0u);
         const long long dc = num("JSNOOP_DEBUG_CAND", 0);
         t.debug = (dc >= 1 ? JSNOOP_DBG_CAND : 0u) | (dc >= 2 ? JSNOOP_DBG_CAND_LINKS : 0u) | (on("JSNOOP_DEBUG_TAIL") ? JSNOOP_DBG_TAIL : 0u) | (on("JSNOOP_DEBUG_TIMING") ? JSNOOP_DBG_TIMING : 0u);
         // the same limits as js_check_tuning: a preset out of range falls back to "automatic" (every later set_tuning writes the whole struct back and
@@ -434,20 +434,22 @@ int JsnoopBatch::upload()
     if (tune.mcus_per_wave > 0) mcus_per_wave = (uint32_t)tune.mcus_per_wave;
     // sub-sequence length: long (512 B) when the batch still yields plenty of lanes, short (128 B, 64 B) for small jobs
     uint64_t scan_total = 0; for (const JsImage& im : imgs) scan_total += im.scan_len;
-    sub_wl = scan_total >= (96ull << 20) ? 7 : (scan_total < (4ull << 20) ? 4 : 6);    // (a single image / a handful: 64-byte pieces give the write pass more lanes; 256-byte pieces between the candidate form and the large batches: 128 x 1080p 2.45 against 2.70 ms with 128-byte pieces)
+    sub_wl = scan_total >= (96ull << 20) ? 7 : (scan_total < (4ull << 20) ? 4 : (scan_total < (64ull << 20) ? 5 : 6));    // (a single image / a handful: 64-byte pieces give the write pass more lanes; 256-byte pieces between the candidate form and the large batches: 128 x 1080p 2.45 against 2.70 ms with 128-byte pieces)
     // Candidate synchronisation (k_cand_*) wants 64-byte pieces and one walk per piece and block of the MCU.  It beats the rounds of k_sync far beyond
     // what the chip holds at once (~500 k lanes): N x 1080p 4:2:0, ms per decode, candidates | rounds: 1: 0.30 | 0.80, 4: 0.37 | 0.83, 8: 0.45 | 0.95,
     // 16: 0.64 | 1.09, 32: 1.04 | 1.31, 48: 1.44 | 1.58 (2.6 M walks); the two meet near 64 images.
     uint32_t max_blk = 0; for (const JsImage& im : imgs) max_blk = std::max(max_blk, im.blk_per_mcu);
-    const uint64_t cand_lanes = tune.cand_max_walks ? tune.cand_max_walks : 4500000;     // (64 x 1080p = 3.6 M walks: 1.59 ms by candidates, 1.77 by rounds; 96 images: 2.21 against 2.12)
+    // (round 6, with the list rounds behind k_sync and 128-byte pieces, N x 1080p candidates | rounds: 24: 0.80 | 0.98, 32: 0.95 | 1.04, 48: 1.29 | 1.25 (2.6 M walks),
+    //  64: 1.56 | 1.43, 96: 1.81 (256-byte pieces, plain launches) | 1.76, 128: 2.25 | 2.23 -- profiles/r06_experiments.txt 18)
+    const uint64_t cand_lanes = tune.cand_max_walks ? tune.cand_max_walks : 2600000;
     const int cand_want = tune.cand_rounds == 0 ? 16 : tune.cand_rounds;
     const bool cand_fits = cand_want >= 0 && max_blk >= 1 && max_blk <= JS_CAND_MAX_BLK && (scan_total / 64 + 64 * n) * max_blk <= cand_lanes;
     if (cand_fits) sub_wl = 4;
     if (tune.sub_wl) sub_wl = tune.sub_wl;
     sync_launches = tune.sync_launches > 0 ? tune.sync_launches : 2;
-    // The large-job form of the classic synchronisation (js_launch_sync_rounds: k_sync cut after two rounds, then list rounds over the whole job) unless the tuning
-    // struct asks for a number of plain k_sync launches: from ~200 1080p images on the workgroups of k_sync come in more than one round over the chip.
-    sync_rounds = (tune.sync_launches == 0 && !(cand_fits && sub_wl == 4) && (scan_total >= (96ull << 20) || (tune.cross_checks & JSNOOP_XC_SYNC_ROUNDS))) ? JS_SYR_ROUNDS : 0;
+    // Synchronisation by rounds = k_sync cut after two rounds, then list rounds over the whole job (js_launch_sync_rounds), unless the tuning struct asks for a
+    // number of plain k_sync launches.
+    sync_rounds = (tune.sync_launches == 0 && !(cand_fits && sub_wl == 4)) ? JS_SYR_ROUNDS : 0;
     const uint32_t sub_bytes = 4u << sub_wl;
     uint32_t wgs = 0; max_mcu_h = 8; max_mcu_w = 8;
     for (size_t i = 0; i < n; i++) {

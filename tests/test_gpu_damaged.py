@@ -194,7 +194,7 @@ def test_overflow_only_files_get_their_bookkeeping_from_the_parallel_side_pass(h
 
 
 @pytest.mark.parametrize("tuning", [dict(split=2), dict(split=2, sub_wl=7, cand_rounds=-1), dict(split=1, sub_wl=7, cand_rounds=-1),
-                                    dict(split=2, sub_wl=7, cand_rounds=-1, cross_checks=64), dict(split=1, sub_wl=5, cand_rounds=-1, cross_checks=64)])   # (64: JSNOOP_XC_SYNC_ROUNDS, the list rounds of large jobs)
+                                    dict(split=2, sub_wl=7, cand_rounds=-1, sync_launches=2), dict(split=1, sub_wl=5, cand_rounds=-1)])   # (cand_rounds = -1: rounds -- list rounds unless sync_launches asks for plain k_sync launches)
 def test_damaged_files_inside_a_batch_on_two_streams(harness, oracle, tuning):
     """Damaged and healthy files mixed in one batch, decoded as two halves on two streams (the default form of a large batch) and with the 512-byte
     sub-sequences of large batches: flags are per image, the repair passes (tail take-over, second attempt, resumed chain) run behind the join of

@@ -123,22 +123,21 @@ def test_fused_unstuffing_agrees_with_the_three_pass_form(harness, oracle):
         b.close()
 
 
-def test_list_rounds_of_the_large_job_synchronisation(harness, oracle):
-    """A job of 96 MB of scan data and more synchronises with ONE cut launch of k_sync (tail walks + one whole walk), per-image lists of the sub-sequences whose
-    entry state is not their left neighbour's exit state, and list rounds over the whole job (js_launch_sync_rounds); JSNOOP_XC_SYNC_ROUNDS runs that form on
-    any job that synchronises by rounds.  Same DIBs as the plain launches, for every sub-sequence length, on one stream and two, repeated decodes included."""
+def test_list_rounds_and_plain_launches_of_the_synchronisation_by_rounds(harness, oracle):
+    """A job that synchronises by rounds runs ONE cut launch of k_sync (tail walks + one whole walk), per-image lists of the sub-sequences whose entry state is not
+    their left neighbour's exit state, and list rounds over the whole job (js_launch_sync_rounds); JsnoopTuning.sync_launches > 0 asks for that many plain launches
+    of k_sync instead (the form before round 6).  Same DIBs either way, for every sub-sequence length, on one stream and two, repeated decodes included."""
     import jpegsnoop_amd as J
-    from jpegsnoop_amd import capi
     want = _decode_all(J, harness)
     for wl in (4, 5, 6, 7, 8):
         for split in (1, 2):
-            got = _decode_all(J, harness, sub_wl=wl, cand_rounds=-1, split=split, cross_checks=capi.XC_SYNC_ROUNDS)
+            got = _decode_all(J, harness, sub_wl=wl, cand_rounds=-1, split=split)
             assert got["sums"] == want["sums"] and set(got["paths"]) == {1} and not any(got["flags"]), (wl, split)
-    plain = _decode_all(J, harness, sub_wl=7, cand_rounds=-1, sync_launches=2)
-    assert plain["sums"] == want["sums"] and set(plain["paths"]) == {1} and not any(plain["flags"])
+        plain = _decode_all(J, harness, sub_wl=wl, cand_rounds=-1, sync_launches=2)
+        assert plain["sums"] == want["sums"] and set(plain["paths"]) == {1} and not any(plain["flags"]), wl
     files = _files(harness) + [harness.synth_jpeg(seed=78, width=3840, height=2160, hs=2, vs=2, restart_interval=7)]
     b = J.JpegBatch()
-    b.set_tuning(sub_wl=6, cand_rounds=-1, cross_checks=capi.XC_SYNC_ROUNDS)
+    b.set_tuning(sub_wl=6, cand_rounds=-1)
     for f in files:
         b.add_jpeg(f)
     b.upload()
