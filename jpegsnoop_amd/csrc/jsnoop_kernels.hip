@@ -1954,21 +1954,33 @@ __device__ __forceinline__ void load_subtabs(SubTabs& T, uint8_t* lds, const JsI
 
 struct Cursor {                        // MSB-first bit cursor: two byte-swapped words, one raw word prefetched.  `sh` = 32 - (bits of w0 already
     const uint32_t* words; uint32_t widx, w0, w1, nxt; int32_t sh; uint32_t p;   // consumed), kept in [0, 31]: at least one bit of w0 is always consumed,
-};                                     // so the window is ONE v_alignbit_b32 with no special case (sh == 0: the window is w1 itself)
+    uint32_t poff;                     // so the window is ONE v_alignbit_b32 with no special case (sh == 0: the window is w1 itself)
+};                                     // poff: byte offset of word `widx` in the interleaved layout, carried along (see cur_fetch)
 __device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
+// The word behind `nxt`.  Its place in the interleaved layout is not computed from the word index every time (phys_word: six vector instructions, four of them at
+// half rate, in a step that every walker of the chip is bound by -- ~15 % of k_sync's vector cycles): consecutive words of a sub-sequence lie one 256-byte row apart,
+// the offset is stepped, and computed afresh only where a sub-sequence ends (a lane crosses that once, at the end of its walk).
+template <int WL> __device__ __forceinline__ uint32_t cur_fetch(Cursor& c)
+{
+    const uint32_t v = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(c.words) + c.poff);
+    c.widx++;
+    if (WL == 4) c.poff += 4u;
+    else { c.poff += 256u; if ((c.widx & ((1u << WL) - 1u)) == 0u) c.poff = phys_word<WL>(c.widx) << 2; }
+    return v;
+}
 template <int WL> __device__ __forceinline__ void cur_init(Cursor& c, const uint32_t* words, uint32_t p)
 {
     const uint32_t wi = p ? ((p - 1u) >> 5) + 1u : 0u;           // index of w1; w0 is the word before it (nothing before bit 0)
     c.words = words; c.p = p; c.sh = (int32_t)(31u - ((p - 1u) & 31u));
     c.w0 = p ? bswap32(words[phys_word<WL>(wi - 1u)]) : 0u; c.w1 = bswap32(words[phys_word<WL>(wi)]);
-    c.nxt = words[phys_word<WL>(wi + 1u)]; c.widx = wi + 2u;
+    c.nxt = words[phys_word<WL>(wi + 1u)]; c.widx = wi + 2u; c.poff = phys_word<WL>(wi + 2u) << 2;
 }
 // the next 32 bits of the stream
 __device__ __forceinline__ uint32_t cur_peek(const Cursor& c) { return __builtin_amdgcn_alignbit(c.w0, c.w1, (uint32_t)c.sh); }
 template <int WL> __device__ __forceinline__ void cur_skip(Cursor& c, uint32_t n)      // n <= 32
 {
     c.sh -= (int32_t)n; c.p += n;
-    if (c.sh < 0) { c.sh += 32; c.w0 = c.w1; c.w1 = bswap32(c.nxt); c.nxt = c.words[phys_word<WL>(c.widx++)]; }
+    if (c.sh < 0) { c.sh += 32; c.w0 = c.w1; c.w1 = bswap32(c.nxt); c.nxt = cur_fetch<WL>(c); }
 }
 
 // state word: [31:12] interval index (up to 2^20 - 1 restart intervals), [11:6] block-in-MCU (< 48), [5:0] next coefficient index (0 = DC)
@@ -2156,7 +2168,7 @@ __device__ __forceinline__ void walk_sync(const JsImage& im, const SubTabs T, ui
         { const uint32_t adv = two ? b12 : b1; cur.sh -= (int32_t)adv; cur.p += adv; }
         if (__builtin_amdgcn_inverse_ballot_w64(WBALLOT(cur.sh < 0) & m_act)) {          // (lanes out of their range must not load)
             cur.sh += 32; cur.w0 = cur.w1; cur.w1 = bswap32(cur.nxt);
-            cur.nxt = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(words) + (phys_word<WL>(cur.widx++) << 2));
+            cur.nxt = cur_fetch<WL>(cur);
         }
         const uint32_t kn = two ? k + (pe >> 24) : k1;
         const uint64_t m_dn = WBALLOT(kn >= 64u) & m_act;
@@ -2842,7 +2854,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
     uint32_t res_p = 0, res_s = 0, res_n = 0;                // what this lane reports for verification
     bool verify = false, check_n = false, active = false, captured = false, skip = false;
     const uint32_t own_end = min((i + 1) * SUB_BITS, total_bits);
-    Cursor cur; cur.words = words; cur.widx = 0; cur.w0 = cur.w1 = cur.nxt = 0; cur.sh = 0; cur.p = 0;
+    Cursor cur; cur.words = words; cur.widx = 0; cur.poff = 0; cur.w0 = cur.w1 = cur.nxt = 0; cur.sh = 0; cur.p = 0;
     if (in_data) {
         const uint32_t p0 = i ? A.out_p[g - 1] : 0u, s0 = i ? A.out_s[g - 1] : 0u;
         blk = A.base[g]; seg = ST_SEG(s0); c = ST_C(s0); k = ST_K(s0);
@@ -3064,7 +3076,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
     uint32_t res_p = 0, res_s = 0, res_n = 0;                // what this lane reports for verification
     bool verify = false, check_n = false, active0 = false, skip0 = false;
     const uint32_t own_end = min(HALF && !hi ? i * SUB_BITS + SUB_BITS / 2 : (i + 1) * SUB_BITS, total_bits);
-    Cursor cur; cur.words = words; cur.widx = 0; cur.w0 = cur.w1 = cur.nxt = 0; cur.sh = 0; cur.p = 0;
+    Cursor cur; cur.words = words; cur.widx = 0; cur.poff = 0; cur.w0 = cur.w1 = cur.nxt = 0; cur.sh = 0; cur.p = 0;
     if (in_data) {
         const uint32_t p0 = hi ? half_p[g] : (i ? A.out_p[g - 1] : 0u), s0 = hi ? half_s[g] : (i ? A.out_s[g - 1] : 0u);
         blk = A.base[g] + (hi ? half_n[g] : 0u); seg = ST_SEG(s0); c = ST_C(s0); k = ST_K(s0);
@@ -3182,7 +3194,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
         { const uint32_t adv = tot + (two ? tot2 : 0u); cur.sh -= (int32_t)adv; cur.p += adv; }
         if (IBAL(WBALLOT(cur.sh < 0) & m_act)) {                 // (lanes that are not active compute on whatever they hold: they must not load)
             cur.sh += 32; cur.w0 = cur.w1; cur.w1 = bswap32(cur.nxt);
-            cur.nxt = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(words) + (phys_word<WL>(cur.widx++) << 2));
+            cur.nxt = cur_fetch<WL>(cur);
         }
         const uint32_t kn = two ? k3 : k2;
         const uint64_t m_eob = (m_two & WBALLOT((run2 | size2) == 0u)) | (~m_two & WBALLOT((run | size) == 0u));
