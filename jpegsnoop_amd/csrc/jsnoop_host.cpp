@@ -313,7 +313,7 @@ int JsnoopBatch::ensure_aux()
 }
 void JsnoopBatch::clear()
 {
-    imgs.clear(); hinfo.clear(); tables.clear(); raw_bytes = 0; uploaded = false; host_flags.clear(); side_done.clear(); side_mode.clear(); side_anoms.clear(); side_chunk_ok.clear(); side_events.clear();
+    imgs.clear(); hinfo.clear(); tables.clear(); raw_bytes = 0; uploaded = false; host_flags.clear(); side_done.clear(); side_mode.clear(); side_anoms.clear(); side_chunk_ok.clear(); side_events.clear(); side_pre.clear();
     js_prog_clear(this);
 }
 int JsnoopBatch::reserve_pinned(size_t need)
@@ -516,7 +516,7 @@ int JsnoopBatch::decode(bool timed)
     HIP_TRY(hipSetDevice(device));
     if (!uploaded && upload()) return -1;
     const uint32_t n = (uint32_t)imgs.size();
-    side_done.assign(n, 0); side_mode.assign(n, 0); side_anoms.assign(n, std::vector<uint32_t>()); side_chunk_ok.assign(n, 0); side_events.assign(n, std::vector<uint32_t>());   // (nothing of an earlier decode's side pass survives)
+    side_done.assign(n, 0); side_mode.assign(n, 0); side_anoms.assign(n, std::vector<uint32_t>()); side_chunk_ok.assign(n, 0); side_events.assign(n, std::vector<uint32_t>()); side_pre.assign(n, 0);   // (nothing of an earlier decode's side pass survives)
     JsRange r_("jsnoop:decode (enqueue)");
     if (js_prog_count(this)) return decode_progressive(timed);     // SOF2 files: every scan of every image, one launch per dependency level
     if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
@@ -753,6 +753,7 @@ void jsnoop_decode_scan_img(JsnoopDecoder* d, const uint8_t* file, size_t len, u
     if (b->upload()) { d->log(2, "*** ERROR: device decode failed: %s", g_err.c_str()); return; }
     if (dbg_t) tp[ntp++] = now_us();
     if (b->decode(false)) { d->log(2, "*** ERROR: device decode failed: %s", g_err.c_str()); return; }
+    if (d->log_fn) (void)js_side_prelaunch(b, 0);                  // the report will ask for the side outputs: their pass goes behind the decode now, not behind the wait
     if (dbg_t) tp[ntp++] = now_us();
     if (b->sync()) { d->log(2, "*** ERROR: device decode failed: %s", g_err.c_str()); return; }
     if (dbg_t) tp[ntp++] = now_us();
@@ -762,8 +763,10 @@ void jsnoop_decode_scan_img(JsnoopDecoder* d, const uint8_t* file, size_t len, u
     d->side_ready = d->last_path == 2;          // the exact-mirror kernel fills the side block as it goes
     // the side block comes back once: with a log callback the report below asks for the side outputs anyway (side pass, then the read-back)
     if (d->log_fn && !d->side_ready) { d->ensure_side(); if (!d->side_ready) d->fetch_side(); } else d->fetch_side();
+    if (dbg_t) tp[ntp++] = now_us();
     d->pending_log.clear();
     if (display) d->stats_pass();
+    if (dbg_t) tp[ntp++] = now_us();
     if (d->log_fn) {                        // the reference's log text (messages of the decode loop, then the report)
         d->ensure_side();
         js_emit_decode_events(d);
@@ -771,7 +774,7 @@ void jsnoop_decode_scan_img(JsnoopDecoder* d, const uint8_t* file, size_t len, u
         d->flush_pending_log();                                     // CalcChannelPreview's warnings (:3643)
         js_emit_report(d, display != 0, quiet != 0);
     }
-    if (dbg_t) { tp[ntp++] = now_us(); fprintf(stderr, "[timing] add %.0f upload %.0f enqueue %.0f wait+fixup %.0f side/stats/report %.0f us\n", tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], tp[5] - tp[4]); }
+    if (dbg_t) { tp[ntp++] = now_us(); fprintf(stderr, "[timing] add %.0f upload %.0f enqueue %.0f wait+fixup %.0f side outputs %.0f statistics %.0f messages+report %.0f us\n", tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], tp[5] - tp[4], tp[6] - tp[5], tp[7] - tp[6]); }
 }
 
 int  jsnoop_is_preview_ready(JsnoopDecoder* d) { return d->preview_is_jpeg; }

@@ -1424,6 +1424,21 @@ void js_launch_clear3(hipStream_t st, void* a, size_t a_bytes, void* b, size_t b
     const uint32_t wgs = (uint32_t)std::min<size_t>(2048, (tot + 1023) / 1024);
     hipLaunchKernelGGL(k_clear3, dim3(wgs), dim3(256), 0, st, (uint4*)a, na, (uint4*)b, nb, (uint4*)c, nc, imgs, nimg, (uint32_t*)a);
 }
+// five word ranges to zero in one launch (the outputs of a side pass: js_side_parallel_enqueue)
+__global__ void __launch_bounds__(256) k_clear5(uint32_t* __restrict__ a, size_t na, uint32_t* __restrict__ b, size_t nb, uint32_t* __restrict__ c, size_t nc,
+                                                uint32_t* __restrict__ d, size_t nd, uint32_t* __restrict__ e, size_t ne)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < na + nb + nc + nd + ne; i += (size_t)gridDim.x * 256) {
+        if (i < na) a[i] = 0u; else if (i < na + nb) b[i - na] = 0u; else if (i < na + nb + nc) c[i - na - nb] = 0u;
+        else if (i < na + nb + nc + nd) d[i - na - nb - nc] = 0u; else e[i - na - nb - nc - nd] = 0u;
+    }
+}
+void js_launch_clear5(hipStream_t st, uint32_t* a, size_t na, uint32_t* b, size_t nb, uint32_t* c, size_t nc, uint32_t* d, size_t nd, uint32_t* e, size_t ne)   // word counts
+{
+    const size_t tot = na + nb + nc + nd + ne;
+    if (!tot) return;
+    hipLaunchKernelGGL(k_clear5, dim3((uint32_t)std::min<size_t>(1024, (tot + 1023) / 1024)), dim3(256), 0, st, a, na, b, nb, c, nc, d, nd, e, ne);
+}
 void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, const uint8_t* dib, unsigned long long* sums)
 {
     if (!nimg) return;

@@ -13,6 +13,7 @@ int  js_launch_idct_color(hipStream_t st, const JsImage* imgs, const uint32_t* w
 void js_launch_unaligned_probe(hipStream_t st, void* buf48);    // one 16-byte store at byte offset 6 of buf48 (halves 1..8), see k_unaligned_probe
 void js_launch_idct_probe(hipStream_t st, const float* lut_t, const int16_t* coef64, float* out64);
 void js_launch_clear3(hipStream_t st, void* a, size_t a_bytes, void* b, size_t b_bytes, void* c, size_t c_bytes, const JsImage* imgs = nullptr, uint32_t nimg = 0);   // three arenas to zero in one launch (sizes rounded up to 16 bytes)
+void js_launch_clear5(hipStream_t st, uint32_t* a, size_t na, uint32_t* b, size_t nb, uint32_t* c, size_t nc, uint32_t* d, size_t nd, uint32_t* e, size_t ne);   // five word ranges to zero in one launch
 void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, const uint8_t* dib, unsigned long long* sums);
 void js_launch_color_probe(hipStream_t st, int y, int cb, int cr, uint32_t* out);
 #define JS_STATS_WORDS 2482          /* public layout, include/jsnoop_gpu.h JSNOOP_STATS_WORDS */

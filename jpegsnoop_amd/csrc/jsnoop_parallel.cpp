@@ -352,6 +352,7 @@ int JsnoopBatch::run_exact(const std::vector<uint32_t>& which)
         HIP_TRY(hipMemsetAsync(dev.coef + im.coef_off * 64, 0, (size_t)im.total_blocks * 128, stream));
         HIP_TRY(hipMemsetAsync(dev.dccum + im.coef_off, 0, (size_t)im.total_blocks * 2, stream));
         HIP_TRY(hipMemsetAsync(dev.side + im.side_off, 0, (size_t)js_side_words(im.mcu_xmax * im.mcu_ymax, im.blk_xmax * im.blk_ymax) * 4, stream));
+        if (event_words) HIP_TRY(hipMemsetAsync(dev.events + im.ev_off, 0, 4, stream));     // (a side pass launched behind the decode may have logged the end-of-scan markers, js_side_prelaunch)
     }
     HIP_TRY(hipMemcpyAsync(dev.sel, which.data(), which.size() * 4, hipMemcpyHostToDevice, stream));
     js_launch_entropy_exact(stream, dev.imgs, dev.sel, (uint32_t)which.size(), dev.tables, dev.raw, dev.coef, dev.dccum, dev.side, 0, event_words ? dev.events : nullptr);
@@ -443,6 +444,8 @@ int js_parallel_fixup(JsnoopBatch* b)
         return 0;
     }
     if (js_read_flags(b)) return -1;
+    // (a side pass launched behind the decode saw what the decode left: any flag -- a chain that needed more rounds included -- makes it stale)
+    for (uint32_t i = 0; i < n && i < b->side_pre.size(); i++) if (b->host_flags[i]) b->side_pre[i] = 0;
     // An unconverged chain is not a malformed stream: give it more synchronisation rounds first.
     for (int attempt = 0, extra = 4; attempt < 4; attempt++, extra *= 4) {
         bool nosync = false;
@@ -671,14 +674,50 @@ static int js_side_via_helper(JsnoopBatch* b, uint32_t i)
     b->side_events[i] = h->side_events[0];
     return 0;
 }
+// The parallel side pass of image i, enqueued on the batch stream (nothing waited for): the side block's outputs cleared, then the inverse map, the side
+// walk and the maps.  with_anoms: the walk records its coefficient-index overflows (an image whose only flag is that one).
+static int js_side_parallel_enqueue(JsnoopBatch* b, uint32_t i, bool with_anoms)
+{
+    const JsImage& im = b->imgs[i];
+    const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax;
+    const size_t words = js_side_words(nmcu, im.blk_xmax * im.blk_ymax);
+    const uint32_t us0 = b->h_us_base[i], usn = b->h_us_base[i + 1] - us0, sy0 = b->h_sy_base[i], syn = b->h_sy_base[i + 1] - sy0;
+    uint32_t *mcu_pos = nullptr, *us_out = nullptr;
+    if (js_side_scratch(b, i, &mcu_pos, &us_out)) return -1;
+    uint32_t* anoms = us_out + (((size_t)usn * 256 + 64 + 15) & ~(size_t)15);
+    // one launch for the five areas to zero (status words 0..7, histogram + maps, MCU positions, overflow records, event counter): a memset each is ~8 us of
+    // enqueue time in a call that takes a few hundred
+    js_launch_clear5(b->stream, b->dev.side + im.side_off, 8, b->dev.side + im.side_off + JS_SIDE_HISTO, words - JS_SIDE_HISTO, mcu_pos, (size_t)nmcu + 1, anoms, 4,
+                     b->event_words ? b->dev.events + im.ev_off : nullptr, b->event_words ? 1 : 0);      // (the pass logs the end-of-scan markers: a repeated pass must not log them twice)
+    js_launch_side_pass(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.us_base, b->dev.sy_base, (uint32_t)b->imgs.size(), i, us0, usn, sy0, syn,
+                        b->dev.tables, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst, b->dev.ustr, b->dev.seg, b->dev.side, (uint32_t*)b->dev.sub, b->total_subseq,
+                        b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out, b->event_words ? b->dev.events : nullptr, with_anoms ? anoms : nullptr);
+    return 0;
+}
+// A caller that will ask for the side outputs of image i in any case (DecodeScanImg with a log callback) has the clean-image side pass enqueued right behind the
+// decode, before the wait: js_side_only finds it done when the image turns out clean (the usual case) and runs its own otherwise.
+int js_side_prelaunch(JsnoopBatch* b, uint32_t i)
+{
+    if (b->side_pre.size() != b->imgs.size()) b->side_pre.assign(b->imgs.size(), 0);
+    b->side_pre[i] = 0;
+    if (i >= b->imgs.size() || !b->uploaded || b->opt_force_exact || !b->last_used_parallel || (b->tune.cross_checks & JSNOOP_XC_SIDE_EXACT) || js_prog_count(b)) return 0;
+    if (!b->tables[b->imgs[i].tableset].lut_ok) return 0;         // (the exact kernel decodes this image and fills the side block itself)
+    HIP_TRY(hipSetDevice(b->device));
+    if (js_side_parallel_enqueue(b, i, false)) return -1;
+    b->side_pre[i] = 1;
+    return 0;
+}
 int js_side_only(JsnoopBatch* b, uint32_t i)
 {
     HIP_TRY(hipSetDevice(b->device));
     const JsImage& im = b->imgs[i];
     const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax;
     const size_t words = js_side_words(nmcu, im.blk_xmax * im.blk_ymax);
-    HIP_TRY(hipMemsetAsync(b->dev.side + im.side_off, 0, 8 * 4, b->stream));
-    HIP_TRY(hipMemsetAsync(b->dev.side + im.side_off + JS_SIDE_HISTO, 0, (words - JS_SIDE_HISTO) * 4, b->stream));
+    const bool prelaunched = i < b->side_pre.size() && b->side_pre[i] == 1 && i < b->host_path.size() && b->host_path[i] == 1 && b->host_flags[i] == 0 && !(b->tune.cross_checks & JSNOOP_XC_SIDE_EXACT);
+    if (!prelaunched) {
+        HIP_TRY(hipMemsetAsync(b->dev.side + im.side_off, 0, 8 * 4, b->stream));
+        HIP_TRY(hipMemsetAsync(b->dev.side + im.side_off + JS_SIDE_HISTO, 0, (words - JS_SIDE_HISTO) * 4, b->stream));
+    }
     // An image whose only flag is the coefficient-index overflow walks exactly as the reference does (js_parallel_fixup): its maps,
     // histogram and final position come from the parallel side pass like a clean image's; what the overflows add -- scan_bad, the
     // warning counter, two messages per block -- is bookkeeping worked out below from the records the side walk leaves.
@@ -686,16 +725,14 @@ int js_side_only(JsnoopBatch* b, uint32_t i)
     if (b->side_mode.size() != b->imgs.size()) { b->side_mode.assign(b->imgs.size(), 0); b->side_anoms.assign(b->imgs.size(), std::vector<uint32_t>()); }
     b->side_anoms[i].clear();
     if (parallel) {
-        const uint32_t us0 = b->h_us_base[i], usn = b->h_us_base[i + 1] - us0, sy0 = b->h_sy_base[i], syn = b->h_sy_base[i + 1] - sy0;
+        const uint32_t usn = b->h_us_base[i + 1] - b->h_us_base[i];
         uint32_t *mcu_pos = nullptr, *us_out = nullptr;
         if (js_side_scratch(b, i, &mcu_pos, &us_out)) return -1;
         uint32_t* anoms = us_out + (((size_t)usn * 256 + 64 + 15) & ~(size_t)15);
-        HIP_TRY(hipMemsetAsync(anoms, 0, 16, b->stream));
-        HIP_TRY(hipMemsetAsync(mcu_pos, 0, ((size_t)nmcu + 1) * 4, b->stream));
-        if (b->event_words) HIP_TRY(hipMemsetAsync(b->dev.events + im.ev_off, 0, 4, b->stream));   // the pass logs the end-of-scan markers: a repeated pass must not log them twice
-        js_launch_side_pass(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.us_base, b->dev.sy_base, (uint32_t)b->imgs.size(), i, us0, usn, sy0, syn,
-                            b->dev.tables, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst, b->dev.ustr, b->dev.seg, b->dev.side, (uint32_t*)b->dev.sub, b->total_subseq,
-                            b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out, b->event_words ? b->dev.events : nullptr, b->host_flags[i] ? anoms : nullptr);
+        // (a clean image's pass may have been launched behind the decode already, js_side_prelaunch)
+        const bool pre = i < b->side_pre.size() && b->side_pre[i] == 1 && b->host_flags[i] == 0;
+        if (!pre && js_side_parallel_enqueue(b, i, b->host_flags[i] != 0)) return -1;
+        if (i < b->side_pre.size()) b->side_pre[i] = 0;
         if (b->host_flags[i]) {
             // overflow records -> bookkeeping.  Not representable here (more records than the list holds; a block that ends on the last bit of
             // a restart interval, where the reader's position array shows a stale slot): the mirror's side-only pass below.
