@@ -844,7 +844,9 @@ void jsnoop_bright_avg(JsnoopDecoder* d, int* o)
     if (yk != 0) {            // some pixel beat the -32768 start value (:4723-4730)
         const uint32_t px = idx % im.img_x, pyy = idx / im.img_x; const size_t pi = (size_t)pyy * im.blk_xmax * 8 + px;
         o[1] = (int)yk - 32768; o[2] = o[3] = 0; o[7] = (int)(px / im.mcu_w); o[8] = (int)(pyy / im.mcu_h);   // (one component: Cb = Cr = 0, :4709-4715)
-        if (im.ncomp == 3) {
+        const bool cached = d->report_cache && d->h_bright[3] == d->h_side[12] && d->h_bright[4] == d->h_side[13];
+        if (im.ncomp == 3 && cached) { o[2] = (int)d->h_bright[0]; o[3] = (int)d->h_bright[1]; }
+        else if (im.ncomp == 3) {
             if (d->host_valid & 2) { const int16_t* hp = (const int16_t*)d->h_planes.p; const size_t psz = (size_t)im.blk_xmax * 8 * im.blk_ymax * 8; o[2] = hp[psz + pi]; o[3] = hp[2 * psz + pi]; }
             else if (d->batch->opt_want_planes) {                   // the two chroma samples of that pixel straight from HBM (not the whole planes)
                 const size_t psz = (size_t)im.blk_xmax * 8 * im.blk_ymax * 8; int16_t c2[2] = { 0, 0 };
@@ -855,7 +857,10 @@ void jsnoop_bright_avg(JsnoopDecoder* d, int* o)
             }
         }
     }
-    {   // RGB of the brightest pixel through the device colour routine (:4805-4811)
+    if (d->report_cache && d->h_bright[3] == d->h_side[12] && d->h_bright[4] == d->h_side[13] && (im.ncomp != 3 || d->batch->opt_want_planes || !(d->host_valid & 2))) {
+        const uint32_t bgra = d->h_bright[2];                      // (fetched with the side block: k_bright_probe ran the same routine on the same three values)
+        o[4] = (bgra >> 16) & 255; o[5] = (bgra >> 8) & 255; o[6] = bgra & 255;
+    } else {   // RGB of the brightest pixel through the device colour routine (:4805-4811)
         JsnoopBatch* b = d->batch; uint32_t bgra = 0; hipSetDevice(b->device);
         js_launch_color_probe(b->stream, o[1], o[2], o[3], (uint32_t*)b->dev.probe);
         HIP_NOTE(hipMemcpyAsync(&bgra, b->dev.probe, 4, hipMemcpyDeviceToHost, b->stream)); HIP_NOTE(hipStreamSynchronize(b->stream));
@@ -1162,12 +1167,45 @@ void JsnoopDecoder::ensure_side()
 void JsnoopDecoder::fetch_side()
 {
     const JsImage& im = batch->imgs[img];
+    JsnoopBatch* b = batch;
     h_side.assign(js_side_words(im.mcu_xmax * im.mcu_ymax, im.blk_xmax * im.blk_ymax), 0);
-    hipSetDevice(batch->device);
+    hipSetDevice(b->device);
+    report_cache = false;
     // before the side pass has run only the sixteen status words are this decode's (the decode clears nothing else of the side block: histogram and
     // maps would be an earlier decode's, or another image's of an earlier batch) -- they stay zero in the host copy until side_ready
     const size_t words = side_ready ? h_side.size() : (size_t)JS_SIDE_HISTO;
-    if (batch->d2h_staged(h_side.data(), batch->dev.side + im.side_off, words * 4)) log(2, "*** ERROR: reading the side block back failed: %s", g_err.c_str());
+    // With a log callback the report follows: what it reads back besides (event list, restart marks, the brightest pixel's chroma and RGB -- a probe launch) comes
+    // in the same round trip, through the page-locked landing buffer: five waits of ~25 us each otherwise.
+    const size_t nmcu = (size_t)im.mcu_xmax * im.mcu_ymax, ev_words = b->event_words ? 1 + (size_t)JS_EV_WORDS * JS_EV_MAX : 0;
+    const bool with_report = log_fn != nullptr && side_ready && preview_is_jpeg && b->uploaded && !js_prog_count(b);
+    const size_t o_side = 0, o_ev = (words * 4 + 63) & ~(size_t)63, o_rst = o_ev + ((ev_words * 4 + 63) & ~(size_t)63), o_br = o_rst + ((nmcu + 63) & ~(size_t)63), total = o_br + 64;
+    if (!with_report || total > (32u << 20)) {
+        if (b->d2h_staged(h_side.data(), b->dev.side + im.side_off, words * 4)) log(2, "*** ERROR: reading the side block back failed: %s", g_err.c_str());
+        return;
+    }
+    bool ok = true;
+    auto note = [&](hipError_t e) { if (e != hipSuccess) { ok = false; js_set_error("%s", hipGetErrorString(e)); } };
+    if (!b->d2h_land) note(hipHostMalloc((void**)&b->d2h_land, 32u << 20, hipHostMallocDefault));
+    if (ok) {
+        size_t c = b->cap.probe; if (grow(&b->dev.probe, &c, 1024)) ok = false; else b->cap.probe = c;
+    }
+    if (ok) {
+        uint8_t* land = (uint8_t*)b->d2h_land;
+        js_launch_bright_probe(b->stream, b->dev.imgs, (uint32_t)img, b->dev.side, b->opt_want_planes ? b->dev.planes : nullptr, (uint32_t*)b->dev.probe);
+        note(hipMemcpyAsync(land + o_side, b->dev.side + im.side_off, words * 4, hipMemcpyDeviceToHost, b->stream));
+        if (ev_words) note(hipMemcpyAsync(land + o_ev, b->dev.events + im.ev_off, ev_words * 4, hipMemcpyDeviceToHost, b->stream));
+        note(hipMemcpyAsync(land + o_rst, b->dev.mcu_rst + im.mcu_off, nmcu, hipMemcpyDeviceToHost, b->stream));
+        note(hipMemcpyAsync(land + o_br, b->dev.probe, 32, hipMemcpyDeviceToHost, b->stream));
+        note(hipStreamSynchronize(b->stream));
+        if (ok) {
+            memcpy(h_side.data(), land + o_side, words * 4);
+            h_events.assign((const uint32_t*)(land + o_ev), (const uint32_t*)(land + o_ev) + ev_words);
+            h_rstf.assign(land + o_rst, land + o_rst + nmcu);
+            memcpy(h_bright, land + o_br, 32);
+            report_cache = true;
+        }
+    }
+    if (!ok) log(2, "*** ERROR: reading the side block back failed: %s", g_err.c_str());
 }
 void JsnoopDecoder::rerender()                                  // CalcChannelPreview :4965 on the retained data: colour kernel only
 {

@@ -42,6 +42,9 @@ struct JsnoopDecoder {
     // costs more (a single-image progressive decode: 2.8 -> 5.1 ms per call after one GetBitmapPtr).
     struct Pinned { void* p = nullptr; size_t cap = 0; int ensure(size_t need); ~Pinned(); };
     Pinned h_dib, h_planes; std::vector<uint32_t> h_side;
+    // what the report reads back besides the side block, fetched with it in ONE round trip (fetch_side): the device's event list, the per-MCU restart marks,
+    // chroma + BGRA of the brightest pixel (k_bright_probe) -- valid for the decode they were fetched behind
+    std::vector<uint32_t> h_events; std::vector<uint8_t> h_rstf; uint32_t h_bright[8] = {0}; bool report_cache = false;
     uint32_t zero_histo[2 * 4 * 17] = {0};
     // what the reference keeps for a preview that does not come from the scan decoder (m_pDibTemp filled by the PSD decoder, m_bDibTempReady,
     // m_rectImgBase: source/ImgDecode.h:508-510, SetImageDimensions :2706)

@@ -1143,6 +1143,23 @@ __global__ void __launch_bounds__(64) k_idct_probe(const float* __restrict__ lut
 
 // ConvertYCCtoRGBFastFloat on one triple (the RGB of the brightest pixel, :4805-4811).
 __global__ void k_color_probe(int y, int cb, int cr, uint32_t* out) { out[0] = ycc_to_bgra<true>(y, cb, cr, 1); }
+// The brightest pixel of image `img` as the report quotes it (:4722-4730, :4805-4811): its chroma samples from the retained planes and its RGB through the colour
+// routine, from the key the back end left in side words 12 / 13 -- out[0] = Cb, [1] = Cr, [2] = BGRA, [3] / [4] = the key these belong to.  One thread.
+__global__ void k_bright_probe(const JsImage* __restrict__ imgs, uint32_t img, const uint32_t* __restrict__ side, const int16_t* __restrict__ planes, uint32_t* __restrict__ out)
+{
+    const JsImage& im = imgs[img];
+    const uint32_t k_lo = side[im.side_off + 12], k_hi = side[im.side_off + 13];
+    int y = -32768, cb = -32768, cr = -32768;
+    if (k_hi != 0u) {
+        const uint32_t idx = 0xFFFFFFFFu - k_lo, px = idx % im.img_x, py = idx / im.img_x;
+        y = (int)k_hi - 32768; cb = 0; cr = 0;
+        if (im.ncomp == 3 && planes) {
+            const size_t psz = (size_t)im.blk_xmax * 8 * im.blk_ymax * 8, pi = (size_t)py * im.blk_xmax * 8 + px;
+            cb = planes[im.plane_off + psz + pi]; cr = planes[im.plane_off + 2 * psz + pi];
+        }
+    }
+    out[0] = (uint32_t)cb; out[1] = (uint32_t)cr; out[2] = ycc_to_bgra<true>(y, cb, cr, 1); out[3] = k_lo; out[4] = k_hi;
+}
 // Every (y, cb, cr) in [-128, 127]^3 through the device colour conversion: out[(y+128)<<16 | (cb+128)<<8 | (cr+128)] = BGRA.
 // Both ways of finishing a pixel (packed bytes straight from the floats; capped integers for the preview modes) must agree:
 // a triple on which they do not comes back with a non-zero alpha byte.
@@ -1395,6 +1412,8 @@ void js_launch_idct_probe(hipStream_t st, const float* lut_t, const int16_t* coe
 { hipLaunchKernelGGL(k_idct_probe, dim3(1), dim3(64), 64 * 64 * sizeof(float) + LIST_BYTES, st, lut_t, coef64, out64); }
 void js_launch_color_probe(hipStream_t st, int y, int cb, int cr, uint32_t* out)
 { hipLaunchKernelGGL(k_color_probe, dim3(1), dim3(1), 0, st, y, cb, cr, out); }
+void js_launch_bright_probe(hipStream_t st, const JsImage* imgs, uint32_t img, const uint32_t* side, const int16_t* planes, uint32_t* out8)
+{ hipLaunchKernelGGL(k_bright_probe, dim3(1), dim3(1), 0, st, imgs, img, side, planes, out8); }
 void js_launch_color_sweep(hipStream_t st, uint32_t* out)
 { hipLaunchKernelGGL(k_color_sweep, dim3(1u << 16), dim3(256), 0, st, out); }
 void js_launch_color_stats(hipStream_t st, const JsImage* imgs, uint32_t img, const int16_t* planes, int hist_en, uint32_t* stats)

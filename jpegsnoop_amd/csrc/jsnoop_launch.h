@@ -16,6 +16,7 @@ void js_launch_clear3(hipStream_t st, void* a, size_t a_bytes, void* b, size_t b
 void js_launch_clear5(hipStream_t st, uint32_t* a, size_t na, uint32_t* b, size_t nb, uint32_t* c, size_t nc, uint32_t* d, size_t nd, uint32_t* e, size_t ne);   // five word ranges to zero in one launch
 void js_launch_dib_checksum(hipStream_t st, const JsImage* imgs, uint32_t nimg, const uint8_t* dib, unsigned long long* sums);
 void js_launch_color_probe(hipStream_t st, int y, int cb, int cr, uint32_t* out);
+void js_launch_bright_probe(hipStream_t st, const JsImage* imgs, uint32_t img, const uint32_t* side, const int16_t* planes /*or null*/, uint32_t* out8);   // chroma + BGRA of the brightest pixel, and the key they belong to
 #define JS_STATS_WORDS 2482          /* public layout, include/jsnoop_gpu.h JSNOOP_STATS_WORDS */
 #define JS_STATS_DEV_WORDS 2496      /* + the six uncapped YCC range-event totals, padded */
 void js_launch_color_stats(hipStream_t st, const JsImage* imgs, uint32_t img, const int16_t* planes, int hist_en, uint32_t* stats);

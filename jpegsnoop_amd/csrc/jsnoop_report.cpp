@@ -102,7 +102,9 @@ void js_emit_decode_events(JsnoopDecoder* d)
         return;
     }
     std::vector<uint32_t> raw(1 + (size_t)JS_EV_WORDS * JS_EV_MAX);
-    if (b->d2h_staged(raw.data(), b->dev.events + im.ev_off, raw.size() * 4)) {   /* page-locked landing buffer: no pageable asynchronous copies */ d->log(2, "*** ERROR: reading the decoder's event log back from the device failed ***"); return; }
+    const bool cached = d->report_cache && d->h_events.size() == raw.size();      // (fetched with the side block, JsnoopDecoder::fetch_side)
+    if (cached) raw = d->h_events;
+    else if (b->d2h_staged(raw.data(), b->dev.events + im.ev_off, raw.size() * 4)) {   /* page-locked landing buffer: no pageable asynchronous copies */ d->log(2, "*** ERROR: reading the decoder's event log back from the device failed ***"); return; }
     std::vector<Ev> evs;
     const uint32_t n = std::min<uint32_t>(raw[0], JS_EV_MAX);
     const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax;
@@ -121,7 +123,8 @@ void js_emit_decode_events(JsnoopDecoder* d)
         // number is not the expected one (:1416-1423, logged when the refill meets it, i.e. before the MCU behind it), and
         // an elapsed restart interval with no marker in the stream (:3180-3200, logged at the top of that MCU).
         std::vector<uint8_t> rstf(nmcu);
-        if (b->d2h_staged(rstf.data(), b->dev.mcu_rst + im.mcu_off, nmcu)) { d->log(2, "*** ERROR: reading the restart flags back from the device failed ***"); return; }
+        if (d->report_cache && d->h_rstf.size() == nmcu) rstf = d->h_rstf;
+        else if (b->d2h_staged(rstf.data(), b->dev.mcu_rst + im.mcu_off, nmcu)) { d->log(2, "*** ERROR: reading the restart flags back from the device failed ***"); return; }
         const uint8_t* f = b->pinned + im.file_off;
         uint32_t q = im.scan_start, expect = 0, left = im.rst_interval;
         const uint32_t end = im.scan_start + im.scan_len;
