@@ -50,6 +50,8 @@ struct ExactReader {
     uint32_t used1, used2, precision, rst_handled;
     uint32_t warn_marker;                                      // of warn_bad: the "Scan Data encountered marker" messages alone
     uint32_t* ev; uint32_t ev_cap, ev_only;                    // event log (JS_EV_*): nullptr = off; ev_only != 0: record just that kind
+    uint32_t ev_end;                                           // the reader covers only the END of the scan (k_side_maps): an RSTn its look-ahead meets is recorded with the
+                                                               // expected index left open (~0) -- the host, which has followed the markers up to there, fills it in or drops the record
     uint64_t win; uint32_t win_at;                             // 8 file bytes in registers (file images are 16-byte aligned and zero padded)
     const uint32_t* fast;                                      // m_anDhtLookupfast of the six slots, [6][1 << JS_FAST_BITS] (LDS copy in k_entropy_exact)
     const uint32_t* meta;                                      // [0..5] m_anDhtLookupSize per slot, [6..11] DHT destination id per slot
@@ -62,7 +64,7 @@ struct ExactReader {
 // One line (group) of what the reference writes to its log while decoding; formatted on the host (jsnoop_report.cpp).
 __device__ __forceinline__ void ex_event(ExactReader& r, uint32_t kind, uint32_t a0 = 0, uint32_t a1 = 0, uint32_t a2 = 0, uint32_t a3 = 0, uint32_t a4 = 0)
 {
-    if (!r.ev || (r.ev_only && r.ev_only != kind)) return;
+    if (!r.ev || (r.ev_only && r.ev_only != kind && !(r.ev_end && kind == JS_EV_RST_INDEX))) return;
     const uint32_t n = r.ev[0];
     if (n < r.ev_cap) { uint32_t* e = r.ev + 1 + (size_t)n * JS_EV_WORDS; e[0] = kind; e[1] = a0; e[2] = a1; e[3] = a2; e[4] = a3; e[5] = a4; }
     r.ev[0] = n + 1;
@@ -111,7 +113,8 @@ __device__ __forceinline__ void ex_add_byte(ExactReader& r)                     
     uint32_t b0 = ex_byte(r, r.ptr), b1 = ex_byte(r, r.ptr + 1);
     if (b0 == 0xFF && b1 >= 0xD0 && b1 <= 0xD7) {
         r.rst_count++; r.rst_last = b1 - 0xD0;
-        if (r.rst_last != r.rst_expect) ex_event(r, JS_EV_RST_INDEX, r.rst_expect, r.rst_last, r.ptr);       // :1416-1423
+        if (r.ev_end) ex_event(r, JS_EV_RST_INDEX, 0xFFFFFFFFu, r.rst_last, r.ptr);
+        else if (r.rst_last != r.rst_expect) ex_event(r, JS_EV_RST_INDEX, r.rst_expect, r.rst_last, r.ptr);       // :1416-1423
         r.rst_expect = (r.rst_last + 1) & 7; r.restart_read = 1; return;
     }
     if (b0 == 0xFF && b1 == 0x00)      { ex_add(r, b0, r.ptr, SB_OK); r.ptr += 2; }
@@ -297,7 +300,7 @@ __global__ void __launch_bounds__(64) k_entropy_exact(const JsImage* __restrict_
     r.file = raw + im.file_off; r.flen = im.file_len; r.ts = tables + im.tableset; r.histo = s_histo; r.fast = s_fast; r.meta = s_meta; r.q = s_q; r.zz = s_zz; r.win_at = 0xFFFFFFFFu; r.win = 0;
     r.rst_interval = im.rst_interval; r.precision = im.precision; r.err_max = im.err_max; r.warn_bad = 0; r.warn_marker = 0;
     r.rst_count = 0; r.rst_last = 0; r.rst_expect = 0; r.rst_handled = 0;
-    r.ev = (im.ev_cap && events) ? events + im.ev_off : nullptr; r.ev_cap = im.ev_cap; r.ev_only = 0;       // (side-only passes log when the caller hands the event area over)
+    r.ev = (im.ev_cap && events) ? events + im.ev_off : nullptr; r.ev_cap = im.ev_cap; r.ev_only = 0; r.ev_end = 0;       // (side-only passes log when the caller hands the event area over)
     ex_restart_scan_buf(r, im.scan_start, false);
     int16_t dc_y = 0, dc_cb = 0, dc_cr = 0;
     int16_t (*css)[16] = s_css;
@@ -3006,6 +3009,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
             nblk += captured ? 0u : 1u;
             if (!SIDE && flush) dbase[blk] = dq0;
             if (SIDE && flush && c == 0) mcu_pos[(blk + 1) / T.nb] = cur.p;      // the next MCU starts here (before any restart handling)
+            if (SIDE && flush && blk + 2u == nblocks) mcu_pos[nblocks / T.nb + 1u] = cur.p;   // ... and the image's LAST block here: where k_side_maps starts its reader for the end of the scan
             skip = false; blk++;
         }
         // ---- the whole wave moves every block that completed in this iteration: one 128-byte line each ----
@@ -3583,17 +3587,28 @@ __device__ uint32_t raw_of_compacted(const JsImage& im, const uint8_t* __restric
 __device__ __forceinline__ uint32_t mirror_to_mcu_top(const JsImage& im, const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ raw, const uint32_t* __restrict__ st,
                                       uint32_t nseg, uint32_t total_bytes, const uint8_t* __restrict__ mcu_rst, const uint32_t* __restrict__ mcu_pos,
                                       const uint32_t* __restrict__ us_out, uint32_t us_threads, uint32_t m_top, ExactReader& r, uint32_t* dummy_histo, int16_t* scratch,
-                                      uint32_t* events, const ExactReader* lds_tabs = nullptr)
+                                      uint32_t* events, const ExactReader* lds_tabs = nullptr, uint32_t p_last_blk = 0 /* m_top == number of MCUs: bit position of the last block's top, or 0 */)
 {
     uint32_t* meta12 = dummy_histo + 2 * 4 * 17;                  // the caller's scratch has room for the 12 slot words behind the histogram
     r.file = raw + im.file_off; r.flen = im.file_len; r.ts = tables + im.tableset; r.histo = dummy_histo; r.fast = &r.ts->fast[0][0]; r.meta = meta12; r.q = &r.ts->qzz[0][0]; r.zz = c_zigzag; r.win_at = 0xFFFFFFFFu; r.win = 0;
     for (int i = 0; i < 6; i++) { meta12[i] = r.ts->size[i]; meta12[6 + i] = r.ts->dest_id[i]; }
     if (lds_tabs) { r.fast = lds_tabs->fast; r.q = lds_tabs->q; r.zz = lds_tabs->zz; }                  // (copies of the same tables in LDS: k_side_chunks)
     // the markers the look-ahead runs into at the end of the scan (":  Scan Data encountered marker", :1536) are logged from here
-    r.ev = (events && im.ev_cap) ? events + im.ev_off : nullptr; r.ev_cap = im.ev_cap; r.ev_only = JS_EV_MARKER;
+    r.ev = (events && im.ev_cap) ? events + im.ev_off : nullptr; r.ev_cap = im.ev_cap; r.ev_only = JS_EV_MARKER; r.ev_end = m_top == im.mcu_xmax * im.mcu_ymax ? 1u : 0u;
     r.rst_interval = im.rst_interval; r.precision = im.precision; r.err_max = im.err_max; r.warn_bad = 0; r.warn_marker = 0;
     r.rst_count = 0; r.rst_last = 0; r.rst_expect = 0; r.rst_handled = 0;
-    uint32_t m0 = m_top ? m_top - 1 : 0, rst_before = 0;
+    uint32_t m0 = m_top ? m_top - 1 : 0, rst_before = 0, c0 = 0;
+    // The end of the scan needs the reader only for what the look-ahead meets there: it may start at the top of the last BLOCK (the state at any symbol
+    // boundary is a function of the bit position, as at an MCU top) -- a sixth of the symbols of a 4:2:0 MCU, at 1.3 us each on one lane.
+    bool from_blk = false;
+    if (p_last_blk && im.blk_per_mcu > 1u && m_top) {
+        const uint32_t sg = find_interval(st, nseg, p_last_blk >> 3);
+        if ((sg + 1 >= nseg || st[sg + 1] * 8 >= p_last_blk + 40) && p_last_blk > mcu_pos[m_top - 1]) {
+            rst_before = sg; c0 = im.blk_per_mcu - 1u; from_blk = true;
+            ex_restart_scan_buf(r, raw_of_compacted(im, raw, us_out, us_threads, p_last_blk >> 3), true); ex_topup(r); ex_consume(r, p_last_blk & 7u);
+        }
+    }
+    if (!from_blk)
     for (;; m0--) {
         if (m0 == 0) { ex_restart_scan_buf(r, im.scan_start, false); ex_topup(r); break; }
         const uint32_t p = mcu_pos[m0];
@@ -3613,7 +3628,7 @@ __device__ __forceinline__ uint32_t mirror_to_mcu_top(const JsImage& im, const J
     r.ptr_first = im.scan_start;
     int16_t dc_y = 0, dc_cb = 0, dc_cr = 0;
     for (uint32_t mi = m0; mi < m_top; mi++) {
-        for (uint32_t c = 0; c < im.blk_per_mcu; c++) {
+        for (uint32_t c = mi == m0 ? c0 : 0u; c < im.blk_per_mcu; c++) {
             ex_decode_block(r, im.blk_comp[c], im.decode_ac, scratch, dc_y, dc_cb, dc_cr);
             if (r.cur_err) { if (r.warn_bad < r.err_max) r.warn_bad++; r.cur_err = 0; }   // CheckScanErrors :2605
         }
@@ -3659,7 +3674,7 @@ __global__ void __launch_bounds__(256) k_side_maps(const JsImage* __restrict__ i
             // look-ahead meets EOI / trailing bytes: take both from the mirror reader itself
             ExactReader r;
             const uint32_t before = mirror_to_mcu_top(im, tables, raw, st, nseg, sd[10], mcu_rst, mcu_pos, us_out, us_threads, m, r, s_mh[wv], s_ms[wv],
-                                                      m == nmcu ? events : nullptr);
+                                                      m == nmcu ? events : nullptr, nullptr, m == nmcu ? mcu_pos[nmcu + 1u] : 0u);
             if (m < nmcu) mcu_map[m] = (r.pos0 << 4) + r.align;
             else {                                                  // status words after the last MCU
                 sd[0] = r.scan_bad; sd[1] = r.scan_end; sd[2] = before + r.rst_count; sd[3] = nmcu * im.samp_h[1] * im.samp_v[1] * 64u;
@@ -3752,7 +3767,7 @@ __global__ void __launch_bounds__(64 * SC_WAVES) k_side_chunks(const JsImage* __
         r.rst_interval = im.rst_interval; r.precision = im.precision;
         r.rst_count = 0; r.rst_last = 0; r.rst_expect = 0; r.rst_handled = 0;
         for (uint32_t i = 0; i < 2 * 4 * 17; i++) histo[i] = 0;
-        r.histo = histo; r.err_max = im.err_max; r.warn_bad = 0; r.warn_marker = 0; r.ev = rec + SC_HDR - 1; r.ev_cap = ev_cap; r.ev_only = 0;
+        r.histo = histo; r.err_max = im.err_max; r.warn_bad = 0; r.warn_marker = 0; r.ev = rec + SC_HDR - 1; r.ev_cap = ev_cap; r.ev_only = 0; r.ev_end = 0;
         ex_restart_scan_buf(r, im.scan_start, false);
         ex_topup(r);
     } else {
@@ -3765,7 +3780,7 @@ __global__ void __launch_bounds__(64 * SC_WAVES) k_side_chunks(const JsImage* __
             if (b1 >= 0xD0u && b1 <= 0xD7u) { r.rst_last = b1 - 0xD0u; r.rst_expect = (r.rst_last + 1u) & 7u; }
         }
         for (uint32_t i = 0; i < 2 * 4 * 17; i++) histo[i] = 0;
-        r.err_max = im.err_max; r.warn_bad = 0; r.warn_marker = 0; r.ev = rec + SC_HDR - 1; r.ev_cap = ev_cap; r.ev_only = 0;
+        r.err_max = im.err_max; r.warn_bad = 0; r.warn_marker = 0; r.ev = rec + SC_HDR - 1; r.ev_cap = ev_cap; r.ev_only = 0; r.ev_end = 0;
         r.scan_bad = 0; r.cur_err = 0;
     }
     r.mcus_left = mcus_left0[chunk];

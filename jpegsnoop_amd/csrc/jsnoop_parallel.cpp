@@ -524,7 +524,7 @@ int js_parallel_fixup(JsnoopBatch* b)
             uint32_t *mcu_pos = nullptr, *us_out = nullptr;
             if (js_side_scratch(b, i, &mcu_pos, &us_out)) return -1;
             const uint32_t us0 = b->h_us_base[i], usn = b->h_us_base[i + 1] - us0, sy0 = b->h_sy_base[i], syn = b->h_sy_base[i + 1] - sy0;
-            HIP_TRY(hipMemsetAsync(mcu_pos, 0, ((size_t)im.mcu_xmax * im.mcu_ymax + 1) * 4, b->stream));
+            HIP_TRY(hipMemsetAsync(mcu_pos, 0, ((size_t)im.mcu_xmax * im.mcu_ymax + 2) * 4, b->stream));
             HIP_TRY(hipMemcpyAsync(b->dev.sel, &i, 4, hipMemcpyHostToDevice, b->stream));
             js_launch_tail_pass(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.us_base, b->dev.sy_base, n, us0, usn, sy0, syn, b->dev.tables, b->dev.raw,
                                 b->dev.chunk_keep, b->dev.chunk_rst, b->dev.ustr, b->dev.seg, b->dev.side, (uint32_t*)b->dev.sub, b->total_subseq,
@@ -567,14 +567,14 @@ static int js_side_scratch(JsnoopBatch* b, uint32_t i, uint32_t** mcu_pos, uint3
 {
     const JsImage& im = b->imgs[i];
     const size_t nmcu = (size_t)im.mcu_xmax * im.mcu_ymax, usn = b->h_us_base[i + 1] - b->h_us_base[i];
-    const size_t need = (nmcu + 1 + usn * 256 + 64 + 16 + 4 + 4 * (size_t)JS_ANOM_MAX) * 4;     // ... and the overflow records of the side walk behind it
+    const size_t need = (nmcu + 2 + usn * 256 + 64 + 16 + 4 + 4 * (size_t)JS_ANOM_MAX) * 4;     // ... and the overflow records of the side walk behind it
     if (need > b->side_tmp_cap) {
         if (b->d_side_tmp) hipFree(b->d_side_tmp);
         b->d_side_tmp = nullptr; b->side_tmp_cap = 0;
         HIP_TRY(hipMalloc((void**)&b->d_side_tmp, need + need / 8));
         b->side_tmp_cap = need + need / 8;
     }
-    *mcu_pos = b->d_side_tmp; *us_out = *mcu_pos + ((nmcu + 1 + 15) & ~(size_t)15);
+    *mcu_pos = b->d_side_tmp; *us_out = *mcu_pos + ((nmcu + 2 + 15) & ~(size_t)15);        // (mcu_pos[nmcu + 1]: the top of the image's last block)
     return 0;
 }
 // The chunked side pass of a flagged image (k_side_chunks): 0 = done (side block complete, b->side_events[i] holds the messages), 1 = not
@@ -587,7 +587,7 @@ static int js_side_chunked(JsnoopBatch* b, uint32_t i)
     if (!usn || !syn || !nmcu) return 1;
     uint32_t *mcu_pos = nullptr, *us_out = nullptr;
     if (js_side_scratch(b, i, &mcu_pos, &us_out)) return -1;
-    HIP_TRY(hipMemsetAsync(mcu_pos, 0, ((size_t)nmcu + 1) * 4, b->stream));
+    HIP_TRY(hipMemsetAsync(mcu_pos, 0, ((size_t)nmcu + 2) * 4, b->stream));
     if (b->event_words) HIP_TRY(hipMemsetAsync(b->dev.events + im.ev_off, 0, 4, b->stream));
     // chunks of at least 8 MCUs, at most 4096 of them; a lane keeps the first err_max counted events and some more of the uncounted kinds
     const uint32_t ch = std::max<uint32_t>(8u, (nmcu + 4095u) / 4096u), nchunks = (nmcu + ch - 1) / ch;
@@ -687,7 +687,7 @@ static int js_side_parallel_enqueue(JsnoopBatch* b, uint32_t i, bool with_anoms)
     uint32_t* anoms = us_out + (((size_t)usn * 256 + 64 + 15) & ~(size_t)15);
     // one launch for the five areas to zero (status words 0..7, histogram + maps, MCU positions, overflow records, event counter): a memset each is ~8 us of
     // enqueue time in a call that takes a few hundred
-    js_launch_clear5(b->stream, b->dev.side + im.side_off, 8, b->dev.side + im.side_off + JS_SIDE_HISTO, words - JS_SIDE_HISTO, mcu_pos, (size_t)nmcu + 1, anoms, 4,
+    js_launch_clear5(b->stream, b->dev.side + im.side_off, 8, b->dev.side + im.side_off + JS_SIDE_HISTO, words - JS_SIDE_HISTO, mcu_pos, (size_t)nmcu + 2, anoms, 4,
                      b->event_words ? b->dev.events + im.ev_off : nullptr, b->event_words ? 1 : 0);      // (the pass logs the end-of-scan markers: a repeated pass must not log them twice)
     js_launch_side_pass(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.us_base, b->dev.sy_base, (uint32_t)b->imgs.size(), i, us0, usn, sy0, syn,
                         b->dev.tables, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst, b->dev.ustr, b->dev.seg, b->dev.side, (uint32_t*)b->dev.sub, b->total_subseq,

@@ -146,6 +146,18 @@ void js_emit_decode_events(JsnoopDecoder* d)
             }
             if (im.rst_en) left--;
         }
+        // An RSTn the reader's look-ahead meets BEHIND the last MCU (a file that goes on past its last MCU: a destroyed marker in front of it, say) is reported like
+        // any other whose number is not the expected one (:1416-1423): the end-of-scan reader of the side pass records it with the expectation left open -- it is the
+        // one the markers up to here leave (tools/fuzz_damaged_log.py seed 701 case 2164, round 6).
+        for (size_t k = 0; k < evs.size();) {
+            Ev& e = evs[k];
+            if (e.kind == JS_EV_RST_INDEX && e.a[0] == 0xFFFFFFFFu) {
+                const uint32_t got = e.a[1];
+                if (got == expect) { expect = (got + 1) & 7; evs.erase(evs.begin() + (long)k); continue; }
+                e.a[0] = expect; expect = (got + 1) & 7;
+            }
+            k++;
+        }
         // Coefficient-index overflows (records of the side walk, block order): "nNumCoeffs>64" where the offending symbol starts (:1723-1735),
         // then CheckScanErrors' two lines at the end of the block (:2605-2650).  Positions are file offsets of bytes of the un-stuffed
         // stream: one pass over the scan bytes with the byte rules of BuffAddByte resolves them.

@@ -439,3 +439,31 @@ def test_scan_that_begins_with_a_restart_marker(harness, oracle, gpu):
     finally:
         if ref is not None:
             ref.close()
+
+
+def test_restart_marker_behind_the_last_mcu(harness, oracle, gpu):
+    """tools/fuzz_damaged_log.py seed 701 case 2164 (round 6; older than the round): garbage over an RST7 -- the decode runs through where the marker was, the image's
+    MCUs are used up while the file still holds two restart intervals, and the look-ahead behind the LAST MCU meets RST0 where RST7 is expected: the reference
+    reports that like any other wrong index (:1416-1423).  The end-of-scan reader of the parallel side pass kept only the "Scan Data encountered marker" messages;
+    now it records the marker with the expectation left open and the host, which has followed the markers up to there, fills it in (or drops the record).
+    The file is the fuzz case itself (tests/golden/fuzz/)."""
+    import os
+    from fuzz_util import differs
+    data = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz", "rst_behind_last_mcu_s701_c2164.jpg"), "rb").read()
+    ref = harness.ref_backend() if harness.have_ref() else None
+    try:
+        for b in (oracle, gpu) + ((ref,) if ref else ()): b.set_options(decode_ac=1, err_max=20)
+        harness.drive(oracle, data)
+        harness.drive(gpu, data, quiet=0)
+        got = gpu.log_lines()
+        assert differs(oracle, gpu) is None
+        assert gpu.lib.jsnoop_last_path(gpu.h) == 1 and gpu.lib.jsnoop_last_side_mode(gpu.h) == 1      # (the parallel side pass with its overflow records)
+        assert any("Expected RST marker index RST7 got RST0 @ 0x000018C1.0" in l for l in got)
+        if ref is not None:
+            harness.drive(ref, data, quiet=0)
+            want = ref.log_lines()
+            assert got == want, next((i, a, b) for i, (a, b) in enumerate(zip(got + [None], want + [None])) if a != b)
+    finally:
+        for b in (oracle, gpu): b.set_options()
+        if ref is not None:
+            ref.set_options(); ref.close()
