@@ -297,6 +297,8 @@ JsnoopBatch::~JsnoopBatch()
     js_prog_free(this);
     if (pinned) hipHostFree(pinned);
     if (d2h_land) hipHostFree(d2h_land);
+    if (h_desc) hipHostFree(h_desc);
+    if (ev_up) hipEventDestroy(ev_up);
     for (auto& e : ev) if (e) hipEventDestroy(e);
     for (auto& e : ev2) if (e) hipEventDestroy(e);
     for (auto& e : aux_ev) if (e) hipEventDestroy(e);
@@ -497,12 +499,25 @@ int JsnoopBatch::upload()
     for (const JsTableSet& t : tables) { tab_rows = std::max(tab_rows, t.n_rows); tab_lut2 = std::max(tab_lut2, t.lut2_used); tdc = std::max(tdc, t.n_dc_rows); tac = std::max(tac, t.n_ac_rows); }
     tab_rows_w = tdc | (tac << 8);                                 // write pass: DC rows (16-bit entries) and AC rows (32-bit pair entries) separately
     HIP_TRY(hipMemcpyAsync(dev.raw, pinned, raw_bytes, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(dev.imgs, imgs.data(), n * sizeof(JsImage), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(dev.tables, tables.data(), tables.size() * sizeof(JsTableSet), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(dev.wg_base, wg.data(), (n + 1) * 4, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(dev.us_base, usb.data(), 2 * (n + 1) * 4, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(dev.sy_base, syb.data(), 2 * (n + 1) * 4, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipStreamSynchronize(stream));          // host vectors above may go out of scope
+    {   // The descriptors go through ONE page-locked staging block of this batch: copies out of pageable vectors are staged by the runtime one by one, and the wait
+        // that kept those vectors alive was a round trip of its own (a single-image call: upload 75 -> ~35 us).  The block is rewritten by the next upload only:
+        // that one waits for this one's copies first (an event; long done in any real sequence of calls).
+        const size_t sz[5] = { n * sizeof(JsImage), tables.size() * sizeof(JsTableSet), (n + 1) * 4, 2 * (n + 1) * 4, 2 * (n + 1) * 4 };
+        const void* src[5] = { imgs.data(), tables.data(), wg.data(), usb.data(), syb.data() };
+        void* dst[5] = { dev.imgs, dev.tables, dev.wg_base, dev.us_base, dev.sy_base };
+        size_t off[5], total = 0;
+        for (int k = 0; k < 5; k++) { off[k] = total; total += (sz[k] + 255) & ~(size_t)255; }
+        if (!ev_up) HIP_TRY(hipEventCreateWithFlags(&ev_up, hipEventDisableTiming));
+        else HIP_TRY(hipEventSynchronize(ev_up));
+        if (total > h_desc_cap) {
+            if (h_desc) hipHostFree(h_desc);
+            h_desc = nullptr; h_desc_cap = 0;
+            HIP_TRY(hipHostMalloc((void**)&h_desc, total + total / 4 + 4096, hipHostMallocDefault));
+            h_desc_cap = total + total / 4 + 4096;
+        }
+        for (int k = 0; k < 5; k++) { memcpy(h_desc + off[k], src[k], sz[k]); HIP_TRY(hipMemcpyAsync(dst[k], h_desc + off[k], sz[k], hipMemcpyHostToDevice, stream)); }
+        HIP_TRY(hipEventRecord(ev_up, stream));
+    }
     h_us_base.assign(usb.begin(), usb.begin() + n + 1); h_us4_base.assign(usb.begin() + n + 1, usb.end()); h_sy_base.assign(syb.begin(), syb.begin() + n + 1); h_sn_base.assign(syb.begin() + n + 1, syb.end()); h_wg_base = wg;
     // two halves on two streams: by default from the batch size at which the long sub-sequences are chosen (96 MB of scan data)
     split_parts = (n >= 2 && (tune.split == 2 || (tune.split == 0 && scan_total >= (96ull << 20)))) ? 2 : 1;

@@ -107,6 +107,7 @@ struct JsnoopBatch {
     uint32_t* d_side_tmp = nullptr; size_t side_tmp_cap = 0;      // scratch of the side-output pass (one image at a time)
     uint8_t* pinned; size_t pinned_cap; uint64_t raw_bytes;
     uint8_t* d2h_land = nullptr;                                  // page-locked landing buffer of the read-back calls (32 MiB, on first use)
+    uint8_t* h_desc = nullptr; size_t h_desc_cap = 0; hipEvent_t ev_up = nullptr;   // page-locked staging block of the descriptors (upload), the event behind its copies
     int  d2h_staged(void* dst, const void* src, size_t bytes);
     JsDeviceArenas dev; JsArenaCaps cap;
     bool uploaded;
