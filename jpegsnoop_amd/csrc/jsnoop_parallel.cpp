@@ -590,7 +590,8 @@ static int js_side_chunked(JsnoopBatch* b, uint32_t i)
     HIP_TRY(hipMemsetAsync(mcu_pos, 0, ((size_t)nmcu + 2) * 4, b->stream));
     if (b->event_words) HIP_TRY(hipMemsetAsync(b->dev.events + im.ev_off, 0, 4, b->stream));
     // chunks of at least 8 MCUs, at most 4096 of them; a lane keeps the first err_max counted events and some more of the uncounted kinds
-    const uint32_t ch = std::max<uint32_t>(8u, (nmcu + 4095u) / 4096u), nchunks = (nmcu + ch - 1) / ch;
+    // (MCUs per exact reader: 8 / 4 / 2 give a 1080p file's report in 2.5-2.9 / 1.6-2.3 / 2.0-2.7 ms -- the readers' latency against the records the host merges)
+    const uint32_t ch = std::max<uint32_t>(4u, (nmcu + 8191u) / 8192u), nchunks = (nmcu + ch - 1) / ch;
     // run_on: the MCU from which the walks do not vouch for the stream (a tail take-over): the lane of its chunk goes on alone -- and keeps the block-DC maps from its
     // chunk's first MCU on, which k_side_maps therefore leaves out (cut)
     const uint32_t run_on = b->side_chunk_ok[i] == 3 ? std::min(b->host_anom[i] / im.blk_per_mcu, nmcu - 1) : 0xFFFFFFFFu;
@@ -598,7 +599,7 @@ static int js_side_chunked(JsnoopBatch* b, uint32_t i)
     js_launch_side_pass(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.us_base, b->dev.sy_base, (uint32_t)b->imgs.size(), i, us0, usn, sy0, syn,
                         b->dev.tables, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst, b->dev.ustr, b->dev.seg, b->dev.side, (uint32_t*)b->dev.sub, b->total_subseq,
                         b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out, nullptr, nullptr, b->side_chunk_ok[i] == 2 ? b->host_anom[i] : 0xFFFFFFFFu, cut);
-    const uint32_t ev_cap = std::min<uint32_t>(im.err_max, 64u) + 64u, stride = JS_SC_HDR + ev_cap * JS_EV_WORDS;
+    const uint32_t ev_cap = std::min<uint32_t>(im.err_max, 64u) + 32u, stride = JS_SC_HDR + ev_cap * JS_EV_WORDS;      // (a chunk with more messages than that: the mirror, below)
     const size_t words = (((size_t)nchunks * stride + nmcu + 1) & ~(size_t)1) + 2 * (size_t)nmcu + nchunks + 64 + 64;
     if (words * 4 > b->chunk_tmp_cap) {
         if (b->d_chunk_tmp) hipFree(b->d_chunk_tmp);
