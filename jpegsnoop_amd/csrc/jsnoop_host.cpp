@@ -767,8 +767,9 @@ void jsnoop_decode_scan_img(JsnoopDecoder* d, const uint8_t* file, size_t len, u
     if (dbg_t) tp[ntp++] = now_us();
     if (b->upload()) { d->log(2, "*** ERROR: device decode failed: %s", g_err.c_str()); return; }
     if (dbg_t) tp[ntp++] = now_us();
-    if (b->decode(false)) { d->log(2, "*** ERROR: device decode failed: %s", g_err.c_str()); return; }
-    if (d->log_fn) (void)js_side_prelaunch(b, 0);                  // the report will ask for the side outputs: their pass goes behind the decode now, not behind the wait
+    if (d->log_fn) (void)js_side_prepare(b, 0);                     // (the report will ask for the side outputs: the decode's write pass records for them)
+    if (b->decode(false)) { b->rec_pos = nullptr; d->log(2, "*** ERROR: device decode failed: %s", g_err.c_str()); return; }
+    if (d->log_fn) (void)js_side_prelaunch(b, 0); else b->rec_pos = nullptr;                  // the report will ask for the side outputs: their pass goes behind the decode now, not behind the wait
     if (dbg_t) tp[ntp++] = now_us();
     if (b->sync()) { d->log(2, "*** ERROR: device decode failed: %s", g_err.c_str()); return; }
     if (dbg_t) tp[ntp++] = now_us();

@@ -86,6 +86,7 @@ struct JsnoopBatch {
     std::vector<JsImage> imgs; std::vector<JsTableSet> tables;
     struct JsImgHost { uint32_t dht_setmax[2] = { 0, 0 }; unsigned err_max = 20; bool display = true; };   // what the per-image report needs beyond the descriptor
     std::vector<JsImgHost> hinfo;
+    uint32_t* rec_pos = nullptr;                                  // js_side_prepare: where the NEXT decode's write pass records MCU-top positions (null: it does not)
     std::vector<uint8_t> side_pre;                                // per image: 1 = the clean-image side pass was enqueued behind the decode (js_side_prelaunch)
     std::vector<uint8_t> side_mode;                               // per image: who produced its side outputs last (1 = parallel side pass, 2 = the exact-mirror reader, 3 = parallel side pass + chunked exact readers)
     std::vector<std::vector<uint32_t>> side_anoms;                // per image: the coefficient-index overflows of the side walk, in block order (4 words each)
@@ -180,6 +181,7 @@ int  js_parallel_entropy_part(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint3
 int  js_parallel_entropy(JsnoopBatch* b, bool timed);                 // 1 = launched, 0 = not applicable, <0 error
 int  js_parallel_fixup(JsnoopBatch* b);
 int  js_side_only(JsnoopBatch* b, uint32_t i);
+int  js_side_prepare(JsnoopBatch* b, uint32_t i);                 // ... and before the decode: its write pass records what the side walk would (one image, 64-byte pieces)
 int  js_side_prelaunch(JsnoopBatch* b, uint32_t i);               // the clean-image side pass enqueued behind the decode, before the wait (a caller that wants the report anyway)
 int  js_jfif_walk(JsnoopDecoder* d, const uint8_t* file, size_t len, unsigned* scan_start);   // jfif_front.cpp
 size_t js_prog_count(const JsnoopBatch* b);                            // jsnoop_progressive.cpp: progressive images in the batch

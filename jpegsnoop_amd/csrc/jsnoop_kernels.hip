@@ -3073,16 +3073,19 @@ __device__ __forceinline__ int32_t extend_bits(uint32_t win, uint32_t skipbits, 
 // HALF (small jobs after the candidate synchronisation): two lanes per sub-sequence -- the second one enters at the state the selected memo
 // walk reported for the middle of the sub-sequence (half_*: position, state word, blocks completed before it) -- twice the lanes, half the steps of
 // the chain a wave is; the lane of the first half verifies against that middle state, the other one against the exit state as before.
-template <int WL, bool HALF = false>
+// REC (a single-image call that will ask for the side outputs anyway, js_side_prepare): the pass also records what the side walk (k_write<., true>) would -- the bit
+// position of every MCU top and of the image's last block top in rec_pos, the code-length histogram (m_anDhtHisto) into the side block -- and that walk is not run.
+template <int WL, bool HALF = false, bool REC = false>
 __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict__ imgs, const uint32_t* __restrict__ sy_base, uint32_t nimg,
                                                        const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr,
                                                        const uint32_t* __restrict__ seg_tab, uint32_t* __restrict__ side, SubArrays A,
                                                        int16_t* __restrict__ coef, int16_t* __restrict__ dccum, uint8_t* __restrict__ mcu_rst, uint32_t* __restrict__ flags,
                                                        uint32_t tab_rows, uint32_t tab_lut2, const uint32_t* __restrict__ half_p = nullptr, const uint32_t* __restrict__ half_s = nullptr,
-                                                       const uint32_t* __restrict__ half_n = nullptr)
+                                                       const uint32_t* __restrict__ half_n = nullptr, uint32_t* __restrict__ rec_pos = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     __shared__ __attribute__((aligned(16))) int16_t s_blk[SY_THREADS][WR_STRIDE];
+    __shared__ uint32_t s_histo[REC ? 2 * 4 * 17 : 1];
     const uint32_t wg = (HALF ? blockIdx.x >> 1 : blockIdx.x) + sy_base[0];
     const uint32_t img = find_image(sy_base, nimg, wg);
     const JsImage& im = imgs[img];
@@ -3100,6 +3103,7 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
     SubTabs T; T.nb = im.blk_per_mcu; T.n1 = im.samp_h[1] * im.samp_v[1]; T.n2 = im.ncomp == 3 ? T.n1 + im.samp_h[2] * im.samp_v[2] : T.nb;
     WriteTabs W; load_wtabs(W, s_dyn, tset, tab_rows, tab_lut2, im.ncomp, threadIdx.x, SY_THREADS);
     { uint32_t* z = reinterpret_cast<uint32_t*>(s_blk[threadIdx.x]); for (int j = 0; j < WR_STRIDE / 2; j++) z[j] = 0u; }
+    if (REC) for (uint32_t q = threadIdx.x; q < 2 * 4 * 17; q += SY_THREADS) s_histo[q] = 0;
     __syncthreads();
 
     const uint32_t* words = reinterpret_cast<const uint32_t*>(ustr + im.ustr_off);
@@ -3210,6 +3214,14 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
             m_norm &= ~m_slow; m_two &= ~m_slow;
             m_nost = WBALLOT(k2 > 64u);
         }
+        if (REC) {                                               // code lengths of what this lane decodes inside its own range (k_write<., true> counts the same symbols)
+            const uint32_t hd = tset.dest_id[comp * 2], ha = tset.dest_id[comp * 2 + 1];
+            if (IBAL(m_norm & ~m_cap) && blk < nblocks) {
+                atomicAdd(&s_histo[(IBAL(m_dc) ? hd : 4u + ha) * 17u + len], 1u);
+                if (IBAL(m_two)) atomicAdd(&s_histo[(4u + ha) * 17u + len2], 1u);
+            }
+            if (IBAL(m_bad & ~m_cap) && blk < nblocks) atomicAdd(&s_histo[(IBAL(m_dc) ? hd : 4u + ha) * 17u + 1u], 1u);     // (one bit "used", :1178-1186)
+        }
         // ---- value bits: EXTEND (HuffmanDc2Signed :859), precision divide (:1234-1238), dequantise (:2278), de-zigzag
         int32_t val = extend_bits(win, len, size), val2 = extend_bits(win, tot + len2, size2);
         if (prec_shift) { val /= (int32_t)(1u << prec_shift); val2 /= (int32_t)(1u << prec_shift); }
@@ -3244,6 +3256,10 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
             if (IBAL(m_done)) {
                 c = c + 1 == T.nb ? 0u : c + 1; comp = comp_of(T, c); wb = comp == 0 ? wb0 : (comp == 1 ? wb1 : wb2);
                 nblk += IBAL(m_cap) ? 0u : 1u;
+                if (REC && IBAL(m_flush)) {                       // the next MCU / the image's last block starts here (before any restart handling)
+                    if (c == 0) rec_pos[(blk + 1) / T.nb] = cur.p;
+                    if (blk + 2u == nblocks) rec_pos[nblocks / T.nb + 1u] = cur.p;
+                }
                 blk++;
             }
             m_skip &= ~m_done;
@@ -3294,6 +3310,11 @@ __global__ void __launch_bounds__(SY_THREADS) k_write2(const JsImage* __restrict
         if (res_p != want_p || res_s != want_s || (check_n && res_n != want_n)) fl |= F_NOSYNC;
     }
     if (fl) { FLAG_OR(flags, img, fl); if (an != 0xFFFFFFFFu) ANOM_MIN(flags, img, an); }
+    if (REC) {
+        __syncthreads();
+        uint32_t* ho = side + im.side_off + JS_SIDE_HISTO;
+        for (uint32_t q = threadIdx.x; q < 2 * 4 * 17; q += SY_THREADS) { const uint32_t v = s_histo[q]; if (v) atomicAdd(&ho[q], v); }
+    }
 }
 
 // One workgroup (1024 lanes) per image: DC differences (in dccum, decode order) -> cumulative DC per block.
@@ -3520,17 +3541,22 @@ void js_launch_block_scan(hipStream_t st, int wl, const JsImage* imgs, uint32_t 
 }
 void js_launch_write(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
                      const uint8_t* ustr, const uint32_t* seg_tab, uint32_t* side, uint32_t* sub, uint64_t nsub,
-                     int16_t* coef, int16_t* dccum, uint8_t* mcu_rst, uint32_t* flags, uint32_t* cand_half, bool v1 /* the first form of the kernel, kept as a cross-check */)
+                     int16_t* coef, int16_t* dccum, uint8_t* mcu_rst, uint32_t* flags, uint32_t* cand_half, bool v1 /* the first form of the kernel, kept as a cross-check */,
+                     uint32_t* rec_pos /* null, or (64-byte pieces, second form only -- js_write_can_record) the MCU-top positions the pass is to record along with the histogram */)
 {
     if (!total_wgs) return;
     if (!v1 && cand_half && wl == 4) {                               // two lanes per sub-sequence, the second from the middle state of the selected memo walk
         const CandArrays C = cand_arrays(cand_half, nsub);
-        hipLaunchKernelGGL((k_write2<4, true>), dim3(2 * total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+        if (rec_pos) hipLaunchKernelGGL((k_write2<4, true, true>), dim3(2 * total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                           sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2, (const uint32_t*)C.hp, (const uint32_t*)C.hs, (const uint32_t*)C.hn, rec_pos);
+        else hipLaunchKernelGGL((k_write2<4, true>), dim3(2 * total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                            sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2, (const uint32_t*)C.hp, (const uint32_t*)C.hs, (const uint32_t*)C.hn);
         return;
     }
     if (!v1) {
-        if (wl == 4) hipLaunchKernelGGL((k_write2<4>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+        if (wl == 4 && rec_pos) hipLaunchKernelGGL((k_write2<4, false, true>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+                           sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, rec_pos);
+        else if (wl == 4) hipLaunchKernelGGL((k_write2<4>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                            sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2);
     else if (wl == 6) hipLaunchKernelGGL((k_write2<6>), dim3(total_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                            sub_arrays(sub, nsub), coef, dccum, mcu_rst, flags, tab_rows, tab_lut2);
@@ -3922,12 +3948,13 @@ void js_launch_side_chunks(hipStream_t st, const JsImage* imgs, uint32_t img, co
 void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* us_base, const uint32_t* sy_base, uint32_t nimg,
                          uint32_t img, uint32_t us_wg0, uint32_t us_wgs, uint32_t sy_wg0, uint32_t sy_wgs, const JsTableSet* tables, const uint8_t* raw,
                          const uint32_t* chunk_keep, const uint32_t* chunk_rst, const uint8_t* ustr, uint32_t* seg_tab, uint32_t* side, uint32_t* sub, uint64_t nsub,
-                         const int16_t* dccum, uint8_t* mcu_rst, uint32_t* mcu_pos, uint32_t* us_out, uint32_t* events, uint32_t* anoms, uint32_t dead_blk, uint32_t cut_mcu)
+                         const int16_t* dccum, uint8_t* mcu_rst, uint32_t* mcu_pos, uint32_t* us_out, uint32_t* events, uint32_t* anoms, uint32_t dead_blk, uint32_t cut_mcu, bool walked)
 {
     if (!us_wgs || !sy_wgs) return;
     hipLaunchKernelGGL(k_unstuff_write<false>, dim3(us_wgs), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, const_cast<uint32_t*>(chunk_keep), const_cast<uint32_t*>(chunk_rst), (uint8_t*)nullptr, seg_tab, us_wg0, us_out,
                        (unsigned long long*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
-    if (wl == 4) hipLaunchKernelGGL((k_write<4, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
+    if (walked) {}                                                 // (the write pass of the decode recorded positions and histogram itself: k_write2<., ., true>)
+    else if (wl == 4) hipLaunchKernelGGL((k_write<4, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, anoms, tab_rows, tab_lut2, sy_wg0, mcu_pos);
     else if (wl == 6) hipLaunchKernelGGL((k_write<6, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side,
                        sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, anoms, tab_rows, tab_lut2, sy_wg0, mcu_pos);

@@ -51,13 +51,14 @@ void js_launch_block_scan(hipStream_t st, int wl, const JsImage* imgs, uint32_t 
 void js_launch_write(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* sy_base, uint32_t nimg, uint32_t total_wgs, const JsTableSet* tables,
                      const uint8_t* ustr, const uint32_t* seg_tab, uint32_t* side, uint32_t* sub, uint64_t nsub,
                      int16_t* coef, int16_t* dccum, uint8_t* mcu_rst, uint32_t* flags,
-                     uint32_t* cand_half /* null, or the candidate arena of a job that was synchronised by candidates: two lanes per sub-sequence (64-byte pieces only) */, bool v1);
+                     uint32_t* cand_half /* null, or the candidate arena of a job that was synchronised by candidates: two lanes per sub-sequence (64-byte pieces only) */, bool v1,
+                     uint32_t* rec_pos = nullptr /* 64-byte pieces, !v1: the pass records MCU-top bit positions here and the code-length histogram in the side block (the side walk's outputs) */);
 // side-output pass over one image the parallel path decoded (MCU file map, block-DC maps, code-length histogram, status words)
 void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* us_base, const uint32_t* sy_base, uint32_t nimg,
                          uint32_t img, uint32_t us_wg0, uint32_t us_wgs, uint32_t sy_wg0, uint32_t sy_wgs, const JsTableSet* tables, const uint8_t* raw,
                          const uint32_t* chunk_keep, const uint32_t* chunk_rst, const uint8_t* ustr, uint32_t* seg_tab, uint32_t* side, uint32_t* sub, uint64_t nsub,
                          const int16_t* dccum, uint8_t* mcu_rst, uint32_t* mcu_pos, uint32_t* us_out, uint32_t* events,
-                         uint32_t* anoms, uint32_t dead_blk = 0xFFFFFFFFu, uint32_t cut_mcu = 0xFFFFFFFFu /* [0] count, 4 words per record from [4]: block, bit position of the symbol, index it ran to, bit position behind the block; or null */);
+                         uint32_t* anoms, uint32_t dead_blk = 0xFFFFFFFFu, uint32_t cut_mcu = 0xFFFFFFFFu /* [0] count, 4 words per record from [4]: block, bit position of the symbol, index it ran to, bit position behind the block; or null */, bool walked = false /* the decode's write pass recorded positions + histogram: no side walk */);
 #define JS_DC_PARTS_IMAGES 8         /* batches of up to this many images take the two-level DC scan */
 #define JS_DC_PARTS_BYTES (JS_DC_PARTS_IMAGES * 64 * 16)
 void js_launch_dead_fill(hipStream_t st, const JsImage* imgs, uint32_t img, uint32_t bstar, uint32_t kind /*ANOM_KEY's death kinds 1..8*/,

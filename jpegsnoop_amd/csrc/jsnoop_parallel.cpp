@@ -326,7 +326,7 @@ int js_parallel_entropy_part(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32
     js_launch_block_scan(st, b->sub_wl, imgs, n, b->dev.tables, sub, b->total_subseq, b->dev.side, flags);
     if (evs) HIP_TRY(hipEventRecord(evs[4], st));
     js_launch_write(st, b->sub_wl, b->tab_rows_w, b->tab_lut2, imgs, sy_base, n, sy_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq,
-                    b->dev.coef, b->dev.dccum, b->dev.mcu_rst, flags, b->cand_half ? b->dev.cand : nullptr, (b->tune.cross_checks & JSNOOP_XC_WRITE_V1) != 0);
+                    b->dev.coef, b->dev.dccum, b->dev.mcu_rst, flags, b->cand_half ? b->dev.cand : nullptr, (b->tune.cross_checks & JSNOOP_XC_WRITE_V1) != 0, b->rec_pos);
     if (evs) HIP_TRY(hipEventRecord(evs[5], st));
     js_launch_dc_scan(st, imgs, n, b->dev.tables, b->dev.dccum, b->dev.mcu_rst, n == N ? b->dev.dc_parts : nullptr);   // (one scratch area: whole-batch launches only)
     roctxRangePop();
@@ -677,7 +677,7 @@ static int js_side_via_helper(JsnoopBatch* b, uint32_t i)
 }
 // The parallel side pass of image i, enqueued on the batch stream (nothing waited for): the side block's outputs cleared, then the inverse map, the side
 // walk and the maps.  with_anoms: the walk records its coefficient-index overflows (an image whose only flag is that one).
-static int js_side_parallel_enqueue(JsnoopBatch* b, uint32_t i, bool with_anoms)
+static int js_side_parallel_enqueue(JsnoopBatch* b, uint32_t i, bool with_anoms, bool clear = true, bool walked = false)
 {
     const JsImage& im = b->imgs[i];
     const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax;
@@ -688,11 +688,32 @@ static int js_side_parallel_enqueue(JsnoopBatch* b, uint32_t i, bool with_anoms)
     uint32_t* anoms = us_out + (((size_t)usn * 256 + 64 + 15) & ~(size_t)15);
     // one launch for the five areas to zero (status words 0..7, histogram + maps, MCU positions, overflow records, event counter): a memset each is ~8 us of
     // enqueue time in a call that takes a few hundred
+    if (clear)
     js_launch_clear5(b->stream, b->dev.side + im.side_off, 8, b->dev.side + im.side_off + JS_SIDE_HISTO, words - JS_SIDE_HISTO, mcu_pos, (size_t)nmcu + 2, anoms, 4,
                      b->event_words ? b->dev.events + im.ev_off : nullptr, b->event_words ? 1 : 0);      // (the pass logs the end-of-scan markers: a repeated pass must not log them twice)
     js_launch_side_pass(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.us_base, b->dev.sy_base, (uint32_t)b->imgs.size(), i, us0, usn, sy0, syn,
                         b->dev.tables, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst, b->dev.ustr, b->dev.seg, b->dev.side, (uint32_t*)b->dev.sub, b->total_subseq,
-                        b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out, b->event_words ? b->dev.events : nullptr, with_anoms ? anoms : nullptr);
+                        b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out, b->event_words ? b->dev.events : nullptr, with_anoms ? anoms : nullptr, 0xFFFFFFFFu, 0xFFFFFFFFu, walked);
+    return 0;
+}
+// ... and, one step earlier: the outputs of the side pass are cleared BEFORE the decode and the decode's own write pass records what the side walk would (MCU-top
+// positions, code-length histogram: k_write2<4, ., true>) -- a one-image job with 64-byte pieces.  js_side_prelaunch then launches the inverse map and the maps only.
+int js_side_prepare(JsnoopBatch* b, uint32_t i)
+{
+    b->rec_pos = nullptr;
+    if (b->imgs.size() != 1 || i != 0 || !b->uploaded || b->opt_force_exact || b->sub_wl != 4 || js_prog_count(b)) return 0;
+    if (b->tune.cross_checks & (JSNOOP_XC_SIDE_EXACT | JSNOOP_XC_WRITE_V1)) return 0;
+    if (!b->tables[b->imgs[0].tableset].lut_ok) return 0;
+    HIP_TRY(hipSetDevice(b->device));
+    const JsImage& im = b->imgs[0];
+    const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax, usn = b->h_us_base[1] - b->h_us_base[0];
+    const size_t words = js_side_words(nmcu, im.blk_xmax * im.blk_ymax);
+    uint32_t *mcu_pos = nullptr, *us_out = nullptr;
+    if (js_side_scratch(b, 0, &mcu_pos, &us_out)) return -1;
+    uint32_t* anoms = us_out + (((size_t)usn * 256 + 64 + 15) & ~(size_t)15);
+    js_launch_clear5(b->stream, b->dev.side + im.side_off, 8, b->dev.side + im.side_off + JS_SIDE_HISTO, words - JS_SIDE_HISTO, mcu_pos, (size_t)nmcu + 2, anoms, 4,
+                     b->event_words ? b->dev.events + im.ev_off : nullptr, b->event_words ? 1 : 0);
+    b->rec_pos = mcu_pos;
     return 0;
 }
 // A caller that will ask for the side outputs of image i in any case (DecodeScanImg with a log callback) has the clean-image side pass enqueued right behind the
@@ -704,7 +725,9 @@ int js_side_prelaunch(JsnoopBatch* b, uint32_t i)
     if (i >= b->imgs.size() || !b->uploaded || b->opt_force_exact || !b->last_used_parallel || (b->tune.cross_checks & JSNOOP_XC_SIDE_EXACT) || js_prog_count(b)) return 0;
     if (!b->tables[b->imgs[i].tableset].lut_ok) return 0;         // (the exact kernel decodes this image and fills the side block itself)
     HIP_TRY(hipSetDevice(b->device));
-    if (js_side_parallel_enqueue(b, i, false)) return -1;
+    const bool recorded = b->rec_pos != nullptr;                   // (js_side_prepare: cleared before the decode, walked by its write pass)
+    b->rec_pos = nullptr;
+    if (js_side_parallel_enqueue(b, i, false, !recorded, recorded)) return -1;
     b->side_pre[i] = 1;
     return 0;
 }
