@@ -293,6 +293,7 @@ JsnoopBatch::~JsnoopBatch()
     delete helper; helper = nullptr;
     if (d_lut) hipFree(d_lut);
     if (d_side_tmp) hipFree(d_side_tmp);
+    if (d_side_all) hipFree(d_side_all);
     if (d_chunk_tmp) hipFree(d_chunk_tmp);
     js_prog_free(this);
     if (pinned) hipHostFree(pinned);
@@ -428,7 +429,7 @@ int JsnoopBatch::upload()
     if (!n) { js_set_error("upload: empty batch"); return -1; }
     uint64_t blocks = 0, dibb = 0, plane = 0, side = 0, ustr = 0, subs = 0;
     std::vector<uint32_t> wg(n + 1), usb(2 * (n + 1)), syb(2 * (n + 1));       // syb: write-pass bases, then sync-pass bases; usb: 4 KiB chunks, then super-chunks of four (k_unstuff_fused)
-    uint64_t segw = 0, mcub = 0; uint32_t usc = 0, us4 = 0, syw = 0, snw = 0;
+    uint64_t segw = 0, mcub = 0, recw = 0; uint32_t usc = 0, us4 = 0, syw = 0, snw = 0;
     strips_per_wg = 0; uint64_t total_mcus = 0; for (const JsImage& im : imgs) total_mcus += (uint64_t)im.mcu_xmax * im.mcu_ymax;
     // back end: 8 waves per workgroup; enough MCUs per wave to amortise a workgroup's table load; a small job as ONE round of workgroups over the
     // chip's 1024 workgroup slots (one 3840x2160 image: 4 MCUs per wave, 1013 workgroups, 47 us; 3 per wave = 1350 workgroups: 51)
@@ -467,6 +468,7 @@ int JsnoopBatch::upload()
         const uint64_t want_seg = im.rst_interval ? (uint64_t)nmcu / im.rst_interval + 2 : 1;
         im.seg_cap = (uint32_t)std::min<uint64_t>((1u << 20) - 1, want_seg * 2 + 16); im.seg_off = segw; segw += align_up(im.seg_cap, 4);   // 20-bit interval index in the state word
         im.mcu_off = mcub; mcub += align_up(nmcu, 16);
+        im.rec_off = (uint32_t)recw; recw += align_up((uint64_t)nmcu + 2, 16);
         im.ev_cap = opt_events ? JS_EV_MAX : 0; im.ev_off = (uint64_t)i * (1 + JS_EV_WORDS * JS_EV_MAX);
         { const uint32_t nck = std::max(1u, (uint32_t)(((im.scan_start & 15) + (uint64_t)im.scan_len + JS_US_CHUNK - 1) / JS_US_CHUNK));   // (at least one chunk: its last chunk leaves the image's totals)
           usb[i] = usc; usc += nck; usb[n + 1 + i] = us4; us4 += (nck + 3) / 4; }
@@ -476,7 +478,7 @@ int JsnoopBatch::upload()
         wg[i] = wgs; wgs += std::max(1u, (nmcu + 8 * mcus_per_wave - 1) / (8 * mcus_per_wave));     // 8 waves per workgroup, one MCU per wave at a time
     }
     usb[n] = usc; usb[2 * n + 1] = us4; syb[n] = syw; syb[2 * n + 1] = snw; us_chunks = usc; sy_wgs = syw; sn_wgs = snw; seg_words = segw; mcu_bytes = mcub;
-    wg[n] = wgs; total_wgs = wgs; total_blocks = blocks; dib_bytes = dibb; side_words = side; total_subseq = subs; ustr_bytes = ustr;
+    wg[n] = wgs; total_wgs = wgs; rec_words = recw; total_blocks = blocks; dib_bytes = dibb; side_words = side; total_subseq = subs; ustr_bytes = ustr;
     if (grow(&dev.raw, &cap.raw, raw_bytes + 64) || grow(&dev.coef, &cap.coef, blocks * 128) || grow(&dev.dccum, &cap.dccum, blocks * 2 + 64) ||
         grow(&dev.dib, &cap.dib, dibb) || grow(&dev.side, &cap.side, side * 4) || grow(&dev.imgs, &cap.imgs, n * sizeof(JsImage)) ||
         grow(&dev.tables, &cap.tables, tables.size() * sizeof(JsTableSet)) || grow(&dev.wg_base, &cap.wg_base, (n + 1) * 4) ||
@@ -531,7 +533,7 @@ int JsnoopBatch::decode(bool timed)
     HIP_TRY(hipSetDevice(device));
     if (!uploaded && upload()) return -1;
     const uint32_t n = (uint32_t)imgs.size();
-    side_done.assign(n, 0); side_mode.assign(n, 0); side_anoms.assign(n, std::vector<uint32_t>()); side_chunk_ok.assign(n, 0); side_events.assign(n, std::vector<uint32_t>()); side_pre.assign(n, 0);   // (nothing of an earlier decode's side pass survives)
+    side_done.assign(n, 0); side_mode.assign(n, 0); side_anoms.assign(n, std::vector<uint32_t>()); side_chunk_ok.assign(n, 0); side_events.assign(n, std::vector<uint32_t>()); side_pre.assign(n, 0); side_requests = 0;   // (nothing of an earlier decode's side pass survives)
     JsRange r_("jsnoop:decode (enqueue)");
     if (js_prog_count(this)) return decode_progressive(timed);     // SOF2 files: every scan of every image, one launch per dependency level
     if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
@@ -1080,6 +1082,7 @@ int jsnoop_batch_side_outputs(JsnoopBatch* b, int i, uint32_t* mcu_map, int16_t*
     if (js_batch_view(b, i, v, "jsnoop_batch_side_outputs")) return -1;
     const JsImage& im = b->imgs[i];
     if (bright_avg10 && im.ncomp == 3 && !b->opt_want_planes) { js_set_error("jsnoop_batch_side_outputs: the brightest pixel's Cb / Cr / RGB need the planes (want_planes)"); return -1; }
+    v.want_bright = bright_avg10 != nullptr;                       // (the brightest pixel's chroma + RGB come back with the side block, one round trip)
     v.ensure_side();
     if (!v.side_ready) return -1;
     if (v.h_side.empty()) v.fetch_side();
@@ -1193,7 +1196,7 @@ void JsnoopDecoder::fetch_side()
     // With a log callback the report follows: what it reads back besides (event list, restart marks, the brightest pixel's chroma and RGB -- a probe launch) comes
     // in the same round trip, through the page-locked landing buffer: five waits of ~25 us each otherwise.
     const size_t nmcu = (size_t)im.mcu_xmax * im.mcu_ymax, ev_words = b->event_words ? 1 + (size_t)JS_EV_WORDS * JS_EV_MAX : 0;
-    const bool with_report = log_fn != nullptr && side_ready && preview_is_jpeg && b->uploaded && !js_prog_count(b);
+    const bool with_report = (log_fn != nullptr || want_bright) && side_ready && preview_is_jpeg && b->uploaded && !js_prog_count(b);
     const size_t o_side = 0, o_ev = (words * 4 + 63) & ~(size_t)63, o_rst = o_ev + ((ev_words * 4 + 63) & ~(size_t)63), o_br = o_rst + ((nmcu + 63) & ~(size_t)63), total = o_br + 64;
     if (!with_report || total > (32u << 20)) {
         if (b->d2h_staged(h_side.data(), b->dev.side + im.side_off, words * 4)) log(2, "*** ERROR: reading the side block back failed: %s", g_err.c_str());

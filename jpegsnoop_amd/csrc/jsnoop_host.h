@@ -44,7 +44,7 @@ struct JsnoopDecoder {
     Pinned h_dib, h_planes; std::vector<uint32_t> h_side;
     // what the report reads back besides the side block, fetched with it in ONE round trip (fetch_side): the device's event list, the per-MCU restart marks,
     // chroma + BGRA of the brightest pixel (k_bright_probe) -- valid for the decode they were fetched behind
-    std::vector<uint32_t> h_events; std::vector<uint8_t> h_rstf; uint32_t h_bright[8] = {0}; bool report_cache = false;
+    std::vector<uint32_t> h_events; std::vector<uint8_t> h_rstf; uint32_t h_bright[8] = {0}; bool report_cache = false, want_bright = false;
     uint32_t zero_histo[2 * 4 * 17] = {0};
     // what the reference keeps for a preview that does not come from the scan decoder (m_pDibTemp filled by the PSD decoder, m_bDibTempReady,
     // m_rectImgBase: source/ImgDecode.h:508-510, SetImageDimensions :2706)
@@ -86,6 +86,9 @@ struct JsnoopBatch {
     std::vector<JsImage> imgs; std::vector<JsTableSet> tables;
     struct JsImgHost { uint32_t dht_setmax[2] = { 0, 0 }; unsigned err_max = 20; bool display = true; };   // what the per-image report needs beyond the descriptor
     std::vector<JsImgHost> hinfo;
+    // js_side_all: the side passes of all clean images behind one decode (mask | positions of every image | inverse map of every chunk), the requests counted per decode
+    uint8_t* d_side_all = nullptr; size_t side_all_cap = 0; int side_requests = 0;
+    uint64_t rec_words = 0;                                       // MCU-top positions of all images (JsImage::rec_off)
     uint32_t* rec_pos = nullptr;                                  // js_side_prepare: where the NEXT decode's write pass records MCU-top positions (null: it does not)
     std::vector<uint8_t> side_pre;                                // per image: 1 = the clean-image side pass was enqueued behind the decode (js_side_prelaunch)
     std::vector<uint8_t> side_mode;                               // per image: who produced its side outputs last (1 = parallel side pass, 2 = the exact-mirror reader, 3 = parallel side pass + chunked exact readers)

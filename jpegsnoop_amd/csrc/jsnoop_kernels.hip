@@ -2859,7 +2859,8 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
                                                       const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ ustr,
                                                       const uint32_t* __restrict__ seg_tab, uint32_t* __restrict__ side, SubArrays A,
                                                       int16_t* __restrict__ coef, int16_t* __restrict__ dccum, uint8_t* __restrict__ mcu_rst, uint32_t* __restrict__ flags,
-                                                      uint32_t tab_rows, uint32_t tab_lut2, uint32_t wg0, uint32_t* __restrict__ mcu_pos)
+                                                      uint32_t tab_rows, uint32_t tab_lut2, uint32_t wg0, uint32_t* __restrict__ mcu_pos_in,
+                                                      const uint8_t* __restrict__ img_mask = nullptr /* SIDE, a whole batch: the images to walk; positions at mcu_pos_in + rec_off of the image */)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     __shared__ __attribute__((aligned(16))) int16_t s_blk[SY_THREADS][WR_STRIDE];
@@ -2868,6 +2869,8 @@ __global__ void __launch_bounds__(SY_THREADS) k_write(const JsImage* __restrict_
     const uint32_t img = find_image(sy_base, nimg, wg);
     const JsImage& im = imgs[img];
     if (!tables[im.tableset].lut_ok) return;
+    if (SIDE && img_mask && !img_mask[img]) return;
+    uint32_t* mcu_pos = (SIDE && img_mask) ? mcu_pos_in + im.rec_off : mcu_pos_in;
     const uint32_t* sd = side + im.side_off;
     const uint32_t total_bits = sd[10] * 8, nseg = min(sd[11], im.seg_cap - 1);
     const uint32_t lane = threadIdx.x & 63, wave0 = threadIdx.x & ~63u;
@@ -3665,10 +3668,14 @@ __device__ __forceinline__ uint32_t mirror_to_mcu_top(const JsImage& im, const J
 
 __global__ void __launch_bounds__(256) k_side_maps(const JsImage* __restrict__ imgs, uint32_t img, const JsTableSet* __restrict__ tables, const uint8_t* __restrict__ raw,
                                                    const uint32_t* __restrict__ seg_tab, const int16_t* __restrict__ dccum, const uint8_t* __restrict__ mcu_rst,
-                                                   const uint32_t* __restrict__ mcu_pos, const uint32_t* __restrict__ us_out, uint32_t us_threads,
-                                                   uint32_t* __restrict__ side, uint32_t* __restrict__ events, uint32_t* __restrict__ anoms, uint32_t dead_blk, uint32_t cut_mcu)
+                                                   const uint32_t* mcu_pos, const uint32_t* us_out, uint32_t us_threads,
+                                                   uint32_t* __restrict__ side, uint32_t* __restrict__ events, uint32_t* __restrict__ anoms, uint32_t dead_blk, uint32_t cut_mcu,
+                                                   const uint8_t* __restrict__ img_mask = nullptr, const uint32_t* __restrict__ us_base = nullptr /* a whole batch: image blockIdx.y if
+                                                   its mask says so; positions at mcu_pos + rec_off, the inverse map of ALL chunks in us_out (256 words per chunk of us_base) */)
 {
+    if (img_mask) { img = blockIdx.y; if (!img_mask[img]) return; }
     const JsImage& im = imgs[img];
+    if (img_mask) { mcu_pos += im.rec_off; us_out += (size_t)us_base[img] * 256u; us_threads = (us_base[img + 1] - us_base[img]) * 256u; }
     uint32_t* sd = side + im.side_off;
     const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax, nblk = im.blk_xmax * im.blk_ymax, nseg = min(sd[11], im.seg_cap - 1);
     // dead_blk: the block in which the reference's own decode ends (none: ~0) -- behind its MCU the row is not visited, and of every later row only the first MCU
@@ -3944,6 +3951,35 @@ void js_launch_side_chunks(hipStream_t st, const JsImage* imgs, uint32_t img, co
     hipLaunchKernelGGL(k_side_chunks, dim3((nchunks + SC_WAVES - 1) / SC_WAVES), dim3(64 * SC_WAVES), 0, st, imgs, img, tables, raw, seg_tab, mcu_rst, mcu_pos, us_out, us_threads, side, dccum,
                        ch_mcus, nchunks, ev_cap, mcus_left0, recs, map_own, map_beyond, run_on_mcu, fill_desc);
     if (run_on_mcu != 0xFFFFFFFFu) hipLaunchKernelGGL(k_side_fill, dim3(128), dim3(256), 0, st, imgs, img, side, map_beyond, fill_desc);
+}
+// The side passes of MANY images of a decoded batch in four launches (js_side_all): the outputs cleared, the inverse byte map of every chunk, the side walk over the
+// whole batch (images outside the mask leave at once), the maps with one grid row per image.  pos_all: rec_off-indexed MCU-top positions (zeroed here by the
+// caller), us_all: 256 words per chunk of the batch.
+__global__ void __launch_bounds__(256) k_side_clear_all(const JsImage* __restrict__ imgs, const uint8_t* __restrict__ img_mask, uint32_t* __restrict__ side, uint32_t* __restrict__ events)
+{
+    const uint32_t img = blockIdx.y;
+    if (!img_mask[img]) return;
+    const JsImage& im = imgs[img];
+    uint32_t* sd = side + im.side_off;
+    const uint32_t words = js_side_words(im.mcu_xmax * im.mcu_ymax, im.blk_xmax * im.blk_ymax);
+    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < words; q += gridDim.x * 256) if (q < 8u || q >= JS_SIDE_HISTO) sd[q] = 0u;
+    if (events && im.ev_cap && blockIdx.x == 0 && threadIdx.x == 0) events[im.ev_off] = 0u;
+}
+void js_launch_side_pass_all(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* us_base, const uint32_t* sy_base, uint32_t nimg,
+                             uint32_t us_wgs, uint32_t sy_wgs, const JsTableSet* tables, const uint8_t* raw, const uint32_t* chunk_keep, const uint32_t* chunk_rst, const uint8_t* ustr,
+                             uint32_t* seg_tab, uint32_t* side, uint32_t* sub, uint64_t nsub, const int16_t* dccum, uint8_t* mcu_rst, uint32_t* pos_all, uint32_t* us_all,
+                             uint32_t* events, const uint8_t* img_mask)
+{
+    if (!us_wgs || !sy_wgs || !nimg) return;
+    hipLaunchKernelGGL(k_side_clear_all, dim3(16, nimg), dim3(256), 0, st, imgs, img_mask, side, events);
+    hipLaunchKernelGGL(k_unstuff_write<false>, dim3(us_wgs), dim3(US_THREADS), 0, st, imgs, us_base, nimg, raw, const_cast<uint32_t*>(chunk_keep), const_cast<uint32_t*>(chunk_rst), (uint8_t*)nullptr, seg_tab, 0u, us_all,
+                       (unsigned long long*)nullptr, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
+#define JS_ALL_WALK(W) hipLaunchKernelGGL((k_write<W, true>), dim3(sy_wgs), dim3(SY_THREADS), wtabs_bytes(tab_rows, tab_lut2), st, imgs, sy_base, nimg, tables, ustr, seg_tab, side, \
+                       sub_arrays(sub, nsub), (int16_t*)nullptr, (int16_t*)nullptr, mcu_rst, (uint32_t*)nullptr, tab_rows, tab_lut2, 0u, pos_all, img_mask)
+    if (wl == 4) JS_ALL_WALK(4); else if (wl == 6) JS_ALL_WALK(6); else if (wl == 8) JS_ALL_WALK(8); else if (wl == 7) JS_ALL_WALK(7); else JS_ALL_WALK(5);
+#undef JS_ALL_WALK
+    hipLaunchKernelGGL(k_side_maps, dim3(16, nimg), dim3(256), 0, st, imgs, 0u, tables, raw, seg_tab, dccum, mcu_rst, pos_all, us_all, 0u, side, events, (uint32_t*)nullptr, 0xFFFFFFFFu, 0xFFFFFFFFu,
+                       img_mask, us_base);
 }
 void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* us_base, const uint32_t* sy_base, uint32_t nimg,
                          uint32_t img, uint32_t us_wg0, uint32_t us_wgs, uint32_t sy_wg0, uint32_t sy_wgs, const JsTableSet* tables, const uint8_t* raw,

@@ -59,6 +59,11 @@ void js_launch_side_pass(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab
                          const uint32_t* chunk_keep, const uint32_t* chunk_rst, const uint8_t* ustr, uint32_t* seg_tab, uint32_t* side, uint32_t* sub, uint64_t nsub,
                          const int16_t* dccum, uint8_t* mcu_rst, uint32_t* mcu_pos, uint32_t* us_out, uint32_t* events,
                          uint32_t* anoms, uint32_t dead_blk = 0xFFFFFFFFu, uint32_t cut_mcu = 0xFFFFFFFFu /* [0] count, 4 words per record from [4]: block, bit position of the symbol, index it ran to, bit position behind the block; or null */, bool walked = false /* the decode's write pass recorded positions + histogram: no side walk */);
+// ... of every image whose byte of img_mask is set, in four launches (pos_all: rec_off-indexed positions, zeroed by the caller; us_all: 256 words per chunk of the batch)
+void js_launch_side_pass_all(hipStream_t st, int wl, uint32_t tab_rows, uint32_t tab_lut2, const JsImage* imgs, const uint32_t* us_base, const uint32_t* sy_base, uint32_t nimg,
+                             uint32_t us_wgs, uint32_t sy_wgs, const JsTableSet* tables, const uint8_t* raw, const uint32_t* chunk_keep, const uint32_t* chunk_rst, const uint8_t* ustr,
+                             uint32_t* seg_tab, uint32_t* side, uint32_t* sub, uint64_t nsub, const int16_t* dccum, uint8_t* mcu_rst, uint32_t* pos_all, uint32_t* us_all,
+                             uint32_t* events, const uint8_t* img_mask);
 #define JS_DC_PARTS_IMAGES 8         /* batches of up to this many images take the two-level DC scan */
 #define JS_DC_PARTS_BYTES (JS_DC_PARTS_IMAGES * 64 * 16)
 void js_launch_dead_fill(hipStream_t st, const JsImage* imgs, uint32_t img, uint32_t bstar, uint32_t kind /*ANOM_KEY's death kinds 1..8*/,

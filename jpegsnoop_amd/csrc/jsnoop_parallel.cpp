@@ -563,6 +563,12 @@ int js_parallel_fixup(JsnoopBatch* b)
 // parallel side pass (k_write<.., true> + k_side_maps + k_side_tail); images that went through the exact-mirror
 // kernel already have them, and that kernel remains the producer for anything flagged.
 // scratch of the side walk of image i: bit position of every MCU top, then the inverse byte map of the un-stuffing pass
+static size_t js_side_scratch_bytes(const JsnoopBatch* b, uint32_t i)
+{
+    const JsImage& im = b->imgs[i];
+    const size_t nmcu = (size_t)im.mcu_xmax * im.mcu_ymax, usn = b->h_us_base[i + 1] - b->h_us_base[i];
+    return (nmcu + 2 + usn * 256 + 64 + 16 + 4 + 4 * (size_t)JS_ANOM_MAX) * 4;
+}
 static int js_side_scratch(JsnoopBatch* b, uint32_t i, uint32_t** mcu_pos, uint32_t** us_out)
 {
     const JsImage& im = b->imgs[i];
@@ -677,8 +683,9 @@ static int js_side_via_helper(JsnoopBatch* b, uint32_t i)
 }
 // The parallel side pass of image i, enqueued on the batch stream (nothing waited for): the side block's outputs cleared, then the inverse map, the side
 // walk and the maps.  with_anoms: the walk records its coefficient-index overflows (an image whose only flag is that one).
-static int js_side_parallel_enqueue(JsnoopBatch* b, uint32_t i, bool with_anoms, bool clear = true, bool walked = false)
+static int js_side_parallel_enqueue(JsnoopBatch* b, uint32_t i, bool with_anoms, bool clear = true, bool walked = false, hipStream_t st = nullptr)
 {
+    if (!st) st = b->stream;
     const JsImage& im = b->imgs[i];
     const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax;
     const size_t words = js_side_words(nmcu, im.blk_xmax * im.blk_ymax);
@@ -689,9 +696,9 @@ static int js_side_parallel_enqueue(JsnoopBatch* b, uint32_t i, bool with_anoms,
     // one launch for the five areas to zero (status words 0..7, histogram + maps, MCU positions, overflow records, event counter): a memset each is ~8 us of
     // enqueue time in a call that takes a few hundred
     if (clear)
-    js_launch_clear5(b->stream, b->dev.side + im.side_off, 8, b->dev.side + im.side_off + JS_SIDE_HISTO, words - JS_SIDE_HISTO, mcu_pos, (size_t)nmcu + 2, anoms, 4,
+    js_launch_clear5(st, b->dev.side + im.side_off, 8, b->dev.side + im.side_off + JS_SIDE_HISTO, words - JS_SIDE_HISTO, mcu_pos, (size_t)nmcu + 2, anoms, 4,
                      b->event_words ? b->dev.events + im.ev_off : nullptr, b->event_words ? 1 : 0);      // (the pass logs the end-of-scan markers: a repeated pass must not log them twice)
-    js_launch_side_pass(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.us_base, b->dev.sy_base, (uint32_t)b->imgs.size(), i, us0, usn, sy0, syn,
+    js_launch_side_pass(st, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.us_base, b->dev.sy_base, (uint32_t)b->imgs.size(), i, us0, usn, sy0, syn,
                         b->dev.tables, b->dev.raw, b->dev.chunk_keep, b->dev.chunk_rst, b->dev.ustr, b->dev.seg, b->dev.side, (uint32_t*)b->dev.sub, b->total_subseq,
                         b->dev.dccum, b->dev.mcu_rst, mcu_pos, us_out, b->event_words ? b->dev.events : nullptr, with_anoms ? anoms : nullptr, 0xFFFFFFFFu, 0xFFFFFFFFu, walked);
     return 0;
@@ -731,9 +738,46 @@ int js_side_prelaunch(JsnoopBatch* b, uint32_t i)
     b->side_pre[i] = 1;
     return 0;
 }
+// The side passes of ALL clean images of a decoded batch at once (a caller that asks for the per-image results of a batch image after image -- what
+// DoBatchFileProcess does per file, source/JPEGsnoopCore.cpp:805-808): one image's pass is a chain of small launches on a nearly empty chip (0.8 ms with its
+// wait; the side walk alone 0.35 ms of one wave's latency), so the second request of a decode runs them for every clean image in four launches over the whole
+// batch (js_launch_side_pass_all: 256 x 1080p 214 -> ~25 ms for the side outputs of every image).  Flagged images keep their own paths (js_side_only).
+static int js_side_all(JsnoopBatch* b)
+{
+    const uint32_t n = (uint32_t)b->imgs.size();
+    if (b->side_done.size() != n) b->side_done.assign(n, 0);
+    if (b->side_mode.size() != n) { b->side_mode.assign(n, 0); b->side_anoms.assign(n, std::vector<uint32_t>()); }
+    if (b->side_events.size() != n) b->side_events.assign(n, std::vector<uint32_t>());
+    std::vector<uint8_t> mask(n, 0); uint32_t cnt = 0;
+    for (uint32_t i = 0; i < n; i++)
+        if (!b->side_done[i] && i < b->host_path.size() && b->host_path[i] == 1 && b->host_flags[i] == 0 && b->tables[b->imgs[i].tableset].lut_ok) { mask[i] = 1; cnt++; }
+    if (cnt < 2) return 0;
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t o_pos = ((size_t)n + 255) & ~(size_t)255, o_us = o_pos + (((size_t)b->rec_words * 4 + 255) & ~(size_t)255), total = o_us + ((size_t)b->us_chunks * 256 + 64) * 4;
+    if (total > b->side_all_cap) {
+        if (b->d_side_all) hipFree(b->d_side_all);
+        b->d_side_all = nullptr; b->side_all_cap = 0;
+        HIP_TRY(hipMalloc((void**)&b->d_side_all, total + total / 8));
+        b->side_all_cap = total + total / 8;
+    }
+    HIP_TRY(hipMemcpyAsync(b->d_side_all, mask.data(), n, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemsetAsync(b->d_side_all + o_pos, 0, (size_t)b->rec_words * 4, b->stream));
+    js_launch_side_pass_all(b->stream, b->sub_wl, b->tab_rows_w, b->tab_lut2, b->dev.imgs, b->dev.us_base, b->dev.sy_base, n, b->us_chunks, b->sy_wgs, b->dev.tables, b->dev.raw,
+                            b->dev.chunk_keep, b->dev.chunk_rst, b->dev.ustr, b->dev.seg, b->dev.side, (uint32_t*)b->dev.sub, b->total_subseq, b->dev.dccum, b->dev.mcu_rst,
+                            reinterpret_cast<uint32_t*>(b->d_side_all + o_pos), reinterpret_cast<uint32_t*>(b->d_side_all + o_us), b->event_words ? b->dev.events : nullptr, b->d_side_all);
+    HIP_TRY(hipStreamSynchronize(b->stream));                     // (the mask vector goes out of scope)
+    HIP_TRY(hipGetLastError());
+    for (uint32_t i = 0; i < n; i++) if (mask[i]) { b->side_done[i] = 1; b->side_mode[i] = 1; b->side_anoms[i].clear(); b->side_events[i].clear(); if (i < b->side_pre.size()) b->side_pre[i] = 0; }
+    return 0;
+}
 int js_side_only(JsnoopBatch* b, uint32_t i)
 {
     HIP_TRY(hipSetDevice(b->device));
+    // the second request for a per-image result of a batch: the clean images' passes all at once (js_side_all)
+    if (b->imgs.size() > 1 && ++b->side_requests == 2 && !(b->tune.cross_checks & JSNOOP_XC_SIDE_EXACT) && !js_prog_count(b)) {
+        if (js_side_all(b)) return -1;
+        if (i < b->side_done.size() && b->side_done[i]) return 0;
+    }
     const JsImage& im = b->imgs[i];
     const uint32_t nmcu = im.mcu_xmax * im.mcu_ymax;
     const size_t words = js_side_words(nmcu, im.blk_xmax * im.blk_ymax);

@@ -86,6 +86,7 @@ struct JsImage {
     uint32_t err_max;
     // event log of the exact-mirror reader (what the reference writes to CDocLog while it decodes); 0 capacity = off
     uint64_t ev_off; uint32_t ev_cap;
+    uint32_t rec_off;       // first word of this image's MCU-top positions in an arena that holds every image's (number of MCUs + 2 each; the batched side pass)
 };
 
 // Event records (6 u32 each, preceded by one count word per image): what the reference logs during the scan decode.
@@ -126,4 +127,4 @@ static inline uint32_t js_tile_bytes(const JsImage& im)
     return (b + 15u) & ~15u;
 }
 
-static inline uint32_t js_side_words(uint32_t nmcu, uint32_t nblk) { return JS_SIDE_MCUMAP + nmcu + 3 * ((nblk + 1) / 2); }
+static inline __host__ __device__ uint32_t js_side_words(uint32_t nmcu, uint32_t nblk) { return JS_SIDE_MCUMAP + nmcu + 3 * ((nblk + 1) / 2); }
