@@ -399,9 +399,48 @@ def extras_single_gpu(J, H, orc, np):
                                                      "side_outputs_equal_oracle": _fm.differs(orc, gcall) is None})
             except Exception as e:
                 dmg["%s_%s" % (label, kind)]["call_error"] = repr(e)
+    # ... the same call on CLEAN files (what JPEGsnoop does with one file: decode + side outputs + messages + report through the drop-in API, log callback installed):
+    # ms per call, the file in pageable host memory, the header walk not included; side outputs and status words against the oracle's
+    calls = {}
+    try:
+        import ctypes as _C, importlib.util as _iu
+        _fu = _iu.spec_from_file_location("fuzz_util", os.path.join(ROOT, "tests", "fuzz_util.py")); _fm = _iu.module_from_spec(_fu); _fu.loader.exec_module(_fm)
+        if gcall is None:
+            gcall = H.Backend(J.load(), "jsnoop_", "hip")
+        for name, kwc in (("640x480_444", dict(width=640, height=480, hs=1, vs=1, seed=3)), ("1080p_420", dict(width=1920, height=1080, hs=2, vs=2, seed=100)),
+                          ("2160p_420", dict(width=3840, height=2160, hs=2, vs=2, seed=77)), ("1080p_422_rst", dict(width=1920, height=1080, hs=2, vs=1, restart_interval=120, seed=55))):
+            fc = H.synth_jpeg(quality=85, **kwc)
+            pc = H.drive(gcall, fc, quiet=0)
+            H.drive(orc, fc)
+            okc = _fm.differs(orc, gcall) is None
+            buf = (_C.c_uint8 * len(fc)).from_buffer_copy(fc)
+            for _ in range(3):
+                gcall.decode_scan_img(_C.cast(buf, _C.c_void_p), len(fc), pc.scan_start, 1, 1)
+            nrep = 30; tc = time.perf_counter()
+            for _ in range(nrep):
+                gcall.decode_scan_img(_C.cast(buf, _C.c_void_p), len(fc), pc.scan_start, 1, 1)
+            calls[name] = {"call_ms": round((time.perf_counter() - tc) / nrep * 1e3, 3), "side_outputs_equal_oracle": okc}
+    except Exception as e:
+        calls["error"] = repr(e)
+    extra["drop_in_call_clean_files"] = calls
     if gcall is not None:
         gcall.close()
     extra["damaged_files"] = dmg
+    # the per-image results of a batch (side outputs of every image behind one decode: what DoBatchFileProcess does per file): ms per image
+    try:
+        nbr = 128
+        fsb = [H.synth_jpeg(width=1920, height=1080, hs=2, vs=2, quality=85, seed=100 + i) for i in range(16)]
+        bb = J.JpegBatch(want_planes=True)
+        for f in fsb:
+            bb.add_jpeg(f)
+        bb.tile(nbr); bb.upload(); bb.decode(); bb.sync()
+        tb = time.perf_counter()
+        for i in range(nbr):
+            bb.side_outputs(i)
+        extra["batch_side_outputs_128x1080p"] = {"ms_per_image": round((time.perf_counter() - tb) * 1e3 / nbr, 3), "note": "jsnoop_batch_side_outputs of every image behind one decode, Python call included"}
+        bb.close()
+    except Exception as e:
+        extra["batch_side_outputs_128x1080p"] = {"error": repr(e)}
     # the baseline (SOF0) form of config 5 through the batch path, oracle-checked directly
     b5 = J.JpegBatch(); b5.add_jpeg(base5); b5.upload(); b5.decode(); b5.sync()
     msb, _ = b5.decode_timed(10)
