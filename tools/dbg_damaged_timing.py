@@ -15,9 +15,9 @@ def damage(base, kind, frac):
     elif kind == "delete": del d[i:i + 3]
     elif kind == "rst": d[i:i] = b"\xff\xd5"
     return bytes(d)
-for rst in (0, 120):
+for rst in ([int(x) for x in os.environ.get("DBG_RST", "0,120").split(",")]):
     base = H.synth_jpeg(width=1920, height=1080, seed=9, restart_interval=rst)
-    for kind in ("cut", "marker", "zeros", "delete", "rst"):
+    for kind in (os.environ.get("DBG_KINDS", "cut,marker,zeros,delete,rst").split(",")):
         data = damage(base, kind, 0.5)
         for _ in range(2): H.drive(gpu, data, quiet=0)
         sys.stderr.write("==== rst %d %s: " % (rst, kind)); sys.stderr.flush()
