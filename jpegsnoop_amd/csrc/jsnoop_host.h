@@ -180,7 +180,7 @@ void js_emit_decode_events(JsnoopDecoder* d);                      // jsnoop_rep
 void js_emit_report(JsnoopDecoder* d, bool display, bool quiet);
 void js_build_parallel_luts(JsTableSet* ts, uint32_t ncomp);          // jsnoop_parallel.cpp
 int js_selftest_tables(unsigned seed, unsigned rounds);                // jsnoop_parallel.cpp (host only)
-int  js_parallel_entropy_part(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32_t n, hipEvent_t* evs /*stage events or null*/);   // images [i0, i0 + n)
+int  js_parallel_entropy_part(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32_t n, hipEvent_t* evs /*stage events or null*/, hipEvent_t after_stage = nullptr /* recorded behind stage `which_stage` (1 un-stuffing, 2 synchronisation) */, int which_stage = 0);   // images [i0, i0 + n)
 int  js_parallel_entropy(JsnoopBatch* b, bool timed);                 // 1 = launched, 0 = not applicable, <0 error
 int  js_parallel_fixup(JsnoopBatch* b);
 int  js_side_only(JsnoopBatch* b, uint32_t i);

@@ -283,7 +283,7 @@ void js_debug_cand_links(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32_t n
 // Launches stages 1..5 (unstuff, sync, block scan, write, DC scan) for images [i0, i0 + n) of the batch on stream st.  The arenas and
 // the prefix tables are the batch's: a part passes pointers to its first image / first prefix entry (the kernels add the first
 // entry to their block index) and the number of workgroups its images own.
-int js_parallel_entropy_part(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32_t n, hipEvent_t* evs)
+int js_parallel_entropy_part(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32_t n, hipEvent_t* evs, hipEvent_t after_stage, int which_stage)
 {
     const uint32_t N = (uint32_t)b->imgs.size();
     uint32_t* sub = (uint32_t*)b->dev.sub;
@@ -299,6 +299,7 @@ int js_parallel_entropy_part(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32
                       reinterpret_cast<uint32_t*>(b->dev.us_state + b->us_chunks) + (i0 ? 1 : 0), &b->us_ticket_base[i0 ? 1 : 0]);
     roctxRangePop();
     if (evs) HIP_TRY(hipEventRecord(evs[2], st));
+    if (after_stage && which_stage == 1) HIP_TRY(hipEventRecord(after_stage, st));
     roctxRangePushA("jsnoop:sub-sequence sync");
     if (b->cand_rounds >= 0) {
         // small job: candidates and a chain of look-ups instead of rounds; what the chain left open is walked by k_sync in its verification mode,
@@ -322,6 +323,7 @@ int js_parallel_entropy_part(JsnoopBatch* b, hipStream_t st, uint32_t i0, uint32
         js_launch_sync(st, b->sub_wl, b->tab_rows, b->tab_lut2, imgs, sn_base, n, sn_wgs, b->dev.tables, b->dev.ustr, b->dev.seg, b->dev.side, sub, b->total_subseq, l == 0);
     roctxRangePop();
     if (evs) HIP_TRY(hipEventRecord(evs[3], st));
+    if (after_stage && which_stage == 2) HIP_TRY(hipEventRecord(after_stage, st));
     roctxRangePushA("jsnoop:block scan + coefficient write + DC scan");
     js_launch_block_scan(st, b->sub_wl, imgs, n, b->dev.tables, sub, b->total_subseq, b->dev.side, flags);
     if (evs) HIP_TRY(hipEventRecord(evs[4], st));
