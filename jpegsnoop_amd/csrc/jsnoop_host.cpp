@@ -421,6 +421,9 @@ template <class T> static int grow(T** p, size_t* cap, size_t need_bytes)
     if (e != hipSuccess) { js_set_error("hipMalloc(%zu) failed: %s", nb, hipGetErrorString(e)); *cap = 0; return -1; }
     *cap = nb; return 0;
 }
+// Two halves on two streams (the second half a stage behind, decode()): from 48 MB of scan data on -- N x 1080p, ms per decode, one stream | two (tools/small_jobs.py,
+// two alternating runs, round 6): 32: 0.93 | 0.88, 48: 1.33 | 1.36, 64: 1.50 | 1.49, 96: 1.87 | 1.82, 128: 2.30 | 2.20, 160: 2.64 | 2.57, 200: 3.12 | 3.13 .. 3.33; 1024: 12.83 | 12.54.
+#define JS_SPLIT_FROM_BYTES (48ull << 20)
 int JsnoopBatch::upload()
 {
     JsRange r_("jsnoop:upload (pinned H2D + descriptors)");
@@ -521,8 +524,8 @@ int JsnoopBatch::upload()
         HIP_TRY(hipEventRecord(ev_up, stream));
     }
     h_us_base.assign(usb.begin(), usb.begin() + n + 1); h_us4_base.assign(usb.begin() + n + 1, usb.end()); h_sy_base.assign(syb.begin(), syb.begin() + n + 1); h_sn_base.assign(syb.begin() + n + 1, syb.end()); h_wg_base = wg;
-    // two halves on two streams: by default from the batch size at which the long sub-sequences are chosen (96 MB of scan data)
-    split_parts = (n >= 2 && (tune.split == 2 || (tune.split == 0 && scan_total >= (96ull << 20)))) ? 2 : 1;
+    // two halves on two streams: by default from JS_SPLIT_FROM_BYTES of scan data on (above)
+    split_parts = (n >= 2 && (tune.split == 2 || (tune.split == 0 && scan_total >= JS_SPLIT_FROM_BYTES))) ? 2 : 1;
     uploaded = true;
     return 0;
 }
@@ -968,7 +971,7 @@ int jsnoop_batch_tile(JsnoopBatch* b, int total) { return b->tile(total); }
 static void js_resolve_split(JsnoopBatch* b)
 {
     uint64_t scan_total = 0; for (const JsImage& im : b->imgs) scan_total += im.scan_len;
-    b->split_parts = (b->imgs.size() >= 2 && (b->tune.split == 2 || (b->tune.split == 0 && scan_total >= (96ull << 20)))) ? 2 : 1;
+    b->split_parts = (b->imgs.size() >= 2 && (b->tune.split == 2 || (b->tune.split == 0 && scan_total >= JS_SPLIT_FROM_BYTES))) ? 2 : 1;
 }
 int jsnoop_batch_set_split(JsnoopBatch* b, int parts)
 {
