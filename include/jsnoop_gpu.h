@@ -237,7 +237,7 @@ int          jsnoop_batch_add_progressive(JsnoopBatch*, const uint8_t* file, siz
 int          jsnoop_batch_tile(JsnoopBatch*, int total);
 /* Beyond the reference: the decodes of a batch may run its two halves on two streams side by side (same arenas, same results; the
    kernels of one half fill the thinly populated phases of the other: about 4 % more throughput on 1024 x 1080p).  parts = 0: the
-   library decides (two streams from 48 MB of scan data in the batch -- the default), 1: one stream (profiling: per-kernel timings
+   library decides (two streams from 8 MB of scan data in the batch -- the default), 1: one stream (profiling: per-kernel timings
    are then those of whole-batch launches), 2: two streams whenever the batch has two images.  0 / -1.                            */
 int          jsnoop_batch_set_split(JsnoopBatch*, int parts);
 int          jsnoop_batch_split_parts(const JsnoopBatch*);              /* what the setting comes to for the images the batch holds now: 1 or 2 */

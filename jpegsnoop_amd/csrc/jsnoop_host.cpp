@@ -421,9 +421,10 @@ template <class T> static int grow(T** p, size_t* cap, size_t need_bytes)
     if (e != hipSuccess) { js_set_error("hipMalloc(%zu) failed: %s", nb, hipGetErrorString(e)); *cap = 0; return -1; }
     *cap = nb; return 0;
 }
-// Two halves on two streams (the second half a stage behind, decode()): from 48 MB of scan data on -- N x 1080p, ms per decode, one stream | two (tools/small_jobs.py,
-// two alternating runs, round 6): 32: 0.93 | 0.88, 48: 1.33 | 1.36, 64: 1.50 | 1.49, 96: 1.87 | 1.82, 128: 2.30 | 2.20, 160: 2.64 | 2.57, 200: 3.12 | 3.13 .. 3.33; 1024: 12.83 | 12.54.
-#define JS_SPLIT_FROM_BYTES (48ull << 20)
+// Two halves on two streams (the second half a stage behind, decode()): from 8 MB of scan data on -- N x 1080p, ms per decode, one stream | two (tools/small_jobs.py,
+// two alternating runs each, round 6): 4: 0.30 | 0.36, 8: 0.38 | 0.43, 16: 0.58 | 0.56, 24: 0.77 | 0.74, 32: 0.93 | 0.88, 40: 1.10 | 1.09, 48: 1.33 | 1.36, 64: 1.50 | 1.50,
+// 96: 1.87 | 1.82, 128: 2.30 | 2.20, 160: 2.64 | 2.57, 200: 3.12 | 3.13 .. 3.33; 1024: 12.83 | 12.54.
+#define JS_SPLIT_FROM_BYTES (8ull << 20)
 int JsnoopBatch::upload()
 {
     JsRange r_("jsnoop:upload (pinned H2D + descriptors)");

@@ -77,7 +77,7 @@ def test_two_stream_split_gives_the_same_batch(harness, oracle):
     b.upload(); b.decode(); b.sync()
     one = b.dib_checksums().copy()
     assert b.split_parts() == 1
-    b.set_split(0); assert b.split_parts() == 1                    # automatic: far below 48 MB of scan data
+    b.set_split(0); assert b.split_parts() == 1                    # automatic: below 8 MB of scan data
     b.set_split(2); assert b.split_parts() == 2
     for _ in range(3):
         b.decode()
