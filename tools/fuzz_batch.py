@@ -20,7 +20,7 @@ for rnd in range(12):
         if mode <= 5: files.append(data)                      # byte-level damage only: add_jpeg parses the header itself
         elif rng.integers(3) == 0: files.append(B[int(rng.integers(len(B)))])
     batch = J.JpegBatch(want_planes=True); idx = []
-    batch.set_tuning(sub_wl=7 if rnd % 2 else 5, **(dict(cand_rounds=-1) if rnd % 4 >= 2 else {}))     # (cand_rounds = -1: synchronisation by rounds -- the list rounds of larger jobs)
+    batch.set_tuning(sub_wl=7 if rnd % 2 else 5, split=2 if rnd % 2 else 0, **(dict(cand_rounds=-1) if rnd % 4 >= 2 else {}))     # (cand_rounds = -1: synchronisation by rounds -- the list rounds of larger jobs; split = 2: two halves on two streams, the second a stage behind)
     for f in files:
         try: idx.append(batch.add_jpeg(f))
         except Exception: idx.append(None)                        # header no longer walkable
